@@ -1,0 +1,770 @@
+/*
+ * kalign_oracle.c -- TEST INFRASTRUCTURE ONLY (the parity checker; see kalign_oracle.h).
+ *
+ * Single-threaded C restatement of Kalign v3.5.1's progressive-alignment hot
+ * path.  Citations are to /root/reference/lib/src.  The arithmetic is IEEE-754
+ * binary32 in source order with no contraction (build with -ffp-contract=off):
+ * the reference is compiled -O3 -mavx2 without FMA, so that evaluation order IS
+ * the specification.
+ *
+ * Structure (deliberately not the reference's): the six forward/backward
+ * functions of aln_seqseq.c / aln_seqprofile.c / aln_profileprofile.c are ONE
+ * routine, ko_pass(), written over a direction-neutral column counter v
+ * (v = 0 is the boundary column that carries the injected state, v = ncols the
+ * far column), with the operand-specific score / gap terms behind small
+ * accessors.  The HIP kernels use the same (u, v) formulation.
+ *
+ * Pinned against: oracle/_ref (the real library) via tests/golden/*.npz --
+ * per-task coded paths, merged-profile hashes, top-level f/b row hashes,
+ * meetup (meet, transition, score), final gap arrays.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kalign_oracle.h"
+
+#define F FLT_MAX
+/* aln_seqseq.c:11-12 -- strict '>' so that ties keep the right-hand value */
+#define MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MAX3(a, b, c) MAX(MAX(a, b), c)
+
+enum { K_SS = 0, K_SP = 1, K_PP = 2 };
+enum { FWD = 0, BWD = 1 };
+
+typedef struct { float a, ga, gb; } st;     /* aln_struct.h:9-14 */
+
+typedef struct {
+        int kind;
+        const uint8_t* s1;      /* row residues (seq-seq) */
+        const uint8_t* s2;      /* column residues (seq-seq, seq-profile) */
+        const float* p1;        /* row profile, 64 floats x (len_a+2) */
+        const float* p2;        /* column profile */
+        int len_a, len_b;
+        const float* subm;      /* 23x23 */
+        float gpo, gpe, tgpe, soff;
+        float sp_open, sp_ext, sp_text;   /* gpo*sip etc. (aln_seqprofile.c:31-33) */
+        const float* bonus;
+        int bstride;
+        st* f;
+        st* b;
+        int* path;
+        float msum;
+        int mcount;
+} dp_t;
+
+/* ---- gap / score terms --------------------------------- */
+
+static inline float row_open(const dp_t* d, int rec) { return d->kind == K_SS ? -d->gpo  : d->p1[(rec << 6) + 27]; }
+static inline float row_ext (const dp_t* d, int rec) { return d->kind == K_SS ? -d->gpe  : d->p1[(rec << 6) + 28]; }
+static inline float row_text(const dp_t* d, int rec) { return d->kind == K_SS ? -d->tgpe : d->p1[(rec << 6) + 29]; }
+
+static inline float col_open(const dp_t* d, int rec)
+{
+        if(d->kind == K_SS) return -d->gpo;
+        if(d->kind == K_SP) return -d->sp_open;
+        return d->p2[(rec << 6) + 27];
+}
+static inline float col_ext(const dp_t* d, int rec)
+{
+        if(d->kind == K_SS) return -d->gpe;
+        if(d->kind == K_SP) return -d->sp_ext;
+        return d->p2[(rec << 6) + 28];
+}
+static inline float col_text(const dp_t* d, int rec)
+{
+        if(d->kind == K_SS) return -d->tgpe;
+        if(d->kind == K_SP) return -d->sp_text;
+        return d->p2[(rec << 6) + 29];
+}
+
+/*
+ * One linear-space Gotoh pass.
+ *   FWD: aln_seqseq.c:15-119, aln_seqprofile.c:13-123, aln_profileprofile.c:17-156
+ *   BWD: aln_seqseq.c:121-238, aln_seqprofile.c:125-230, aln_profileprofile.c:158-298
+ * rows [r0, r1) (0-based positions of the row operand); columns window
+ * [startb, endb] in s[]-index space.  Column counter v runs 0..ncols;
+ * s-index j(v) = startb+v (FWD) or endb-v (BWD).  The column record scoring
+ * s-index j is j (FWD, 1-based cell j scores position j-1) or j+1 (BWD).
+ */
+static void ko_pass(dp_t* d, int dir, int r0, int r1, int startb, int endb)
+{
+        st* s = (dir == FWD) ? d->f : d->b;
+        const int ncols = endb - startb;
+        const int nrows = r1 - r0;
+        const int near_terminal = (dir == FWD) ? (startb == 0) : (endb == d->len_b);
+        const int far_terminal  = (dir == FWD) ? (endb == d->len_b) : (startb == 0);
+        unsigned int nz[24];
+        int v, u;
+
+#define SJ(v_) ((dir == FWD) ? (startb + (v_)) : (endb - (v_)))
+#define CREC(j_) ((dir == FWD) ? (j_) : ((j_) + 1))
+#define CPREV(rec_) ((dir == FWD) ? ((rec_) - 1) : ((rec_) + 1))
+
+        /* row "-1": the injected state in s[0], then a pure horizontal-gap run */
+        s[SJ(0)] = s[0];
+        for(v = 1; v < ncols; v++){
+                const int j = SJ(v), jp = SJ(v - 1), rec = CREC(j);
+                s[j].a = -F;
+                if(!near_terminal){
+                        s[j].ga = MAX(s[jp].ga + col_ext(d, rec), s[jp].a + col_open(d, rec));
+                }else{
+                        s[j].ga = MAX(s[jp].ga, s[jp].a) + col_text(d, rec);
+                }
+                s[j].gb = -F;
+        }
+        s[SJ(ncols)].a = -F; s[SJ(ncols)].ga = -F; s[SJ(ncols)].gb = -F;
+
+        for(u = 0; u < nrows; u++){
+                const int i = (dir == FWD) ? (r0 + u) : (r1 - 1 - u);
+                const int rrec = i + 1;
+                const int rprev = (dir == FWD) ? rrec - 1 : rrec + 1;
+                const float o_row = row_open(d, rrec), e_row = row_ext(d, rrec), t_row = row_text(d, rrec);
+                const float o_rowprev = row_open(d, rprev);
+                const float* subp = NULL;
+                const float* prow = NULL;
+                int nnz = 0;
+                float pa, pga, pgb, ca, xa, xga;
+                const int j0 = SJ(0);
+
+                if(d->kind == K_SS){
+                        subp = d->subm + 23 * d->s1[i];
+                }else{
+                        prow = d->p1 + (rrec << 6);
+                        if(d->kind == K_PP){
+                                /* aln_profileprofile.c:70-77 */
+                                for(int c = 0; c < 23; c++) if(prow[c]) nz[nnz++] = (unsigned int)c;
+                        }
+                }
+
+                pa = s[j0].a; pga = s[j0].ga; pgb = s[j0].gb;
+                s[j0].a = -F; s[j0].ga = -F;
+                xa = -F; xga = -F;
+                if(!near_terminal){
+                        s[j0].gb = MAX(pgb + e_row, pa + o_row);
+                }else{
+                        s[j0].gb = MAX(pgb, pa) + t_row;
+                }
+
+                for(v = 1; v <= ncols; v++){
+                        const int j = SJ(v), rec = CREC(j);
+                        ca = s[j].a;
+                        pa = MAX3(pa, pga + col_open(d, CPREV(rec)), pgb + o_rowprev);
+                        if(d->kind == K_SS){
+                                pa += subp[d->s2[rec - 1]] - d->soff;            /* aln_seqseq.c:82 */
+                        }else if(d->kind == K_SP){
+                                pa += prow[32 + d->s2[rec - 1]];                 /* aln_seqprofile.c:81 */
+                        }else{
+                                const float* pc = d->p2 + (rec << 6) + 32;
+                                for(int c = nnz - 1; c >= 0; c--){               /* aln_profileprofile.c:101-107 */
+                                        pa += prow[nz[c]] * pc[nz[c]];
+                                }
+                        }
+                        if(d->bonus){
+                                /* FWD indexes with the 1-based cell column, BWD with the
+                                   0-based one (aln_seqseq.c:83-85 vs :199-201): both are j here */
+                                pa += d->bonus[i * d->bstride + j];
+                        }
+                        s[j].a = pa;
+                        if(v < ncols){
+                                pga = s[j].ga;
+                                s[j].ga = MAX(xga + col_ext(d, rec), xa + col_open(d, rec));
+                                pgb = s[j].gb;
+                                s[j].gb = MAX(pgb + e_row, ca + o_row);
+                                pa = ca;
+                                xa = s[j].a;
+                                xga = s[j].ga;
+                        }else{
+                                s[j].ga = -F;
+                                if(!far_terminal){
+                                        s[j].gb = MAX(s[j].gb + e_row, ca + o_row);
+                                }else{
+                                        s[j].gb = MAX(s[j].gb, ca) + t_row;
+                                }
+                        }
+                }
+        }
+#undef SJ
+#undef CREC
+#undef CPREV
+}
+
+/*
+ * Meetup at the Hirschberg split row (aln_seqseq.c:241-420, aln_seqprofile.c:232-415,
+ * aln_profileprofile.c:301-483).  Candidate order per column: codes 1,2,3,5,6,7;
+ * at the last column only 3 and 6.  First strictly-greater wins.
+ */
+typedef struct { float max, max2; int c, t; } best_t;
+
+static inline void consider(best_t* b, float s, int i, int code)
+{
+        if(s > b->max){
+                b->max2 = b->max;
+                b->max = s; b->t = code; b->c = i;
+        }else if(s > b->max2){
+                b->max2 = s;
+        }
+}
+
+static void ko_meetup(dp_t* d, int startb, int endb, int mid, int* meet, int* tr, float* score)
+{
+        const st* f = d->f;
+        const st* b = d->b;
+        best_t B = { -F, -F, -1, -1 };
+        const float middle = (float)(endb - startb) / 2.0F + (float)startb;
+        const int rrec = mid + 1;                 /* R  = P1[mid+1], R- = P1[mid] */
+        const float g3 = row_open(d, rrec);
+        const float g7 = row_open(d, rrec - 1);
+        const float g6_near = (startb == 0) ? row_text(d, rrec) : row_ext(d, rrec);
+        const float g6_far = (endb == d->len_b) ? row_text(d, rrec) : row_ext(d, rrec);
+        float sub;
+        int i;
+        for(i = startb; i < endb; i++){
+                sub = fabsf(middle - (float)i);
+                sub /= 1000.0F;
+                consider(&B, f[i].a + b[i].a - sub, i, 1);
+                consider(&B, f[i].a + b[i].ga + col_open(d, i + 1) - sub, i, 2);
+                consider(&B, f[i].a + b[i].gb + g3 - sub, i, 3);
+                consider(&B, f[i].ga + b[i].a + col_open(d, i) - sub, i, 5);
+                consider(&B, f[i].gb + b[i].gb + g6_near - sub, i, 6);
+                consider(&B, f[i].gb + b[i].a + g7 - sub, i, 7);
+        }
+        i = endb;
+        sub = fabsf(middle - (float)i);
+        sub /= 1000.0F;
+        consider(&B, f[i].a + b[i].gb + g3 - sub, i, 3);
+        consider(&B, f[i].gb + b[i].gb + g6_far - sub, i, 6);
+
+        if(B.max2 > -F){                          /* aln_seqseq.c:376-383 */
+                d->msum += B.max - B.max2;
+                d->mcount++;
+        }
+        *meet = B.c; *tr = B.t; *score = B.max;
+}
+
+/*
+ * Hirschberg driver: aln_runner_serial + aln_continue (aln_controller.c:122-436).
+ * fin / bin are the boundary states injected into f[0] / b[0].
+ */
+typedef struct { int top_meet, top_tr; float top_score; int have_top; uint64_t fhash, bhash; float* f_out; float* b_out; } probe_t;
+
+static const st Z  = { 0.0F, -F, -F };
+static const st GA = { -F, 0.0F, -F };
+static const st GB = { -F, -F, 0.0F };
+
+static void ko_hirschberg(dp_t* d, int starta, int enda, int startb, int endb, st fin, st bin, probe_t* probe)
+{
+        int mid, meet, tr;
+        float score;
+        if(starta >= enda) return;
+        if(startb >= endb) return;
+        mid = ((enda - starta) / 2) + starta;
+        d->f[0] = fin;
+        d->b[0] = bin;
+        ko_pass(d, FWD, starta, mid, startb, endb);
+        ko_pass(d, BWD, mid, enda, startb, endb);
+        ko_meetup(d, startb, endb, mid, &meet, &tr, &score);
+        if(probe && !probe->have_top){
+                probe->have_top = 1;
+                probe->top_meet = meet; probe->top_tr = tr; probe->top_score = score;
+                probe->fhash = ko_fnv1a(d->f, sizeof(st) * (uint64_t)(endb + 1));
+                probe->bhash = ko_fnv1a(d->b, sizeof(st) * (uint64_t)(endb + 1));
+                if(probe->f_out) memcpy(probe->f_out, d->f, sizeof(st) * (size_t)(endb + 1));
+                if(probe->b_out) memcpy(probe->b_out, d->b, sizeof(st) * (size_t)(endb + 1));
+        }
+        switch(tr){
+        case 1:
+                d->path[mid] = meet; d->path[mid + 1] = meet + 1;
+                ko_hirschberg(d, starta, mid - 1, startb, meet - 1, fin, Z, probe);
+                ko_hirschberg(d, mid + 1, enda, meet + 1, endb, Z, bin, probe);
+                break;
+        case 2:
+                d->path[mid] = meet;
+                ko_hirschberg(d, starta, mid - 1, startb, meet - 1, fin, Z, probe);
+                ko_hirschberg(d, mid, enda, meet + 1, endb, GA, bin, probe);
+                break;
+        case 3:
+                d->path[mid] = meet;
+                ko_hirschberg(d, starta, mid - 1, startb, meet - 1, fin, Z, probe);
+                ko_hirschberg(d, mid + 1, enda, meet, endb, GB, bin, probe);
+                break;
+        case 5:
+                d->path[mid + 1] = meet + 1;
+                ko_hirschberg(d, starta, mid, startb, meet - 1, fin, GA, probe);
+                ko_hirschberg(d, mid + 1, enda, meet + 1, endb, Z, bin, probe);
+                break;
+        case 6:
+                ko_hirschberg(d, starta, mid - 1, startb, meet, fin, GB, probe);
+                ko_hirschberg(d, mid + 1, enda, meet, endb, GB, bin, probe);
+                break;
+        case 7:
+                d->path[mid + 1] = meet + 1;
+                ko_hirschberg(d, starta, mid - 1, startb, meet, fin, GB, probe);
+                ko_hirschberg(d, mid + 1, enda, meet + 1, endb, Z, bin, probe);
+                break;
+        default:
+                break;
+        }
+}
+
+/* init_alnmem (aln_setup.c:13-38) + run; d->f, d->b, d->path must hold
+   max(len_a,len_b)+2 states / len_a+len_b+2 ints. */
+static void ko_align(dp_t* d, probe_t* probe)
+{
+        const int g = (d->len_a > d->len_b ? d->len_a : d->len_b) + 2;
+        for(int i = 0; i < g; i++) d->path[i] = -1;
+        d->msum = 0.0F; d->mcount = 0;
+        ko_hirschberg(d, 0, d->len_a, 0, d->len_b, Z, Z, probe);
+}
+
+uint64_t ko_fnv1a(const void* p, uint64_t n)
+{
+        const unsigned char* c = (const unsigned char*)p;
+        uint64_t h = 1469598103934665603ULL;
+        for(uint64_t i = 0; i < n; i++){ h ^= c[i]; h *= 1099511628211ULL; }
+        return h;
+}
+
+/* ---- per-task glue --------------------------------------------------------------- */
+
+/* make_profile_n (aln_setup.c:40-99), weight 1.0; prof holds (len+2)*64 floats */
+int ko_make_profile(const uint8_t* seq, int len, const float* subm,
+                    float gpo, float gpe, float tgpe, float soff, float* prof)
+{
+        memset(prof, 0, sizeof(float) * 64 * (size_t)(len + 2));
+        for(int r = 0; r <= len + 1; r++){
+                float* p = prof + ((size_t)r << 6);
+                if(r >= 1 && r <= len){
+                        const int c = seq[r - 1];
+                        p[c] += 1.0F;
+                        for(int j = 0; j < 23; j++) p[32 + j] = subm[23 * c + j] - soff;
+                }
+                p[55] = -gpo; p[56] = -gpe; p[57] = -tgpe;
+        }
+        return 0;
+}
+
+/* set_gap_penalties_n (aln_setup.c:101-119) */
+int ko_set_gap_penalties(float* prof, int len, int nsip)
+{
+        for(int r = 0; r <= len + 1; r++){
+                float* p = prof + ((size_t)r << 6);
+                p[27] = p[55] * (float)nsip;
+                p[28] = p[56] * (float)nsip;
+                p[29] = p[57] * (float)nsip;
+        }
+        return 0;
+}
+
+/* mirror_path_n (aln_setup.c:438-462): raw_in is indexed by DP rows (= b
+   positions, 1..len_b) and holds a-columns; raw_out is indexed by a positions. */
+int ko_mirror_path(const int* raw_in, int len_a, int len_b, int* raw_out)
+{
+        for(int i = 0; i < len_a + 2; i++) raw_out[i] = -1;
+        for(int i = 1; i <= len_b; i++) if(raw_in[i] != -1) raw_out[raw_in[i]] = i;
+        return 0;
+}
+
+/*
+ * add_gap_info_to_path_n (aln_setup.c:121-228).  Ops: 0 match, 1 gap in a,
+ * 2 gap in b; coded[0] = alignment length, coded[alnlen+1] = 3.
+ * NOTE (as executed, not as intended): the open/extend/close flag loop at
+ * aln_setup.c:193-207 tests `o_path[j] != 3` with j parked on the terminator it
+ * has just written, so it never runs; bits 4/8/16 are never set.  Only the
+ * terminal-run flag 32 (:209-219) is applied.  We restate what executes.
+ * coded must hold len_a+len_b+2 ints.
+ */
+int ko_code_path(const int* raw, int len_a, int len_b, int* coded)
+{
+        int j = 1, prev;
+        for(int i = 0; i < len_a + len_b + 2; i++) coded[i] = 0;
+        if(raw[1] == -1){
+                coded[j++] = 2;
+        }else{
+                for(int k = 0; k < raw[1] - 1; k++) coded[j++] = 1;
+                coded[j++] = 0;
+        }
+        prev = raw[1];
+        for(int i = 2; i <= len_a; i++){
+                if(raw[i] == -1){
+                        coded[j++] = 2;
+                }else{
+                        if(raw[i] - 1 != prev && prev != -1){
+                                for(int k = 0; k < raw[i] - prev - 1; k++) coded[j++] = 1;
+                        }
+                        coded[j++] = 0;
+                }
+                prev = raw[i];
+        }
+        if(raw[len_a] < len_b && raw[len_a] != -1){
+                for(int k = 0; k < len_b - raw[len_a]; k++) coded[j++] = 1;
+        }
+        coded[0] = j - 1;
+        coded[j] = 3;
+        {
+                int i = 1;
+                while(coded[i] != 0){ coded[i] |= 32; i++; }
+                i = coded[0];
+                while(coded[i] != 0){ coded[i] |= 32; i--; }
+        }
+        return 0;
+}
+
+/*
+ * update_n (aln_setup.c:230-436): merged profile along a coded path.
+ * out holds (coded[0]+2)*64 floats.
+ */
+static void gap_column(float* np, const float* src, int code, float sip_absent,
+                       float gpo, float gpe, float tgpe)
+{
+        float gp;
+        for(int i = 64; i--;) np[i] = src[i];
+        if(!(code & 20)){
+                if(code & 32){ np[25] += sip_absent; gp = tgpe * sip_absent; }
+                else         { np[24] += sip_absent; gp = gpe * sip_absent; }
+                for(int j = 32; j < 55; j++) np[j] -= gp;
+        }else{
+                if(code & 16){
+                        if(code & 32){
+                                np[25] += sip_absent; gp = tgpe * sip_absent;
+                                np[23] += sip_absent; gp += gpo * sip_absent;
+                        }else{
+                                np[23] += sip_absent; gp = gpo * sip_absent;
+                        }
+                        for(int j = 32; j < 55; j++) np[j] -= gp;
+                }
+                if(code & 4){
+                        if(code & 32){
+                                np[25] += sip_absent; gp = tgpe * sip_absent;
+                                np[23] += sip_absent; gp += gpo * sip_absent;
+                        }else{
+                                np[23] += sip_absent; gp = gpo * sip_absent;
+                        }
+                        for(int j = 32; j < 55; j++) np[j] -= gp;
+                }
+        }
+}
+
+static void sum_column(float* np, const float* pa, const float* pb, int rebalance, float sA, float sB)
+{
+        if(rebalance){
+                for(int i = 0; i < 23; i++) np[i] = pa[i] * sA + pb[i] * sB;
+                for(int i = 23; i < 64; i++) np[i] = pa[i] + pb[i];
+        }else{
+                for(int i = 64; i--;) np[i] = pa[i] + pb[i];
+        }
+}
+
+int ko_update_profile(const float* pa, const float* pb, float* out, const int* coded,
+                      int sipa, int sipb, const float* subm,
+                      float gpo, float gpe, float tgpe, float use_seq_weights)
+{
+        float sA = 1.0f, sB = 1.0f;
+        int rebalance = 0;
+        int c = 1;
+        if(use_seq_weights > 0.0f && sipa > 0 && sipb > 0){          /* aln_setup.c:255-262 */
+                const float pseudo = use_seq_weights;
+                const float total = (float)(sipa + sipb);
+                const float denom = total + 2.0f * pseudo;
+                sA = total * ((float)sipa + pseudo) / (denom * (float)sipa);
+                sB = total * ((float)sipb + pseudo) / (denom * (float)sipb);
+                rebalance = 1;
+        }
+        sum_column(out, pa, pb, rebalance, sA, sB);
+        pa += 64; pb += 64; out += 64;
+        while(coded[c] != 3){
+                const int code = coded[c];
+                if(!code){
+                        sum_column(out, pa, pb, rebalance, sA, sB);
+                        if(rebalance){                                   /* aln_setup.c:289-302 */
+                                const float dA = sA - 1.0f, dB = sB - 1.0f;
+                                for(int j = 0; j < 23; j++){
+                                        float delta = 0.0f;
+                                        for(int aa = 0; aa < 23; aa++){
+                                                delta += (pa[aa] * dA + pb[aa] * dB) * subm[23 * aa + j];
+                                        }
+                                        out[32 + j] += delta;
+                                }
+                        }
+                        pa += 64; pb += 64;
+                }
+                if(code & 1){
+                        gap_column(out, pb, code, (float)sipa, gpo, gpe, tgpe);
+                        pb += 64;
+                }
+                if(code & 2){
+                        gap_column(out, pa, code, (float)sipb, gpo, gpe, tgpe);
+                        pa += 64;
+                }
+                out += 64;
+                c++;
+        }
+        sum_column(out, pa, pb, rebalance, sA, sB);
+        return 0;
+}
+
+/* make_seq + update_gaps (weave_alignment.c:41-112) */
+static void fold_gaps(int len, int* gis, const int* newgaps)
+{
+        int rel = 0;
+        for(int i = 0; i <= len; i++){
+                int add = 0;
+                for(int j = rel; j <= rel + gis[i]; j++) add += newgaps[j];
+                rel += gis[i] + 1;
+                gis[i] += add;
+        }
+}
+
+static void weave(const int* coded, const int* mem_a, int na, const int* mem_b, int nb,
+                  const int* lens, int** gaps)
+{
+        const int n = coded[0] + 1;
+        int* ga = calloc((size_t)n, sizeof(int));
+        int* gb = calloc((size_t)n, sizeof(int));
+        int posa = 0, posb = 0;
+        for(int c = 1; coded[c] != 3; c++){
+                if(!coded[c]){ posa++; posb++; }
+                else if(coded[c] & 1){ ga[posa] += 1; posb++; }
+                else if(coded[c] & 2){ gb[posb] += 1; posa++; }
+        }
+        for(int i = na; i--;) fold_gaps(lens[mem_a[i]], gaps[mem_a[i]], ga);
+        for(int i = nb; i--;) fold_gaps(lens[mem_b[i]], gaps[mem_b[i]], gb);
+        free(ga); free(gb);
+}
+
+/* mean of seq_distances over both clusters, in sip order (aln_run.c:126-203) */
+static float mean_distance(const float* dist, const int* ma, int na, const int* mb, int nb, int numseq, int* count)
+{
+        float sum = 0.0f;
+        int n = 0;
+        for(int i = 0; i < na; i++) if(ma[i] < numseq){ sum += dist[ma[i]]; n++; }
+        for(int i = 0; i < nb; i++) if(mb[i] < numseq){ sum += dist[mb[i]]; n++; }
+        *count = n;
+        return n ? sum / (float)n : 0.0f;
+}
+
+/*
+ * The dispatcher: create_msa_tree / do_align without consistency
+ * (aln_run.c:43-124, :213-441).  Tasks must be in TASK_ORDER_TREE order
+ * (children before parents; the last task is the root).
+ */
+int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                const float* seq_distances,
+                int n_tasks, const int* abc,
+                const float* subm, const float* scal,
+                ko_task_rec* recs, int* paths_out, long long paths_cap,
+                int* gaps_out, int dump_task, float* prof_dump)
+{
+        const int nprof = 2 * numseq - 1;
+        const float gpo0 = scal[0], gpe0 = scal[1], tgpe0 = scal[2];
+        const float dist_scale = scal[3], vsm_amax = scal[4], usw = scal[5];
+        float** prof = calloc((size_t)nprof, sizeof(float*));
+        int** sip = calloc((size_t)nprof, sizeof(int*));
+        int* nsip = calloc((size_t)nprof, sizeof(int));
+        int* plen = calloc((size_t)nprof, sizeof(int));
+        int** gaps = calloc((size_t)numseq, sizeof(int*));
+        long long poff = 0;
+        int rc = 0;
+
+        for(int i = 0; i < numseq; i++){
+                sip[i] = malloc(sizeof(int)); sip[i][0] = i; nsip[i] = 1;
+                gaps[i] = calloc((size_t)lens[i] + 1, sizeof(int));
+        }
+        for(int tid = 0; tid < n_tasks && !rc; tid++){
+                const int a = abc[3 * tid], b = abc[3 * tid + 1], c = abc[3 * tid + 2];
+                ko_task_rec* r = &recs[tid];
+                float gap_scale = 1.0f, soff = 0.0f, gpo = gpo0, gpe = gpe0, tgpe = tgpe0;
+                int len_a, len_b, cnt, g, swapped = 0;
+                dp_t d;
+                probe_t probe;
+                int *raw, *raw2, *coded;
+                float* merged;
+
+                memset(&d, 0, sizeof(d));
+                memset(&probe, 0, sizeof(probe));
+                if(dist_scale > 0.0f && seq_distances){                   /* compute_gap_scale */
+                        float avg = mean_distance(seq_distances, sip[a], nsip[a], sip[b], nsip[b], numseq, &cnt);
+                        if(cnt){
+                                gap_scale = 1.0f - dist_scale * avg;
+                                if(gap_scale < 0.3f) gap_scale = 0.3f;
+                                if(gap_scale > 1.0f) gap_scale = 1.0f;
+                        }
+                }
+                if(vsm_amax > 0.0f && seq_distances){                      /* compute_subm_offset */
+                        float avg = mean_distance(seq_distances, sip[a], nsip[a], sip[b], nsip[b], numseq, &cnt);
+                        if(cnt){
+                                soff = vsm_amax - avg;
+                                if(soff < 0.0f) soff = 0.0f;
+                        }
+                }
+                if(gap_scale < 1.0f || soff > 0.0f){                       /* aln_run.c:229-237 */
+                        gpo *= gap_scale; gpe *= gap_scale; tgpe *= gap_scale;
+                }else{
+                        soff = 0.0f;
+                }
+                if(nsip[a] == 1){
+                        len_a = lens[a];
+                        prof[a] = malloc(sizeof(float) * 64 * (size_t)(len_a + 2));
+                        ko_make_profile(codes + off[a], len_a, subm, gpo, gpe, tgpe, soff, prof[a]);
+                }else{
+                        len_a = plen[a];
+                        ko_set_gap_penalties(prof[a], len_a, nsip[b]);
+                }
+                if(nsip[b] == 1){
+                        len_b = lens[b];
+                        prof[b] = malloc(sizeof(float) * 64 * (size_t)(len_b + 2));
+                        ko_make_profile(codes + off[b], len_b, subm, gpo, gpe, tgpe, soff, prof[b]);
+                }else{
+                        len_b = plen[b];
+                        ko_set_gap_penalties(prof[b], len_b, nsip[a]);
+                }
+
+                /* operand selection / swap (aln_run.c:297-388) */
+                d.subm = subm; d.gpo = gpo; d.gpe = gpe; d.tgpe = tgpe; d.soff = soff;
+                if(nsip[a] == 1 && nsip[b] == 1){
+                        d.kind = K_SS;
+                        if(len_a < len_b){ d.s1 = codes + off[a]; d.s2 = codes + off[b]; }
+                        else{ swapped = 1; d.s1 = codes + off[b]; d.s2 = codes + off[a]; }
+                }else if(nsip[a] == 1){
+                        d.kind = K_SP; swapped = 1;
+                        d.s2 = codes + off[a]; d.p1 = prof[b];
+                        d.sp_open = gpo * (float)nsip[b]; d.sp_ext = gpe * (float)nsip[b]; d.sp_text = tgpe * (float)nsip[b];
+                }else if(nsip[b] == 1){
+                        d.kind = K_SP;
+                        d.s2 = codes + off[b]; d.p1 = prof[a];
+                        d.sp_open = gpo * (float)nsip[a]; d.sp_ext = gpe * (float)nsip[a]; d.sp_text = tgpe * (float)nsip[a];
+                }else{
+                        d.kind = K_PP;
+                        if(len_a < len_b){ d.p1 = prof[a]; d.p2 = prof[b]; }
+                        else{ swapped = 1; d.p1 = prof[b]; d.p2 = prof[a]; }
+                }
+                d.len_a = swapped ? len_b : len_a;
+                d.len_b = swapped ? len_a : len_b;
+                g = (len_a > len_b ? len_a : len_b) + 2;
+                d.f = malloc(sizeof(st) * (size_t)g);
+                d.b = malloc(sizeof(st) * (size_t)g);
+                raw = malloc(sizeof(int) * (size_t)(len_a + len_b + 2));
+                raw2 = malloc(sizeof(int) * (size_t)(len_a + len_b + 2));
+                coded = malloc(sizeof(int) * (size_t)(len_a + len_b + 3));
+                d.path = raw;
+                ko_align(&d, &probe);
+                if(swapped){
+                        ko_mirror_path(raw, len_a, len_b, raw2);
+                        ko_code_path(raw2, len_a, len_b, coded);
+                }else{
+                        ko_code_path(raw, len_a, len_b, coded);
+                }
+
+                r->a = a; r->b = b; r->c = c;
+                r->len_a = len_a; r->len_b = len_b; r->nsip_a = nsip[a]; r->nsip_b = nsip[b];
+                r->plen = coded[0]; r->kind = d.kind; r->swapped = swapped;
+                r->meet = probe.have_top ? probe.top_meet : -1;
+                r->transition = probe.have_top ? probe.top_tr : -1;
+                r->score = probe.have_top ? probe.top_score : 0.0f;
+                r->fhash = probe.fhash; r->bhash = probe.bhash;
+                r->gap_scale = gap_scale; r->subm_off = soff;
+                r->confidence = d.mcount > 0 ? d.msum / (float)d.mcount : 0.0f;
+                r->prof_hash = 0;
+                if(poff + coded[0] + 2 > paths_cap){
+                        rc = 2;
+                }else{
+                        r->path_off = (int)poff;
+                        memcpy(paths_out + poff, coded, sizeof(int) * (size_t)(coded[0] + 2));
+                        poff += coded[0] + 2;
+                }
+
+                /* merged profile with the UNSCALED penalties (aln_run.c:405-413) */
+                merged = malloc(sizeof(float) * 64 * (size_t)(coded[0] + 2));
+                if(tid != n_tasks - 1){
+                        ko_update_profile(prof[a], prof[b], merged, coded, nsip[a], nsip[b], subm, gpo0, gpe0, tgpe0, usw);
+                        r->prof_hash = ko_fnv1a(merged, sizeof(float) * 64 * (uint64_t)(coded[0] + 2));
+                        if(tid == dump_task && prof_dump){
+                                memcpy(prof_dump, merged, sizeof(float) * 64 * (size_t)(coded[0] + 2));
+                        }
+                }
+                free(prof[a]); free(prof[b]); prof[a] = NULL; prof[b] = NULL;
+                prof[c] = merged;
+                weave(coded, sip[a], nsip[a], sip[b], nsip[b], lens, gaps);
+                plen[c] = coded[0];
+                nsip[c] = nsip[a] + nsip[b];
+                sip[c] = malloc(sizeof(int) * (size_t)nsip[c]);
+                g = 0;
+                for(int j = nsip[a]; j--;) sip[c][g++] = sip[a][j];          /* aln_run.c:428-436 */
+                for(int j = nsip[b]; j--;) sip[c][g++] = sip[b][j];
+                free(d.f); free(d.b); free(raw); free(raw2); free(coded);
+        }
+        if(gaps_out){
+                int o = 0;
+                for(int i = 0; i < numseq; i++) for(int j = 0; j <= lens[i]; j++) gaps_out[o++] = gaps[i][j];
+        }
+        for(int i = 0; i < nprof; i++){ free(prof[i]); free(sip[i]); }
+        for(int i = 0; i < numseq; i++) free(gaps[i]);
+        free(prof); free(sip); free(nsip); free(plen); free(gaps);
+        return rc;
+}
+
+/* N x seq-seq as pairwise_align_map runs them (anchor_consistency.c:19-120) */
+int ko_pairwise_batch(const uint8_t* codes, const int* off, const int* lens,
+                      const int* ia, const int* ib, int npairs,
+                      const float* subm, float gpo, float gpe, float tgpe,
+                      int* paths_out, const long long* poff, float* scores_out)
+{
+        for(int k = 0; k < npairs; k++){
+                const int i = ia[k], j = ib[k];
+                const int len_i = lens[i], len_j = lens[j];
+                const int swapped = !(len_i <= len_j);
+                const int g = (len_i > len_j ? len_i : len_j) + 2;
+                dp_t d;
+                probe_t probe;
+                int* raw = malloc(sizeof(int) * (size_t)(len_i + len_j + 2));
+                int* raw2 = malloc(sizeof(int) * (size_t)(len_i + len_j + 2));
+                memset(&d, 0, sizeof(d));
+                memset(&probe, 0, sizeof(probe));
+                d.kind = K_SS; d.subm = subm; d.gpo = gpo; d.gpe = gpe; d.tgpe = tgpe; d.soff = 0.0f;
+                d.s1 = codes + off[swapped ? j : i]; d.s2 = codes + off[swapped ? i : j];
+                d.len_a = swapped ? len_j : len_i; d.len_b = swapped ? len_i : len_j;
+                d.f = malloc(sizeof(st) * (size_t)g); d.b = malloc(sizeof(st) * (size_t)g);
+                d.path = raw;
+                ko_align(&d, &probe);
+                if(swapped){
+                        ko_mirror_path(raw, len_i, len_j, raw2);
+                        ko_code_path(raw2, len_i, len_j, paths_out + poff[k]);
+                }else{
+                        ko_code_path(raw, len_i, len_j, paths_out + poff[k]);
+                }
+                if(scores_out) scores_out[k] = probe.have_top ? probe.top_score : 0.0f;
+                free(d.f); free(d.b); free(raw); free(raw2);
+        }
+        return 0;
+}
+
+int ko_dp_single(int kind, const uint8_t* seq1, const uint8_t* seq2,
+                 const float* prof1, const float* prof2, int len_a, int len_b,
+                 const float* subm, float gpo, float gpe, float tgpe, float soff, int sip,
+                 const float* bonus, int bonus_stride,
+                 int* raw_path, float* f_out, float* b_out,
+                 int* meet, int* transition, float* score, float* confidence)
+{
+        dp_t d;
+        probe_t probe;
+        const int g = (len_a > len_b ? len_a : len_b) + 2;
+        memset(&d, 0, sizeof(d));
+        memset(&probe, 0, sizeof(probe));
+        d.kind = kind; d.s1 = seq1; d.s2 = seq2; d.p1 = prof1; d.p2 = prof2;
+        d.len_a = len_a; d.len_b = len_b; d.subm = subm;
+        d.gpo = gpo; d.gpe = gpe; d.tgpe = tgpe; d.soff = soff;
+        d.sp_open = gpo * (float)sip; d.sp_ext = gpe * (float)sip; d.sp_text = tgpe * (float)sip;
+        d.bonus = bonus; d.bstride = bonus_stride;
+        d.f = malloc(sizeof(st) * (size_t)g); d.b = malloc(sizeof(st) * (size_t)g);
+        d.path = malloc(sizeof(int) * (size_t)(len_a + len_b + 2));
+        probe.f_out = f_out; probe.b_out = b_out;
+        ko_align(&d, &probe);
+        memcpy(raw_path, d.path, sizeof(int) * (size_t)(len_a + 2));
+        if(meet) *meet = probe.have_top ? probe.top_meet : -1;
+        if(transition) *transition = probe.have_top ? probe.top_tr : -1;
+        if(score) *score = probe.have_top ? probe.top_score : 0.0f;
+        if(confidence) *confidence = d.mcount > 0 ? d.msum / (float)d.mcount : 0.0f;
+        free(d.f); free(d.b); free(d.path);
+        return 0;
+}

@@ -1,0 +1,76 @@
+/*
+ * kalign_oracle.h -- TEST INFRASTRUCTURE ONLY (the parity checker).
+ *
+ * A plain-C, single-threaded restatement of Kalign's progressive-alignment hot
+ * path (Hirschberg/Gotoh DP + per-task glue).  It exists so that tests can check
+ * the HIP product bit-for-bit on the GPU box, where /root/reference does not
+ * exist.  It is itself pinned against the real reference (oracle/_ref, golden
+ * vectors under tests/golden/).  Nothing under kalign_amd/ may link, load or
+ * call this.
+ */
+#ifndef KALIGN_ORACLE_H
+#define KALIGN_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as struct refh_task_rec in ref_harness.c (and ka_task_rec in
+   include/kalign_amd.h) so one ctypes definition serves all three. */
+typedef struct ko_task_rec {
+        int a, b, c;
+        int len_a, len_b;
+        int nsip_a, nsip_b;
+        int plen;
+        int kind;          /* 0 seq-seq, 1 seq-profile, 2 profile-profile */
+        int swapped;
+        int meet, transition;
+        int path_off;
+        float gap_scale, subm_off;
+        float score;
+        float confidence;
+        uint64_t prof_hash;
+        uint64_t fhash, bhash;
+} ko_task_rec;
+
+/* scal[6] = gpo, gpe, tgpe, dist_scale, vsm_amax, use_seq_weights */
+int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                const float* seq_distances,
+                int n_tasks, const int* tasks_abc,
+                const float* subm, const float* scal,
+                ko_task_rec* recs, int* paths_out, long long paths_cap,
+                int* gaps_out, int dump_task, float* prof_dump);
+
+int ko_pairwise_batch(const uint8_t* codes, const int* off, const int* lens,
+                      const int* ia, const int* ib, int npairs,
+                      const float* subm, float gpo, float gpe, float tgpe,
+                      int* paths_out, const long long* poff, float* scores_out);
+
+/* One DP between explicit operands, for kernel-level tests.
+   kind 0: seq1/seq2; kind 1: prof1 (rows) / seq2; kind 2: prof1 / prof2.
+   raw_path: len_a+2 ints (path[i] = matched column, 1-based, or -1).
+   f_out/b_out: top-level forward/backward rows, 3*(len_b+1) floats each. */
+int ko_dp_single(int kind, const uint8_t* seq1, const uint8_t* seq2,
+                 const float* prof1, const float* prof2, int len_a, int len_b,
+                 const float* subm, float gpo, float gpe, float tgpe, float soff, int sip,
+                 const float* bonus, int bonus_stride,
+                 int* raw_path, float* f_out, float* b_out,
+                 int* meet, int* transition, float* score, float* confidence);
+
+int ko_make_profile(const uint8_t* seq, int len, const float* subm,
+                    float gpo, float gpe, float tgpe, float soff, float* prof);
+int ko_set_gap_penalties(float* prof, int len, int nsip);
+int ko_code_path(const int* raw_path, int len_a, int len_b, int* coded);
+int ko_mirror_path(const int* raw_in, int len_a, int len_b, int* raw_out);
+int ko_update_profile(const float* pa, const float* pb, float* out, const int* coded,
+                      int sipa, int sipb, const float* subm,
+                      float gpo, float gpe, float tgpe, float use_seq_weights);
+
+uint64_t ko_fnv1a(const void* p, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""Regenerates tests/golden/*.npz from the REAL reference (oracle/_ref).
+
+Runs only in the build container (needs `make -C oracle ref`, i.e.
+/root/reference).  The committed .npz files hold data only: inputs (sequences),
+what the reference's own pipeline produced up to the dispatcher seam (encoded
+sequences, guide-tree task list, seq_distances, scoring parameters) and what its
+dispatcher / DP produced (per-task coded paths, top-level meetup, hashes of the
+merged profiles and f/b rows, final gap arrays, aligned rows).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kalign_amd import synth            # noqa: E402
+from oracle import oracledrv, refdrv    # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tree_case(name, seqs, **kw):
+    job = refdrv.RefJob(seqs, **kw)
+    dump_task = 0
+    recs, paths, gaps, dump = job.run_tree_traced(dump_task=dump_task)
+    rows = job.finalise()
+    # cross-check: the real create_msa_tree must give the same gap arrays as the traced replay
+    job2 = refdrv.RefJob(seqs, **kw)
+    gaps2, _ = job2.run_tree()
+    assert all(np.array_equal(a, b) for a, b in zip(gaps, gaps2)), name
+    used = recs[-1].path_off + recs[-1].plen + 2
+    d = dict(
+        seqs=np.array(seqs), kw=np.array(repr(sorted(kw.items()))),
+        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes),
+        seq_distances=job.seq_distances if job.seq_distances is not None else np.zeros(0, np.float32),
+        tasks=job.tasks, subm=job.subm,
+        scal=np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32),
+        biotype=np.int32(job.biotype),
+        paths=paths[:used], gaps=np.concatenate(gaps), rows=np.array(rows),
+        dump_task=np.int32(dump_task), dump=dump[:64 * (recs[dump_task].plen + 2)],
+    )
+    for k, v in oracledrv.recs_to_dict(recs).items():
+        d["rec_" + k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "n=%d" % job.n, "alnlen=%d" % len(rows[0]))
+
+
+def pairwise_case(name, seqs, type_):
+    job = refdrv.RefJob(seqs, type_=type_)
+    n = job.n
+    ia, ib = np.meshgrid(np.arange(n), np.arange(min(n, 4)), indexing="ij")
+    keep = ia.ravel() != ib.ravel()
+    ia, ib = ia.ravel()[keep].astype(np.int32), ib.ravel()[keep].astype(np.int32)
+    paths, _ = refdrv.pairwise_batch(job.codes, ia, ib, job.subm, float(job.gpo), float(job.gpe), float(job.tgpe))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        lens=job.lens, codes=np.concatenate(job.codes), ia=ia, ib=ib, subm=job.subm,
+                        scal=np.array([job.gpo, job.gpe, job.tgpe], np.float32),
+                        paths=np.concatenate(paths), plen=np.array([p[0] for p in paths], np.int32))
+    print(name, "pairs=%d" % len(ia))
+
+
+def param_tables():
+    out = {}
+    for biotype, types in ((0, (3, 4, 5, 6, 8)), (1, (0, 1, 2, 8))):
+        for t in types:
+            subm, scal = refdrv.param_table(biotype, t)
+            out["subm_%d_%d" % (biotype, t)] = subm
+            out["scal_%d_%d" % (biotype, t)] = scal
+    np.savez_compressed(os.path.join(HERE, "param_tables.npz"), **out)
+    print("param_tables", sorted(out))
+
+
+def main():
+    data = os.path.join(HERE, "data")
+    for f in ("BB11001", "BB12006", "BB30014"):
+        tree_case("tree_" + f, synth.read_fasta(os.path.join(data, f + ".tfa"))[1])
+    tree_case("tree_prot32x200", synth.family(32, 200, seed=1))
+    tree_case("tree_dna16x300", synth.family(16, 300, dna=True, seed=1), type_=0)
+    tree_case("tree_rna16x300", synth.family(16, 300, dna=True, seed=2))
+    tree_case("tree_prot24_scaled", synth.family(24, 120, seed=5), dist_scale=0.5, use_seq_weights=1.0)
+    tree_case("tree_prot64_gon", synth.family(64, 150, seed=7), type_=4)
+    tree_case("tree_ragged", ["ACDEFGHIKL", "A", "ACDEFGHIKLMNPQRSTVWYACDEFGHIKLMNPQRSTVWY", "MKV", "ACDKL", "WYACDEFG"])
+    # the 4-sequence DNA case of the reference's own library test (tests/kalign_lib_test.c:33-46 shape)
+    tree_case("tree_dna4", ["GAGGTCCATCAAGTTGCGAGCGGGGCGTTTCTG", "GAGGTCATCAAGTTGCAGCGAGGGGCGTTTCTGA",
+                            "GAGGTCCATCAAGTTGCGAGCGGGGCGTTCTG", "GAGGTCCATCAGTTGCGAGCGGGGCGTTTCTGAAAA"])
+    pairwise_case("pairs_prot12x90", synth.family(12, 90, seed=11), -1)
+    pairwise_case("pairs_dna8x200", synth.family(8, 200, dna=True, seed=12), 0)
+    param_tables()
+
+
+if __name__ == "__main__":
+    if not refdrv.available():
+        sys.exit("oracle/_ref/libkalign_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
+    main()
