@@ -1,0 +1,120 @@
+/*
+ * kalign_amd.h -- C ABI of the MI355X (gfx950) implementation of Kalign's
+ * progressive-alignment hot path: the batched seq-seq / seq-profile /
+ * profile-profile affine-gap Gotoh DP under a linear-space Hirschberg
+ * recursion, and the guide-tree task dispatcher that feeds it.
+ *
+ * The seam this replaces in the reference (TimoLassmann/kalign v3.5.1) is
+ * link-time and in-process:
+ *
+ *   ka_msa_tree()        <->  create_msa_tree(struct msa*, struct aln_param*, struct aln_tasks*)
+ *                              lib/src/aln_run.c:43-78, with do_align :213-441 per task
+ *   ka_pairwise_batch()  <->  the N x K loop over pairwise_align_map() -> aln_runner()
+ *                              lib/src/anchor_consistency.c:19-120, :246-267
+ *   ka_tree_upload/run/download: the same dispatcher split so that a caller can
+ *                              keep inputs resident in HBM (bench.py times ka_tree_run only)
+ *
+ * All pointers are plain host pointers unless a name says "dev".  Return
+ * value 0 = OK, non-zero = FAIL (the reference's convention, tldevel.h:29-45);
+ * ka_last_error() gives a message.  INTEGRATION.md shows the exact glue a
+ * Kalign maintainer adds in aln_run.c / anchor_consistency.c.
+ *
+ * Sequence encoding is the reference's internal alphabet (alphabet.c:179-245):
+ * protein 0..22, nucleotide 0..4.  Profiles use the reference's 64-float record
+ * layout (aln_setup.c:40-99).  Paths are the reference's coded paths
+ * (add_gap_info_to_path_n, aln_setup.c:121-228): p[0] = alignment length,
+ * p[1..len] ops (0 match, 1 gap in a, 2 gap in b, |32 terminal run), p[len+1] = 3.
+ */
+#ifndef KALIGN_AMD_H
+#define KALIGN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KA_OK 0
+#define KA_FAIL 1
+#define KA_ERR_PATHS_CAP 2      /* caller's paths_out too small; required size in ka_tree_paths_size() */
+
+/* flags for ka_msa_tree / ka_tree_upload */
+#define KA_FLAG_DEBUG_ROWS 1    /* also keep each task's top-level f/b rows (tests: row hashes) */
+
+typedef struct ka_ctx ka_ctx;
+
+/* Per-task result; field-for-field what do_align leaves behind plus the top-level
+   Hirschberg meetup (aln_controller.c:21-120).  Same layout as the oracle's ko_task_rec. */
+typedef struct ka_task_rec {
+        int a, b, c;            /* task (a, b) -> c, struct task (task.h:14-22) */
+        int len_a, len_b;       /* operand lengths in (a, b) order */
+        int nsip_a, nsip_b;     /* member counts, msa->nsip[] */
+        int plen;               /* alignment length, msa->plen[c] */
+        int kind;               /* 0 seq-seq, 1 seq-profile, 2 profile-profile */
+        int swapped;            /* DP ran with b as rows (aln_run.c:297-388 swap rules) */
+        int meet, transition;   /* top-level meetup column / transition code 1,2,3,5,6,7 */
+        int path_off;           /* offset of this task's coded path in paths_out */
+        float gap_scale;        /* compute_gap_scale (aln_run.c:126-164) */
+        float subm_off;         /* compute_subm_offset (aln_run.c:166-203) */
+        float score;            /* top-level meetup score (== m->score of ALN_MODE_SCORE_ONLY) */
+        float confidence;       /* mean Hirschberg margin, task.confidence (aln_run.c:391-395) */
+        uint64_t prof_hash;     /* FNV-1a of the merged profile bytes, 0 for the root / when not requested */
+        uint64_t fhash, bhash;  /* FNV-1a of top-level f / b rows (KA_FLAG_DEBUG_ROWS), else 0 */
+} ka_task_rec;
+
+int  ka_ctx_create(int device, ka_ctx** out);
+void ka_ctx_destroy(ka_ctx* ctx);
+/* Launch on the caller's HIP stream (a hipStream_t, e.g. torch's current stream). NULL = default stream. */
+int  ka_ctx_set_stream(ka_ctx* ctx, void* hip_stream);
+const char* ka_last_error(void);
+/* number of exported entry points, for the "library loads" test */
+int  ka_abi_version(void);
+
+/*
+ * The dispatcher.  numseq sequences (concatenated codes, off[i], lens[i]),
+ * n_tasks = numseq-1 tasks in TASK_ORDER_TREE order (children before parents,
+ * root last; task.c:114-136) as abc[3*t + {0,1,2}].
+ * subm: 23*23 floats; scal[6] = gpo, gpe, tgpe, dist_scale, vsm_amax, use_seq_weights
+ * (struct aln_param, aln_param.h:19-34, after the sentinel resolution of aln_param_init).
+ * seq_distances: numseq floats or NULL (msa->seq_distances).
+ * Outputs: recs[n_tasks]; coded paths packed into paths_out (capacity paths_cap ints);
+ * gaps_out: concatenated gaps[len+1] per sequence (msa->sequences[i]->gaps after make_seq,
+ * weave_alignment.c:41-112) or NULL.
+ */
+int ka_msa_tree(ka_ctx* ctx, int numseq, const uint8_t* codes, const int* off, const int* lens,
+                const float* seq_distances, int n_tasks, const int* tasks_abc,
+                const float* subm, const float* scal, int flags,
+                ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
+
+/* The same, staged: upload (H2D + host-side task preparation), run (device only; may be
+   called repeatedly -- it resets the device state first), download (D2H + gap weaving). */
+int ka_tree_upload(ka_ctx* ctx, int numseq, const uint8_t* codes, const int* off, const int* lens,
+                   const float* seq_distances, int n_tasks, const int* tasks_abc,
+                   const float* subm, const float* scal, int flags);
+int ka_tree_run(ka_ctx* ctx);
+int ka_tree_sync(ka_ctx* ctx);
+long long ka_tree_paths_size(ka_ctx* ctx);      /* ints needed for paths_out (valid after run+sync) */
+int ka_tree_download(ka_ctx* ctx, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
+/* Merged profile of node `node` ((plen+2)*64 floats) after a run; for tests. */
+int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats);
+/* Work done by the last run: sum over tasks of len_a*len_b ("useful cells") */
+double ka_tree_cells(ka_ctx* ctx);
+/* Milliseconds spent in the DP kernels of the last ka_tree_run, measured with HIP events
+   on the launch stream; n_launches receives the number of kernel launches. */
+int ka_tree_kernel_ms(ka_ctx* ctx, float* ms, int* n_launches);
+
+/*
+ * npairs independent seq-seq alignments (pair k = sequences ia[k], ib[k]) with unscaled
+ * parameters, rows = the shorter sequence with `len_i <= len_j` deciding the swap
+ * (anchor_consistency.c:44-61).  paths_out receives the coded path of pair k at poff[k]
+ * (room for lens[ia]+lens[ib]+3 ints each); scores_out (optional) the top-level score.
+ */
+int ka_pairwise_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                      const int* ia, const int* ib, int npairs,
+                      const float* subm, float gpo, float gpe, float tgpe,
+                      int* paths_out, const long long* poff, float* scores_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,203 @@
+"""ctypes binding of include/kalign_amd.h (host mirror of the reference's dispatcher seam).
+
+Function names follow the reference: msa_tree() stands where create_msa_tree()
+(lib/src/aln_run.c:43) is called, pairwise_batch() where anchor_consistency_build loops over
+pairwise_align_map() (lib/src/anchor_consistency.c:246-267).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+FLAG_DEBUG_ROWS = 1
+
+
+class KalignAmdError(RuntimeError):
+    pass
+
+
+class TaskRec(C.Structure):
+    """ka_task_rec (include/kalign_amd.h)"""
+    _fields_ = [
+        ("a", C.c_int), ("b", C.c_int), ("c", C.c_int),
+        ("len_a", C.c_int), ("len_b", C.c_int),
+        ("nsip_a", C.c_int), ("nsip_b", C.c_int),
+        ("plen", C.c_int), ("kind", C.c_int), ("swapped", C.c_int),
+        ("meet", C.c_int), ("transition", C.c_int), ("path_off", C.c_int),
+        ("gap_scale", C.c_float), ("subm_off", C.c_float),
+        ("score", C.c_float), ("confidence", C.c_float),
+        ("prof_hash", C.c_uint64), ("fhash", C.c_uint64), ("bhash", C.c_uint64),
+    ]
+
+
+EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_error", "ka_abi_version",
+           "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
+           "ka_tree_download", "ka_tree_get_profile", "ka_tree_cells", "ka_tree_kernel_ms",
+           "ka_pairwise_batch"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libkalign_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise KalignAmdError("%s not built: run `make -C kalign_amd/csrc` or __graft_entry__.build()" % p)
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.ka_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ka_ctx_destroy.argtypes = [vp]
+    L.ka_ctx_destroy.restype = None
+    L.ka_ctx_set_stream.argtypes = [vp, vp]
+    L.ka_last_error.restype = C.c_char_p
+    L.ka_abi_version.restype = C.c_int
+    L.ka_msa_tree.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                              C.POINTER(TaskRec), vp, C.c_longlong, vp]
+    L.ka_tree_upload.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int]
+    L.ka_tree_run.argtypes = [vp]
+    L.ka_tree_sync.argtypes = [vp]
+    L.ka_tree_paths_size.argtypes = [vp]
+    L.ka_tree_paths_size.restype = C.c_longlong
+    L.ka_tree_download.argtypes = [vp, C.POINTER(TaskRec), vp, C.c_longlong, vp]
+    L.ka_tree_get_profile.argtypes = [vp, C.c_int, vp, C.c_longlong]
+    L.ka_tree_cells.argtypes = [vp]
+    L.ka_tree_cells.restype = C.c_double
+    L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
+                                    C.c_float, C.c_float, C.c_float, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _flatten(codes):
+    lens = np.array([len(c) for c in codes], np.int32)
+    off = np.zeros(len(codes), np.int32)
+    off[1:] = np.cumsum(lens)[:-1]
+    flat = np.ascontiguousarray(np.concatenate(codes), np.uint8)
+    return flat, off, lens
+
+
+class Context:
+    """One GPU context (ka_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        if self.L.ka_ctx_create(device, C.byref(h)):
+            raise KalignAmdError(self.L.ka_last_error().decode())
+        self.h = h
+        if stream is not None:
+            self.L.ka_ctx_set_stream(self.h, C.c_void_p(stream))
+        self._job = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ka_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise KalignAmdError("rc=%d: %s" % (rc, self.L.ka_last_error().decode()))
+
+    # ---- staged dispatcher -------------------------------------------------------------
+    def tree_upload(self, codes, tasks, subm, scal, seq_distances=None, flags=0):
+        flat, off, lens = _flatten(codes)
+        tasks = np.ascontiguousarray(tasks, np.int32)
+        sd = None if seq_distances is None else np.ascontiguousarray(seq_distances, np.float32)
+        sub = np.ascontiguousarray(subm, np.float32).reshape(-1)
+        sc = np.ascontiguousarray(scal, np.float32)
+        self._chk(self.L.ka_tree_upload(self.h, len(codes), _ptr(flat), _ptr(off), _ptr(lens), _ptr(sd),
+                                        len(tasks), _ptr(tasks), _ptr(sub), _ptr(sc), flags))
+        self._job = dict(lens=lens, ntasks=len(tasks), n=len(codes))
+
+    def tree_run(self):
+        self._chk(self.L.ka_tree_run(self.h))
+
+    def tree_sync(self):
+        self._chk(self.L.ka_tree_sync(self.h))
+
+    def tree_kernel_ms(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        self._chk(self.L.ka_tree_kernel_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def tree_cells(self):
+        return self.L.ka_tree_cells(self.h)
+
+    def tree_download(self, want_gaps=True):
+        j = self._job
+        self.tree_sync()
+        cap = self.L.ka_tree_paths_size(self.h)
+        recs = (TaskRec * j["ntasks"])()
+        paths = np.zeros(max(int(cap), 1), np.int32)
+        gaps = np.zeros(int(j["lens"].sum()) + j["n"], np.int32) if want_gaps else None
+        self._chk(self.L.ka_tree_download(self.h, recs, _ptr(paths), cap, _ptr(gaps)))
+        g = None
+        if want_gaps:
+            g, o = [], 0
+            for n in j["lens"]:
+                g.append(gaps[o:o + int(n) + 1].copy())
+                o += int(n) + 1
+        return recs, paths, g
+
+    def tree_profile(self, node, max_cols):
+        out = np.zeros(64 * (max_cols + 2), np.float32)
+        self._chk(self.L.ka_tree_get_profile(self.h, node, _ptr(out), out.size))
+        return out
+
+    # ---- one-shot -----------------------------------------------------------------------
+    def msa_tree(self, codes, tasks, subm, scal, seq_distances=None, flags=0):
+        self.tree_upload(codes, tasks, subm, scal, seq_distances, flags)
+        self.tree_run()
+        return self.tree_download()
+
+    def pairwise_batch(self, codes, ia, ib, subm, gpo, gpe, tgpe):
+        flat, off, lens = _flatten(codes)
+        ia = np.ascontiguousarray(ia, np.int32)
+        ib = np.ascontiguousarray(ib, np.int32)
+        sizes = lens[ia].astype(np.int64) + lens[ib] + 3
+        poff = np.zeros(len(ia), np.int64)
+        poff[1:] = np.cumsum(sizes)[:-1]
+        paths = np.zeros(int(sizes.sum()), np.int32)
+        scores = np.zeros(len(ia), np.float32)
+        sub = np.ascontiguousarray(subm, np.float32).reshape(-1)
+        self._chk(self.L.ka_pairwise_batch(self.h, _ptr(flat), _ptr(off), _ptr(lens), len(codes),
+                                           _ptr(ia), _ptr(ib), len(ia), _ptr(sub),
+                                           float(gpo), float(gpe), float(tgpe), _ptr(paths), _ptr(poff), _ptr(scores)))
+        return [paths[poff[k]:poff[k] + paths[poff[k]] + 2].copy() for k in range(len(ia))], scores
+
+
+def msa_tree(codes, tasks, subm, scal, seq_distances=None, flags=0, device=0):
+    ctx = Context(device)
+    try:
+        return ctx.msa_tree(codes, tasks, subm, scal, seq_distances, flags)
+    finally:
+        ctx.close()
+
+
+def pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe, device=0):
+    ctx = Context(device)
+    try:
+        return ctx.pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe)
+    finally:
+        ctx.close()

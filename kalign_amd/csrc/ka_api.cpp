@@ -1,0 +1,510 @@
+// ka_api.cpp -- host side of the C ABI (include/kalign_amd.h): the guide-tree level scheduler
+// that replaces create_msa_tree / recursive_aln (aln_run.c:43-124) and the gap weaving that
+// follows each task (weave_alignment.c:41-112).
+//
+// The reference walks the guide tree post-order with OpenMP tasks, one do_align per node.
+// Here the tree is cut into dependency levels on the host (level(c) = 1 + max(level(a),
+// level(b))); every level is ONE kernel launch with one workgroup per task, and profiles,
+// paths and all per-task state stay in HBM between levels.  Only the coded paths and the
+// per-task records come back to the host, once, at the end.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ka_device.h"
+
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int* task_ids_dev, int ntasks, hipStream_t stream);
+extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
+extern "C" long long ka_scratch_bytes_host(long long la, long long lb);
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return KA_FAIL; }
+
+#define HIPCHK(x)                                                                         \
+        do {                                                                              \
+                hipError_t e_ = (x);                                                      \
+                if (e_ != hipSuccess) {                                                   \
+                        return fail(std::string(#x) + ": " + hipGetErrorString(e_));      \
+                }                                                                         \
+        } while (0)
+
+template <typename T>
+struct DevBuf {
+        T* p = nullptr;
+        size_t n = 0;
+        int alloc(size_t count)
+        {
+                if (count <= n && p) return 0;
+                release();
+                if (hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { p = nullptr; n = 0; return 1; }
+                n = count;
+                return 0;
+        }
+        void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct ka_ctx {
+        int device = 0;
+        hipStream_t stream = nullptr;
+        // ---- tree job ----
+        bool have_job = false;
+        int numseq = 0, n_tasks = 0, flags = 0;
+        std::vector<int> lens, off;
+        std::vector<int> abc;
+        std::vector<KaTaskDesc> descs;
+        std::vector<std::vector<int>> levels;        // task ids per dependency level
+        std::vector<int> level_ids_flat, level_off;
+        std::vector<long long> leaf_prof_off;
+        long long leaf_prof_total = 0;
+        long long sum_len = 0;
+        int max_len = 0;
+        float subm[23 * 23];
+        float scal[6];
+        DevBuf<uint8_t> d_codes;
+        DevBuf<int> d_seq_off, d_node_len, d_level_ids, d_path_arena, d_error;
+        DevBuf<long long> d_node_prof, d_dbg_off;
+        DevBuf<float> d_prof_arena, d_subm, d_dbg_arena;
+        DevBuf<unsigned long long> d_counters;
+        DevBuf<char> d_scratch;
+        DevBuf<KaTaskDesc> d_tasks;
+        DevBuf<ka_task_rec> d_recs;
+        long long prof_cap = 0, path_cap = 0, scratch_cap = 0, dbg_cap = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool ran = false, synced = false;
+        int n_launches = 0;
+        double cells = 0.0;
+        std::vector<ka_task_rec> h_recs;
+        unsigned long long h_counters[4] = {0, 0, 0, 0};
+};
+
+extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
+extern "C" int ka_abi_version(void) { return 1; }
+
+extern "C" int ka_ctx_create(int device, ka_ctx** out)
+{
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("no HIP device visible (the HIP path has no CPU fallback)");
+        if (device < 0 || device >= n) return fail("bad device index");
+        HIPCHK(hipSetDevice(device));
+        ka_ctx* c = new ka_ctx();
+        c->device = device;
+        HIPCHK(hipEventCreate(&c->ev0));
+        HIPCHK(hipEventCreate(&c->ev1));
+        *out = c;
+        return KA_OK;
+}
+
+extern "C" void ka_ctx_destroy(ka_ctx* c)
+{
+        if (!c) return;
+        (void)hipSetDevice(c->device);
+        c->d_codes.release(); c->d_seq_off.release(); c->d_node_len.release(); c->d_level_ids.release();
+        c->d_path_arena.release(); c->d_error.release(); c->d_node_prof.release(); c->d_dbg_off.release();
+        c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
+        c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release();
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        delete c;
+}
+
+extern "C" int ka_ctx_set_stream(ka_ctx* c, void* s)
+{
+        if (!c) return fail("null ctx");
+        c->stream = (hipStream_t)s;
+        return KA_OK;
+}
+
+// mean seq_distance over both clusters in sip order (aln_run.c:126-203)
+static float mean_distance(const float* dist, const std::vector<int>& ma, const std::vector<int>& mb, int numseq, int* count)
+{
+        float sum = 0.0f;
+        int n = 0;
+        for (int x : ma) if (x < numseq) { sum += dist[x]; n++; }
+        for (int x : mb) if (x < numseq) { sum += dist[x]; n++; }
+        *count = n;
+        return n ? sum / (float)n : 0.0f;
+}
+
+extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const int* off, const int* lens,
+                              const float* seq_distances, int n_tasks, const int* abc,
+                              const float* subm, const float* scal, int flags)
+{
+        if (!c) return fail("null ctx");
+        if (numseq < 2 || n_tasks != numseq - 1) return fail("need numseq >= 2 and n_tasks == numseq-1");
+        HIPCHK(hipSetDevice(c->device));
+        const int nprof = 2 * numseq - 1;
+        c->have_job = false; c->ran = false; c->synced = false;
+        c->numseq = numseq; c->n_tasks = n_tasks; c->flags = flags;
+        c->lens.assign(lens, lens + numseq);
+        c->off.assign(off, off + numseq);
+        c->abc.assign(abc, abc + 3 * n_tasks);
+        memcpy(c->subm, subm, sizeof(c->subm));
+        memcpy(c->scal, scal, sizeof(c->scal));
+        c->sum_len = 0; c->max_len = 0;
+        long long codes_bytes = 0;
+        for (int i = 0; i < numseq; i++) {
+                if (lens[i] < 1) return fail("zero-length sequence (the reference removes them before the dispatcher, msa_check.c:66)");
+                c->sum_len += lens[i];
+                c->max_len = std::max(c->max_len, lens[i]);
+                codes_bytes = std::max<long long>(codes_bytes, (long long)off[i] + lens[i]);
+        }
+
+        // ---- host-side task preparation: nsip, sip order, gap_scale / subm_offset, levels ----
+        std::vector<int> nsip(nprof, 0), level(nprof, 0);
+        std::vector<std::vector<int>> sip(nprof);
+        std::vector<char> made(nprof, 0);
+        for (int i = 0; i < numseq; i++) { nsip[i] = 1; sip[i] = {i}; made[i] = 1; }
+        c->descs.assign(n_tasks, KaTaskDesc());
+        const float gpo0 = scal[0], gpe0 = scal[1], tgpe0 = scal[2], dist_scale = scal[3], vsm_amax = scal[4];
+        int max_level = 0;
+        for (int t = 0; t < n_tasks; t++) {
+                const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                if (a < 0 || b < 0 || cc < numseq || a >= nprof || b >= nprof || cc >= nprof || !made[a] || !made[b] || made[cc])
+                        return fail("task list is not in TASK_ORDER_TREE order (children before parents)");
+                KaTaskDesc& d = c->descs[t];
+                float gap_scale = 1.0f, soff = 0.0f;
+                int cnt = 0;
+                if (dist_scale > 0.0f && seq_distances) {
+                        const float avg = mean_distance(seq_distances, sip[a], sip[b], numseq, &cnt);
+                        if (cnt) {
+                                gap_scale = 1.0f - dist_scale * avg;
+                                if (gap_scale < 0.3f) gap_scale = 0.3f;
+                                if (gap_scale > 1.0f) gap_scale = 1.0f;
+                        }
+                }
+                if (vsm_amax > 0.0f && seq_distances) {
+                        const float avg = mean_distance(seq_distances, sip[a], sip[b], numseq, &cnt);
+                        if (cnt) {
+                                soff = vsm_amax - avg;
+                                if (soff < 0.0f) soff = 0.0f;
+                        }
+                }
+                d.a = a; d.b = b; d.c = cc;
+                d.nsip_a = nsip[a]; d.nsip_b = nsip[b];
+                d.is_root = (t == n_tasks - 1);
+                d.gpo = gpo0; d.gpe = gpe0; d.tgpe = tgpe0;
+                if (gap_scale < 1.0f || soff > 0.0f) { d.gpo *= gap_scale; d.gpe *= gap_scale; d.tgpe *= gap_scale; }
+                else soff = 0.0f;
+                d.soff = soff; d.gap_scale = gap_scale; d.pad = 0;
+                nsip[cc] = nsip[a] + nsip[b];
+                sip[cc].reserve(nsip[cc]);
+                for (int j = nsip[a]; j--;) sip[cc].push_back(sip[a][j]);        // aln_run.c:428-436
+                for (int j = nsip[b]; j--;) sip[cc].push_back(sip[b][j]);
+                std::vector<int>().swap(sip[a]);
+                std::vector<int>().swap(sip[b]);
+                made[cc] = 1;
+                level[cc] = 1 + std::max(level[a], level[b]);
+                max_level = std::max(max_level, level[cc]);
+        }
+        c->levels.assign(max_level, std::vector<int>());
+        for (int t = 0; t < n_tasks; t++) c->levels[level[abc[3 * t + 2]] - 1].push_back(t);
+        c->level_ids_flat.clear(); c->level_off.assign(1, 0);
+        for (auto& L : c->levels) {
+                c->level_ids_flat.insert(c->level_ids_flat.end(), L.begin(), L.end());
+                c->level_off.push_back((int)c->level_ids_flat.size());
+        }
+
+        // ---- arenas ----
+        c->leaf_prof_off.assign(numseq, 0);
+        long long top = 0;
+        for (int i = 0; i < numseq; i++) { c->leaf_prof_off[i] = top; top += (long long)(lens[i] + 2) * KA_REC; }
+        c->leaf_prof_total = top;
+        // merged profiles: alignment lengths are only known on the device; start with a generous
+        // estimate and let ka_tree_sync grow + re-run on overflow.
+        const long long worst_cols = c->sum_len * (long long)std::max(1, max_level) + 2LL * n_tasks;
+        const long long est_cols = 3LL * (long long)n_tasks * (c->max_len + 2) + 1024;
+        const long long cols = std::min(worst_cols, est_cols);
+        c->prof_cap = std::max(c->prof_cap, top + cols * KA_REC);
+        c->path_cap = std::max(c->path_cap, cols + c->sum_len + 2LL * numseq + 1024);
+        long long scr = 0;
+        // per level every sequence is a member of at most one task; profile lengths never exceed
+        // the sum of their members' lengths
+        scr = ka_scratch_bytes_host(c->sum_len, c->sum_len) / 2 + (long long)numseq * 2048 + 65536;
+        c->scratch_cap = std::max(c->scratch_cap, scr);
+        c->dbg_cap = (flags & KA_FLAG_DEBUG_ROWS) ? std::max<long long>(c->dbg_cap, 6LL * (cols + 2LL * n_tasks + c->sum_len)) : c->dbg_cap;
+
+        if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
+            c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
+            c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
+            c->d_counters.alloc(4) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
+            c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
+            c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
+                return fail("hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(c->d_codes.p, codes, (size_t)codes_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_seq_off.p, off, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_level_ids.p, c->level_ids_flat.data(), sizeof(int) * c->level_ids_flat.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_tasks.p, c->descs.data(), sizeof(KaTaskDesc) * n_tasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_subm.p, subm, sizeof(float) * 23 * 23, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->have_job = true;
+        return KA_OK;
+}
+
+static int tree_launch(ka_ctx* c)
+{
+        const int numseq = c->numseq, nprof = 2 * numseq - 1;
+        // reset the device state so that run() is repeatable
+        std::vector<int> node_len(nprof, 0);
+        std::vector<long long> node_prof(nprof, -1);
+        for (int i = 0; i < numseq; i++) { node_len[i] = c->lens[i]; node_prof[i] = c->leaf_prof_off[i]; }
+        unsigned long long counters[4] = { (unsigned long long)c->leaf_prof_total, 0, 0, 0 };
+        int zero = 0;
+        HIPCHK(hipMemcpyAsync(c->d_node_len.p, node_len.data(), sizeof(int) * nprof, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_node_prof.p, node_prof.data(), sizeof(long long) * nprof, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_counters.p, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_error.p, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));          // the staging vectors above are stack/heap temporaries
+
+        KaTreeDev D;
+        D.codes = c->d_codes.p; D.seq_off = c->d_seq_off.p;
+        D.node_len = c->d_node_len.p; D.node_prof = c->d_node_prof.p;
+        D.prof_arena = c->d_prof_arena.p; D.counters = c->d_counters.p;
+        D.prof_cap = c->prof_cap; D.scratch_cap = c->scratch_cap; D.path_cap = c->path_cap; D.dbg_cap = c->dbg_cap;
+        D.scratch = c->d_scratch.p; D.path_arena = c->d_path_arena.p;
+        D.dbg_arena = c->d_dbg_arena.p; D.dbg_off = c->d_dbg_off.p;
+        D.tasks = c->d_tasks.p; D.recs = c->d_recs.p; D.subm = c->d_subm.p;
+        D.gpo0 = c->scal[0]; D.gpe0 = c->scal[1]; D.tgpe0 = c->scal[2]; D.usw = c->scal[5];
+        D.numseq = numseq; D.flags = c->flags; D.error = c->d_error.p;
+
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        c->n_launches = 0;
+        for (size_t L = 0; L < c->levels.size(); L++) {
+                const int n = (int)c->levels[L].size();
+                if (!n) continue;
+                if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                ka_launch_task_level(&D, c->d_level_ids.p + c->level_off[L], n, c->stream);
+                c->n_launches++;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        return KA_OK;
+}
+
+extern "C" int ka_tree_run(ka_ctx* c)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        HIPCHK(hipSetDevice(c->device));
+        c->ran = false; c->synced = false;
+        if (tree_launch(c)) return KA_FAIL;
+        c->ran = true;
+        return KA_OK;
+}
+
+extern "C" int ka_tree_sync(ka_ctx* c)
+{
+        if (!c || !c->ran) return fail("nothing running");
+        HIPCHK(hipSetDevice(c->device));
+        for (int attempt = 0; attempt < 6; attempt++) {
+                int err = 0;
+                HIPCHK(hipStreamSynchronize(c->stream));
+                HIPCHK(hipMemcpy(&err, c->d_error.p, sizeof(int), hipMemcpyDeviceToHost));
+                if (!err) {
+                        HIPCHK(hipMemcpy(c->h_counters, c->d_counters.p, sizeof(c->h_counters), hipMemcpyDeviceToHost));
+                        c->synced = true;
+                        return KA_OK;
+                }
+                // an arena overflowed: grow it and run again (results are only trusted from a clean run)
+                if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
+                else if (err == 2) { c->scratch_cap *= 2; c->d_scratch.release(); }
+                else if (err == 3) { c->path_cap *= 2; c->d_path_arena.release(); }
+                else { c->dbg_cap *= 2; c->d_dbg_arena.release(); }
+                if (c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
+                    c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
+                        return fail("hipMalloc failed while growing an arena");
+                if (tree_launch(c)) return KA_FAIL;
+        }
+        return fail("device arenas kept overflowing");
+}
+
+extern "C" long long ka_tree_paths_size(ka_ctx* c)
+{
+        if (!c || !c->synced) return -1;
+        return (long long)c->h_counters[2];
+}
+
+// make_seq + update_gaps (weave_alignment.c:41-112): fold one task's gap columns into the
+// gaps[] arrays of every member sequence.
+static void fold_gaps(int len, int* gis, const int* newgaps)
+{
+        int rel = 0;
+        for (int i = 0; i <= len; i++) {
+                int add = 0;
+                for (int j = rel; j <= rel + gis[i]; j++) add += newgaps[j];
+                rel += gis[i] + 1;
+                gis[i] += add;
+        }
+}
+
+extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
+{
+        if (!c || !c->ran) return fail("nothing to download");
+        if (!c->synced && ka_tree_sync(c)) return KA_FAIL;
+        HIPCHK(hipSetDevice(c->device));
+        const long long used = (long long)c->h_counters[2];
+        if (used > paths_cap) { g_err = "paths_out too small"; return KA_ERR_PATHS_CAP; }
+        c->h_recs.resize(c->n_tasks);
+        HIPCHK(hipMemcpy(c->h_recs.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
+        std::vector<int> arena((size_t)used);
+        HIPCHK(hipMemcpy(arena.data(), c->d_path_arena.p, sizeof(int) * (size_t)used, hipMemcpyDeviceToHost));
+        // repack the paths in task order (arena order depends on workgroup scheduling)
+        long long o = 0;
+        double cells = 0.0;
+        for (int t = 0; t < c->n_tasks; t++) {
+                ka_task_rec& r = c->h_recs[t];
+                const int n = r.plen + 2;
+                memcpy(paths_out + o, arena.data() + r.path_off, sizeof(int) * n);
+                r.path_off = (int)o;
+                o += n;
+                cells += (double)r.len_a * (double)r.len_b;
+        }
+        c->cells = cells;
+        if (c->flags & KA_FLAG_DEBUG_ROWS) {
+                // FNV-1a of the top-level rows, to compare with the reference harness
+                std::vector<long long> dbg_off(c->n_tasks);
+                HIPCHK(hipMemcpy(dbg_off.data(), c->d_dbg_off.p, sizeof(long long) * c->n_tasks, hipMemcpyDeviceToHost));
+                std::vector<float> rows;
+                for (int t = 0; t < c->n_tasks; t++) {
+                        ka_task_rec& r = c->h_recs[t];
+                        const int lb = r.swapped ? r.len_a : r.len_b;
+                        const size_t n = 3 * (size_t)(lb + 1);
+                        if (dbg_off[t] < 0) continue;
+                        rows.resize(2 * n);
+                        HIPCHK(hipMemcpy(rows.data(), c->d_dbg_arena.p + dbg_off[t], sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+                        auto fnv = [](const void* p, size_t bytes) {
+                                const unsigned char* b = (const unsigned char*)p;
+                                uint64_t h = 1469598103934665603ULL;
+                                for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+                                return h;
+                        };
+                        r.fhash = fnv(rows.data(), sizeof(float) * n);
+                        r.bhash = fnv(rows.data() + n, sizeof(float) * n);
+                }
+        }
+        if (recs) memcpy(recs, c->h_recs.data(), sizeof(ka_task_rec) * c->n_tasks);
+
+        if (gaps_out) {
+                const int numseq = c->numseq, nprof = 2 * numseq - 1;
+                std::vector<int> goff(numseq);
+                long long g = 0;
+                for (int i = 0; i < numseq; i++) { goff[i] = (int)g; g += c->lens[i] + 1; }
+                memset(gaps_out, 0, sizeof(int) * (size_t)g);
+                std::vector<std::vector<int>> sip(nprof);
+                for (int i = 0; i < numseq; i++) sip[i] = {i};
+                std::vector<int> ga, gb;
+                for (int t = 0; t < c->n_tasks; t++) {
+                        const ka_task_rec& r = c->h_recs[t];
+                        const int* p = paths_out + r.path_off;
+                        ga.assign(p[0] + 1, 0); gb.assign(p[0] + 1, 0);
+                        int posa = 0, posb = 0;
+                        for (int k = 1; p[k] != 3; k++) {
+                                if (!p[k]) { posa++; posb++; }
+                                else if (p[k] & 1) { ga[posa] += 1; posb++; }
+                                else if (p[k] & 2) { gb[posb] += 1; posa++; }
+                        }
+                        for (int x : sip[r.a]) fold_gaps(c->lens[x], gaps_out + goff[x], ga.data());
+                        for (int x : sip[r.b]) fold_gaps(c->lens[x], gaps_out + goff[x], gb.data());
+                        sip[r.c].reserve(sip[r.a].size() + sip[r.b].size());
+                        sip[r.c].insert(sip[r.c].end(), sip[r.a].begin(), sip[r.a].end());
+                        sip[r.c].insert(sip[r.c].end(), sip[r.b].begin(), sip[r.b].end());
+                        std::vector<int>().swap(sip[r.a]);
+                        std::vector<int>().swap(sip[r.b]);
+                }
+        }
+        return KA_OK;
+}
+
+extern "C" int ka_tree_get_profile(ka_ctx* c, int node, float* out, long long cap_floats)
+{
+        if (!c || !c->synced) return fail("run + sync first");
+        HIPCHK(hipSetDevice(c->device));
+        const int nprof = 2 * c->numseq - 1;
+        if (node < 0 || node >= nprof) return fail("bad node");
+        int len = 0;
+        long long po = -1;
+        HIPCHK(hipMemcpy(&len, c->d_node_len.p + node, sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&po, c->d_node_prof.p + node, sizeof(long long), hipMemcpyDeviceToHost));
+        if (po < 0) return fail("node has no profile (root, or not computed)");
+        const long long n = (long long)(len + 2) * KA_REC;
+        if (n > cap_floats) return fail("profile buffer too small");
+        HIPCHK(hipMemcpy(out, c->d_prof_arena.p + po, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+        return KA_OK;
+}
+
+extern "C" double ka_tree_cells(ka_ctx* c) { return c ? c->cells : 0.0; }
+
+extern "C" int ka_tree_kernel_ms(ka_ctx* c, float* ms, int* n_launches)
+{
+        if (!c || !c->synced) return fail("run + sync first");
+        HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+        if (n_launches) *n_launches = c->n_launches;
+        return KA_OK;
+}
+
+extern "C" int ka_msa_tree(ka_ctx* c, int numseq, const uint8_t* codes, const int* off, const int* lens,
+                           const float* seq_distances, int n_tasks, const int* abc,
+                           const float* subm, const float* scal, int flags,
+                           ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
+{
+        if (ka_tree_upload(c, numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, flags)) return KA_FAIL;
+        if (ka_tree_run(c)) return KA_FAIL;
+        if (ka_tree_sync(c)) return KA_FAIL;
+        return ka_tree_download(c, recs, paths_out, paths_cap, gaps_out);
+}
+
+extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                                 const int* ia, const int* ib, int npairs,
+                                 const float* subm, float gpo, float gpe, float tgpe,
+                                 int* paths_out, const long long* poff, float* scores_out)
+{
+        if (!c) return fail("null ctx");
+        if (npairs <= 0) return KA_OK;
+        HIPCHK(hipSetDevice(c->device));
+        long long codes_bytes = 0, stride = 0, ptotal = 0;
+        for (int i = 0; i < numseq; i++) codes_bytes = std::max<long long>(codes_bytes, (long long)off[i] + lens[i]);
+        for (int k = 0; k < npairs; k++) {
+                if (ia[k] < 0 || ia[k] >= numseq || ib[k] < 0 || ib[k] >= numseq) return fail("pair index out of range");
+                const long long li = lens[ia[k]], lj = lens[ib[k]];
+                if (li < 1 || lj < 1) return fail("zero-length sequence");
+                stride = std::max(stride, ka_scratch_bytes_host(li, lj));
+                ptotal = std::max(ptotal, poff[k] + li + lj + 3);
+        }
+        stride = (stride + 255) / 256 * 256;
+        DevBuf<uint8_t> d_codes; DevBuf<int> d_off, d_len, d_ia, d_ib, d_paths; DevBuf<float> d_subm, d_scores;
+        DevBuf<long long> d_poff; DevBuf<char> d_scr;
+        int rc = KA_OK;
+        if (d_codes.alloc((size_t)codes_bytes) || d_off.alloc(numseq) || d_len.alloc(numseq) || d_ia.alloc(npairs) ||
+            d_ib.alloc(npairs) || d_paths.alloc((size_t)ptotal) || d_subm.alloc(23 * 23) || d_scores.alloc(npairs) ||
+            d_poff.alloc(npairs) || d_scr.alloc((size_t)(stride * npairs)))
+                rc = fail("hipMalloc failed");
+        auto cleanup = [&]() {
+                d_codes.release(); d_off.release(); d_len.release(); d_ia.release(); d_ib.release(); d_paths.release();
+                d_subm.release(); d_scores.release(); d_poff.release(); d_scr.release();
+        };
+        if (rc) { cleanup(); return rc; }
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+        PCHK(hipMemcpyAsync(d_codes.p, codes, (size_t)codes_bytes, hipMemcpyHostToDevice, c->stream));
+        PCHK(hipMemcpyAsync(d_off.p, off, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
+        PCHK(hipMemcpyAsync(d_len.p, lens, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
+        PCHK(hipMemcpyAsync(d_ia.p, ia, sizeof(int) * npairs, hipMemcpyHostToDevice, c->stream));
+        PCHK(hipMemcpyAsync(d_ib.p, ib, sizeof(int) * npairs, hipMemcpyHostToDevice, c->stream));
+        PCHK(hipMemcpyAsync(d_subm.p, subm, sizeof(float) * 23 * 23, hipMemcpyHostToDevice, c->stream));
+        PCHK(hipMemcpyAsync(d_poff.p, poff, sizeof(long long) * npairs, hipMemcpyHostToDevice, c->stream));
+        KaPairDev P;
+        P.codes = d_codes.p; P.seq_off = d_off.p; P.seq_len = d_len.p; P.ia = d_ia.p; P.ib = d_ib.p;
+        P.subm = d_subm.p; P.gpo = gpo; P.gpe = gpe; P.tgpe = tgpe;
+        P.scratch = d_scr.p; P.scratch_stride = stride;
+        P.paths_out = d_paths.p; P.poff = d_poff.p; P.scores = d_scores.p; P.npairs = npairs;
+        ka_launch_pairs(&P, c->stream);
+        PCHK(hipGetLastError());
+        PCHK(hipStreamSynchronize(c->stream));
+        PCHK(hipMemcpy(paths_out, d_paths.p, sizeof(int) * (size_t)ptotal, hipMemcpyDeviceToHost));
+        if (scores_out) PCHK(hipMemcpy(scores_out, d_scores.p, sizeof(float) * npairs, hipMemcpyDeviceToHost));
+#undef PCHK
+        cleanup();
+        return KA_OK;
+}

@@ -1,0 +1,69 @@
+// ka_device.h -- device-side data layout shared by the kernels and the host dispatcher.
+#pragma once
+#include <stdint.h>
+#include "kalign_amd.h"
+
+#define KA_F 3.402823466e+38f          // FLT_MAX: the reference's "minus infinity" is -FLT_MAX (aln_seqseq.c:45)
+#define KA_REC 64                      // floats per profile record (aln_setup.c:40-99)
+
+enum { KA_SS = 0, KA_SP = 1, KA_PP = 2 };
+enum { KA_FWD = 0, KA_BWD = 1 };
+
+struct KaState { float a, ga, gb; };   // struct states, aln_struct.h:9-14
+
+// One task (a, b) -> c, prepared on the host: everything do_align derives before the DP
+// (aln_run.c:213-237) that depends on the tree only.
+struct KaTaskDesc {
+        int a, b, c;
+        int nsip_a, nsip_b;
+        int is_root;
+        float gpo, gpe, tgpe;          // scaled by gap_scale when scaling applies
+        float soff;                    // subm_offset
+        float gap_scale;
+        int pad;
+};
+
+// One Hirschberg sub-problem: window + injected boundary states (aln_controller.c:194-436)
+struct KaSub {
+        int starta, enda, startb, endb;
+        KaState fin, bin;
+        int roff;                      // offset of its f/b row slices in the task's row buffers
+        int pad;
+};
+
+struct KaTreeDev {
+        const uint8_t* codes;
+        const int* seq_off;
+        int* node_len;                 // [2N-1] sequence length / profile length (msa->plen)
+        long long* node_prof;          // [2N-1] offset (floats) of the node's profile in prof_arena
+        float* prof_arena;
+        unsigned long long* counters;  // [0] prof_top, [1] scratch_top, [2] path_top, [3] dbg_top (floats)
+        long long prof_cap, scratch_cap, path_cap, dbg_cap;
+        char* scratch;
+        int* path_arena;
+        float* dbg_arena;
+        long long* dbg_off;            // [n_tasks] offset of the task's debug rows, -1 if none
+        const KaTaskDesc* tasks;
+        ka_task_rec* recs;
+        const float* subm;             // 23*23
+        float gpo0, gpe0, tgpe0, usw;  // unscaled penalties for update_n, use_seq_weights
+        int numseq;
+        int flags;
+        int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow
+};
+
+struct KaPairDev {
+        const uint8_t* codes;
+        const int* seq_off;
+        const int* seq_len;
+        const int* ia;
+        const int* ib;
+        const float* subm;
+        float gpo, gpe, tgpe;
+        char* scratch;
+        long long scratch_stride;      // bytes per pair
+        int* paths_out;
+        const long long* poff;
+        float* scores;
+        int npairs;
+};

@@ -1,0 +1,783 @@
+// ka_kernels.hip -- CDNA4 (gfx950) kernels for Kalign's progressive-alignment hot path.
+//
+// One workgroup aligns one pairwise task (a, b) -> c end to end:
+//   P1  operand preparation   make_profile_n / set_gap_penalties_n   (aln_setup.c:40-119)
+//   P2  Hirschberg recursion  aln_runner / aln_continue              (aln_controller.c:21-436)
+//         level-synchronous inside the workgroup: every wave pulls (sub-problem, direction)
+//         passes of the current recursion level, then the waves run the meetups and emit
+//         the next level's sub-problems
+//       each pass is an anti-diagonal wavefront: lane l owns DP row u0+l of a 64-row strip
+//       and walks the columns one step behind lane l-1; the three cell states move to the
+//       next lane with a DPP wave shift (v_mov_b32_dpp wave_shr:1)
+//   P3  path post-processing  mirror_path_n / add_gap_info_to_path_n (aln_setup.c:121-228,438-462)
+//   P4  profile merge         update_n                               (aln_setup.c:230-436)
+//
+// Arithmetic is IEEE binary32 in the reference's source order with NO contraction
+// (compile with -ffp-contract=off): the traceback is an argmax over float sums and must be
+// bit-identical to the CPU reference (hard part 1).
+//
+// The formulation of a pass over (u, v) = (row counter, column counter) is the same as
+// oracle/kalign_oracle.c:ko_pass; see there for the mapping to the reference's six functions.
+#include <hip/hip_runtime.h>
+#include "ka_device.h"
+
+#define KA_BLOCK 256
+#define KA_WAVES (KA_BLOCK / 64)
+
+__device__ __forceinline__ float kmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float kmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// lane l receives lane l-1's value (lane 0 keeps its own): v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ float wave_shr1(float x)
+{
+        int xi = __float_as_int(x);
+        return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x138, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float lane_bcast(float x, int src_lane)
+{
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
+}
+
+// Everything the waves of a workgroup share about the task being aligned.
+struct TaskShared {
+        int kind, swapped;
+        int len_a, len_b;              // operand lengths in (a, b) order
+        int La, Lb;                    // DP rows / columns
+        const uint8_t* s1;             // row residues (seq-seq)
+        const uint8_t* s2;             // column residues (seq-seq, seq-profile)
+        const float* p1;               // row profile
+        const float* p2;               // column profile
+        float* profa;                  // operand profiles in (a, b) order
+        float* profb;
+        const float* subm;
+        float gpo, gpe, tgpe, soff;
+        float sp_open, sp_ext, sp_text;
+        KaState* fbuf;
+        KaState* bbuf;
+        KaSub* q[2];
+        int* raw;
+        int* raw2;
+        int* coded;
+        int* srcA;
+        int* srcB;
+        int ncur, nnext, rowalloc;
+        double msum;
+        int mcount;
+        int top_meet, top_tr;
+        float top_score;
+        int alnlen;
+        float* newp;
+        int* path_dst;
+        int fail;
+};
+
+// ------------------------------------------------------------------------------------------
+// column-operand terms for column record `rec`
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void col_terms(const TaskShared& S, int rec, float& copen, float& cext, float& ctext)
+{
+        if (KIND == KA_SS) { copen = -S.gpo; cext = -S.gpe; ctext = -S.tgpe; }
+        else if (KIND == KA_SP) { copen = -S.sp_open; cext = -S.sp_ext; ctext = -S.sp_text; }
+        else {
+                const float* c = S.p2 + ((long long)rec << 6);
+                copen = c[27]; cext = c[28]; ctext = c[29];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// One Gotoh pass of one sub-problem by one wave.
+// rows: this sub-problem's slice of the task's f (FWD) or b (BWD) row buffer, indexed by
+// (s-index - startb); on return it holds the last DP row of the pass.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ void ka_pass(const TaskShared& S, const KaSub& sb, const int dir, KaState* rows, const int lane)
+{
+        const int startb = sb.startb, endb = sb.endb;
+        const int ncols = endb - startb;
+        const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
+        const int r0 = (dir == KA_FWD) ? sb.starta : mid;
+        const int r1 = (dir == KA_FWD) ? mid : sb.enda;
+        const int nrows = r1 - r0;
+        const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == S.Lb);
+        const bool far_t = (dir == KA_FWD) ? (endb == S.Lb) : (startb == 0);
+        const KaState inj = (dir == KA_FWD) ? sb.fin : sb.bin;
+
+#define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
+#define IDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
+
+        if (nrows == 0) {
+                // only the "row -1" initialisation survives (aln_seqseq.c:40-58): a serial chain
+                if (lane == 0) {
+                        KaState ini = inj;
+                        rows[IDX(0)] = ini;
+                        for (int v = 1; v < ncols; ++v) {
+                                float copen, cext, ctext;
+                                col_terms<KIND>(S, REC(v), copen, cext, ctext);
+                                const float g = near_t ? kmax(ini.ga, ini.a) + ctext : kmax(ini.ga + cext, ini.a + copen);
+                                ini.a = -KA_F; ini.ga = g; ini.gb = -KA_F;
+                                rows[IDX(v)] = ini;
+                        }
+                        ini.a = -KA_F; ini.ga = -KA_F; ini.gb = -KA_F;
+                        rows[IDX(ncols)] = ini;
+                }
+                return;
+        }
+
+        for (int u0 = 0; u0 < nrows; u0 += 64) {
+                const int nl = min(64, nrows - u0);
+                const bool first = (u0 == 0);
+                const int u = u0 + min(lane, nl - 1);                  // idle lanes shadow the last row
+                const int i = (dir == KA_FWD) ? (r0 + u) : (r1 - 1 - u);
+                const int rrec = i + 1;
+                const int rprev = (dir == KA_FWD) ? rrec - 1 : rrec + 1;
+
+                // ---- stationary (row) operand of this lane ----
+                float o_row, e_row, t_row, o_rowprev;
+                float p1v[23];
+                int res1 = 0;
+                const float* p1row = nullptr;
+                if (KIND == KA_SS) {
+                        o_row = -S.gpo; e_row = -S.gpe; t_row = -S.tgpe; o_rowprev = -S.gpo;
+                        res1 = S.s1[i];
+                } else {
+                        p1row = S.p1 + ((long long)rrec << 6);
+                        o_row = p1row[27]; e_row = p1row[28]; t_row = p1row[29];
+                        o_rowprev = S.p1[((long long)rprev << 6) + 27];
+                        if (KIND == KA_PP) {
+#pragma unroll
+                                for (int c = 0; c < 23; ++c) p1v[c] = p1row[c];
+                        }
+                }
+
+                KaState cur = { -KA_F, -KA_F, -KA_F };
+                KaState diag = cur;
+                KaState ini = inj;
+                KaState batch = cur;                                   // 64 prefetched boundary states (strips > 0)
+                float copen_prev = 0.0f;
+
+                const int nsteps = ncols + nl;                         // t = 0 .. ncols + nl - 1
+                for (int t = 0; t < nsteps; ++t) {
+                        const int v = t - lane;
+                        const bool inrange = (v >= 0) && (v <= ncols) && (lane < nl);
+                        const int vc = min(max(v, 0), ncols);
+                        const int rec = REC(vc);
+
+                        float copen, cext, ctext;
+                        col_terms<KIND>(S, rec, copen, cext, ctext);
+
+                        // ---- boundary state for lane 0 at column t ----
+                        KaState b0;
+                        if (first) {
+                                // row "-1" generated on the fly; lane 0's column terms are those of column t
+                                if (t == 0) {
+                                        ini = inj;
+                                } else if (t < ncols) {
+                                        const float g = near_t ? kmax(ini.ga, ini.a) + ctext : kmax(ini.ga + cext, ini.a + copen);
+                                        ini.a = -KA_F; ini.ga = g; ini.gb = -KA_F;
+                                } else {
+                                        ini.a = -KA_F; ini.ga = -KA_F; ini.gb = -KA_F;
+                                }
+                                b0 = ini;
+                        } else {
+                                if ((t & 63) == 0) {
+                                        const int vb = min(t + lane, ncols);
+                                        batch = rows[IDX(vb)];             // previous strip's last row, not yet overwritten
+                                }
+                                b0.a = lane_bcast(batch.a, t & 63);
+                                b0.ga = lane_bcast(batch.ga, t & 63);
+                                b0.gb = lane_bcast(batch.gb, t & 63);
+                        }
+
+                        KaState up;
+                        up.a = wave_shr1(cur.a); up.ga = wave_shr1(cur.ga); up.gb = wave_shr1(cur.gb);
+                        if (lane == 0) up = b0;
+
+                        if (inrange) {
+                                KaState nx;
+                                if (v == 0) {
+                                        nx.a = -KA_F; nx.ga = -KA_F;
+                                        nx.gb = near_t ? kmax(up.gb, up.a) + t_row : kmax(up.gb + e_row, up.a + o_row);
+                                } else {
+                                        float a = kmax3(diag.a, diag.ga + copen_prev, diag.gb + o_rowprev);
+                                        if (KIND == KA_SS) {
+                                                const int res2 = S.s2[rec - 1];
+                                                a += S.subm[res1 * 23 + res2] - S.soff;
+                                        } else if (KIND == KA_SP) {
+                                                const int res2 = S.s2[rec - 1];
+                                                a += p1row[32 + res2];
+                                        } else {
+                                                const float* pc = S.p2 + ((long long)rec << 6) + 32;
+#pragma unroll
+                                                for (int c = 22; c >= 0; --c) a += p1v[c] * pc[c];
+                                        }
+                                        nx.a = a;
+                                        if (v < ncols) {
+                                                nx.ga = kmax(cur.ga + cext, cur.a + copen);
+                                                nx.gb = kmax(up.gb + e_row, up.a + o_row);
+                                        } else {
+                                                nx.ga = -KA_F;
+                                                nx.gb = far_t ? kmax(up.gb, up.a) + t_row : kmax(up.gb + e_row, up.a + o_row);
+                                        }
+                                }
+                                cur = nx;
+                                if (lane == nl - 1) rows[IDX(v)] = cur;
+                        }
+                        diag = up;
+                        copen_prev = copen;
+                }
+                // the next strip (same wave) reads rows[] written by this one
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0);
+        }
+#undef REC
+#undef IDX
+}
+
+// ------------------------------------------------------------------------------------------
+// Meetup of one sub-problem by one wave (aln_seqseq.c:241-420 and the two profile variants),
+// then aln_continue: path writes and the two child sub-problems (aln_controller.c:194-436).
+// ------------------------------------------------------------------------------------------
+struct Best { float mx; float mx2; int key; };
+
+__device__ __forceinline__ void best_consider(Best& b, float s, int key)
+{
+        if (s > b.mx) { b.mx2 = b.mx; b.mx = s; b.key = key; }
+        else if (s > b.mx2) { b.mx2 = s; }
+}
+
+__device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int okey)
+{
+        if (omx > x.mx || (omx == x.mx && okey < x.key)) {
+                const float second = (omx > x.mx) ? fmaxf(x.mx, omx2) : x.mx;
+                x.mx2 = second; x.mx = omx; x.key = okey;
+        } else {
+                x.mx2 = (x.mx > omx) ? fmaxf(omx, x.mx2) : omx;        // equal maxima: the duplicate is the runner-up
+        }
+}
+
+template <int KIND>
+__device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const int lane, const bool is_top)
+{
+        const int startb = sb.startb, endb = sb.endb;
+        const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
+        const KaState* f = S.fbuf + sb.roff;
+        const KaState* b = S.bbuf + sb.roff;
+        const float middle = (float)(endb - startb) / 2.0f + (float)startb;
+        const int rrec = mid + 1;
+        float g3, g7, g6n, g6f;
+        if (KIND == KA_SS) {
+                g3 = -S.gpo; g7 = -S.gpo;
+                g6n = (startb == 0) ? -S.tgpe : -S.gpe;
+                g6f = (endb == S.Lb) ? -S.tgpe : -S.gpe;
+        } else {
+                const float* R = S.p1 + ((long long)rrec << 6);
+                g3 = R[27]; g7 = R[27 - 64];
+                g6n = (startb == 0) ? R[29] : R[28];
+                g6f = (endb == S.Lb) ? R[29] : R[28];
+        }
+        Best B = { -KA_F, -KA_F, 0x7fffffff };
+        for (int i = startb + lane; i <= endb; i += 64) {
+                const KaState fi = f[i - startb], bi = b[i - startb];
+                float sub = fabsf(middle - (float)i);
+                sub = sub / 1000.0f;
+                const int kb = (i - startb) * 8;
+                if (i < endb) {
+                        float c2, c5, dummy1, dummy2;
+                        col_terms<KIND>(S, i + 1, c2, dummy1, dummy2);
+                        col_terms<KIND>(S, i, c5, dummy1, dummy2);
+                        best_consider(B, fi.a + bi.a - sub, kb + 0);
+                        best_consider(B, fi.a + bi.ga + c2 - sub, kb + 1);
+                        best_consider(B, fi.a + bi.gb + g3 - sub, kb + 2);
+                        best_consider(B, fi.ga + bi.a + c5 - sub, kb + 3);
+                        best_consider(B, fi.gb + bi.gb + g6n - sub, kb + 4);
+                        best_consider(B, fi.gb + bi.a + g7 - sub, kb + 5);
+                } else {
+                        best_consider(B, fi.a + bi.gb + g3 - sub, kb + 2);
+                        best_consider(B, fi.gb + bi.gb + g6f - sub, kb + 4);
+                }
+        }
+        // wave reduction (butterfly); every lane ends with the same answer
+        for (int off = 32; off >= 1; off >>= 1) {
+                const float omx = __shfl_xor(B.mx, off, 64);
+                const float omx2 = __shfl_xor(B.mx2, off, 64);
+                const int okey = __shfl_xor(B.key, off, 64);
+                best_merge(B, omx, omx2, okey);
+        }
+        if (lane != 0) return;
+
+        int meet = -1, tr = -1;
+        if (B.key != 0x7fffffff) {
+                const int ord = B.key & 7;                           // candidate order 0..5 -> codes 1,2,3,5,6,7
+                meet = startb + (B.key >> 3);
+                tr = ord + 1 + (ord >= 3 ? 1 : 0);
+        }
+        if (B.mx2 > -KA_F) {
+                atomicAdd(&S.msum, (double)(B.mx - B.mx2));
+                atomicAdd(&S.mcount, 1);
+        }
+        if (is_top) { S.top_meet = meet; S.top_tr = tr; S.top_score = B.mx; }
+        if (tr < 0) return;
+
+        const KaState Z = { 0.0f, -KA_F, -KA_F };
+        const KaState GA = { -KA_F, 0.0f, -KA_F };
+        const KaState GB = { -KA_F, -KA_F, 0.0f };
+        KaSub c1, c2;
+        c1.starta = sb.starta; c1.startb = startb; c1.fin = sb.fin;
+        c2.enda = sb.enda; c2.endb = endb; c2.bin = sb.bin;
+        c1.pad = 0; c2.pad = 0;
+        int* path = S.raw;
+        switch (tr) {
+        case 1:
+                path[mid] = meet; path[mid + 1] = meet + 1;
+                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                break;
+        case 2:
+                path[mid] = meet;
+                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                c2.starta = mid; c2.startb = meet + 1; c2.fin = GA;
+                break;
+        case 3:
+                path[mid] = meet;
+                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
+                break;
+        case 5:
+                path[mid + 1] = meet + 1;
+                c1.enda = mid; c1.endb = meet - 1; c1.bin = GA;
+                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                break;
+        case 6:
+                c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
+                c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
+                break;
+        default: /* 7 */
+                path[mid + 1] = meet + 1;
+                c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
+                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                break;
+        }
+        if (c1.starta < c1.enda && c1.startb < c1.endb) {
+                const int slot = atomicAdd(&S.nnext, 1);
+                c1.roff = atomicAdd(&S.rowalloc, c1.endb - c1.startb + 1);
+                qnext[slot] = c1;
+        }
+        if (c2.starta < c2.enda && c2.startb < c2.endb) {
+                const int slot = atomicAdd(&S.nnext, 1);
+                c2.roff = atomicAdd(&S.rowalloc, c2.endb - c2.startb + 1);
+                qnext[slot] = c2;
+        }
+}
+
+// The whole recursion for the task described by S (all threads of the workgroup).
+template <int KIND>
+__device__ void ka_hirschberg(TaskShared& S, float* dbg_rows)
+{
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const int g = max(S.La, S.Lb) + 2;
+        for (int i = tid; i < g; i += KA_BLOCK) S.raw[i] = -1;            // init_alnmem, aln_setup.c:33-36
+        if (tid == 0) {
+                KaSub root;
+                const KaState Z = { 0.0f, -KA_F, -KA_F };
+                root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
+                root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
+                S.q[0][0] = root;
+                S.ncur = (S.La > 0 && S.Lb > 0) ? 1 : 0;
+                S.nnext = 0; S.rowalloc = 0;
+                S.msum = 0.0; S.mcount = 0;
+                S.top_meet = -1; S.top_tr = -1; S.top_score = 0.0f;
+        }
+        __syncthreads();
+        int level = 0;
+        while (true) {
+                const int ncur = S.ncur;
+                if (ncur == 0) break;
+                KaSub* qc = S.q[level & 1];
+                KaSub* qn = S.q[(level + 1) & 1];
+                for (int p = wave; p < 2 * ncur; p += KA_WAVES) {
+                        const KaSub sb = qc[p >> 1];
+                        const int dir = p & 1;
+                        ka_pass<KIND>(S, sb, dir, (dir == KA_FWD ? S.fbuf : S.bbuf) + sb.roff, lane);
+                }
+                __syncthreads();
+                if (level == 0 && dbg_rows) {
+                        // tests only: keep the top-level rows f[0..Lb], b[0..Lb]
+                        const int n = 3 * (S.Lb + 1);
+                        const float* f = (const float*)S.fbuf;
+                        const float* b = (const float*)S.bbuf;
+                        for (int i = tid; i < n; i += KA_BLOCK) { dbg_rows[i] = f[i]; dbg_rows[n + i] = b[i]; }
+                }
+                for (int k = wave; k < ncur; k += KA_WAVES) {
+                        const KaSub sb = qc[k];
+                        ka_meetup<KIND>(S, sb, qn, lane, level == 0);
+                }
+                __syncthreads();
+                if (tid == 0) { S.ncur = S.nnext; S.nnext = 0; S.rowalloc = 0; }
+                __syncthreads();
+                ++level;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// P3: mirror + coding of the raw path (one thread; see oracle/kalign_oracle.c:ko_code_path for
+// the as-executed semantics of add_gap_info_to_path_n).  Also records, per output column,
+// which record of profile a / b feeds it (srcA/srcB, -1 = none) for the parallel update_n.
+// ------------------------------------------------------------------------------------------
+__device__ void ka_code_path(TaskShared& S)
+{
+        const int len_a = S.len_a, len_b = S.len_b;
+        const int* raw = S.raw;
+        if (S.swapped) {
+                int* r2 = S.raw2;
+                for (int i = 0; i < len_a + 2; ++i) r2[i] = -1;
+                for (int i = 1; i <= len_b; ++i) if (raw[i] != -1) r2[raw[i]] = i;
+                raw = r2;
+        }
+        int* o = S.coded;
+        int j = 1, prev;
+        if (raw[1] == -1) {
+                o[j++] = 2;
+        } else {
+                for (int k = 0; k < raw[1] - 1; ++k) o[j++] = 1;
+                o[j++] = 0;
+        }
+        prev = raw[1];
+        for (int i = 2; i <= len_a; ++i) {
+                if (raw[i] == -1) {
+                        o[j++] = 2;
+                } else {
+                        if (raw[i] - 1 != prev && prev != -1) {
+                                for (int k = 0; k < raw[i] - prev - 1; ++k) o[j++] = 1;
+                        }
+                        o[j++] = 0;
+                }
+                prev = raw[i];
+        }
+        if (raw[len_a] < len_b && raw[len_a] != -1) {
+                for (int k = 0; k < len_b - raw[len_a]; ++k) o[j++] = 1;
+        }
+        const int alnlen = j - 1;
+        o[0] = alnlen;
+        o[j] = 3;
+        // terminal-run flag (aln_setup.c:209-219); the 4/8/16 flag loop never executes in the reference
+        {
+                int i = 1;
+                while (i <= alnlen && o[i] != 0) { o[i] |= 32; ++i; }
+                i = alnlen;
+                while (i >= 1 && o[i] != 0) { o[i] |= 32; --i; }
+        }
+        // source records for update_n
+        int ra = 1, rb = 1;
+        for (int c = 1; c <= alnlen; ++c) {
+                const int code = o[c];
+                if (!code) { S.srcA[c] = ra++; S.srcB[c] = rb++; }
+                else if (code & 1) { S.srcA[c] = -1; S.srcB[c] = rb++; }
+                else { S.srcA[c] = ra++; S.srcB[c] = -1; }
+        }
+        S.alnlen = alnlen;
+}
+
+// ------------------------------------------------------------------------------------------
+// P4: update_n (aln_setup.c:230-436), one thread per (output column, field).
+// ------------------------------------------------------------------------------------------
+__device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+{
+        const int alnlen = S.alnlen;
+        const float* pa = S.profa;
+        const float* pb = S.profb;
+        float* np = S.newp;
+        const float sipa = (float)T.nsip_a, sipb = (float)T.nsip_b;
+        float sA = 1.0f, sB = 1.0f;
+        bool rebalance = false;
+        if (D.usw > 0.0f && T.nsip_a > 0 && T.nsip_b > 0) {
+                const float pseudo = D.usw;
+                const float total = (float)(T.nsip_a + T.nsip_b);
+                const float denom = total + 2.0f * pseudo;
+                sA = total * (sipa + pseudo) / (denom * sipa);
+                sB = total * (sipb + pseudo) / (denom * sipb);
+                rebalance = true;
+        }
+        const long long total = (long long)(alnlen + 2) * 64;
+        for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
+                const int c = (int)(x >> 6);
+                const int k = (int)(x & 63);
+                float val;
+                if (c == 0 || c == alnlen + 1) {
+                        const float va = (c == 0) ? pa[k] : pa[((long long)(S.len_a + 1) << 6) + k];
+                        const float vb = (c == 0) ? pb[k] : pb[((long long)(S.len_b + 1) << 6) + k];
+                        val = (rebalance && k < 23) ? (va * sA + vb * sB) : (va + vb);
+                } else {
+                        const int code = S.coded[c];
+                        if (!code) {
+                                const float* ra = pa + ((long long)S.srcA[c] << 6);
+                                const float* rb = pb + ((long long)S.srcB[c] << 6);
+                                if (rebalance && k < 23) {
+                                        val = ra[k] * sA + rb[k] * sB;
+                                } else {
+                                        val = ra[k] + rb[k];
+                                        if (rebalance && k >= 32 && k < 55) {
+                                                const float dA = sA - 1.0f, dB = sB - 1.0f;
+                                                const int jj = k - 32;
+                                                float delta = 0.0f;
+                                                for (int aa = 0; aa < 23; ++aa) {
+                                                        delta += (ra[aa] * dA + rb[aa] * dB) * D.subm[23 * aa + jj];
+                                                }
+                                                val += delta;
+                                        }
+                                }
+                        } else {
+                                const bool gap_in_a = (code & 1) != 0;
+                                const float* src = gap_in_a ? (pb + ((long long)S.srcB[c] << 6)) : (pa + ((long long)S.srcA[c] << 6));
+                                const float sip = gap_in_a ? sipa : sipb;
+                                val = src[k];
+                                // as the reference: up to two successive adjustments (close, then open)
+                                if (!(code & 20)) {
+                                        if (code & 32) {
+                                                if (k == 25) val += sip;
+                                                if (k >= 32 && k < 55) val -= D.tgpe0 * sip;
+                                        } else {
+                                                if (k == 24) val += sip;
+                                                if (k >= 32 && k < 55) val -= D.gpe0 * sip;
+                                        }
+                                } else {
+                                        for (int pass = 0; pass < 2; ++pass) {
+                                                const int bit = pass == 0 ? 16 : 4;
+                                                if (!(code & bit)) continue;
+                                                float gp;
+                                                if (code & 32) {
+                                                        if (k == 25) val += sip;
+                                                        gp = D.tgpe0 * sip;
+                                                        if (k == 23) val += sip;
+                                                        gp += D.gpo0 * sip;
+                                                } else {
+                                                        if (k == 23) val += sip;
+                                                        gp = D.gpo0 * sip;
+                                                }
+                                                if (k >= 32 && k < 55) val -= gp;
+                                        }
+                                }
+                        }
+                }
+                np[x] = val;
+        }
+}
+
+// Leaf profile (make_profile_n, aln_setup.c:40-99) or gap-penalty refresh (set_gap_penalties_n, :101-119)
+__device__ void ka_prepare_operand(const KaTreeDev& D, float* prof, int len, int nsip, int nsip_other,
+                                   const uint8_t* seq, float gpo, float gpe, float tgpe, float soff)
+{
+        if (nsip == 1) {
+                const long long total = (long long)(len + 2) * 64;
+                for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
+                        const int r = (int)(x >> 6);
+                        const int k = (int)(x & 63);
+                        float val = 0.0f;
+                        if (k == 55) val = -gpo;
+                        else if (k == 56) val = -gpe;
+                        else if (k == 57) val = -tgpe;
+                        else if (r >= 1 && r <= len) {
+                                const int c = seq[r - 1];
+                                if (k == c) val = 1.0f;
+                                else if (k >= 32 && k < 55) val = D.subm[23 * c + (k - 32)] - soff;
+                        }
+                        prof[x] = val;
+                }
+        } else {
+                const float fn = (float)nsip_other;
+                for (int r = threadIdx.x; r < len + 2; r += KA_BLOCK) {
+                        float* p = prof + ((long long)r << 6);
+                        p[27] = p[55] * fn;
+                        p[28] = p[56] * fn;
+                        p[29] = p[57] * fn;
+                }
+        }
+}
+
+__device__ __forceinline__ long long ka_align_up(long long x, long long a) { return (x + a - 1) / a * a; }
+
+// carve the per-task scratch region
+__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb)
+{
+        const long long n = (long long)la + lb + 8;
+        long long o = 0;
+        S.raw = (int*)(base + o);   o += ka_align_up(n * 4, 16);
+        S.raw2 = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+        S.coded = (int*)(base + o); o += ka_align_up(n * 4, 16);
+        S.srcA = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+        S.srcB = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+        S.fbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+        S.bbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+        const long long nq = (long long)(la < lb ? la : lb) + 4;
+        S.q[0] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
+        S.q[1] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
+        return o;
+}
+
+__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb)
+{
+        const long long n = la + lb + 8;
+        const long long nq = (la < lb ? la : lb) + 4;
+        return 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
+             + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16) + 64;
+}
+
+// ------------------------------------------------------------------------------------------
+// The task kernel: one workgroup per task of the current guide-tree level.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int* __restrict__ task_ids)
+{
+        __shared__ TaskShared S;
+        __shared__ float* s_dbg;
+        const int task = task_ids[blockIdx.x];
+        const KaTaskDesc T = D.tasks[task];
+        const int tid = threadIdx.x;
+
+        if (tid == 0) {
+                const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
+                S.fail = 0;
+                S.len_a = len_a; S.len_b = len_b;
+                S.profa = D.prof_arena + D.node_prof[T.a];
+                S.profb = D.prof_arena + D.node_prof[T.b];
+                S.subm = D.subm;
+                S.gpo = T.gpo; S.gpe = T.gpe; S.tgpe = T.tgpe; S.soff = T.soff;
+                S.s1 = nullptr; S.s2 = nullptr; S.p1 = nullptr; S.p2 = nullptr;
+                S.sp_open = 0.0f; S.sp_ext = 0.0f; S.sp_text = 0.0f;
+                int swapped = 0, kind;
+                // operand selection and swap rules, aln_run.c:297-388
+                if (T.nsip_a == 1 && T.nsip_b == 1) {
+                        kind = KA_SS;
+                        if (len_a < len_b) { S.s1 = D.codes + D.seq_off[T.a]; S.s2 = D.codes + D.seq_off[T.b]; }
+                        else { swapped = 1; S.s1 = D.codes + D.seq_off[T.b]; S.s2 = D.codes + D.seq_off[T.a]; }
+                } else if (T.nsip_a == 1) {
+                        kind = KA_SP; swapped = 1;
+                        S.s2 = D.codes + D.seq_off[T.a]; S.p1 = S.profb;
+                        S.sp_open = T.gpo * (float)T.nsip_b; S.sp_ext = T.gpe * (float)T.nsip_b; S.sp_text = T.tgpe * (float)T.nsip_b;
+                } else if (T.nsip_b == 1) {
+                        kind = KA_SP;
+                        S.s2 = D.codes + D.seq_off[T.b]; S.p1 = S.profa;
+                        S.sp_open = T.gpo * (float)T.nsip_a; S.sp_ext = T.gpe * (float)T.nsip_a; S.sp_text = T.tgpe * (float)T.nsip_a;
+                } else {
+                        kind = KA_PP;
+                        if (len_a < len_b) { S.p1 = S.profa; S.p2 = S.profb; }
+                        else { swapped = 1; S.p1 = S.profb; S.p2 = S.profa; }
+                }
+                S.kind = kind; S.swapped = swapped;
+                S.La = swapped ? len_b : len_a;
+                S.Lb = swapped ? len_a : len_b;
+                const long long need = ka_scratch_bytes(len_a, len_b);
+                const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
+                if ((long long)so + need > D.scratch_cap) { S.fail = 1; atomicExch(D.error, 2); }
+                else ka_carve(S, D.scratch + so, len_a, len_b);
+                s_dbg = nullptr;
+                if (D.flags & KA_FLAG_DEBUG_ROWS) {
+                        const unsigned long long nd = 6ull * (unsigned long long)(S.Lb + 1);
+                        const unsigned long long d0 = atomicAdd(&D.counters[3], nd);
+                        if ((long long)(d0 + nd) <= D.dbg_cap) { s_dbg = D.dbg_arena + d0; D.dbg_off[task] = (long long)d0; }
+                        else { D.dbg_off[task] = -1; atomicExch(D.error, 4); }
+                }
+        }
+        __syncthreads();
+        if (S.fail) return;
+
+        // P1
+        ka_prepare_operand(D, S.profa, S.len_a, T.nsip_a, T.nsip_b, D.codes + (T.nsip_a == 1 ? D.seq_off[T.a] : 0), T.gpo, T.gpe, T.tgpe, T.soff);
+        ka_prepare_operand(D, S.profb, S.len_b, T.nsip_b, T.nsip_a, D.codes + (T.nsip_b == 1 ? D.seq_off[T.b] : 0), T.gpo, T.gpe, T.tgpe, T.soff);
+        __syncthreads();
+
+        // P2
+        if (S.kind == KA_SS) ka_hirschberg<KA_SS>(S, s_dbg);
+        else if (S.kind == KA_SP) ka_hirschberg<KA_SP>(S, s_dbg);
+        else ka_hirschberg<KA_PP>(S, s_dbg);
+        __syncthreads();
+
+        // P3
+        if (tid == 0) {
+                ka_code_path(S);
+                const int alnlen = S.alnlen;
+                const unsigned long long pn = (unsigned long long)alnlen + 2;
+                const unsigned long long po = atomicAdd(&D.counters[2], pn);
+                if ((long long)(po + pn) > D.path_cap) { S.fail = 1; atomicExch(D.error, 3); }
+                S.path_dst = D.path_arena + po;
+                S.newp = nullptr;
+                D.node_len[T.c] = alnlen;
+                if (!T.is_root) {
+                        const unsigned long long fn = pn * 64ull;
+                        const unsigned long long fo = atomicAdd(&D.counters[0], fn);
+                        if ((long long)(fo + fn) > D.prof_cap) { S.fail = 1; atomicExch(D.error, 1); }
+                        else { S.newp = D.prof_arena + fo; D.node_prof[T.c] = (long long)fo; }
+                }
+                ka_task_rec r;
+                r.a = T.a; r.b = T.b; r.c = T.c;
+                r.len_a = S.len_a; r.len_b = S.len_b; r.nsip_a = T.nsip_a; r.nsip_b = T.nsip_b;
+                r.plen = alnlen; r.kind = S.kind; r.swapped = S.swapped;
+                r.meet = S.top_meet; r.transition = S.top_tr;
+                r.path_off = (int)po;
+                r.gap_scale = T.gap_scale; r.subm_off = T.soff;
+                r.score = S.top_score;
+                r.confidence = (S.mcount > 0) ? (float)S.msum / (float)S.mcount : 0.0f;
+                r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
+                D.recs[task] = r;
+        }
+        __syncthreads();
+        if (S.fail) return;
+
+        // P4
+        for (int i = tid; i < S.alnlen + 2; i += KA_BLOCK) S.path_dst[i] = S.coded[i];
+        if (S.newp) ka_update_profile(S, D, T);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch of independent seq-seq alignments (pairwise_align_map, anchor_consistency.c:19-120)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
+{
+        __shared__ TaskShared S;
+        const int k = blockIdx.x;
+        const int tid = threadIdx.x;
+        if (tid == 0) {
+                const int i = P.ia[k], j = P.ib[k];
+                const int len_i = P.seq_len[i], len_j = P.seq_len[j];
+                const int swapped = !(len_i <= len_j);
+                S.fail = 0;
+                S.kind = KA_SS; S.swapped = swapped;
+                S.len_a = len_i; S.len_b = len_j;
+                S.La = swapped ? len_j : len_i;
+                S.Lb = swapped ? len_i : len_j;
+                S.s1 = P.codes + P.seq_off[swapped ? j : i];
+                S.s2 = P.codes + P.seq_off[swapped ? i : j];
+                S.p1 = nullptr; S.p2 = nullptr; S.profa = nullptr; S.profb = nullptr;
+                S.subm = P.subm;
+                S.gpo = P.gpo; S.gpe = P.gpe; S.tgpe = P.tgpe; S.soff = 0.0f;
+                S.sp_open = 0.0f; S.sp_ext = 0.0f; S.sp_text = 0.0f;
+                ka_carve(S, P.scratch + (long long)k * P.scratch_stride, len_i, len_j);
+        }
+        __syncthreads();
+        ka_hirschberg<KA_SS>(S, nullptr);
+        __syncthreads();
+        if (tid == 0) {
+                ka_code_path(S);
+                if (P.scores) P.scores[k] = S.top_score;
+        }
+        __syncthreads();
+        int* dst = P.paths_out + P.poff[k];
+        for (int i = tid; i < S.alnlen + 2; i += KA_BLOCK) dst[i] = S.coded[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (called from ka_api.cpp)
+// ------------------------------------------------------------------------------------------
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int* task_ids_dev, int ntasks, hipStream_t stream)
+{
+        hipLaunchKernelGGL(ka_task_kernel, dim3(ntasks), dim3(KA_BLOCK), 0, stream, *D, task_ids_dev);
+}
+
+extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
+{
+        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_BLOCK), 0, stream, *P);
+}
+
+extern "C" long long ka_scratch_bytes_host(long long la, long long lb) { return ka_scratch_bytes(la, lb); }
