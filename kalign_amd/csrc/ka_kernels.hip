@@ -53,6 +53,7 @@ struct TaskShared {
         const float* subm;
         float gpo, gpe, tgpe, soff;
         float sp_open, sp_ext, sp_text;
+        float p1_mult, p2_mult;        // (float)nsip of the OTHER operand: set_gap_penalties_n folded into the loads
         KaState* fbuf;
         KaState* bbuf;
         KaSub* q[2];
@@ -81,8 +82,10 @@ __device__ __forceinline__ void col_terms(const TaskShared& S, int rec, float& c
         if (KIND == KA_SS) { copen = -S.gpo; cext = -S.gpe; ctext = -S.tgpe; }
         else if (KIND == KA_SP) { copen = -S.sp_open; cext = -S.sp_ext; ctext = -S.sp_text; }
         else {
+                // set_gap_penalties_n (aln_setup.c:101-119): [27..29] = [55..57] * nsip_other, applied
+                // on the fly so that profiles stay immutable in HBM
                 const float* c = S.p2 + ((long long)rec << 6);
-                copen = c[27]; cext = c[28]; ctext = c[29];
+                copen = c[55] * S.p2_mult; cext = c[56] * S.p2_mult; ctext = c[57] * S.p2_mult;
         }
 }
 
@@ -143,8 +146,8 @@ __device__ void ka_pass(const TaskShared& S, const KaSub& sb, const int dir, KaS
                         res1 = S.s1[i];
                 } else {
                         p1row = S.p1 + ((long long)rrec << 6);
-                        o_row = p1row[27]; e_row = p1row[28]; t_row = p1row[29];
-                        o_rowprev = S.p1[((long long)rprev << 6) + 27];
+                        o_row = p1row[55] * S.p1_mult; e_row = p1row[56] * S.p1_mult; t_row = p1row[57] * S.p1_mult;
+                        o_rowprev = S.p1[((long long)rprev << 6) + 55] * S.p1_mult;
                         if (KIND == KA_PP) {
 #pragma unroll
                                 for (int c = 0; c < 23; ++c) p1v[c] = p1row[c];
@@ -273,9 +276,9 @@ __device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const in
                 g6f = (endb == S.Lb) ? -S.tgpe : -S.gpe;
         } else {
                 const float* R = S.p1 + ((long long)rrec << 6);
-                g3 = R[27]; g7 = R[27 - 64];
-                g6n = (startb == 0) ? R[29] : R[28];
-                g6f = (endb == S.Lb) ? R[29] : R[28];
+                g3 = R[55] * S.p1_mult; g7 = R[55 - 64] * S.p1_mult;
+                g6n = (startb == 0) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
+                g6f = (endb == S.Lb) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
         }
         Best B = { -KA_F, -KA_F, 0x7fffffff };
         for (int i = startb + lane; i <= endb; i += 64) {
@@ -501,14 +504,27 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 sB = total * (sipb + pseudo) / (denom * sipb);
                 rebalance = true;
         }
+        // fields 27..29 of an operand as the reference would see them at this point: zero for a
+        // leaf (make_profile_n), [55..57] * nsip_other for a profile (set_gap_penalties_n ran on it
+        // for this merge, aln_run.c:239-253).  They are dead values (always rewritten before
+        // use) but part of the merged record, so they are reproduced for bit-identical profiles.
+        const bool leaf_a = (T.nsip_a == 1), leaf_b = (T.nsip_b == 1);
+        auto fa = [&](const float* rec, int k) -> float {
+                if (k >= 27 && k <= 29) return leaf_a ? 0.0f : rec[k + 28] * sipb;
+                return rec[k];
+        };
+        auto fb = [&](const float* rec, int k) -> float {
+                if (k >= 27 && k <= 29) return leaf_b ? 0.0f : rec[k + 28] * sipa;
+                return rec[k];
+        };
         const long long total = (long long)(alnlen + 2) * 64;
         for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
                 const int c = (int)(x >> 6);
                 const int k = (int)(x & 63);
                 float val;
                 if (c == 0 || c == alnlen + 1) {
-                        const float va = (c == 0) ? pa[k] : pa[((long long)(S.len_a + 1) << 6) + k];
-                        const float vb = (c == 0) ? pb[k] : pb[((long long)(S.len_b + 1) << 6) + k];
+                        const float va = (c == 0) ? fa(pa, k) : fa(pa + ((long long)(S.len_a + 1) << 6), k);
+                        const float vb = (c == 0) ? fb(pb, k) : fb(pb + ((long long)(S.len_b + 1) << 6), k);
                         val = (rebalance && k < 23) ? (va * sA + vb * sB) : (va + vb);
                 } else {
                         const int code = S.coded[c];
@@ -518,7 +534,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                                 if (rebalance && k < 23) {
                                         val = ra[k] * sA + rb[k] * sB;
                                 } else {
-                                        val = ra[k] + rb[k];
+                                        val = fa(ra, k) + fb(rb, k);
                                         if (rebalance && k >= 32 && k < 55) {
                                                 const float dA = sA - 1.0f, dB = sB - 1.0f;
                                                 const int jj = k - 32;
@@ -533,7 +549,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                                 const bool gap_in_a = (code & 1) != 0;
                                 const float* src = gap_in_a ? (pb + ((long long)S.srcB[c] << 6)) : (pa + ((long long)S.srcA[c] << 6));
                                 const float sip = gap_in_a ? sipa : sipb;
-                                val = src[k];
+                                val = gap_in_a ? fb(src, k) : fa(src, k);
                                 // as the reference: up to two successive adjustments (close, then open)
                                 if (!(code & 20)) {
                                         if (code & 32) {
@@ -566,34 +582,25 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
         }
 }
 
-// Leaf profile (make_profile_n, aln_setup.c:40-99) or gap-penalty refresh (set_gap_penalties_n, :101-119)
-__device__ void ka_prepare_operand(const KaTreeDev& D, float* prof, int len, int nsip, int nsip_other,
-                                   const uint8_t* seq, float gpo, float gpe, float tgpe, float soff)
+// Leaf profile (make_profile_n, aln_setup.c:40-99).  Non-leaf operands need nothing here:
+// set_gap_penalties_n is folded into the loads (see col_terms).
+__device__ void ka_make_leaf_profile(const KaTreeDev& D, float* prof, int len, const uint8_t* seq,
+                                     float gpo, float gpe, float tgpe, float soff)
 {
-        if (nsip == 1) {
-                const long long total = (long long)(len + 2) * 64;
-                for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
-                        const int r = (int)(x >> 6);
-                        const int k = (int)(x & 63);
-                        float val = 0.0f;
-                        if (k == 55) val = -gpo;
-                        else if (k == 56) val = -gpe;
-                        else if (k == 57) val = -tgpe;
-                        else if (r >= 1 && r <= len) {
-                                const int c = seq[r - 1];
-                                if (k == c) val = 1.0f;
-                                else if (k >= 32 && k < 55) val = D.subm[23 * c + (k - 32)] - soff;
-                        }
-                        prof[x] = val;
+        const long long total = (long long)(len + 2) * 64;
+        for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
+                const int r = (int)(x >> 6);
+                const int k = (int)(x & 63);
+                float val = 0.0f;
+                if (k == 55) val = -gpo;
+                else if (k == 56) val = -gpe;
+                else if (k == 57) val = -tgpe;
+                else if (r >= 1 && r <= len) {
+                        const int c = seq[r - 1];
+                        if (k == c) val = 1.0f;
+                        else if (k >= 32 && k < 55) val = D.subm[23 * c + (k - 32)] - soff;
                 }
-        } else {
-                const float fn = (float)nsip_other;
-                for (int r = threadIdx.x; r < len + 2; r += KA_BLOCK) {
-                        float* p = prof + ((long long)r << 6);
-                        p[27] = p[55] * fn;
-                        p[28] = p[56] * fn;
-                        p[29] = p[57] * fn;
-                }
+                prof[x] = val;
         }
 }
 
@@ -666,6 +673,9 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
                         else { swapped = 1; S.p1 = S.profb; S.p2 = S.profa; }
                 }
                 S.kind = kind; S.swapped = swapped;
+                // p1 is profile b when swapped, else profile a; its gap terms scale with the other side's nsip
+                S.p1_mult = swapped ? (float)T.nsip_a : (float)T.nsip_b;
+                S.p2_mult = swapped ? (float)T.nsip_b : (float)T.nsip_a;
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
                 const long long need = ka_scratch_bytes(len_a, len_b);
@@ -684,8 +694,8 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         if (S.fail) return;
 
         // P1
-        ka_prepare_operand(D, S.profa, S.len_a, T.nsip_a, T.nsip_b, D.codes + (T.nsip_a == 1 ? D.seq_off[T.a] : 0), T.gpo, T.gpe, T.tgpe, T.soff);
-        ka_prepare_operand(D, S.profb, S.len_b, T.nsip_b, T.nsip_a, D.codes + (T.nsip_b == 1 ? D.seq_off[T.b] : 0), T.gpo, T.gpe, T.tgpe, T.soff);
+        if (T.nsip_a == 1) ka_make_leaf_profile(D, S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, T.soff);
+        if (T.nsip_b == 1) ka_make_leaf_profile(D, S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, T.soff);
         __syncthreads();
 
         // P2
@@ -753,6 +763,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
                 S.subm = P.subm;
                 S.gpo = P.gpo; S.gpe = P.gpe; S.tgpe = P.tgpe; S.soff = 0.0f;
                 S.sp_open = 0.0f; S.sp_ext = 0.0f; S.sp_text = 0.0f;
+                S.p1_mult = 1.0f; S.p2_mult = 1.0f;
                 ka_carve(S, P.scratch + (long long)k * P.scratch_stride, len_i, len_j);
         }
         __syncthreads();
