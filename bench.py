@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- GCUPS of the progressive-alignment hot path on MI355X.
+
+One "step" = one pass of the hot path over one synthetic N x L sequence set: every task of the
+guide tree (seq-seq, seq-profile and profile-profile Gotoh/Hirschberg DP, profile merge, path
+coding) through ka_tree_run(), with sequences, task list and scoring tables already resident in
+HBM.  GCUPS = sum over tasks of len_a*len_b ("useful" cell updates) / time.
+
+    python bench.py [--gpus N --steps K --warmup W] [--nseq 1024 --len 400 --dna]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank aligns its own
+independent sequence set of the same shape (the unit the path partitions into without a
+data-path collective) -> weak scaling; the timing is barrier-bracketed and max-reduced.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(recs):
+    """per task D*(wa*La + wb*Lb + 48*Lb) + 4*(La+Lb+2) + 256*(alnlen+2) [merged
+    profile written on the device; not for the root], D = ceil(log2 La)+1, w = 1 B/position for a
+    sequence operand, 256 B/position for a profile operand; La/Lb = DP rows/cols."""
+    total = 0.0
+    for i, r in enumerate(recs):
+        la, lb = (r.len_b, r.len_a) if r.swapped else (r.len_a, r.len_b)
+        wa = 1 if r.kind == 0 else 256
+        wb = 256 if r.kind == 2 else 1
+        depth = math.ceil(math.log2(max(la, 2))) + 1
+        total += depth * (wa * la + wb * lb + 48 * lb) + 4 * (la + lb + 2)
+        if i != len(recs) - 1:
+            total += 256 * (r.plen + 2)
+    return total
+
+
+def make_workload(nseq, length, dna, seed):
+    from kalign_amd import guide, synth
+    seqs = synth.family(nseq, length, dna=dna, seed=seed)
+    codes = guide.encode(seqs, dna=dna)
+    tasks = guide.bisecting_tree(nseq, seed=seed)
+    dist = np.random.RandomState(seed).uniform(0.3, 0.9, nseq).astype(np.float32)
+    return codes, tasks, dist
+
+
+def scoring(dna):
+    """Default matrices of the reference (aln_param.c): PFASUM43 7/1.25/1 for protein,
+    the +5/-4 8/6/0 DNA matrix for --type dna; tables are data fixtures dumped from the reference."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "param_tables.npz"))
+    key = "1_0" if dna else "0_3"
+    return z["subm_" + key], z["scal_" + key].copy()
+
+
+def cpu_baseline(codes, tasks, dist, dna, cells):
+    """The reference's own dispatcher (oracle/_ref = the real Kalign sources compiled as they
+    lie) on the host cores, same task list, bounded to ~10-30 s of CPU work."""
+    ncores = os.cpu_count() or 1
+    try:
+        from oracle import refdrv
+        if not refdrv.available():
+            raise RuntimeError("no oracle/_ref")
+        best = None
+        tried = []
+        budget = time.time() + 25.0
+        for nt in sorted({ncores, min(ncores, 16), 1}, reverse=True):
+            reps = 0
+            while reps < 2 and time.time() < budget:
+                job = refdrv.EncodedJob(codes, tasks, dist, biotype=1 if dna else 0, type_=0 if dna else -1, n_threads=nt)
+                _, secs = job.run_tree()
+                job.close()
+                reps += 1
+                tried.append((nt, secs))
+                if best is None or secs < best[1]:
+                    best = (nt, secs)
+        return {"value": cells / best[1] / 1e9, "unit": "GCUPS", "cores": best[0], "kind": "reference",
+                "sample": "full workload, create_msa_tree of the reference (OpenMP), best of %s (threads, s)" % (
+                    ["%d:%.3f" % t for t in tried])}
+    except Exception as e:  # pragma: no cover - only when the prebuilt reference is missing
+        from oracle import oracledrv
+        n = min(len(codes), 128)
+        from kalign_amd import guide
+        sub_tasks = guide.bisecting_tree(n, seed=1)
+        subm, scal = scoring(dna)
+        t0 = time.time()
+        recs, _, _, _ = oracledrv.msa_tree(codes[:n], sub_tasks, subm, scal, dist[:n])
+        secs = time.time() - t0
+        c = sum(r.len_a * r.len_b for r in recs)
+        return {"value": c / secs / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+                "sample": "first %d sequences, oracle C restatement, 1 thread (%s)" % (n, e)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nseq", type=int, default=1024)
+    ap.add_argument("--len", type=int, default=400)
+    ap.add_argument("--dna", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import kalign_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    codes, tasks, seq_dist = make_workload(args.nseq, args.len, args.dna, seed=1 + rank)
+    subm, scal = scoring(args.dna)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = kalign_amd.Context(local_rank, stream=stream)
+    ctx.tree_upload(codes, tasks, subm, scal, seq_dist)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.tree_run()
+        ctx.tree_sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.tree_run()
+    ctx.tree_sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    recs, paths, _ = ctx.tree_download(want_gaps=False)
+    cells = float(sum(r.len_a * r.len_b for r in recs))
+    kern_ms, n_launch = ctx.tree_kernel_ms()          # HIP events on the launch stream, last step
+    total_cells = cells
+    if dist_on:
+        t = torch.tensor([cells], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_cells = float(t.item())
+
+    if rank == 0:
+        abytes = algorithmic_bytes(recs)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        kinds = np.bincount([r.kind for r in recs], minlength=3)
+        out = {
+            "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA",
+            "value": total_cells * args.steps / elapsed / 1e9,
+            "unit": "GCUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d %s seqs x ~%d, whole guide tree per step: %d seq-seq + %d seq-profile + %d profile-profile DP tasks (Hirschberg), profile merge, path coding; one independent set per GPU"
+                            % (args.nseq, "DNA" if args.dna else "protein", args.len, kinds[0], kinds[1], kinds[2]),
+                "nseq": args.nseq, "len": args.len, "type": "dna" if args.dna else "protein",
+                "useful_cells_per_step": cells, "tree_levels": n_launch,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "ka_task_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_step": abytes, "launches_per_step": n_launch,
+                "avg_launch_ms": kern_ms / max(n_launch, 1),
+                "kernel_ms_per_step": kern_ms,
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
+        print(json.dumps(out))
+    ctx.close()
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

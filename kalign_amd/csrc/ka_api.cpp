@@ -65,6 +65,7 @@ struct ka_ctx {
         int max_len = 0;
         float subm[23 * 23];
         float scal[6];
+        int nres = 23;
         DevBuf<uint8_t> d_codes;
         DevBuf<int> d_seq_off, d_node_len, d_level_ids, d_path_arena, d_error;
         DevBuf<long long> d_node_prof, d_dbg_off;
@@ -147,6 +148,11 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         memcpy(c->scal, scal, sizeof(c->scal));
         c->sum_len = 0; c->max_len = 0;
         long long codes_bytes = 0;
+        int max_code = 0;
+        for (int i = 0; i < numseq; i++)
+                for (int j = 0; j < lens[i]; j++) max_code = std::max<int>(max_code, codes[off[i] + j]);
+        if (max_code > 22) return fail("sequence code out of range (alphabet is 0..22)");
+        c->nres = (max_code < 5) ? 5 : 23;      // nucleotide alphabets use codes 0..4 (alphabet.c:206-245)
         for (int i = 0; i < numseq; i++) {
                 if (lens[i] < 1) return fail("zero-length sequence (the reference removes them before the dispatcher, msa_check.c:66)");
                 c->sum_len += lens[i];
@@ -270,6 +276,7 @@ static int tree_launch(ka_ctx* c)
         D.tasks = c->d_tasks.p; D.recs = c->d_recs.p; D.subm = c->d_subm.p;
         D.gpo0 = c->scal[0]; D.gpe0 = c->scal[1]; D.tgpe0 = c->scal[2]; D.usw = c->scal[5];
         D.numseq = numseq; D.flags = c->flags; D.error = c->d_error.p;
+        D.nres = c->nres;
 
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;

@@ -49,6 +49,7 @@ struct KaTreeDev {
         float gpo0, gpe0, tgpe0, usw;  // unscaled penalties for update_n, use_seq_weights
         int numseq;
         int flags;
+        int nres;                      // alphabet size: 23 protein, 5 nucleotide (alphabet.c)
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow
 };
 

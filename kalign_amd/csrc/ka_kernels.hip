@@ -89,154 +89,7 @@ __device__ __forceinline__ void col_terms(const TaskShared& S, int rec, float& c
         }
 }
 
-// ------------------------------------------------------------------------------------------
-// One Gotoh pass of one sub-problem by one wave.
-// rows: this sub-problem's slice of the task's f (FWD) or b (BWD) row buffer, indexed by
-// (s-index - startb); on return it holds the last DP row of the pass.
-// ------------------------------------------------------------------------------------------
-template <int KIND>
-__device__ void ka_pass(const TaskShared& S, const KaSub& sb, const int dir, KaState* rows, const int lane)
-{
-        const int startb = sb.startb, endb = sb.endb;
-        const int ncols = endb - startb;
-        const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
-        const int r0 = (dir == KA_FWD) ? sb.starta : mid;
-        const int r1 = (dir == KA_FWD) ? mid : sb.enda;
-        const int nrows = r1 - r0;
-        const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == S.Lb);
-        const bool far_t = (dir == KA_FWD) ? (endb == S.Lb) : (startb == 0);
-        const KaState inj = (dir == KA_FWD) ? sb.fin : sb.bin;
-
-#define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
-#define IDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
-
-        if (nrows == 0) {
-                // only the "row -1" initialisation survives (aln_seqseq.c:40-58): a serial chain
-                if (lane == 0) {
-                        KaState ini = inj;
-                        rows[IDX(0)] = ini;
-                        for (int v = 1; v < ncols; ++v) {
-                                float copen, cext, ctext;
-                                col_terms<KIND>(S, REC(v), copen, cext, ctext);
-                                const float g = near_t ? kmax(ini.ga, ini.a) + ctext : kmax(ini.ga + cext, ini.a + copen);
-                                ini.a = -KA_F; ini.ga = g; ini.gb = -KA_F;
-                                rows[IDX(v)] = ini;
-                        }
-                        ini.a = -KA_F; ini.ga = -KA_F; ini.gb = -KA_F;
-                        rows[IDX(ncols)] = ini;
-                }
-                return;
-        }
-
-        for (int u0 = 0; u0 < nrows; u0 += 64) {
-                const int nl = min(64, nrows - u0);
-                const bool first = (u0 == 0);
-                const int u = u0 + min(lane, nl - 1);                  // idle lanes shadow the last row
-                const int i = (dir == KA_FWD) ? (r0 + u) : (r1 - 1 - u);
-                const int rrec = i + 1;
-                const int rprev = (dir == KA_FWD) ? rrec - 1 : rrec + 1;
-
-                // ---- stationary (row) operand of this lane ----
-                float o_row, e_row, t_row, o_rowprev;
-                float p1v[23];
-                int res1 = 0;
-                const float* p1row = nullptr;
-                if (KIND == KA_SS) {
-                        o_row = -S.gpo; e_row = -S.gpe; t_row = -S.tgpe; o_rowprev = -S.gpo;
-                        res1 = S.s1[i];
-                } else {
-                        p1row = S.p1 + ((long long)rrec << 6);
-                        o_row = p1row[55] * S.p1_mult; e_row = p1row[56] * S.p1_mult; t_row = p1row[57] * S.p1_mult;
-                        o_rowprev = S.p1[((long long)rprev << 6) + 55] * S.p1_mult;
-                        if (KIND == KA_PP) {
-#pragma unroll
-                                for (int c = 0; c < 23; ++c) p1v[c] = p1row[c];
-                        }
-                }
-
-                KaState cur = { -KA_F, -KA_F, -KA_F };
-                KaState diag = cur;
-                KaState ini = inj;
-                KaState batch = cur;                                   // 64 prefetched boundary states (strips > 0)
-                float copen_prev = 0.0f;
-
-                const int nsteps = ncols + nl;                         // t = 0 .. ncols + nl - 1
-                for (int t = 0; t < nsteps; ++t) {
-                        const int v = t - lane;
-                        const bool inrange = (v >= 0) && (v <= ncols) && (lane < nl);
-                        const int vc = min(max(v, 0), ncols);
-                        const int rec = REC(vc);
-
-                        float copen, cext, ctext;
-                        col_terms<KIND>(S, rec, copen, cext, ctext);
-
-                        // ---- boundary state for lane 0 at column t ----
-                        KaState b0;
-                        if (first) {
-                                // row "-1" generated on the fly; lane 0's column terms are those of column t
-                                if (t == 0) {
-                                        ini = inj;
-                                } else if (t < ncols) {
-                                        const float g = near_t ? kmax(ini.ga, ini.a) + ctext : kmax(ini.ga + cext, ini.a + copen);
-                                        ini.a = -KA_F; ini.ga = g; ini.gb = -KA_F;
-                                } else {
-                                        ini.a = -KA_F; ini.ga = -KA_F; ini.gb = -KA_F;
-                                }
-                                b0 = ini;
-                        } else {
-                                if ((t & 63) == 0) {
-                                        const int vb = min(t + lane, ncols);
-                                        batch = rows[IDX(vb)];             // previous strip's last row, not yet overwritten
-                                }
-                                b0.a = lane_bcast(batch.a, t & 63);
-                                b0.ga = lane_bcast(batch.ga, t & 63);
-                                b0.gb = lane_bcast(batch.gb, t & 63);
-                        }
-
-                        KaState up;
-                        up.a = wave_shr1(cur.a); up.ga = wave_shr1(cur.ga); up.gb = wave_shr1(cur.gb);
-                        if (lane == 0) up = b0;
-
-                        if (inrange) {
-                                KaState nx;
-                                if (v == 0) {
-                                        nx.a = -KA_F; nx.ga = -KA_F;
-                                        nx.gb = near_t ? kmax(up.gb, up.a) + t_row : kmax(up.gb + e_row, up.a + o_row);
-                                } else {
-                                        float a = kmax3(diag.a, diag.ga + copen_prev, diag.gb + o_rowprev);
-                                        if (KIND == KA_SS) {
-                                                const int res2 = S.s2[rec - 1];
-                                                a += S.subm[res1 * 23 + res2] - S.soff;
-                                        } else if (KIND == KA_SP) {
-                                                const int res2 = S.s2[rec - 1];
-                                                a += p1row[32 + res2];
-                                        } else {
-                                                const float* pc = S.p2 + ((long long)rec << 6) + 32;
-#pragma unroll
-                                                for (int c = 22; c >= 0; --c) a += p1v[c] * pc[c];
-                                        }
-                                        nx.a = a;
-                                        if (v < ncols) {
-                                                nx.ga = kmax(cur.ga + cext, cur.a + copen);
-                                                nx.gb = kmax(up.gb + e_row, up.a + o_row);
-                                        } else {
-                                                nx.ga = -KA_F;
-                                                nx.gb = far_t ? kmax(up.gb, up.a) + t_row : kmax(up.gb + e_row, up.a + o_row);
-                                        }
-                                }
-                                cur = nx;
-                                if (lane == nl - 1) rows[IDX(v)] = cur;
-                        }
-                        diag = up;
-                        copen_prev = copen;
-                }
-                // the next strip (same wave) reads rows[] written by this one
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_s_waitcnt(0);
-        }
-#undef REC
-#undef IDX
-}
+#include "ka_pass.h"
 
 // ------------------------------------------------------------------------------------------
 // Meetup of one sub-problem by one wave (aln_seqseq.c:241-420 and the two profile variants),
@@ -375,8 +228,8 @@ __device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const in
 }
 
 // The whole recursion for the task described by S (all threads of the workgroup).
-template <int KIND>
-__device__ void ka_hirschberg(TaskShared& S, float* dbg_rows)
+template <int KIND, int NRES>
+__device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss)
 {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
@@ -404,7 +257,8 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows)
                 for (int p = wave; p < 2 * ncur; p += KA_WAVES) {
                         const KaSub sb = qc[p >> 1];
                         const int dir = p & 1;
-                        ka_pass<KIND>(S, sb, dir, (dir == KA_FWD ? S.fbuf : S.bbuf) + sb.roff, lane);
+                        ka_pass<KIND, NRES>(S, sb, dir, (dir == KA_FWD ? S.fbuf : S.bbuf) + sb.roff, lane,
+                                            lds_waves + wave * KA_WAVE_LDS, tss);
                 }
                 __syncthreads();
                 if (level == 0 && dbg_rows) {
@@ -604,6 +458,23 @@ __device__ void ka_make_leaf_profile(const KaTreeDev& D, float* prof, int len, c
         }
 }
 
+// dynamic-LDS layout of a workgroup
+#define KA_LDS_DBG 512
+#define KA_LDS_TSS 528
+#define KA_LDS_WAVES (KA_LDS_TSS + 23 * KA_T_STRIDE * 4)          // 2736, multiple of 16
+#define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
+static_assert(sizeof(TaskShared) <= KA_LDS_DBG, "TaskShared outgrew its LDS slot");
+static_assert(KA_LDS_WAVES % 16 == 0, "wave regions must be 16-B aligned");
+
+// seq-seq score table T[a][b] = subm[a][b] - soff (one rounding, as aln_seqseq.c:82 evaluates it)
+__device__ void ka_build_tss(float* tss, const float* subm, float soff)
+{
+        for (int x = threadIdx.x; x < 23 * KA_T_STRIDE; x += KA_BLOCK) {
+                const int a = x / KA_T_STRIDE, b = x % KA_T_STRIDE;
+                tss[x] = (b < 23) ? (subm[23 * a + b] - soff) : 0.0f;
+        }
+}
+
 __device__ __forceinline__ long long ka_align_up(long long x, long long a) { return (x + a - 1) / a * a; }
 
 // carve the per-task scratch region
@@ -637,8 +508,13 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int* __restrict__ task_ids)
 {
-        __shared__ TaskShared S;
-        __shared__ float* s_dbg;
+        // all LDS lives in the dynamic region (16-B aligned carve-outs, guide section 6 G17)
+        extern __shared__ __attribute__((aligned(16))) char ka_smem[];
+        TaskShared& S = *(TaskShared*)ka_smem;
+        float** s_dbg_p = (float**)(ka_smem + KA_LDS_DBG);
+        float* tss = (float*)(ka_smem + KA_LDS_TSS);
+        char* lds_waves = ka_smem + KA_LDS_WAVES;
+#define s_dbg (*s_dbg_p)
         const int task = task_ids[blockIdx.x];
         const KaTaskDesc T = D.tasks[task];
         const int tid = threadIdx.x;
@@ -696,13 +572,16 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         // P1
         if (T.nsip_a == 1) ka_make_leaf_profile(D, S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, T.soff);
         if (T.nsip_b == 1) ka_make_leaf_profile(D, S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, T.soff);
+        ka_build_tss(tss, D.subm, T.soff);
         __syncthreads();
 
         // P2
-        if (S.kind == KA_SS) ka_hirschberg<KA_SS>(S, s_dbg);
-        else if (S.kind == KA_SP) ka_hirschberg<KA_SP>(S, s_dbg);
-        else ka_hirschberg<KA_PP>(S, s_dbg);
+        if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23>(S, s_dbg, lds_waves, tss);
+        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23>(S, s_dbg, lds_waves, tss);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5>(S, s_dbg, lds_waves, tss);
+        else ka_hirschberg<KA_PP, 23>(S, s_dbg, lds_waves, tss);
         __syncthreads();
+#undef s_dbg
 
         // P3
         if (tid == 0) {
@@ -745,7 +624,10 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
 {
-        __shared__ TaskShared S;
+        extern __shared__ __attribute__((aligned(16))) char ka_smem[];
+        TaskShared& S = *(TaskShared*)ka_smem;
+        float* tss = (float*)(ka_smem + KA_LDS_TSS);
+        char* lds_waves = ka_smem + KA_LDS_WAVES;
         const int k = blockIdx.x;
         const int tid = threadIdx.x;
         if (tid == 0) {
@@ -766,8 +648,9 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
                 S.p1_mult = 1.0f; S.p2_mult = 1.0f;
                 ka_carve(S, P.scratch + (long long)k * P.scratch_stride, len_i, len_j);
         }
+        ka_build_tss(tss, P.subm, 0.0f);
         __syncthreads();
-        ka_hirschberg<KA_SS>(S, nullptr);
+        ka_hirschberg<KA_SS, 23>(S, nullptr, lds_waves, tss);
         __syncthreads();
         if (tid == 0) {
                 ka_code_path(S);
@@ -783,12 +666,12 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
 // ------------------------------------------------------------------------------------------
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int* task_ids_dev, int ntasks, hipStream_t stream)
 {
-        hipLaunchKernelGGL(ka_task_kernel, dim3(ntasks), dim3(KA_BLOCK), 0, stream, *D, task_ids_dev);
+        hipLaunchKernelGGL(ka_task_kernel, dim3(ntasks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, task_ids_dev);
 }
 
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 {
-        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_BLOCK), 0, stream, *P);
+        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *P);
 }
 
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb) { return ka_scratch_bytes(la, lb); }

@@ -1,0 +1,43 @@
+"""Synthetic guide trees for benchmarks and tests.
+
+The real guide tree comes from Kalign's bisecting k-means (lib/src/bisectingKmeans.c), which is
+outside the hot path.  For synthetic workloads we only need a task list
+with the same contract create_tasks() produces (bisectingKmeans.c:1067-1110): post-order,
+task t merges (a, b) into node c = numseq + t, children before parents, root last.
+"""
+import numpy as np
+
+
+def bisecting_tree(n, seed=1, jitter=0.15):
+    """Recursive bisection of the leaf range with a randomised split point: depth ~ log2 n,
+    like the k-means tree on a well-mixed family."""
+    rng = np.random.RandomState(seed)
+    order = rng.permutation(n)
+    tasks = []
+    counter = [n]
+
+    def build(lo, hi):
+        if hi - lo == 1:
+            return int(order[lo])
+        m = hi - lo
+        split = lo + int(np.clip(round(m * (0.5 + rng.uniform(-jitter, jitter))), 1, m - 1))
+        a = build(lo, split)
+        b = build(split, hi)
+        c = counter[0]
+        counter[0] += 1
+        tasks.append((a, b, c))
+        return c
+
+    import sys
+    sys.setrecursionlimit(max(10000, 4 * n))
+    build(0, n)
+    return np.array(tasks, np.int32)
+
+
+def encode(seqs, dna=False):
+    """Kalign's internal codes (alphabet.c:179-245) for the unambiguous letters."""
+    alpha = "ACGT" if dna else "ARNDCQEGHILKMFPSTWYV"
+    lut = np.full(256, 255, np.uint8)
+    for i, ch in enumerate(alpha):
+        lut[ord(ch)] = i
+    return [lut[np.frombuffer(s.encode(), np.uint8)] for s in seqs]

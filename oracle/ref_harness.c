@@ -177,6 +177,66 @@ void refh_get_tasks(void* hv, int* abc)
         }
 }
 
+/* Replace the guide tree by a caller-supplied task list (a, b, c = numseq + index, children
+   first) and optionally the per-sequence distances; everything else stays as prepared. */
+int refh_set_tasks(void* hv, const int* abc, int n_tasks, const float* seq_distances)
+{
+        struct refh* h = (struct refh*)hv;
+        struct aln_tasks* t = h->tasks;
+        if(n_tasks != h->msa->numseq - 1) return 1;
+        for(int i = 0; i < n_tasks; i++){
+                t->list[i]->a = abc[3*i]; t->list[i]->b = abc[3*i+1]; t->list[i]->c = abc[3*i+2];
+                t->list[i]->p = i; t->list[i]->n = 0; t->list[i]->score = 0.0f; t->list[i]->confidence = 0.0f;
+                if(abc[3*i+2] != h->msa->numseq + i) return 1;
+        }
+        t->n_tasks = n_tasks;
+        if(seq_distances){
+                if(!h->msa->seq_distances) h->msa->seq_distances = malloc(sizeof(float) * h->msa->numseq);
+                memcpy(h->msa->seq_distances, seq_distances, sizeof(float) * h->msa->numseq);
+        }
+        return 0;
+}
+
+/* Prepare WITHOUT the reference's own tree building: sequences arrive already encoded and
+   ordered; the caller supplies tasks + distances via refh_set_tasks.  Used by bench.py's
+   cpu_baseline leg so that CPU and GPU run the identical task list. */
+void* refh_prepare_encoded(const uint8_t* codes, const int* off, const int* lens, int numseq,
+                           int biotype, int type, float gpo, float gpe, float tgpe, int n_threads,
+                           float dist_scale, float vsm_amax, float use_seq_weights)
+{
+        struct refh* h = calloc(1, sizeof(struct refh));
+        struct msa* msa = NULL;
+        char** tmp = malloc(sizeof(char*) * numseq);
+        for(int i = 0; i < numseq; i++){
+                tmp[i] = malloc(lens[i] + 1);
+                for(int j = 0; j < lens[i]; j++) tmp[i][j] = biotype == ALN_BIOTYPE_DNA ? "ACGTN"[codes[off[i]+j] % 5] : "ARNDCQEGHILKMFPSTWYVBZX"[codes[off[i]+j] % 23];
+                tmp[i][lens[i]] = 0;
+        }
+        if(kalign_arr_to_msa(tmp, (int*)lens, numseq, &msa) != OK) goto ERROR;
+        h->msa = msa;
+        msa->quiet = 1;
+        msa->biotype = biotype;
+        for(int i = 0; i < numseq; i++){
+                snprintf(msa->sequences[i]->name, MSA_NAME_LEN, "s%07d", i);
+                msa->sequences[i]->rank = i;
+                memcpy(msa->sequences[i]->s, codes + off[i], lens[i]);
+        }
+        msa->L = biotype == ALN_BIOTYPE_DNA ? ALPHA_defDNA : ALPHA_ambigiousPROTEIN;
+        if(alloc_tasks(&h->tasks, msa->numseq) != OK) goto ERROR;
+        if(aln_param_init(&h->ap, msa->biotype, n_threads, type, gpo, gpe, tgpe) != OK) goto ERROR;
+        if(use_seq_weights >= 0.0f) h->ap->use_seq_weights = use_seq_weights;
+        if(dist_scale > 0.0f) h->ap->dist_scale = dist_scale;
+        if(vsm_amax >= 0.0f) h->ap->vsm_amax = vsm_amax;
+        for(int i = 0; i < numseq; i++) free(tmp[i]);
+        free(tmp);
+        return h;
+ERROR:
+        for(int i = 0; i < numseq; i++) free(tmp[i]);
+        free(tmp);
+        refh_free(h);
+        return NULL;
+}
+
 static void collect_gaps(struct msa* msa, int* gaps_out)
 {
         int o = 0;

@@ -61,6 +61,11 @@ def lib():
         L.refh_pairwise_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                           C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.refh_set_tasks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.refh_prepare_encoded.restype = C.c_void_p
+        L.refh_prepare_encoded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_float, C.c_float, C.c_float, C.c_int,
+                                           C.c_float, C.c_float, C.c_float]
         L.refh_kalign.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_float, C.c_float, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
         _lib = L
@@ -157,6 +162,37 @@ class RefJob:
         if lib().refh_finalise(self.h, rows, C.byref(n)):
             raise RuntimeError("finalise failed")
         return [b.value.decode() for b in bufs]
+
+
+class EncodedJob(RefJob):
+    """The reference dispatcher on caller-supplied encoded sequences + task list (no tree
+    building): what bench.py's cpu_baseline leg times."""
+
+    def __init__(self, codes, tasks, seq_distances, biotype, type_=-1, gpo=-1.0, gpe=-1.0, tgpe=-1.0,
+                 n_threads=1, dist_scale=0.0, vsm_amax=-1.0, use_seq_weights=-1.0):
+        L = lib()
+        self.lens = np.array([len(c) for c in codes], np.int32)
+        off = np.zeros(len(codes), np.int32)
+        off[1:] = np.cumsum(self.lens)[:-1]
+        flat = np.ascontiguousarray(np.concatenate(codes), np.uint8)
+        self.n = len(codes)
+        self.h = L.refh_prepare_encoded(_ptr(flat), _ptr(off), _ptr(self.lens), self.n, biotype,
+                                        8 if type_ < 0 else type_, gpo, gpe, tgpe, n_threads,
+                                        dist_scale, vsm_amax, use_seq_weights)
+        if not self.h:
+            raise RuntimeError("reference refused the input")
+        tasks = np.ascontiguousarray(tasks, np.int32)
+        sd = None if seq_distances is None else np.ascontiguousarray(seq_distances, np.float32)
+        if L.refh_set_tasks(self.h, _ptr(tasks), len(tasks), _ptr(sd) if sd is not None else None):
+            raise RuntimeError("bad task list")
+        self.codes = codes
+        self.tasks = tasks
+        self.ntasks = len(tasks)
+        self.seq_distances = sd
+        self.subm = np.zeros(23 * 23, np.float32)
+        scal = np.zeros(6, np.float32)
+        L.refh_get_params(self.h, _ptr(self.subm), _ptr(scal))
+        self.scal = scal
 
 
 def kalign(seqs, type_=-1, gpo=-1.0, gpe=-1.0, tgpe=-1.0, n_threads=1):
