@@ -40,6 +40,7 @@ extern "C" {
 
 /* flags for ka_msa_tree / ka_tree_upload */
 #define KA_FLAG_DEBUG_ROWS 1    /* also keep each task's top-level f/b rows (tests: row hashes) */
+#define KA_FLAG_TIMING 2        /* record per-task phase cycle counts (ka_tree_get_timing) */
 
 typedef struct ka_ctx ka_ctx;
 
@@ -97,6 +98,14 @@ long long ka_tree_paths_size(ka_ctx* ctx);      /* ints needed for paths_out (va
 int ka_tree_download(ka_ctx* ctx, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
 /* Merged profile of node `node` ((plen+2)*64 floats) after a run; for tests. */
 int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats);
+/* Per-task phase timings of the last run (KA_FLAG_TIMING): out[8*t + k], shader-clock cycles:
+   0 operand prep, 1 Hirschberg, 2 path coding, 3 profile merge, 4 passes, 5 meetups, 6 recursion
+   levels, 7 DP rows*cols; followed by 16 x (sub-problems, pass cycles, meetup cycles) per
+   recursion level of the root task: out must hold 8*n_tasks + 48 values. */
+int ka_tree_get_timing(ka_ctx* ctx, long long* out);
+/* Debug: 64 breadcrumb words written by workgroup 0 (context created with KA_TRACE=1 in the
+   environment); readable while a kernel is still running. */
+int ka_debug_trace(ka_ctx* ctx, int* out64);
 /* Work done by the last run: sum over tasks of len_a*len_b ("useful cells") */
 double ka_tree_cells(ka_ctx* ctx);
 /* Milliseconds spent in the DP kernels of the last ka_tree_run, measured with HIP events

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 FLAG_DEBUG_ROWS = 1
+FLAG_TIMING = 2
 
 
 class KalignAmdError(RuntimeError):
@@ -34,7 +35,7 @@ class TaskRec(C.Structure):
 
 EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
-           "ka_tree_download", "ka_tree_get_profile", "ka_tree_cells", "ka_tree_kernel_ms",
+           "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch"]
 
 
@@ -70,6 +71,8 @@ def load_library():
     L.ka_tree_paths_size.restype = C.c_longlong
     L.ka_tree_download.argtypes = [vp, C.POINTER(TaskRec), vp, C.c_longlong, vp]
     L.ka_tree_get_profile.argtypes = [vp, C.c_int, vp, C.c_longlong]
+    L.ka_tree_get_timing.argtypes = [vp, vp]
+    L.ka_debug_trace.argtypes = [vp, vp]
     L.ka_tree_cells.argtypes = [vp]
     L.ka_tree_cells.restype = C.c_double
     L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -159,6 +162,18 @@ class Context:
                 g.append(gaps[o:o + int(n) + 1].copy())
                 o += int(n) + 1
         return recs, paths, g
+
+    def tree_timing(self):
+        n = self._job["ntasks"]
+        out = np.zeros(8 * n + 48, np.int64)
+        self._chk(self.L.ka_tree_get_timing(self.h, _ptr(out)))
+        self.root_levels = out[8 * n:].reshape(16, 3)      # per recursion level of the root task: n, pass, meetup
+        return out[:8 * n].reshape(n, 8)
+
+    def debug_trace(self):
+        out = np.zeros(64, np.int32)
+        self._chk(self.L.ka_debug_trace(self.h, _ptr(out)))
+        return out
 
     def tree_profile(self, node, max_cols):
         out = np.zeros(64 * (max_cols + 2), np.float32)

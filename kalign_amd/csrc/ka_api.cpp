@@ -68,7 +68,7 @@ struct ka_ctx {
         int nres = 23;
         DevBuf<uint8_t> d_codes;
         DevBuf<int> d_seq_off, d_node_len, d_level_ids, d_path_arena, d_error;
-        DevBuf<long long> d_node_prof, d_dbg_off;
+        DevBuf<long long> d_node_prof, d_dbg_off, d_timing;
         DevBuf<float> d_prof_arena, d_subm, d_dbg_arena;
         DevBuf<unsigned long long> d_counters;
         DevBuf<char> d_scratch;
@@ -76,6 +76,7 @@ struct ka_ctx {
         DevBuf<ka_task_rec> d_recs;
         long long prof_cap = 0, path_cap = 0, scratch_cap = 0, dbg_cap = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        int* h_trace = nullptr;       // pinned, device-visible breadcrumbs (KA_TRACE=1)
         bool ran = false, synced = false;
         int n_launches = 0;
         double cells = 0.0;
@@ -96,6 +97,10 @@ extern "C" int ka_ctx_create(int device, ka_ctx** out)
         c->device = device;
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
+        if (getenv("KA_TRACE")) {
+                HIPCHK(hipHostMalloc((void**)&c->h_trace, 64 * sizeof(int), hipHostMallocMapped));
+                memset(c->h_trace, 0xff, 64 * sizeof(int));
+        }
         *out = c;
         return KA_OK;
 }
@@ -107,7 +112,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_codes.release(); c->d_seq_off.release(); c->d_node_len.release(); c->d_level_ids.release();
         c->d_path_arena.release(); c->d_error.release(); c->d_node_prof.release(); c->d_dbg_off.release();
         c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
-        c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release();
+        c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release(); c->d_timing.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -237,7 +242,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
             c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
             c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
-            c->d_counters.alloc(4) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
+            c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 64) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
             c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
             c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
                 return fail("hipMalloc failed");
@@ -277,6 +282,8 @@ static int tree_launch(ka_ctx* c)
         D.gpo0 = c->scal[0]; D.gpe0 = c->scal[1]; D.tgpe0 = c->scal[2]; D.usw = c->scal[5];
         D.numseq = numseq; D.flags = c->flags; D.error = c->d_error.p;
         D.nres = c->nres;
+        D.trace = c->h_trace;
+        D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
 
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
@@ -315,6 +322,7 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         c->synced = true;
                         return KA_OK;
                 }
+                if (err == 5) return fail("device watchdog: a strip pipeline inside a workgroup stopped making progress");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)
                 if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
                 else if (err == 2) { c->scratch_cap *= 2; c->d_scratch.release(); }
@@ -442,6 +450,22 @@ extern "C" int ka_tree_get_profile(ka_ctx* c, int node, float* out, long long ca
         return KA_OK;
 }
 
+extern "C" int ka_tree_get_timing(ka_ctx* c, long long* out)
+{
+        if (!c || !c->synced) return fail("run + sync first");
+        if (!(c->flags & KA_FLAG_TIMING)) return fail("KA_FLAG_TIMING was not set");
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMemcpy(out, c->d_timing.p, sizeof(long long) * (8 * c->n_tasks + 48), hipMemcpyDeviceToHost));
+        return KA_OK;
+}
+
+extern "C" int ka_debug_trace(ka_ctx* c, int* out64)
+{
+        if (!c || !c->h_trace) return fail("KA_TRACE was not set when the context was created");
+        memcpy(out64, c->h_trace, 64 * sizeof(int));
+        return KA_OK;
+}
+
 extern "C" double ka_tree_cells(ka_ctx* c) { return c ? c->cells : 0.0; }
 
 extern "C" int ka_tree_kernel_ms(ka_ctx* c, float* ms, int* n_launches)
@@ -482,15 +506,15 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
         }
         stride = (stride + 255) / 256 * 256;
         DevBuf<uint8_t> d_codes; DevBuf<int> d_off, d_len, d_ia, d_ib, d_paths; DevBuf<float> d_subm, d_scores;
-        DevBuf<long long> d_poff; DevBuf<char> d_scr;
+        DevBuf<long long> d_poff; DevBuf<char> d_scr; DevBuf<int> d_err;
         int rc = KA_OK;
         if (d_codes.alloc((size_t)codes_bytes) || d_off.alloc(numseq) || d_len.alloc(numseq) || d_ia.alloc(npairs) ||
             d_ib.alloc(npairs) || d_paths.alloc((size_t)ptotal) || d_subm.alloc(23 * 23) || d_scores.alloc(npairs) ||
-            d_poff.alloc(npairs) || d_scr.alloc((size_t)(stride * npairs)))
+            d_poff.alloc(npairs) || d_scr.alloc((size_t)(stride * npairs)) || d_err.alloc(1))
                 rc = fail("hipMalloc failed");
         auto cleanup = [&]() {
                 d_codes.release(); d_off.release(); d_len.release(); d_ia.release(); d_ib.release(); d_paths.release();
-                d_subm.release(); d_scores.release(); d_poff.release(); d_scr.release();
+                d_subm.release(); d_scores.release(); d_poff.release(); d_scr.release(); d_err.release();
         };
         if (rc) { cleanup(); return rc; }
 #define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -506,9 +530,16 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
         P.subm = d_subm.p; P.gpo = gpo; P.gpe = gpe; P.tgpe = tgpe;
         P.scratch = d_scr.p; P.scratch_stride = stride;
         P.paths_out = d_paths.p; P.poff = d_poff.p; P.scores = d_scores.p; P.npairs = npairs;
+        P.error = d_err.p;
+        PCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), c->stream));
         ka_launch_pairs(&P, c->stream);
         PCHK(hipGetLastError());
         PCHK(hipStreamSynchronize(c->stream));
+        {
+                int err = 0;
+                PCHK(hipMemcpy(&err, d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+                if (err) { cleanup(); return fail("device watchdog: a strip pipeline inside a workgroup stopped making progress"); }
+        }
         PCHK(hipMemcpy(paths_out, d_paths.p, sizeof(int) * (size_t)ptotal, hipMemcpyDeviceToHost));
         if (scores_out) PCHK(hipMemcpy(scores_out, d_scores.p, sizeof(float) * npairs, hipMemcpyDeviceToHost));
 #undef PCHK

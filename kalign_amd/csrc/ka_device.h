@@ -50,6 +50,8 @@ struct KaTreeDev {
         int numseq;
         int flags;
         int nres;                      // alphabet size: 23 protein, 5 nucleotide (alphabet.c)
+        long long* timing;             // [n_tasks][8] phase cycle counts (KA_FLAG_TIMING) or null
+        int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow
 };
 
@@ -66,5 +68,6 @@ struct KaPairDev {
         int* paths_out;
         const long long* poff;
         float* scores;
+        int* error;
         int npairs;
 };

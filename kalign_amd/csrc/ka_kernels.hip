@@ -20,8 +20,9 @@
 // oracle/kalign_oracle.c:ko_pass; see there for the mapping to the reference's six functions.
 #include <hip/hip_runtime.h>
 #include "ka_device.h"
+// #define KA_TRACE_STRIP 1   // per-step breadcrumbs into D.trace (debugging hangs)
 
-#define KA_BLOCK 256
+#define KA_BLOCK 512
 #define KA_WAVES (KA_BLOCK / 64)
 
 __device__ __forceinline__ float kmax(float a, float b) { return fmaxf(a, b); }
@@ -32,6 +33,11 @@ __device__ __forceinline__ float wave_shr1(float x)
 {
         int xi = __float_as_int(x);
         return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x138, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float ka_uniform_f(float x)
+{
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
 __device__ __forceinline__ float lane_bcast(float x, int src_lane)
@@ -63,6 +69,9 @@ struct TaskShared {
         int* srcA;
         int* srcB;
         int ncur, nnext, rowalloc;
+        int2* items[2];                // work items of the current / next recursion level: (sub-problem, dir<<16 | strip)
+        int* prog[2];                  // per-item progress words (columns of the strip's last row published)
+        int nitems_cur, nitems_next, next_item;
         double msum;
         int mcount;
         int top_meet, top_tr;
@@ -71,6 +80,12 @@ struct TaskShared {
         float* newp;
         int* path_dst;
         int fail;
+        int* trace;
+        int* watchdog;                 // device error word: a bounded spin that expired writes 5 here
+        long long t_pass, t_meet;      // KA_FLAG_TIMING: shader-clock cycles spent in passes / meetups
+        int n_levels;
+        int lvl_n[16];                 // per recursion level: sub-problems, pass / meetup cycles
+        int lvl_pass[16], lvl_meet[16];
 };
 
 // ------------------------------------------------------------------------------------------
@@ -113,8 +128,20 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
         }
 }
 
+// Append the work items of sub-problem `slot` (its forward strips, then its backward strips) to
+// the next level's item list.  Items of one pass are contiguous and ascending, so strip k-1 is
+// always pulled before strip k.
+__device__ __forceinline__ void ka_emit_items(TaskShared& S, int2* items, int* prog, int* counter, int slot, int starta, int enda)
+{
+        const int mid = ((enda - starta) / 2) + starta;
+        const int nf = ka_strips_of(mid - starta), nb = ka_strips_of(enda - mid);
+        const int base = atomicAdd(counter, nf + nb);
+        for (int k = 0; k < nf; ++k) { items[base + k] = make_int2(slot, (KA_FWD << 16) | k); prog[base + k] = 0; }
+        for (int k = 0; k < nb; ++k) { items[base + nf + k] = make_int2(slot, (KA_BWD << 16) | k); prog[base + nf + k] = 0; }
+}
+
 template <int KIND>
-__device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const int lane, const bool is_top)
+__device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, int2* items_next, int* prog_next, const int lane, const bool is_top)
 {
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
@@ -219,17 +246,22 @@ __device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const in
                 const int slot = atomicAdd(&S.nnext, 1);
                 c1.roff = atomicAdd(&S.rowalloc, c1.endb - c1.startb + 1);
                 qnext[slot] = c1;
+                ka_emit_items(S, items_next, prog_next, &S.nitems_next, slot, c1.starta, c1.enda);
         }
         if (c2.starta < c2.enda && c2.startb < c2.endb) {
                 const int slot = atomicAdd(&S.nnext, 1);
                 c2.roff = atomicAdd(&S.rowalloc, c2.endb - c2.startb + 1);
                 qnext[slot] = c2;
+                ka_emit_items(S, items_next, prog_next, &S.nitems_next, slot, c2.starta, c2.enda);
         }
 }
 
 // The whole recursion for the task described by S (all threads of the workgroup).
+// debug breadcrumbs into a host-pinned buffer (KA_TRACE=1): survives a hung kernel
+#define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
+
 template <int KIND, int NRES>
-__device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss)
+__device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
@@ -244,8 +276,11 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                 S.q[0][0] = root;
                 S.ncur = (S.La > 0 && S.Lb > 0) ? 1 : 0;
                 S.nnext = 0; S.rowalloc = 0;
+                S.nitems_cur = 0; S.nitems_next = 0; S.next_item = 0;
+                if (S.ncur) ka_emit_items(S, S.items[0], S.prog[0], &S.nitems_cur, 0, 0, S.La);
                 S.msum = 0.0; S.mcount = 0;
                 S.top_meet = -1; S.top_tr = -1; S.top_score = 0.0f;
+                S.t_pass = 0; S.t_meet = 0; S.n_levels = 0;
         }
         __syncthreads();
         int level = 0;
@@ -254,13 +289,49 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                 if (ncur == 0) break;
                 KaSub* qc = S.q[level & 1];
                 KaSub* qn = S.q[(level + 1) & 1];
-                for (int p = wave; p < 2 * ncur; p += KA_WAVES) {
-                        const KaSub sb = qc[p >> 1];
-                        const int dir = p & 1;
-                        ka_pass<KIND, NRES>(S, sb, dir, (dir == KA_FWD ? S.fbuf : S.bbuf) + sb.roff, lane,
-                                            lds_waves + wave * KA_WAVE_LDS, tss);
+                const long long tp0 = __builtin_amdgcn_s_memtime();
+                {
+                        const int2* items = S.items[level & 1];
+                        int* prog = S.prog[level & 1];
+                        const int nitems = S.nitems_cur;
+                        if (tid == 0 && blockIdx.x == 0) { KA_CRUMB(trace, 0, level); KA_CRUMB(trace, 1, ncur); KA_CRUMB(trace, 2, nitems); }
+                        while (true) {
+                                // One lane takes the next item, then it is broadcast.  The puller lane is
+                                // compared through an opaque copy: with a plain `lane == 0` the optimiser
+                                // threads this test with the `lane == 0` regions inside ka_strip, splits the
+                                // loop per lane set and runs readfirstlane without lane 0 (observed: lanes
+                                // 1..63 spinning on item 0 forever).
+                                int puller = lane;
+                                asm volatile("" : "+v"(puller));
+                                int it = 0;
+                                if (puller == 0) it = atomicAdd(&S.next_item, 1);
+                                it = __builtin_amdgcn_readfirstlane(it);
+                                if (lane == 0 && blockIdx.x == 0) KA_CRUMB(trace, 8 + wave, 1000 * level + it);
+                                if (it >= nitems) break;
+                                // everything about the item is wave-uniform: keep it in SGPRs
+                                const int2 item = items[it];
+                                const int subi = __builtin_amdgcn_readfirstlane(item.x);
+                                const int dk = __builtin_amdgcn_readfirstlane(item.y);
+                                const KaSub* sp = qc + subi;
+                                const int dir = dk >> 16, k = dk & 0xffff;
+                                const int sa = __builtin_amdgcn_readfirstlane(sp->starta);
+                                const int ea = __builtin_amdgcn_readfirstlane(sp->enda);
+                                const int sbb = __builtin_amdgcn_readfirstlane(sp->startb);
+                                const int eb = __builtin_amdgcn_readfirstlane(sp->endb);
+                                const int roff = __builtin_amdgcn_readfirstlane(sp->roff);
+                                const float ja = ka_uniform_f(dir == KA_FWD ? sp->fin.a : sp->bin.a);
+                                const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
+                                const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
+                                ka_strip<KIND, NRES>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                                     (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
+                                                     lds_waves + wave * KA_WAVE_LDS, tss);
+                                if (lane == 0 && blockIdx.x == 0) KA_CRUMB(trace, 16 + wave, 1000 * level + it);
+                        }
                 }
+                if (lane == 0 && blockIdx.x == 0) KA_CRUMB(trace, 24 + wave, 1000 * level + 1);
                 __syncthreads();
+                if (tid == 0 && blockIdx.x == 0) KA_CRUMB(trace, 3, 1000 * level + 1);
+                const long long tp1 = __builtin_amdgcn_s_memtime();
                 if (level == 0 && dbg_rows) {
                         // tests only: keep the top-level rows f[0..Lb], b[0..Lb]
                         const int n = 3 * (S.Lb + 1);
@@ -270,10 +341,16 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                 }
                 for (int k = wave; k < ncur; k += KA_WAVES) {
                         const KaSub sb = qc[k];
-                        ka_meetup<KIND>(S, sb, qn, lane, level == 0);
+                        ka_meetup<KIND>(S, sb, qn, S.items[(level + 1) & 1], S.prog[(level + 1) & 1], lane, level == 0);
                 }
                 __syncthreads();
-                if (tid == 0) { S.ncur = S.nnext; S.nnext = 0; S.rowalloc = 0; }
+                if (tid == 0) {
+                        S.ncur = S.nnext; S.nnext = 0; S.rowalloc = 0;
+                        S.nitems_cur = S.nitems_next; S.nitems_next = 0; S.next_item = 0;
+                        const long long tp2 = __builtin_amdgcn_s_memtime();
+                        S.t_pass += tp1 - tp0; S.t_meet += tp2 - tp1; S.n_levels = level + 1;
+                        if (level < 16) { S.lvl_n[level] = ncur; S.lvl_pass[level] = (int)(tp1 - tp0); S.lvl_meet[level] = (int)(tp2 - tp1); }
+                }
                 __syncthreads();
                 ++level;
         }
@@ -459,8 +536,8 @@ __device__ void ka_make_leaf_profile(const KaTreeDev& D, float* prof, int len, c
 }
 
 // dynamic-LDS layout of a workgroup
-#define KA_LDS_DBG 512
-#define KA_LDS_TSS 528
+#define KA_LDS_DBG 768
+#define KA_LDS_TSS 784
 #define KA_LDS_WAVES (KA_LDS_TSS + 23 * KA_T_STRIDE * 4)          // 2736, multiple of 16
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
 static_assert(sizeof(TaskShared) <= KA_LDS_DBG, "TaskShared outgrew its LDS slot");
@@ -492,6 +569,11 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb)
         const long long nq = (long long)(la < lb ? la : lb) + 4;
         S.q[0] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
         S.q[1] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
+        const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
+        S.items[0] = (int2*)(base + o); o += ka_align_up(ni * 8, 16);
+        S.items[1] = (int2*)(base + o); o += ka_align_up(ni * 8, 16);
+        S.prog[0] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
+        S.prog[1] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
         return o;
 }
 
@@ -499,8 +581,10 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 {
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 4;
+        const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
         return 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
-             + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16) + 64;
+             + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
+             + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16) + 64;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -518,10 +602,14 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         const int task = task_ids[blockIdx.x];
         const KaTaskDesc T = D.tasks[task];
         const int tid = threadIdx.x;
+        const long long tk0 = __builtin_amdgcn_s_memtime();
+        long long tk1 = 0, tk2 = 0, tk3 = 0;
 
+        if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 1);
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
                 S.fail = 0;
+                S.watchdog = D.error; S.trace = D.trace;
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
                 S.profb = D.prof_arena + D.node_prof[T.b];
@@ -574,13 +662,17 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         if (T.nsip_b == 1) ka_make_leaf_profile(D, S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, T.soff);
         ka_build_tss(tss, D.subm, T.soff);
         __syncthreads();
+        tk1 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
 
         // P2
-        if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23>(S, s_dbg, lds_waves, tss);
-        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23>(S, s_dbg, lds_waves, tss);
-        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5>(S, s_dbg, lds_waves, tss);
-        else ka_hirschberg<KA_PP, 23>(S, s_dbg, lds_waves, tss);
+        if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5>(S, s_dbg, lds_waves, tss, D.trace);
+        else ka_hirschberg<KA_PP, 23>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
+        tk2 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 3);
 #undef s_dbg
 
         // P3
@@ -612,11 +704,28 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
                 D.recs[task] = r;
         }
         __syncthreads();
+        tk3 = __builtin_amdgcn_s_memtime();
         if (S.fail) return;
 
         // P4
         for (int i = tid; i < S.alnlen + 2; i += KA_BLOCK) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T);
+        if (D.timing) {
+                __syncthreads();
+                if (tid == 0) {
+                        long long* tm = D.timing + 8ll * task;
+                        tm[0] = tk1 - tk0; tm[1] = tk2 - tk1; tm[2] = tk3 - tk2; tm[3] = __builtin_amdgcn_s_memtime() - tk3;
+                        tm[4] = S.t_pass; tm[5] = S.t_meet; tm[6] = S.n_levels; tm[7] = (long long)S.La * S.Lb;
+                        if (T.is_root) {
+                                long long* lv = D.timing + 8ll * (D.numseq - 1);
+                                for (int l = 0; l < 16; ++l) {
+                                        lv[3 * l] = l < S.n_levels ? S.lvl_n[l] : 0;
+                                        lv[3 * l + 1] = l < S.n_levels ? S.lvl_pass[l] : 0;
+                                        lv[3 * l + 2] = l < S.n_levels ? S.lvl_meet[l] : 0;
+                                }
+                        }
+                }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,6 +744,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.fail = 0;
+                S.watchdog = P.error; S.trace = nullptr;
                 S.kind = KA_SS; S.swapped = swapped;
                 S.len_a = len_i; S.len_b = len_j;
                 S.La = swapped ? len_j : len_i;
@@ -650,7 +760,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
         }
         ka_build_tss(tss, P.subm, 0.0f);
         __syncthreads();
-        ka_hirschberg<KA_SS, 23>(S, nullptr, lds_waves, tss);
+        ka_hirschberg<KA_SS, 23>(S, nullptr, lds_waves, tss, nullptr);
         __syncthreads();
         if (tid == 0) {
                 ka_code_path(S);
@@ -664,13 +774,28 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
 // ------------------------------------------------------------------------------------------
 // launchers (called from ka_api.cpp)
 // ------------------------------------------------------------------------------------------
+// more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+static hipError_t ka_lds_optin()
+{
+        static bool done = false;
+        if (done) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute((const void*)ka_task_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ka_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        done = true;
+        return hipSuccess;
+}
+
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int* task_ids_dev, int ntasks, hipStream_t stream)
 {
+        if (ka_lds_optin() != hipSuccess) return;
         hipLaunchKernelGGL(ka_task_kernel, dim3(ntasks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, task_ids_dev);
 }
 
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 {
+        if (ka_lds_optin() != hipSuccess) return;
         hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *P);
 }
 
