@@ -72,6 +72,8 @@ struct TaskShared {
         int2* items[2];                // work items of the current / next recursion level: (sub-problem, dir<<16 | strip)
         int* prog[2];                  // per-item progress words (columns of the strip's last row published)
         int nitems_cur, nitems_next, next_item;
+        int2* pack[2][2];              // [level parity][class]: small passes (sub-problem, dir); class 0: 16-lane slots, 1: 4-lane slots
+        int npack_cur[2], npack_next[2];
         double msum;
         int mcount;
         int top_meet, top_tr;
@@ -128,20 +130,45 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
         }
 }
 
-// Append the work items of sub-problem `slot` (its forward strips, then its backward strips) to
-// the next level's item list.  Items of one pass are contiguous and ascending, so strip k-1 is
-// always pulled before strip k.
-__device__ __forceinline__ void ka_emit_items(TaskShared& S, int2* items, int* prog, int* counter, int slot, int starta, int enda)
+// Queue the two passes of sub-problem `slot` for the next recursion level.  A pass with more
+// than 32 rows becomes strip items (its strips are contiguous and ascending, so strip k-1 is
+// always pulled before strip k); smaller passes go to the packed lists (16-lane slots for up
+// to 32 rows, 4-lane slots for up to 8 rows).
+struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; };
+
+__device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows)
+{
+        if (nrows > 32) {
+                const int ns = ka_strips_of(nrows);
+                const int base = atomicAdd(o.nitems, ns);
+                for (int k = 0; k < ns; ++k) { o.items[base + k] = make_int2(slot, (dir << 16) | k); o.prog[base + k] = 0; }
+        } else if (nrows > 8) {
+                o.pack16[atomicAdd(o.n16, 1)] = make_int2(slot, dir);
+        } else {
+                o.pack4[atomicAdd(o.n4, 1)] = make_int2(slot, dir);
+        }
+}
+
+__device__ __forceinline__ void ka_emit_items(const KaLevelOut& o, int slot, int starta, int enda)
 {
         const int mid = ((enda - starta) / 2) + starta;
-        const int nf = ka_strips_of(mid - starta), nb = ka_strips_of(enda - mid);
-        const int base = atomicAdd(counter, nf + nb);
-        for (int k = 0; k < nf; ++k) { items[base + k] = make_int2(slot, (KA_FWD << 16) | k); prog[base + k] = 0; }
-        for (int k = 0; k < nb; ++k) { items[base + nf + k] = make_int2(slot, (KA_BWD << 16) | k); prog[base + nf + k] = 0; }
+        ka_emit_pass(o, slot, KA_FWD, mid - starta);
+        ka_emit_pass(o, slot, KA_BWD, enda - mid);
+}
+
+__device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bool next)
+{
+        KaLevelOut o;
+        o.items = S.items[parity]; o.prog = S.prog[parity];
+        o.pack16 = S.pack[parity][0]; o.pack4 = S.pack[parity][1];
+        o.nitems = next ? &S.nitems_next : &S.nitems_cur;
+        o.n16 = next ? &S.npack_next[0] : &S.npack_cur[0];
+        o.n4 = next ? &S.npack_next[1] : &S.npack_cur[1];
+        return o;
 }
 
 template <int KIND>
-__device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, int2* items_next, int* prog_next, const int lane, const bool is_top)
+__device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const KaLevelOut& lout, const int lane, const bool is_top)
 {
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
@@ -246,13 +273,13 @@ __device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, int2* it
                 const int slot = atomicAdd(&S.nnext, 1);
                 c1.roff = atomicAdd(&S.rowalloc, c1.endb - c1.startb + 1);
                 qnext[slot] = c1;
-                ka_emit_items(S, items_next, prog_next, &S.nitems_next, slot, c1.starta, c1.enda);
+                ka_emit_items(lout, slot, c1.starta, c1.enda);
         }
         if (c2.starta < c2.enda && c2.startb < c2.endb) {
                 const int slot = atomicAdd(&S.nnext, 1);
                 c2.roff = atomicAdd(&S.rowalloc, c2.endb - c2.startb + 1);
                 qnext[slot] = c2;
-                ka_emit_items(S, items_next, prog_next, &S.nitems_next, slot, c2.starta, c2.enda);
+                ka_emit_items(lout, slot, c2.starta, c2.enda);
         }
 }
 
@@ -277,7 +304,8 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                 S.ncur = (S.La > 0 && S.Lb > 0) ? 1 : 0;
                 S.nnext = 0; S.rowalloc = 0;
                 S.nitems_cur = 0; S.nitems_next = 0; S.next_item = 0;
-                if (S.ncur) ka_emit_items(S, S.items[0], S.prog[0], &S.nitems_cur, 0, 0, S.La);
+                S.npack_cur[0] = 0; S.npack_cur[1] = 0; S.npack_next[0] = 0; S.npack_next[1] = 0;
+                if (S.ncur) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La);
                 S.msum = 0.0; S.mcount = 0;
                 S.top_meet = -1; S.top_tr = -1; S.top_score = 0.0f;
                 S.t_pass = 0; S.t_meet = 0; S.n_levels = 0;
@@ -294,7 +322,11 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                         const int2* items = S.items[level & 1];
                         int* prog = S.prog[level & 1];
                         const int nitems = S.nitems_cur;
-                        if (tid == 0 && blockIdx.x == 0) { KA_CRUMB(trace, 0, level); KA_CRUMB(trace, 1, ncur); KA_CRUMB(trace, 2, nitems); }
+                        const int n16 = S.npack_cur[0], n4 = S.npack_cur[1];
+                        const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
+                        const int ntotal = nitems + njobs16 + njobs4;
+                        const int2* pack16 = S.pack[level & 1][0];
+                        const int2* pack4 = S.pack[level & 1][1];
                         while (true) {
                                 // One lane takes the next item, then it is broadcast.  The puller lane is
                                 // compared through an opaque copy: with a plain `lane == 0` the optimiser
@@ -306,8 +338,15 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                                 int it = 0;
                                 if (puller == 0) it = atomicAdd(&S.next_item, 1);
                                 it = __builtin_amdgcn_readfirstlane(it);
-                                if (lane == 0 && blockIdx.x == 0) KA_CRUMB(trace, 8 + wave, 1000 * level + it);
-                                if (it >= nitems) break;
+                                if (it >= ntotal) break;
+                                if (it >= nitems + njobs16) {
+                                        ka_packed<KIND, NRES, 4>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss);
+                                        continue;
+                                }
+                                if (it >= nitems) {
+                                        ka_packed<KIND, NRES, 16>(S, qc, pack16, n16, it - nitems, lane, tss);
+                                        continue;
+                                }
                                 // everything about the item is wave-uniform: keep it in SGPRs
                                 const int2 item = items[it];
                                 const int subi = __builtin_amdgcn_readfirstlane(item.x);
@@ -325,10 +364,8 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                                 ka_strip<KIND, NRES>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                      (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
                                                      lds_waves + wave * KA_WAVE_LDS, tss);
-                                if (lane == 0 && blockIdx.x == 0) KA_CRUMB(trace, 16 + wave, 1000 * level + it);
                         }
                 }
-                if (lane == 0 && blockIdx.x == 0) KA_CRUMB(trace, 24 + wave, 1000 * level + 1);
                 __syncthreads();
                 if (tid == 0 && blockIdx.x == 0) KA_CRUMB(trace, 3, 1000 * level + 1);
                 const long long tp1 = __builtin_amdgcn_s_memtime();
@@ -341,12 +378,14 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                 }
                 for (int k = wave; k < ncur; k += KA_WAVES) {
                         const KaSub sb = qc[k];
-                        ka_meetup<KIND>(S, sb, qn, S.items[(level + 1) & 1], S.prog[(level + 1) & 1], lane, level == 0);
+                        ka_meetup<KIND>(S, sb, qn, ka_level_out(S, (level + 1) & 1, true), lane, level == 0);
                 }
                 __syncthreads();
                 if (tid == 0) {
                         S.ncur = S.nnext; S.nnext = 0; S.rowalloc = 0;
                         S.nitems_cur = S.nitems_next; S.nitems_next = 0; S.next_item = 0;
+                        S.npack_cur[0] = S.npack_next[0]; S.npack_cur[1] = S.npack_next[1];
+                        S.npack_next[0] = 0; S.npack_next[1] = 0;
                         const long long tp2 = __builtin_amdgcn_s_memtime();
                         S.t_pass += tp1 - tp0; S.t_meet += tp2 - tp1; S.n_levels = level + 1;
                         if (level < 16) { S.lvl_n[level] = ncur; S.lvl_pass[level] = (int)(tp1 - tp0); S.lvl_meet[level] = (int)(tp2 - tp1); }
@@ -574,6 +613,8 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb)
         S.items[1] = (int2*)(base + o); o += ka_align_up(ni * 8, 16);
         S.prog[0] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
         S.prog[1] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
+        for (int par = 0; par < 2; ++par)
+                for (int cls = 0; cls < 2; ++cls) { S.pack[par][cls] = (int2*)(base + o); o += ka_align_up(2 * nq * 8, 16); }
         return o;
 }
 
@@ -584,7 +625,8 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
         const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
         return 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
-             + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16) + 64;
+             + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
+             + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
 }
 
 // ------------------------------------------------------------------------------------------

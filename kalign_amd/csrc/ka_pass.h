@@ -48,6 +48,23 @@ __device__ __forceinline__ int wave_shr1_i(int x)
         return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);
 }
 
+// lane l <- lane l-1 of src; lane 0 keeps its own `old` (used to splice the boundary state in)
+__device__ __forceinline__ float wave_shr1_old(float old, float src)
+{
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x138, 0xf, 0xf, false));
+}
+// lane l <- lane l+1 of src; lane 63 keeps its own `old` (shift register fed at the top lane)
+__device__ __forceinline__ float wave_shl1_old(float old, float src)
+{
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x130, 0xf, 0xf, false));
+}
+// rotate: lane l <- lane (l+1) mod 64
+__device__ __forceinline__ float wave_rol1(float x)
+{
+        const int xi = __float_as_int(x);
+        return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x134, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ int ka_strips_of(int nrows) { return nrows <= 0 ? 1 : (nrows + KA_STRIP_ROWS - 1) / KA_STRIP_ROWS; }
 
 template <int KIND, int NRES>
@@ -148,11 +165,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
         float dga = -KA_F, dgga = -KA_F, dggb = -KA_F;
         float inia = inj_a, iniga = inj_ga, inigb = inj_gb;
-        float bta = -KA_F, btga = -KA_F, btgb = -KA_F;                // boundary batch (strips > 0)
-        float oba = -KA_F, obga = -KA_F, obgb = -KA_F;                // output batch: lane j holds column 64*b + j
+        // boundary batch (strips > 0): lane 0 always holds the state of column t (rotated every step)
+        float bta = -KA_F, btga = -KA_F, btgb = -KA_F;
+        // output batch of the strip's last row.  FULL strips: a shift register fed at lane 63;
+        // partial strips: lane j holds column 64*b + j
+        float oba = -KA_F, obga = -KA_F, obgb = -KA_F;
         float copen_prev = 0.0f;
         int res2 = 0, resb = 0;
-        float4v q[KA_REC_CHUNKS];
+        float4v q[2][KA_REC_CHUNKS];                                  // column record: current / next step (ping-pong)
 
         auto ring_issue = [&](int nb) {
                 // start the global->LDS copy of column batch nb (32 columns x 7 chunks)
@@ -165,10 +185,10 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 512), 16, 0, 0);
                 }
         };
-        auto ring_read = [&](int vcol) {
+        auto ring_read = [&](float4v* dstq, int vcol) {
                 const char* src = wlds + ((vcol >> 5) & (KA_RING_SLOTS - 1)) * KA_SLOT_BYTES + (vcol & 31) * 16;
 #pragma unroll
-                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) q[ch] = *(const float4v*)(src + ch * 512);
+                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = *(const float4v*)(src + ch * 512);
         };
 
         if (KIND == KA_PP) {
@@ -176,32 +196,37 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 ring_issue(0);
                 ring_issue(1);
                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
-                ring_read(min(max(-lane, 0), ncols));
+                ring_read(q[0], min(max(-lane, 0), ncols));
         }
 
-        // one wavefront step; STEADY = every active lane is strictly inside the column range
-        auto step = [&](const int t, auto steady_tag) {
-                constexpr bool ST = decltype(steady_tag)::value;
+        // One wavefront step.
+        //   ST   : steady state, every active lane is strictly inside the column range (no edge cases)
+        //   FULL : the strip has all 128 rows (64 active lanes, last row = row B of lane 63)
+        //   P    : which half of q[] holds this step's column record (the other half receives the next)
+        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag) {
+                constexpr bool ST = decltype(st_tag)::value;
+                constexpr bool FULL = decltype(full_tag)::value;
+                constexpr int P = decltype(par_tag)::value;
                 const int v = t - lane;
-                const bool inr = ST ? actA : ((v >= 0) && (v <= ncols) && actA);
+                const bool inr = (ST && FULL) ? true : (ST ? actA : ((v >= 0) && (v <= ncols) && actA));
 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
                 if (KIND == KA_PP) {
-                        copen = q[5].w * m2; cext = q[6].x * m2; ctext = q[6].y * m2;
+                        copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
                         col_terms<KIND>(S, 0, copen, cext, ctext);
                         if ((t & 63) == 0) {
                                 const int vv = min(max(t + lane, 1), ncols);
                                 resb = S.s2[REC(vv) - 1];
+                        } else {
+                                resb = __builtin_amdgcn_update_dpp(resb, resb, 0x134, 0xf, 0xf, false);   // wave_rol:1
                         }
-                        res2 = wave_shr1_i(res2);
-                        const int r0_ = __builtin_amdgcn_readlane(resb, t & 63);
-                        if (lane == 0) res2 = r0_;
+                        // lanes > 0 take their upper neighbour's residue, lane 0 the next one of the batch
+                        res2 = __builtin_amdgcn_update_dpp(resb, res2, 0x138, 0xf, 0xf, false);
                 }
 
-                // ---- boundary state for lane 0 at column t ----
-                float b0a, b0ga, b0gb;
+                // ---- state of the row above A: lane l-1's row B, lane 0 takes the boundary ----
                 if (first) {
                         if (t == 0) {
                                 inia = inj_a; iniga = inj_ga; inigb = inj_gb;
@@ -211,30 +236,29 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         } else {
                                 inia = -KA_F; iniga = -KA_F; inigb = -KA_F;
                         }
-                        b0a = inia; b0ga = iniga; b0gb = inigb;
+                        bta = inia; btga = iniga; btgb = inigb;
                 } else {
-                        if ((t & 63) == 0 && t <= ncols) {
-                                // the previous strip must have published columns t .. t+63
-                                const int need = min(t + 64, ncols + 1);
-                                if (lane == 0) {
-                                        // bounded spin: a stuck pipeline must surface as an error, never as a hung GPU
-                                        int spins = 0;
-                                        while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                                                __builtin_amdgcn_s_sleep(2);
-                                                if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                        if ((t & 63) == 0) {
+                                if (t <= ncols) {
+                                        // the previous strip must have published columns t .. t+63
+                                        const int need = min(t + 64, ncols + 1);
+                                        if (lane == 0) {
+                                                // bounded spin: a stuck pipeline must surface as an error, never as a hung GPU
+                                                int spins = 0;
+                                                while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                                                        __builtin_amdgcn_s_sleep(2);
+                                                        if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                                                }
                                         }
+                                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                        const ka_gfloat* r = grows + 3 * IDX(min(t + lane, ncols));
+                                        bta = r[0]; btga = r[1]; btgb = r[2];
                                 }
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                const ka_gfloat* r = grows + 3 * IDX(min(t + lane, ncols));
-                                bta = r[0]; btga = r[1]; btgb = r[2];
+                        } else {
+                                bta = wave_rol1(bta); btga = wave_rol1(btga); btgb = wave_rol1(btgb);
                         }
-                        b0a = lane_bcast(bta, t & 63);
-                        b0ga = lane_bcast(btga, t & 63);
-                        b0gb = lane_bcast(btgb, t & 63);
                 }
-
-                float upa = wave_shr1(cBa), upga = wave_shr1(cBga), upgb = wave_shr1(cBgb);
-                if (lane == 0) { upa = b0a; upga = b0ga; upgb = b0gb; }
+                const float upa = wave_shr1_old(bta, cBa), upga = wave_shr1_old(btga, cBga), upgb = wave_shr1_old(btgb, cBgb);
 
                 // ---- the two cells of this lane ----
                 float2v acc;
@@ -247,20 +271,20 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         acc.x += sp_tbl[(2 * lane) * KA_SP_STRIDE + res2];
                         acc.y += sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2];
                 } else {
-#pragma unroll
-                        for (int c = NRES - 1; c >= 0; --c) {
-                                const float sc = q[c >> 2][c & 3];
-                                float2v w; w.x = sc; w.y = sc;
-                                acc = acc + p1v[c] * w;
-                        }
-                        // q is dead: fetch the next step's column record now so the LDS latency
-                        // hides behind the rest of this step
+                        // fetch the next step's column record into the other half of q while this
+                        // step's dot products run
                         const int tn = t + 1;
                         if ((tn & (KA_RING_BATCH - 1)) == 0) {
                                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
                                 ring_issue((tn >> 5) + 1);
                         }
-                        ring_read(ST ? (v + 1) : min(max(v + 1, 0), ncols));
+                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols));
+#pragma unroll
+                        for (int c = NRES - 1; c >= 0; --c) {
+                                const float sc = q[P][c >> 2][c & 3];
+                                float2v w; w.x = sc; w.y = sc;
+                                acc = acc + p1v[c] * w;
+                        }
                 }
                 float nAa, nAga, nAgb, nBa, nBga, nBgb;
                 if (ST) {
@@ -289,17 +313,24 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 dga = upa; dgga = upga; dggb = upgb;
                 copen_prev = copen;
 
-                // ---- collect the strip's last row: column vL of lane `lastl` goes to lane vL & 63 ----
+                // ---- collect the strip's last row and hand it on 64 columns at a time ----
                 const int vL = t - lastl;
                 if (ST || (vL >= 0 && vL <= ncols)) {
-                        const float la = lane_bcast(last_is_b ? cBa : cAa, lastl);
-                        const float lga = lane_bcast(last_is_b ? cBga : cAga, lastl);
-                        const float lgb = lane_bcast(last_is_b ? cBgb : cAgb, lastl);
-                        if (lane == (vL & 63)) { oba = la; obga = lga; obgb = lgb; }
+                        if (FULL) {
+                                // shift register: lane 63 (the last row's owner) feeds its fresh state in
+                                oba = wave_shl1_old(cBa, oba); obga = wave_shl1_old(cBga, obga); obgb = wave_shl1_old(cBgb, obgb);
+                        } else {
+                                const float la = lane_bcast(last_is_b ? cBa : cAa, lastl);
+                                const float lga = lane_bcast(last_is_b ? cBga : cAga, lastl);
+                                const float lgb = lane_bcast(last_is_b ? cBgb : cAgb, lastl);
+                                if (lane == (vL & 63)) { oba = la; obga = lga; obgb = lgb; }
+                        }
                         if ((vL & 63) == 63 || vL == ncols) {
+                                // FULL: lane i holds column vL - 63 + i; partial: lane i holds column (vL & ~63) + i
                                 const int c0 = vL & ~63;
-                                if (c0 + lane <= vL) {
-                                        ka_gfloat* w = grows + 3 * IDX(c0 + lane);
+                                const int col = FULL ? (vL - 63 + lane) : (c0 + lane);
+                                if (col >= c0 && col <= vL) {
+                                        ka_gfloat* w = grows + 3 * IDX(col);
                                         w[0] = oba; w[1] = obga; w[2] = obgb;
                                 }
                                 // publish: the next strip (another wave of this workgroup) may read them
@@ -309,23 +340,209 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 }
         };
 
+        // run steps [t, tend): pairs with alternating q halves; an odd leftover step is followed
+        // by a copy so that every phase starts on half 0
+        auto run = [&](int& t, const int tend, auto st_tag, auto full_tag) {
+                for (; t + 1 < tend; t += 2) {
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>());
+                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>());
+                }
+                if (t < tend) {
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>());
+                        if (KIND == KA_PP) {
+#pragma unroll
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) q[0][ch] = q[1][ch];
+                        }
+                        ++t;
+                }
+        };
+
         const int nsteps = ncols + nl;                                // t = 0 .. ncols + nl - 1
-        const int t_steady0 = nl;                                     // first step with every active lane at v >= 1
-        const int t_steady1 = ncols - 1;                              // last step with every active lane at v <= ncols-1
+        const int t_steady0 = min(nl, nsteps);                        // first step with every active lane at v >= 1
+        const int t_steady1 = ncols;                                  // one past the last step with every lane at v <= ncols-1
         int t = 0;
-#ifdef KA_TRACE_STRIP
-        volatile int* tr = (volatile int*)S.trace;
-        const int wv = threadIdx.x >> 6;
-        if (tr && blockIdx.x == 0 && lane == 0) { tr[32 + wv] = nrows * 1000 + ncols; tr[40 + wv] = dir * 100000 + starta * 100 + startb; tr[48 + wv] = -5; __threadfence_system(); }
-        for (; t < min(t_steady0, nsteps); ++t) { step(t, std::false_type()); if (tr && blockIdx.x == 0 && lane == 0) { tr[48 + wv] = t; __threadfence_system(); } }
-        for (; t <= t_steady1; ++t) { step(t, std::true_type()); if (tr && blockIdx.x == 0 && lane == 0) { tr[48 + wv] = 10000 + t; __threadfence_system(); } }
-        for (; t < nsteps; ++t) { step(t, std::false_type()); if (tr && blockIdx.x == 0 && lane == 0) { tr[48 + wv] = 20000 + t; __threadfence_system(); } }
-        if (tr && blockIdx.x == 0 && lane == 0) { tr[56 + wv] = nsteps; __threadfence_system(); }
-#else
-        for (; t < min(t_steady0, nsteps); ++t) step(t, std::false_type());
-        for (; t <= t_steady1; ++t) step(t, std::true_type());
-        for (; t < nsteps; ++t) step(t, std::false_type());
-#endif
+        if (nr == KA_STRIP_ROWS) {
+                run(t, t_steady0, std::false_type(), std::true_type());
+                run(t, t_steady1, std::true_type(), std::true_type());
+                run(t, nsteps, std::false_type(), std::true_type());
+        } else {
+                run(t, t_steady0, std::false_type(), std::false_type());
+                run(t, t_steady1, std::true_type(), std::false_type());
+                run(t, nsteps, std::false_type(), std::false_type());
+        }
+#undef REC
+#undef IDX
+}
+
+// ------------------------------------------------------------------------------------------
+// Packed passes: below the top few recursion levels a task has hundreds of tiny sub-problems
+// (a few rows x a few dozen columns).  One wave per pass would be almost pure latency, so
+// small passes (<= 2*SLOT rows) are packed SLOT lanes apiece, 64/SLOT passes per wave, and
+// stepped in lock-step.  Same cell code as ka_strip, but everything that is wave-uniform
+// there (window, direction, terminal flags, row-buffer base) is per-lane here, the column
+// record comes straight from L2 one step ahead instead of the LDS ring, and the slot's last
+// lane writes the last row state by state.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int NRES, int SLOT>
+__device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, const int2* pack, const int nslots,
+                                          const int job, const int lane, const float* tss)
+{
+        constexpr int SPW = 64 / SLOT;                                // slots per wave
+        const int slot = job * SPW + lane / SLOT;
+        const int ls = lane % SLOT;                                   // lane within the slot
+        const bool live = slot < nslots;
+        const int2 d = pack[live ? slot : 0];
+        const KaSub* sp = qc + d.x;
+        const int dir = d.y;
+        const int starta = sp->starta, enda = sp->enda, startb = sp->startb, endb = sp->endb;
+        const int ncols = endb - startb;
+        const int mid = ((enda - starta) / 2) + starta;
+        const int r0 = (dir == KA_FWD) ? starta : mid;
+        const int r1 = (dir == KA_FWD) ? mid : enda;
+        const int nrows = r1 - r0;                                    // 0 .. 2*SLOT
+        const int nl = (nrows + 1) >> 1;                              // active lanes of the slot (0 for an init-only pass)
+        const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == S.Lb);
+        const bool far_t = (dir == KA_FWD) ? (endb == S.Lb) : (startb == 0);
+        const float inj_a = (dir == KA_FWD) ? sp->fin.a : sp->bin.a;
+        const float inj_ga = (dir == KA_FWD) ? sp->fin.ga : sp->bin.ga;
+        const float inj_gb = (dir == KA_FWD) ? sp->fin.gb : sp->bin.gb;
+        ka_gfloat* const grows = (ka_gfloat*)(((dir == KA_FWD) ? S.fbuf : S.bbuf) + sp->roff);
+
+#define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
+#define IDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
+
+        const bool actA = live && (2 * ls < nrows);
+        const bool actB = live && (2 * ls + 1 < nrows);
+        const bool writer = live && (ls == (nl > 0 ? nl - 1 : 0));    // owner of the pass's last row (or of the init row)
+        const bool last_is_b = (nrows & 1) == 0;
+        const int uA = min(2 * ls, max(nrows - 1, 0));
+        const int uB = min(2 * ls + 1, max(nrows - 1, 0));
+        const int iA = (dir == KA_FWD) ? (r0 + uA) : (r1 - 1 - uA);
+        const int iB = (dir == KA_FWD) ? (r0 + uB) : (r1 - 1 - uB);
+        const int recA = iA + 1, recB = iB + 1;
+        const int prevA = (dir == KA_FWD) ? recA - 1 : recA + 1;
+        const int prevB = (dir == KA_FWD) ? recB - 1 : recB + 1;
+        const float m1 = S.p1_mult, m2 = S.p2_mult;
+
+        float oA, eA, tA, oB, eB, tB, orpA, orpB;
+        float2v p1v[NRES];
+        int res1A = 0, res1B = 0;
+        const float* pA = nullptr;
+        const float* pB = nullptr;
+        if (KIND == KA_SS) {
+                oA = oB = -S.gpo; eA = eB = -S.gpe; tA = tB = -S.tgpe; orpA = orpB = -S.gpo;
+                res1A = S.s1[min(iA, S.La - 1)] * KA_T_STRIDE; res1B = S.s1[min(iB, S.La - 1)] * KA_T_STRIDE;
+        } else {
+                pA = S.p1 + ((long long)min(recA, S.La + 1) << 6);
+                pB = S.p1 + ((long long)min(recB, S.La + 1) << 6);
+                oA = pA[55] * m1; eA = pA[56] * m1; tA = pA[57] * m1;
+                oB = pB[55] * m1; eB = pB[56] * m1; tB = pB[57] * m1;
+                orpA = S.p1[((long long)min(prevA, S.La + 1) << 6) + 55] * m1;
+                orpB = S.p1[((long long)min(prevB, S.La + 1) << 6) + 55] * m1;
+                if (KIND == KA_PP) {
+#pragma unroll
+                        for (int c = 0; c < NRES; ++c) {
+                                p1v[c].x = pA[c];
+                                p1v[c].y = actB ? pB[c] : 0.0f;
+                        }
+                }
+        }
+
+        float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
+        float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
+        float dga = -KA_F, dgga = -KA_F, dggb = -KA_F;
+        float inia = inj_a, iniga = inj_ga, inigb = inj_gb;
+        float copen_prev = 0.0f;
+        float4v q[2][KA_REC_CHUNKS];
+        int resq[2] = {0, 0};
+
+        auto fetch = [&](float4v* dstq, int& dstres, int vcol) {
+                // column operand for column counter vcol (clamped), straight from L2
+                const int vv = min(max(vcol, 0), ncols);
+                if (KIND == KA_PP) {
+                        const float4v* g = (const float4v*)(S.p2 + ((long long)REC(vv) << 6) + 32);
+#pragma unroll
+                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = g[ch];
+                } else {
+                        dstres = S.s2[min(max(REC(max(vv, 1)) - 1, 0), S.Lb - 1)];
+                }
+        };
+        fetch(q[0], resq[0], -ls);
+
+        int nsteps = live ? (ncols + max(nl, 1)) : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, off, 64));
+
+        auto step = [&](const int t, auto par_tag) {
+                constexpr int P = decltype(par_tag)::value;
+                const int v = t - ls;
+                const bool vin = live && (v >= 0) && (v <= ncols);
+                fetch(q[1 - P], resq[1 - P], v + 1);
+
+                float copen, cext, ctext;
+                if (KIND == KA_PP) { copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2; }
+                else col_terms<KIND>(S, 0, copen, cext, ctext);
+
+                // "row -1" of the pass, generated by the slot's first lane (v == t there)
+                if (v == 0) {
+                        inia = inj_a; iniga = inj_ga; inigb = inj_gb;
+                } else if (v < ncols) {
+                        const float g = near_t ? kmax(iniga, inia) + ctext : kmax(iniga + cext, inia + copen);
+                        inia = -KA_F; iniga = g; inigb = -KA_F;
+                } else {
+                        inia = -KA_F; iniga = -KA_F; inigb = -KA_F;
+                }
+                float upa = wave_shr1(cBa), upga = wave_shr1(cBga), upgb = wave_shr1(cBgb);
+                if (ls == 0) { upa = inia; upga = iniga; upgb = inigb; }
+
+                float2v acc;
+                acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
+                acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
+                if (KIND == KA_SS) {
+                        acc.x += tss[res1A + resq[P]];
+                        acc.y += tss[res1B + resq[P]];
+                } else if (KIND == KA_SP) {
+                        acc.x += pA[32 + resq[P]];
+                        acc.y += pB[32 + resq[P]];
+                } else {
+#pragma unroll
+                        for (int c = NRES - 1; c >= 0; --c) {
+                                const float sc = q[P][c >> 2][c & 3];
+                                float2v w; w.x = sc; w.y = sc;
+                                acc = acc + p1v[c] * w;
+                        }
+                }
+                const bool at0 = (v == 0), atN = (v == ncols);
+                const bool edge = at0 || atN;
+                const bool term = (at0 && near_t) || (atN && far_t);
+                const float nAa = at0 ? -KA_F : acc.x;
+                const float nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
+                const float nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
+                const float nBa = at0 ? -KA_F : acc.y;
+                const float nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
+                const float nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
+                if (vin && actA) {
+                        cAa = nAa; cAga = nAga; cAgb = nAgb;
+                        cBa = nBa; cBga = nBga; cBgb = nBgb;
+                }
+                dga = upa; dgga = upga; dggb = upgb;
+                copen_prev = copen;
+                if (vin && writer) {
+                        ka_gfloat* w = grows + 3 * IDX(v);
+                        if (nrows == 0) { w[0] = inia; w[1] = iniga; w[2] = inigb; }
+                        else {
+                                w[0] = last_is_b ? cBa : cAa;
+                                w[1] = last_is_b ? cBga : cAga;
+                                w[2] = last_is_b ? cBgb : cAgb;
+                        }
+                }
+        };
+        int t = 0;
+        for (; t + 1 < nsteps; t += 2) {
+                step(t, std::integral_constant<int, 0>());
+                step(t + 1, std::integral_constant<int, 1>());
+        }
+        if (t < nsteps) step(t, std::integral_constant<int, 0>());
 #undef REC
 #undef IDX
 }
