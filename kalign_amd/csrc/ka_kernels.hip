@@ -396,62 +396,79 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
 }
 
 // ------------------------------------------------------------------------------------------
-// P3: mirror + coding of the raw path (one thread; see oracle/kalign_oracle.c:ko_code_path for
-// the as-executed semantics of add_gap_info_to_path_n).  Also records, per output column,
-// which record of profile a / b feeds it (srcA/srcB, -1 = none) for the parallel update_n.
+// P3: mirror + coding of the raw path by the whole workgroup (see
+// oracle/kalign_oracle.c:ko_code_path for the as-executed semantics of add_gap_info_to_path_n).
+// Row i of the (a-indexed) raw path emits g_i gap-in-a ops followed by one op (match or
+// gap-in-b); two block-wide prefix sums (ops emitted, b positions consumed) place every row's
+// ops independently.  Also records, per output column, which record of profile a / b feeds
+// it (srcA/srcB, -1 = none) for the parallel update_n.  `lds` = 2*KA_BLOCK+4 ints of scratch.
 // ------------------------------------------------------------------------------------------
-__device__ void ka_code_path(TaskShared& S)
+__device__ void ka_code_path(TaskShared& S, int* lds)
 {
+        const int tid = threadIdx.x;
         const int len_a = S.len_a, len_b = S.len_b;
         const int* raw = S.raw;
         if (S.swapped) {
                 int* r2 = S.raw2;
-                for (int i = 0; i < len_a + 2; ++i) r2[i] = -1;
-                for (int i = 1; i <= len_b; ++i) if (raw[i] != -1) r2[raw[i]] = i;
+                for (int i = tid; i < len_a + 2; i += KA_BLOCK) r2[i] = -1;
+                __syncthreads();
+                for (int i = 1 + tid; i <= len_b; i += KA_BLOCK) { const int c = S.raw[i]; if (c != -1) r2[c] = i; }
+                __syncthreads();
                 raw = r2;
         }
         int* o = S.coded;
-        int j = 1, prev;
-        if (raw[1] == -1) {
-                o[j++] = 2;
-        } else {
-                for (int k = 0; k < raw[1] - 1; ++k) o[j++] = 1;
-                o[j++] = 0;
+        int* tot_ops = lds;
+        int* tot_b = lds + KA_BLOCK;
+        int* zmin = lds + 2 * KA_BLOCK;
+        int* zmax = zmin + 1;
+        // rows [lo, hi) of this thread (1-based rows 1..len_a)
+        const int per = (len_a + KA_BLOCK - 1) / KA_BLOCK;
+        const int lo = 1 + tid * per, hi = min(len_a + 1, lo + per);
+        auto row_gaps = [&](int i, int cur, int prev) -> int {
+                // gap-in-a ops emitted before row i's own op (aln_setup.c:145-188)
+                if (cur == -1) return 0;
+                if (i == 1) return cur - 1;
+                return (cur - 1 != prev && prev != -1) ? (cur - prev - 1) : 0;
+        };
+        int nops = 0, nb = 0;
+        for (int i = lo; i < hi; ++i) {
+                const int cur = raw[i], prev = (i > 1) ? raw[i - 1] : -1;
+                const int g = row_gaps(i, cur, prev);
+                nops += g + 1;
+                nb += g + (cur != -1 ? 1 : 0);
         }
-        prev = raw[1];
-        for (int i = 2; i <= len_a; ++i) {
-                if (raw[i] == -1) {
-                        o[j++] = 2;
-                } else {
-                        if (raw[i] - 1 != prev && prev != -1) {
-                                for (int k = 0; k < raw[i] - prev - 1; ++k) o[j++] = 1;
-                        }
-                        o[j++] = 0;
-                }
-                prev = raw[i];
+        tot_ops[tid] = nops; tot_b[tid] = nb;
+        if (tid == 0) { *zmin = 0x7fffffff; *zmax = 0; }
+        __syncthreads();
+        int off = 0, offb = 0, all_ops = 0;
+        for (int k = 0; k < KA_BLOCK; ++k) {
+                const int a = tot_ops[k];
+                if (k < tid) { off += a; offb += tot_b[k]; }
+                all_ops += a;
         }
-        if (raw[len_a] < len_b && raw[len_a] != -1) {
-                for (int k = 0; k < len_b - raw[len_a]; ++k) o[j++] = 1;
+        // trailing gap-in-a run (aln_setup.c:180-186)
+        const int last = raw[len_a];
+        const int tail = (last != -1 && last < len_b) ? (len_b - last) : 0;
+        const int alnlen = all_ops + tail;
+        int total_b = 0;
+        for (int k = 0; k < KA_BLOCK; ++k) total_b += tot_b[k];
+        int j = 1 + off, rb = 1 + offb;
+        for (int i = lo; i < hi; ++i) {
+                const int cur = raw[i], prev = (i > 1) ? raw[i - 1] : -1;
+                const int g = row_gaps(i, cur, prev);
+                for (int k = 0; k < g; ++k) { o[j] = 1; S.srcA[j] = -1; S.srcB[j] = rb++; ++j; }
+                if (cur == -1) { o[j] = 2; S.srcA[j] = i; S.srcB[j] = -1; }
+                else { o[j] = 0; S.srcA[j] = i; S.srcB[j] = rb++; atomicMin(zmin, j); atomicMax(zmax, j); }
+                ++j;
         }
-        const int alnlen = j - 1;
-        o[0] = alnlen;
-        o[j] = 3;
-        // terminal-run flag (aln_setup.c:209-219); the 4/8/16 flag loop never executes in the reference
-        {
-                int i = 1;
-                while (i <= alnlen && o[i] != 0) { o[i] |= 32; ++i; }
-                i = alnlen;
-                while (i >= 1 && o[i] != 0) { o[i] |= 32; --i; }
-        }
-        // source records for update_n
-        int ra = 1, rb = 1;
-        for (int c = 1; c <= alnlen; ++c) {
-                const int code = o[c];
-                if (!code) { S.srcA[c] = ra++; S.srcB[c] = rb++; }
-                else if (code & 1) { S.srcA[c] = -1; S.srcB[c] = rb++; }
-                else { S.srcA[c] = ra++; S.srcB[c] = -1; }
-        }
-        S.alnlen = alnlen;
+        for (int k = tid; k < tail; k += KA_BLOCK) { o[1 + all_ops + k] = 1; S.srcA[1 + all_ops + k] = -1; S.srcB[1 + all_ops + k] = 1 + total_b + k; }
+        if (tid == 0) { o[0] = alnlen; o[alnlen + 1] = 3; S.alnlen = alnlen; }
+        __syncthreads();
+        // terminal-run flag (aln_setup.c:209-219): everything before the first and after the last
+        // match column; the 4/8/16 flag loop never executes in the reference
+        const int z1 = *zmin, z2 = *zmax;
+        for (int c = 1 + tid; c <= alnlen; c += KA_BLOCK) if (c < z1 || c > z2) o[c] |= 32;
+        __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -718,8 +735,8 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
 #undef s_dbg
 
         // P3
+        ka_code_path(S, (int*)lds_waves);
         if (tid == 0) {
-                ka_code_path(S);
                 const int alnlen = S.alnlen;
                 const unsigned long long pn = (unsigned long long)alnlen + 2;
                 const unsigned long long po = atomicAdd(&D.counters[2], pn);
@@ -804,10 +821,8 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
         __syncthreads();
         ka_hirschberg<KA_SS, 23>(S, nullptr, lds_waves, tss, nullptr);
         __syncthreads();
-        if (tid == 0) {
-                ka_code_path(S);
-                if (P.scores) P.scores[k] = S.top_score;
-        }
+        ka_code_path(S, (int*)lds_waves);
+        if (tid == 0 && P.scores) P.scores[k] = S.top_score;
         __syncthreads();
         int* dst = P.paths_out + P.poff[k];
         for (int i = tid; i < S.alnlen + 2; i += KA_BLOCK) dst[i] = S.coded[i];
