@@ -119,10 +119,10 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist_on = world > 1
+    from kalign_amd import dist as kd
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        kd.init("nccl", device=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
 
     codes, tasks, seq_dist = make_workload(args.nseq, args.len, args.dna, seed=1 + rank)
     subm, scal = scoring(args.dna)
@@ -146,19 +146,12 @@ def main():
     ctx.tree_sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = kd.reduce_scalar(elapsed, "max", device="cuda")      # MAX over ranks
 
     recs, paths, _ = ctx.tree_download(want_gaps=False)
     cells = float(sum(r.len_a * r.len_b for r in recs))
     kern_ms, n_launch = ctx.tree_kernel_ms()          # HIP events on the launch stream, last step
-    total_cells = cells
-    if dist_on:
-        t = torch.tensor([cells], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_cells = float(t.item())
+    total_cells = kd.reduce_scalar(cells, "sum", device="cuda")    # every rank aligned its own set
 
     if rank == 0:
         abytes = algorithmic_bytes(recs)
