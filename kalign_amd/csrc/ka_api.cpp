@@ -18,7 +18,8 @@
 
 #include "ka_device.h"
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int* task_ids_dev, int ntasks, hipStream_t stream);
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
+extern "C" long long ka_ctl_bytes_host(void);
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb);
 
@@ -59,6 +60,9 @@ struct ka_ctx {
         std::vector<KaTaskDesc> descs;
         std::vector<std::vector<int>> levels;        // task ids per dependency level
         std::vector<int> level_ids_flat, level_off;
+        std::vector<int2> blocks_flat;               // per level: (task, member | cluster size << 8) per workgroup
+        std::vector<int> blocks_off;
+        int max_cluster = 4;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
         std::vector<long long> leaf_prof_off;
         long long leaf_prof_total = 0;
         long long sum_len = 0;
@@ -71,7 +75,8 @@ struct ka_ctx {
         DevBuf<long long> d_node_prof, d_dbg_off, d_timing;
         DevBuf<float> d_prof_arena, d_subm, d_dbg_arena;
         DevBuf<unsigned long long> d_counters;
-        DevBuf<char> d_scratch;
+        DevBuf<char> d_scratch, d_ctl;
+        DevBuf<int2> d_blocks;
         DevBuf<KaTaskDesc> d_tasks;
         DevBuf<ka_task_rec> d_recs;
         long long prof_cap = 0, path_cap = 0, scratch_cap = 0, dbg_cap = 0;
@@ -113,6 +118,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_path_arena.release(); c->d_error.release(); c->d_node_prof.release(); c->d_dbg_off.release();
         c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
         c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release(); c->d_timing.release();
+        c->d_ctl.release(); c->d_blocks.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -220,6 +226,25 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 c->level_off.push_back((int)c->level_ids_flat.size());
         }
 
+        // ---- workgroup tables: near the top of the tree there are fewer tasks than CUs, so a task
+        // gets a cluster of up to max_cluster workgroups (the kernel decides from the actual operand
+        // lengths how many of them it uses).  Workgroups of one cluster are spaced 8 blocks apart:
+        // block b runs on XCD b % 8 (observed, not contractual -- used for L2 locality only).
+        if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
+        c->blocks_flat.clear(); c->blocks_off.assign(1, 0);
+        for (auto& L : c->levels) {
+                const int nt = (int)L.size();
+                int G = 1;
+                while (G * 2 <= c->max_cluster && nt * G * 2 <= 256) G *= 2;
+                const int groups = (nt + 7) / 8;
+                std::vector<int2> tbl((size_t)groups * 8 * G, make_int2(-1, 0));
+                for (int j = 0; j < nt; j++)
+                        for (int m = 0; m < G; m++)
+                                tbl[(size_t)(j % 8) + 8 * ((size_t)m + (size_t)G * (j / 8))] = make_int2(L[j], m | (G << 8));
+                c->blocks_flat.insert(c->blocks_flat.end(), tbl.begin(), tbl.end());
+                c->blocks_off.push_back((int)c->blocks_flat.size());
+        }
+
         // ---- arenas ----
         c->leaf_prof_off.assign(numseq, 0);
         long long top = 0;
@@ -242,7 +267,8 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
             c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
             c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
-            c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 64) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
+            c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 64) ||
+            c->d_ctl.alloc((size_t)ka_ctl_bytes_host() * n_tasks) || c->d_blocks.alloc(c->blocks_flat.size()) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
             c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
             c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
                 return fail("hipMalloc failed");
@@ -250,6 +276,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         HIPCHK(hipMemcpyAsync(c->d_seq_off.p, off, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_level_ids.p, c->level_ids_flat.data(), sizeof(int) * c->level_ids_flat.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_tasks.p, c->descs.data(), sizeof(KaTaskDesc) * n_tasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_blocks.p, c->blocks_flat.data(), sizeof(int2) * c->blocks_flat.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_subm.p, subm, sizeof(float) * 23 * 23, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_job = true;
@@ -269,6 +296,7 @@ static int tree_launch(ka_ctx* c)
         HIPCHK(hipMemcpyAsync(c->d_node_prof.p, node_prof.data(), sizeof(long long) * nprof, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_counters.p, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_error.p, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_ctl.p, 0, (size_t)ka_ctl_bytes_host() * c->n_tasks, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));          // the staging vectors above are stack/heap temporaries
 
         KaTreeDev D;
@@ -279,6 +307,7 @@ static int tree_launch(ka_ctx* c)
         D.scratch = c->d_scratch.p; D.path_arena = c->d_path_arena.p;
         D.dbg_arena = c->d_dbg_arena.p; D.dbg_off = c->d_dbg_off.p;
         D.tasks = c->d_tasks.p; D.recs = c->d_recs.p; D.subm = c->d_subm.p;
+        D.ctl = (KaCtl*)c->d_ctl.p;
         D.gpo0 = c->scal[0]; D.gpe0 = c->scal[1]; D.tgpe0 = c->scal[2]; D.usw = c->scal[5];
         D.numseq = numseq; D.flags = c->flags; D.error = c->d_error.p;
         D.nres = c->nres;
@@ -291,7 +320,7 @@ static int tree_launch(ka_ctx* c)
                 const int n = (int)c->levels[L].size();
                 if (!n) continue;
                 if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
-                ka_launch_task_level(&D, c->d_level_ids.p + c->level_off[L], n, c->stream);
+                ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->stream);
                 c->n_launches++;
         }
         HIPCHK(hipGetLastError());
@@ -322,7 +351,8 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         c->synced = true;
                         return KA_OK;
                 }
-                if (err == 5) return fail("device watchdog: a strip pipeline inside a workgroup stopped making progress");
+                if (err == 5) return fail("device watchdog: a strip pipeline stopped making progress");
+                if (err == 6) return fail("device watchdog: a cluster barrier was never completed (workgroups of one task not co-resident?)");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)
                 if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
                 else if (err == 2) { c->scratch_cap *= 2; c->d_scratch.release(); }

@@ -31,6 +31,8 @@ struct KaSub {
         int pad;
 };
 
+struct KaCtl;
+
 struct KaTreeDev {
         const uint8_t* codes;
         const int* seq_off;
@@ -44,6 +46,7 @@ struct KaTreeDev {
         float* dbg_arena;
         long long* dbg_off;            // [n_tasks] offset of the task's debug rows, -1 if none
         const KaTaskDesc* tasks;
+        KaCtl* ctl;                    // [n_tasks] cluster control blocks, zeroed before every run
         ka_task_rec* recs;
         const float* subm;             // 23*23
         float gpo0, gpe0, tgpe0, usw;  // unscaled penalties for update_n, use_seq_weights

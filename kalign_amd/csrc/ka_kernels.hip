@@ -45,6 +45,25 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane)
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
 }
 
+// The mutable state of one task's recursion: lives in LDS when one workgroup owns the task, in
+// HBM (zeroed by the host before the run) when a cluster of workgroups on different CUs shares it.
+struct KaCtl {
+        int ncur, nnext, rowalloc;
+        int nitems_cur, nitems_next, next_item;
+        int npack_cur[2], npack_next[2];
+        int mcount;
+        int top_meet, top_tr;
+        float top_score;
+        double msum;
+        int alnlen;
+        int fail;
+        unsigned int bar;               // cluster barrier: arrivals so far (monotonic)
+        int pad;
+        long long scratch_off;          // cluster: scratch block allocated by member 0
+        long long newp_off;             // merged profile offset in the arena (-1: root / none)
+        long long path_off;             // coded path offset in the path arena
+};
+
 // Everything the waves of a workgroup share about the task being aligned.
 struct TaskShared {
         int kind, swapped;
@@ -68,20 +87,15 @@ struct TaskShared {
         int* coded;
         int* srcA;
         int* srcB;
-        int ncur, nnext, rowalloc;
+        KaCtl* ctl;                    // -> ctl_lds (one workgroup) or the task's block in HBM (cluster)
+        KaCtl ctl_lds;
+        int G, member;                 // cluster size / this workgroup's index in it
+        unsigned int bar_phase;        // cluster barriers passed so far
         int2* items[2];                // work items of the current / next recursion level: (sub-problem, dir<<16 | strip)
         int* prog[2];                  // per-item progress words (columns of the strip's last row published)
-        int nitems_cur, nitems_next, next_item;
         int2* pack[2][2];              // [level parity][class]: small passes (sub-problem, dir); class 0: 16-lane slots, 1: 4-lane slots
-        int npack_cur[2], npack_next[2];
-        double msum;
-        int mcount;
-        int top_meet, top_tr;
-        float top_score;
-        int alnlen;
         float* newp;
         int* path_dst;
-        int fail;
         int* trace;
         int* watchdog;                 // device error word: a bounded spin that expired writes 5 here
         long long t_pass, t_meet;      // KA_FLAG_TIMING: shader-clock cycles spent in passes / meetups
@@ -161,9 +175,9 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         KaLevelOut o;
         o.items = S.items[parity]; o.prog = S.prog[parity];
         o.pack16 = S.pack[parity][0]; o.pack4 = S.pack[parity][1];
-        o.nitems = next ? &S.nitems_next : &S.nitems_cur;
-        o.n16 = next ? &S.npack_next[0] : &S.npack_cur[0];
-        o.n4 = next ? &S.npack_next[1] : &S.npack_cur[1];
+        o.nitems = next ? &S.ctl->nitems_next : &S.ctl->nitems_cur;
+        o.n16 = next ? &S.ctl->npack_next[0] : &S.ctl->npack_cur[0];
+        o.n4 = next ? &S.ctl->npack_next[1] : &S.ctl->npack_cur[1];
         return o;
 }
 
@@ -224,10 +238,10 @@ __device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const Ka
                 tr = ord + 1 + (ord >= 3 ? 1 : 0);
         }
         if (B.mx2 > -KA_F) {
-                atomicAdd(&S.msum, (double)(B.mx - B.mx2));
-                atomicAdd(&S.mcount, 1);
+                atomicAdd(&S.ctl->msum, (double)(B.mx - B.mx2));
+                atomicAdd(&S.ctl->mcount, 1);
         }
-        if (is_top) { S.top_meet = meet; S.top_tr = tr; S.top_score = B.mx; }
+        if (is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
         if (tr < 0) return;
 
         const KaState Z = { 0.0f, -KA_F, -KA_F };
@@ -270,20 +284,44 @@ __device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const Ka
                 break;
         }
         if (c1.starta < c1.enda && c1.startb < c1.endb) {
-                const int slot = atomicAdd(&S.nnext, 1);
-                c1.roff = atomicAdd(&S.rowalloc, c1.endb - c1.startb + 1);
+                const int slot = atomicAdd(&S.ctl->nnext, 1);
+                c1.roff = atomicAdd(&S.ctl->rowalloc, c1.endb - c1.startb + 1);
                 qnext[slot] = c1;
                 ka_emit_items(lout, slot, c1.starta, c1.enda);
         }
         if (c2.starta < c2.enda && c2.startb < c2.endb) {
-                const int slot = atomicAdd(&S.nnext, 1);
-                c2.roff = atomicAdd(&S.rowalloc, c2.endb - c2.startb + 1);
+                const int slot = atomicAdd(&S.ctl->nnext, 1);
+                c2.roff = atomicAdd(&S.ctl->rowalloc, c2.endb - c2.startb + 1);
                 qnext[slot] = c2;
                 ka_emit_items(lout, slot, c2.starta, c2.enda);
         }
 }
 
 // The whole recursion for the task described by S (all threads of the workgroup).
+// Barrier over all workgroups of the task's cluster (plain __syncthreads for a single workgroup).
+// Monotonic arrival counter in HBM; lane 0 releases at agent scope before arriving and acquires
+// after the last arrival, the surrounding __syncthreads extend both to the whole workgroup
+// (guide section 6 G16).  Bounded spin -> device watchdog.
+__device__ void ka_cluster_sync(TaskShared& S)
+{
+        __syncthreads();
+        if (S.G == 1) return;
+        if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                S.bar_phase += 1;
+                const unsigned int target = S.bar_phase * (unsigned int)S.G;
+                __hip_atomic_fetch_add(&S.ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__hip_atomic_load(&S.ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1 << 24)) { *S.watchdog = 6; break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+}
+
 // debug breadcrumbs into a host-pinned buffer (KA_TRACE=1): survives a hung kernel
 #define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
 
@@ -294,26 +332,27 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
         const int lane = tid & 63;
         const int wave = tid >> 6;
         const int g = max(S.La, S.Lb) + 2;
-        for (int i = tid; i < g; i += KA_BLOCK) S.raw[i] = -1;            // init_alnmem, aln_setup.c:33-36
-        if (tid == 0) {
+        const bool lead = (S.member == 0);
+        if (lead) for (int i = tid; i < g; i += KA_BLOCK) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
+        if (lead && tid == 0) {
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
                 root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
                 root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
                 S.q[0][0] = root;
-                S.ncur = (S.La > 0 && S.Lb > 0) ? 1 : 0;
-                S.nnext = 0; S.rowalloc = 0;
-                S.nitems_cur = 0; S.nitems_next = 0; S.next_item = 0;
-                S.npack_cur[0] = 0; S.npack_cur[1] = 0; S.npack_next[0] = 0; S.npack_next[1] = 0;
-                if (S.ncur) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La);
-                S.msum = 0.0; S.mcount = 0;
-                S.top_meet = -1; S.top_tr = -1; S.top_score = 0.0f;
+                S.ctl->ncur = (S.La > 0 && S.Lb > 0) ? 1 : 0;
+                S.ctl->nnext = 0; S.ctl->rowalloc = 0;
+                S.ctl->nitems_cur = 0; S.ctl->nitems_next = 0; S.ctl->next_item = 0;
+                S.ctl->npack_cur[0] = 0; S.ctl->npack_cur[1] = 0; S.ctl->npack_next[0] = 0; S.ctl->npack_next[1] = 0;
+                if (S.ctl->ncur) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La);
+                S.ctl->msum = 0.0; S.ctl->mcount = 0;
+                S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f;
                 S.t_pass = 0; S.t_meet = 0; S.n_levels = 0;
         }
-        __syncthreads();
+        ka_cluster_sync(S);
         int level = 0;
         while (true) {
-                const int ncur = S.ncur;
+                const int ncur = S.ctl->ncur;
                 if (ncur == 0) break;
                 KaSub* qc = S.q[level & 1];
                 KaSub* qn = S.q[(level + 1) & 1];
@@ -321,8 +360,8 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                 {
                         const int2* items = S.items[level & 1];
                         int* prog = S.prog[level & 1];
-                        const int nitems = S.nitems_cur;
-                        const int n16 = S.npack_cur[0], n4 = S.npack_cur[1];
+                        const int nitems = S.ctl->nitems_cur;
+                        const int n16 = S.ctl->npack_cur[0], n4 = S.ctl->npack_cur[1];
                         const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
                         const int ntotal = nitems + njobs16 + njobs4;
                         const int2* pack16 = S.pack[level & 1][0];
@@ -336,7 +375,7 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                                 int puller = lane;
                                 asm volatile("" : "+v"(puller));
                                 int it = 0;
-                                if (puller == 0) it = atomicAdd(&S.next_item, 1);
+                                if (puller == 0) it = atomicAdd(&S.ctl->next_item, 1);
                                 it = __builtin_amdgcn_readfirstlane(it);
                                 if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
@@ -366,31 +405,31 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                                                      lds_waves + wave * KA_WAVE_LDS, tss);
                         }
                 }
-                __syncthreads();
+                ka_cluster_sync(S);
                 if (tid == 0 && blockIdx.x == 0) KA_CRUMB(trace, 3, 1000 * level + 1);
                 const long long tp1 = __builtin_amdgcn_s_memtime();
-                if (level == 0 && dbg_rows) {
+                if (level == 0 && dbg_rows && lead) {
                         // tests only: keep the top-level rows f[0..Lb], b[0..Lb]
                         const int n = 3 * (S.Lb + 1);
                         const float* f = (const float*)S.fbuf;
                         const float* b = (const float*)S.bbuf;
                         for (int i = tid; i < n; i += KA_BLOCK) { dbg_rows[i] = f[i]; dbg_rows[n + i] = b[i]; }
                 }
-                for (int k = wave; k < ncur; k += KA_WAVES) {
+                for (int k = S.member * KA_WAVES + wave; k < ncur; k += KA_WAVES * S.G) {
                         const KaSub sb = qc[k];
                         ka_meetup<KIND>(S, sb, qn, ka_level_out(S, (level + 1) & 1, true), lane, level == 0);
                 }
-                __syncthreads();
-                if (tid == 0) {
-                        S.ncur = S.nnext; S.nnext = 0; S.rowalloc = 0;
-                        S.nitems_cur = S.nitems_next; S.nitems_next = 0; S.next_item = 0;
-                        S.npack_cur[0] = S.npack_next[0]; S.npack_cur[1] = S.npack_next[1];
-                        S.npack_next[0] = 0; S.npack_next[1] = 0;
+                ka_cluster_sync(S);
+                if (lead && tid == 0) {
+                        S.ctl->ncur = S.ctl->nnext; S.ctl->nnext = 0; S.ctl->rowalloc = 0;
+                        S.ctl->nitems_cur = S.ctl->nitems_next; S.ctl->nitems_next = 0; S.ctl->next_item = 0;
+                        S.ctl->npack_cur[0] = S.ctl->npack_next[0]; S.ctl->npack_cur[1] = S.ctl->npack_next[1];
+                        S.ctl->npack_next[0] = 0; S.ctl->npack_next[1] = 0;
                         const long long tp2 = __builtin_amdgcn_s_memtime();
                         S.t_pass += tp1 - tp0; S.t_meet += tp2 - tp1; S.n_levels = level + 1;
                         if (level < 16) { S.lvl_n[level] = ncur; S.lvl_pass[level] = (int)(tp1 - tp0); S.lvl_meet[level] = (int)(tp2 - tp1); }
                 }
-                __syncthreads();
+                ka_cluster_sync(S);
                 ++level;
         }
 }
@@ -462,7 +501,7 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
                 ++j;
         }
         for (int k = tid; k < tail; k += KA_BLOCK) { o[1 + all_ops + k] = 1; S.srcA[1 + all_ops + k] = -1; S.srcB[1 + all_ops + k] = 1 + total_b + k; }
-        if (tid == 0) { o[0] = alnlen; o[alnlen + 1] = 3; S.alnlen = alnlen; }
+        if (tid == 0) { o[0] = alnlen; o[alnlen + 1] = 3; S.ctl->alnlen = alnlen; }
         __syncthreads();
         // terminal-run flag (aln_setup.c:209-219): everything before the first and after the last
         // match column; the 4/8/16 flag loop never executes in the reference
@@ -474,9 +513,8 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
 // ------------------------------------------------------------------------------------------
 // P4: update_n (aln_setup.c:230-436), one thread per (output column, field).
 // ------------------------------------------------------------------------------------------
-__device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+__device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen)
 {
-        const int alnlen = S.alnlen;
         const float* pa = S.profa;
         const float* pb = S.profb;
         float* np = S.newp;
@@ -505,7 +543,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 return rec[k];
         };
         const long long total = (long long)(alnlen + 2) * 64;
-        for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
+        for (long long x = (long long)S.member * KA_BLOCK + threadIdx.x; x < total; x += (long long)S.G * KA_BLOCK) {
                 const int c = (int)(x >> 6);
                 const int k = (int)(x & 63);
                 float val;
@@ -649,7 +687,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ------------------------------------------------------------------------------------------
 // The task kernel: one workgroup per task of the current guide-tree level.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int* __restrict__ task_ids)
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks)
 {
         // all LDS lives in the dynamic region (16-B aligned carve-outs, guide section 6 G17)
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
@@ -658,7 +696,11 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         float* tss = (float*)(ka_smem + KA_LDS_TSS);
         char* lds_waves = ka_smem + KA_LDS_WAVES;
 #define s_dbg (*s_dbg_p)
-        const int task = task_ids[blockIdx.x];
+        // blocks[b] = (task, member | launched cluster size << 8); task < 0: padding block
+        const int2 blk = blocks[blockIdx.x];
+        const int task = blk.x;
+        if (task < 0) return;
+        const int member = blk.y & 0xff, g_launch = blk.y >> 8;
         const KaTaskDesc T = D.tasks[task];
         const int tid = threadIdx.x;
         const long long tk0 = __builtin_amdgcn_s_memtime();
@@ -667,7 +709,6 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 1);
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
-                S.fail = 0;
                 S.watchdog = D.error; S.trace = D.trace;
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
@@ -701,26 +742,40 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
                 S.p2_mult = swapped ? (float)T.nsip_b : (float)T.nsip_a;
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
-                const long long need = ka_scratch_bytes(len_a, len_b);
-                const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
-                if ((long long)so + need > D.scratch_cap) { S.fail = 1; atomicExch(D.error, 2); }
-                else ka_carve(S, D.scratch + so, len_a, len_b);
+                // how many of the launched workgroups this task really uses (every member derives the
+                // same number from the operand lengths): one CU saturates at about 8 strips in flight
+                int g_eff = (S.La >= 768) ? 4 : ((S.La >= 320) ? 2 : 1);
+                if (g_eff > g_launch) g_eff = g_launch;
+                S.G = g_eff; S.member = member; S.bar_phase = 0;
+                S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
+                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; }
                 s_dbg = nullptr;
-                if (D.flags & KA_FLAG_DEBUG_ROWS) {
-                        const unsigned long long nd = 6ull * (unsigned long long)(S.Lb + 1);
-                        const unsigned long long d0 = atomicAdd(&D.counters[3], nd);
-                        if ((long long)(d0 + nd) <= D.dbg_cap) { s_dbg = D.dbg_arena + d0; D.dbg_off[task] = (long long)d0; }
-                        else { D.dbg_off[task] = -1; atomicExch(D.error, 4); }
+                if (member == 0) {
+                        const long long need = ka_scratch_bytes(len_a, len_b);
+                        const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
+                        if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
+                        S.ctl->scratch_off = (long long)so;
+                        if (D.flags & KA_FLAG_DEBUG_ROWS) {
+                                const unsigned long long nd = 6ull * (unsigned long long)(S.Lb + 1);
+                                const unsigned long long d0 = atomicAdd(&D.counters[3], nd);
+                                if ((long long)(d0 + nd) <= D.dbg_cap) { s_dbg = D.dbg_arena + d0; D.dbg_off[task] = (long long)d0; }
+                                else { D.dbg_off[task] = -1; atomicExch(D.error, 4); }
+                        }
                 }
         }
         __syncthreads();
-        if (S.fail) return;
+        if (S.member >= S.G) return;                         // surplus workgroup of an over-provisioned cluster
+        ka_cluster_sync(S);
+        if (S.ctl->fail) return;
+        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b);
 
         // P1
-        if (T.nsip_a == 1) ka_make_leaf_profile(D, S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, T.soff);
-        if (T.nsip_b == 1) ka_make_leaf_profile(D, S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, T.soff);
+        if (S.member == 0) {
+                if (T.nsip_a == 1) ka_make_leaf_profile(D, S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, T.soff);
+                if (T.nsip_b == 1) ka_make_leaf_profile(D, S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, T.soff);
+        }
         ka_build_tss(tss, D.subm, T.soff);
-        __syncthreads();
+        ka_cluster_sync(S);
         tk1 = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
 
@@ -734,42 +789,50 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 3);
 #undef s_dbg
 
-        // P3
-        ka_code_path(S, (int*)lds_waves);
-        if (tid == 0) {
-                const int alnlen = S.alnlen;
-                const unsigned long long pn = (unsigned long long)alnlen + 2;
-                const unsigned long long po = atomicAdd(&D.counters[2], pn);
-                if ((long long)(po + pn) > D.path_cap) { S.fail = 1; atomicExch(D.error, 3); }
-                S.path_dst = D.path_arena + po;
-                S.newp = nullptr;
-                D.node_len[T.c] = alnlen;
-                if (!T.is_root) {
-                        const unsigned long long fn = pn * 64ull;
-                        const unsigned long long fo = atomicAdd(&D.counters[0], fn);
-                        if ((long long)(fo + fn) > D.prof_cap) { S.fail = 1; atomicExch(D.error, 1); }
-                        else { S.newp = D.prof_arena + fo; D.node_prof[T.c] = (long long)fo; }
+        // P3 (the cluster's first workgroup)
+        if (S.member == 0) {
+                ka_code_path(S, (int*)lds_waves);
+                if (tid == 0) {
+                        const int alnlen = S.ctl->alnlen;
+                        const unsigned long long pn = (unsigned long long)alnlen + 2;
+                        const unsigned long long po = atomicAdd(&D.counters[2], pn);
+                        if ((long long)(po + pn) > D.path_cap) { S.ctl->fail = 1; atomicExch(D.error, 3); }
+                        S.ctl->path_off = (long long)po;
+                        S.ctl->newp_off = -1;
+                        D.node_len[T.c] = alnlen;
+                        if (!T.is_root) {
+                                const unsigned long long fn = pn * 64ull;
+                                const unsigned long long fo = atomicAdd(&D.counters[0], fn);
+                                if ((long long)(fo + fn) > D.prof_cap) { S.ctl->fail = 1; atomicExch(D.error, 1); }
+                                else { S.ctl->newp_off = (long long)fo; D.node_prof[T.c] = (long long)fo; }
+                        }
+                        ka_task_rec r;
+                        r.a = T.a; r.b = T.b; r.c = T.c;
+                        r.len_a = S.len_a; r.len_b = S.len_b; r.nsip_a = T.nsip_a; r.nsip_b = T.nsip_b;
+                        r.plen = alnlen; r.kind = S.kind; r.swapped = S.swapped;
+                        r.meet = S.ctl->top_meet; r.transition = S.ctl->top_tr;
+                        r.path_off = (int)po;
+                        r.gap_scale = T.gap_scale; r.subm_off = T.soff;
+                        r.score = S.ctl->top_score;
+                        r.confidence = (S.ctl->mcount > 0) ? (float)S.ctl->msum / (float)S.ctl->mcount : 0.0f;
+                        r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
+                        D.recs[task] = r;
                 }
-                ka_task_rec r;
-                r.a = T.a; r.b = T.b; r.c = T.c;
-                r.len_a = S.len_a; r.len_b = S.len_b; r.nsip_a = T.nsip_a; r.nsip_b = T.nsip_b;
-                r.plen = alnlen; r.kind = S.kind; r.swapped = S.swapped;
-                r.meet = S.top_meet; r.transition = S.top_tr;
-                r.path_off = (int)po;
-                r.gap_scale = T.gap_scale; r.subm_off = T.soff;
-                r.score = S.top_score;
-                r.confidence = (S.mcount > 0) ? (float)S.msum / (float)S.mcount : 0.0f;
-                r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
-                D.recs[task] = r;
+        }
+        ka_cluster_sync(S);
+        tk3 = __builtin_amdgcn_s_memtime();
+        if (S.ctl->fail) return;
+
+        // P4 (all workgroups of the cluster)
+        if (tid == 0) {
+                S.path_dst = D.path_arena + S.ctl->path_off;
+                S.newp = (S.ctl->newp_off >= 0) ? (D.prof_arena + S.ctl->newp_off) : nullptr;
         }
         __syncthreads();
-        tk3 = __builtin_amdgcn_s_memtime();
-        if (S.fail) return;
-
-        // P4
-        for (int i = tid; i < S.alnlen + 2; i += KA_BLOCK) S.path_dst[i] = S.coded[i];
-        if (S.newp) ka_update_profile(S, D, T);
-        if (D.timing) {
+        const int alnlen = S.ctl->alnlen;
+        if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_BLOCK) S.path_dst[i] = S.coded[i];
+        if (S.newp) ka_update_profile(S, D, T, alnlen);
+        if (D.timing && S.member == 0) {
                 __syncthreads();
                 if (tid == 0) {
                         long long* tm = D.timing + 8ll * task;
@@ -802,7 +865,8 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
                 const int i = P.ia[k], j = P.ib[k];
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
-                S.fail = 0;
+                S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0;
+                S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr;
                 S.kind = KA_SS; S.swapped = swapped;
                 S.len_a = len_i; S.len_b = len_j;
@@ -822,10 +886,10 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
         ka_hirschberg<KA_SS, 23>(S, nullptr, lds_waves, tss, nullptr);
         __syncthreads();
         ka_code_path(S, (int*)lds_waves);
-        if (tid == 0 && P.scores) P.scores[k] = S.top_score;
+        if (tid == 0 && P.scores) P.scores[k] = S.ctl->top_score;
         __syncthreads();
         int* dst = P.paths_out + P.poff[k];
-        for (int i = tid; i < S.alnlen + 2; i += KA_BLOCK) dst[i] = S.coded[i];
+        for (int i = tid; i < S.ctl->alnlen + 2; i += KA_BLOCK) dst[i] = S.coded[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -844,10 +908,10 @@ static hipError_t ka_lds_optin()
         return hipSuccess;
 }
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int* task_ids_dev, int ntasks, hipStream_t stream)
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream)
 {
         if (ka_lds_optin() != hipSuccess) return;
-        hipLaunchKernelGGL(ka_task_kernel, dim3(ntasks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, task_ids_dev);
+        hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
 }
 
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
@@ -857,3 +921,4 @@ extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 }
 
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb) { return ka_scratch_bytes(la, lb); }
+extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }

@@ -120,6 +120,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const int lastl = nl - 1;                                     // lane holding the strip's last row
         const bool last_is_b = (nr & 1) == 0;
         const bool first = (k == 0);
+        const bool clustered = __builtin_amdgcn_readfirstlane(S.G) > 1;
         const bool actA = 2 * lane < nr;
         const bool actB = 2 * lane + 1 < nr;
         const int uA = u0 + min(2 * lane, nr - 1);
@@ -245,12 +246,21 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                         if (lane == 0) {
                                                 // bounded spin: a stuck pipeline must surface as an error, never as a hung GPU
                                                 int spins = 0;
-                                                while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                                                        __builtin_amdgcn_s_sleep(2);
-                                                        if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                                                if (clustered) {
+                                                        while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                                                                __builtin_amdgcn_s_sleep(4);
+                                                                if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                                                        }
+                                                } else {
+                                                        while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                                                                __builtin_amdgcn_s_sleep(2);
+                                                                if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                                                        }
                                                 }
                                         }
-                                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                        // the producer may be a wave of another workgroup (another CU) of the cluster
+                                        if (clustered) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                                         const ka_gfloat* r = grows + 3 * IDX(min(t + lane, ncols));
                                         bta = r[0]; btga = r[1]; btgb = r[2];
                                 }
@@ -333,9 +343,16 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                         ka_gfloat* w = grows + 3 * IDX(col);
                                         w[0] = oba; w[1] = obga; w[2] = obgb;
                                 }
-                                // publish: the next strip (another wave of this workgroup) may read them
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                if (lane == 0) __hip_atomic_store(prog + k, vL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                // publish: the next strip (another wave of this workgroup, or of another
+                                // workgroup of the cluster) may read them
+                                if (clustered) {
+                                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                        if (lane == 0) __hip_atomic_store(prog + k, vL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else {
+                                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                        if (lane == 0) __hip_atomic_store(prog + k, vL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
                         }
                 }
         };
