@@ -45,7 +45,9 @@ def algorithmic_bytes(recs):
 
 def make_workload(nseq, length, dna, seed):
     from kalign_amd import guide, synth
-    seqs = synth.family(nseq, length, dna=dna, seed=seed)
+    # the reference's own benchmark generator, restated: independent samples of one profile HMM
+    # (tests/dssim.c)
+    seqs = synth.dssim(nseq, length, dna=dna, seed=seed)
     codes = guide.encode(seqs, dna=dna)
     tasks = guide.bisecting_tree(nseq, seed=seed)
     dist = np.random.RandomState(seed).uniform(0.3, 0.9, nseq).astype(np.float32)

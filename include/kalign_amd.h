@@ -123,6 +123,9 @@ int ka_pairwise_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const i
                       const float* subm, float gpo, float gpe, float tgpe,
                       int* paths_out, const long long* poff, float* scores_out);
 
+/* Kernel time (HIP events on the launch stream) of the last ka_pairwise_batch, milliseconds. */
+float ka_pairwise_kernel_ms(ka_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

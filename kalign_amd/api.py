@@ -36,7 +36,7 @@ class TaskRec(C.Structure):
 EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
-           "ka_pairwise_batch"]
+           "ka_pairwise_batch", "ka_pairwise_kernel_ms"]
 
 
 def lib_path():
@@ -73,6 +73,8 @@ def load_library():
     L.ka_tree_get_profile.argtypes = [vp, C.c_int, vp, C.c_longlong]
     L.ka_tree_get_timing.argtypes = [vp, vp]
     L.ka_debug_trace.argtypes = [vp, vp]
+    L.ka_pairwise_kernel_ms.argtypes = [vp]
+    L.ka_pairwise_kernel_ms.restype = C.c_float
     L.ka_tree_cells.argtypes = [vp]
     L.ka_tree_cells.restype = C.c_double
     L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -169,6 +171,9 @@ class Context:
         self._chk(self.L.ka_tree_get_timing(self.h, _ptr(out)))
         self.root_levels = out[8 * n:].reshape(16, 3)      # per recursion level of the root task: n, pass, meetup
         return out[:8 * n].reshape(n, 8)
+
+    def pairwise_kernel_ms(self):
+        return float(self.L.ka_pairwise_kernel_ms(self.h))
 
     def debug_trace(self):
         out = np.zeros(64, np.int32)

@@ -85,6 +85,7 @@ struct ka_ctx {
         bool ran = false, synced = false;
         int n_launches = 0;
         double cells = 0.0;
+        float pair_ms = 0.0f;                        // kernel time of the last ka_pairwise_batch
         std::vector<ka_task_rec> h_recs;
         unsigned long long h_counters[4] = {0, 0, 0, 0};
 };
@@ -489,6 +490,8 @@ extern "C" int ka_tree_get_timing(ka_ctx* c, long long* out)
         return KA_OK;
 }
 
+extern "C" float ka_pairwise_kernel_ms(ka_ctx* c) { return c ? c->pair_ms : 0.0f; }
+
 extern "C" int ka_debug_trace(ka_ctx* c, int* out64)
 {
         if (!c || !c->h_trace) return fail("KA_TRACE was not set when the context was created");
@@ -562,9 +565,12 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
         P.paths_out = d_paths.p; P.poff = d_poff.p; P.scores = d_scores.p; P.npairs = npairs;
         P.error = d_err.p;
         PCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), c->stream));
+        PCHK(hipEventRecord(c->ev0, c->stream));
         ka_launch_pairs(&P, c->stream);
         PCHK(hipGetLastError());
+        PCHK(hipEventRecord(c->ev1, c->stream));
         PCHK(hipStreamSynchronize(c->stream));
+        PCHK(hipEventElapsedTime(&c->pair_ms, c->ev0, c->ev1));
         {
                 int err = 0;
                 PCHK(hipMemcpy(&err, d_err.p, sizeof(int), hipMemcpyDeviceToHost));

@@ -22,8 +22,11 @@
 #include "ka_device.h"
 // #define KA_TRACE_STRIP 1   // per-step breadcrumbs into D.trace (debugging hangs)
 
-#define KA_BLOCK 512
+#define KA_BLOCK 512                     // task kernel: 8 waves, one workgroup per CU (LDS ring per wave)
 #define KA_WAVES (KA_BLOCK / 64)
+#define KA_PAIR_BLOCK 256                // seq-seq pair kernel: 4 waves, no ring -> several workgroups per CU
+#define KA_NT ((int)blockDim.x)          // threads / waves of the running workgroup
+#define KA_NW ((int)blockDim.x >> 6)
 
 __device__ __forceinline__ float kmax(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ float kmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -97,6 +100,7 @@ struct TaskShared {
         float* newp;
         int* path_dst;
         int* trace;
+        int dbgskip;
         int* watchdog;                 // device error word: a bounded spin that expired writes 5 here
         long long t_pass, t_meet;      // KA_FLAG_TIMING: shader-clock cycles spent in passes / meetups
         int n_levels;
@@ -182,7 +186,7 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
 }
 
 template <int KIND>
-__device__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const KaLevelOut& lout, const int lane, const bool is_top)
+__device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const KaLevelOut& lout, const int lane, const bool is_top)
 {
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
@@ -326,14 +330,14 @@ __device__ void ka_cluster_sync(TaskShared& S)
 #define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
 
 template <int KIND, int NRES>
-__device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
+__device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
         const int wave = tid >> 6;
         const int g = max(S.La, S.Lb) + 2;
         const bool lead = (S.member == 0);
-        if (lead) for (int i = tid; i < g; i += KA_BLOCK) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
+        if (lead) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
         if (lead && tid == 0) {
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
@@ -413,9 +417,9 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
                         const int n = 3 * (S.Lb + 1);
                         const float* f = (const float*)S.fbuf;
                         const float* b = (const float*)S.bbuf;
-                        for (int i = tid; i < n; i += KA_BLOCK) { dbg_rows[i] = f[i]; dbg_rows[n + i] = b[i]; }
+                        for (int i = tid; i < n; i += KA_NT) { dbg_rows[i] = f[i]; dbg_rows[n + i] = b[i]; }
                 }
-                for (int k = S.member * KA_WAVES + wave; k < ncur; k += KA_WAVES * S.G) {
+                for (int k = S.member * KA_NW + wave; k < ncur; k += KA_NW * S.G) {
                         const KaSub sb = qc[k];
                         ka_meetup<KIND>(S, sb, qn, ka_level_out(S, (level + 1) & 1, true), lane, level == 0);
                 }
@@ -440,7 +444,7 @@ __device__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, c
 // Row i of the (a-indexed) raw path emits g_i gap-in-a ops followed by one op (match or
 // gap-in-b); two block-wide prefix sums (ops emitted, b positions consumed) place every row's
 // ops independently.  Also records, per output column, which record of profile a / b feeds
-// it (srcA/srcB, -1 = none) for the parallel update_n.  `lds` = 2*KA_BLOCK+4 ints of scratch.
+// it (srcA/srcB, -1 = none) for the parallel update_n.  `lds` = 2*blockDim.x+4 ints of scratch.
 // ------------------------------------------------------------------------------------------
 __device__ void ka_code_path(TaskShared& S, int* lds)
 {
@@ -449,19 +453,19 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
         const int* raw = S.raw;
         if (S.swapped) {
                 int* r2 = S.raw2;
-                for (int i = tid; i < len_a + 2; i += KA_BLOCK) r2[i] = -1;
+                for (int i = tid; i < len_a + 2; i += KA_NT) r2[i] = -1;
                 __syncthreads();
-                for (int i = 1 + tid; i <= len_b; i += KA_BLOCK) { const int c = S.raw[i]; if (c != -1) r2[c] = i; }
+                for (int i = 1 + tid; i <= len_b; i += KA_NT) { const int c = S.raw[i]; if (c != -1) r2[c] = i; }
                 __syncthreads();
                 raw = r2;
         }
         int* o = S.coded;
         int* tot_ops = lds;
-        int* tot_b = lds + KA_BLOCK;
-        int* zmin = lds + 2 * KA_BLOCK;
+        int* tot_b = lds + KA_NT;
+        int* zmin = lds + 2 * KA_NT;
         int* zmax = zmin + 1;
         // rows [lo, hi) of this thread (1-based rows 1..len_a)
-        const int per = (len_a + KA_BLOCK - 1) / KA_BLOCK;
+        const int per = (len_a + KA_NT - 1) / KA_NT;
         const int lo = 1 + tid * per, hi = min(len_a + 1, lo + per);
         auto row_gaps = [&](int i, int cur, int prev) -> int {
                 // gap-in-a ops emitted before row i's own op (aln_setup.c:145-188)
@@ -480,7 +484,7 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
         if (tid == 0) { *zmin = 0x7fffffff; *zmax = 0; }
         __syncthreads();
         int off = 0, offb = 0, all_ops = 0;
-        for (int k = 0; k < KA_BLOCK; ++k) {
+        for (int k = 0; k < KA_NT; ++k) {
                 const int a = tot_ops[k];
                 if (k < tid) { off += a; offb += tot_b[k]; }
                 all_ops += a;
@@ -490,7 +494,7 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
         const int tail = (last != -1 && last < len_b) ? (len_b - last) : 0;
         const int alnlen = all_ops + tail;
         int total_b = 0;
-        for (int k = 0; k < KA_BLOCK; ++k) total_b += tot_b[k];
+        for (int k = 0; k < KA_NT; ++k) total_b += tot_b[k];
         int j = 1 + off, rb = 1 + offb;
         for (int i = lo; i < hi; ++i) {
                 const int cur = raw[i], prev = (i > 1) ? raw[i - 1] : -1;
@@ -500,13 +504,13 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
                 else { o[j] = 0; S.srcA[j] = i; S.srcB[j] = rb++; atomicMin(zmin, j); atomicMax(zmax, j); }
                 ++j;
         }
-        for (int k = tid; k < tail; k += KA_BLOCK) { o[1 + all_ops + k] = 1; S.srcA[1 + all_ops + k] = -1; S.srcB[1 + all_ops + k] = 1 + total_b + k; }
+        for (int k = tid; k < tail; k += KA_NT) { o[1 + all_ops + k] = 1; S.srcA[1 + all_ops + k] = -1; S.srcB[1 + all_ops + k] = 1 + total_b + k; }
         if (tid == 0) { o[0] = alnlen; o[alnlen + 1] = 3; S.ctl->alnlen = alnlen; }
         __syncthreads();
         // terminal-run flag (aln_setup.c:209-219): everything before the first and after the last
         // match column; the 4/8/16 flag loop never executes in the reference
         const int z1 = *zmin, z2 = *zmax;
-        for (int c = 1 + tid; c <= alnlen; c += KA_BLOCK) if (c < z1 || c > z2) o[c] |= 32;
+        for (int c = 1 + tid; c <= alnlen; c += KA_NT) if (c < z1 || c > z2) o[c] |= 32;
         __syncthreads();
 }
 
@@ -543,7 +547,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 return rec[k];
         };
         const long long total = (long long)(alnlen + 2) * 64;
-        for (long long x = (long long)S.member * KA_BLOCK + threadIdx.x; x < total; x += (long long)S.G * KA_BLOCK) {
+        for (long long x = (long long)S.member * KA_NT + threadIdx.x; x < total; x += (long long)S.G * KA_NT) {
                 const int c = (int)(x >> 6);
                 const int k = (int)(x & 63);
                 float val;
@@ -613,7 +617,7 @@ __device__ void ka_make_leaf_profile(const KaTreeDev& D, float* prof, int len, c
                                      float gpo, float gpe, float tgpe, float soff)
 {
         const long long total = (long long)(len + 2) * 64;
-        for (long long x = threadIdx.x; x < total; x += KA_BLOCK) {
+        for (long long x = threadIdx.x; x < total; x += KA_NT) {
                 const int r = (int)(x >> 6);
                 const int k = (int)(x & 63);
                 float val = 0.0f;
@@ -634,13 +638,14 @@ __device__ void ka_make_leaf_profile(const KaTreeDev& D, float* prof, int len, c
 #define KA_LDS_TSS 784
 #define KA_LDS_WAVES (KA_LDS_TSS + 23 * KA_T_STRIDE * 4)          // 2736, multiple of 16
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
+#define KA_LDS_PAIR (KA_LDS_WAVES + (2 * KA_PAIR_BLOCK + 16) * 4)   // seq-seq: only the path-coding scratch follows the table
 static_assert(sizeof(TaskShared) <= KA_LDS_DBG, "TaskShared outgrew its LDS slot");
 static_assert(KA_LDS_WAVES % 16 == 0, "wave regions must be 16-B aligned");
 
 // seq-seq score table T[a][b] = subm[a][b] - soff (one rounding, as aln_seqseq.c:82 evaluates it)
 __device__ void ka_build_tss(float* tss, const float* subm, float soff)
 {
-        for (int x = threadIdx.x; x < 23 * KA_T_STRIDE; x += KA_BLOCK) {
+        for (int x = threadIdx.x; x < 23 * KA_T_STRIDE; x += KA_NT) {
                 const int a = x / KA_T_STRIDE, b = x % KA_T_STRIDE;
                 tss[x] = (b < 23) ? (subm[23 * a + b] - soff) : 0.0f;
         }
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 1);
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
-                S.watchdog = D.error; S.trace = D.trace;
+                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = D.flags >> 16;
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
                 S.profb = D.prof_arena + D.node_prof[T.b];
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         }
         __syncthreads();
         const int alnlen = S.ctl->alnlen;
-        if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_BLOCK) S.path_dst[i] = S.coded[i];
+        if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T, alnlen);
         if (D.timing && S.member == 0) {
                 __syncthreads();
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
 // ------------------------------------------------------------------------------------------
 // Batch of independent seq-seq alignments (pairwise_align_map, anchor_consistency.c:19-120)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
+__global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairDev P)
 {
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
         TaskShared& S = *(TaskShared*)ka_smem;
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
-                S.watchdog = P.error; S.trace = nullptr;
+                S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0;
                 S.kind = KA_SS; S.swapped = swapped;
                 S.len_a = len_i; S.len_b = len_j;
                 S.La = swapped ? len_j : len_i;
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_pair_kernel(const KaPairDev P)
         if (tid == 0 && P.scores) P.scores[k] = S.ctl->top_score;
         __syncthreads();
         int* dst = P.paths_out + P.poff[k];
-        for (int i = tid; i < S.ctl->alnlen + 2; i += KA_BLOCK) dst[i] = S.coded[i];
+        for (int i = tid; i < S.ctl->alnlen + 2; i += KA_NT) dst[i] = S.coded[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -902,7 +907,7 @@ static hipError_t ka_lds_optin()
         if (done) return hipSuccess;
         hipError_t e = hipFuncSetAttribute((const void*)ka_task_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
+        e = hipFuncSetAttribute((const void*)ka_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
         if (e != hipSuccess) return e;
         done = true;
         return hipSuccess;
@@ -917,7 +922,7 @@ extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev,
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 {
         if (ka_lds_optin() != hipSuccess) return;
-        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *P);
+        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *P);
 }
 
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb) { return ka_scratch_bytes(la, lb); }

@@ -204,10 +204,13 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         //   ST   : steady state, every active lane is strictly inside the column range (no edge cases)
         //   FULL : the strip has all 128 rows (64 active lanes, last row = row B of lane 63)
         //   P    : which half of q[] holds this step's column record (the other half receives the next)
-        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag) {
+        //   EV   : this step may carry a periodic event (ring batch hand-over, boundary / residue batch
+        //          reload, flush of the output batch); EV = false steps are branch-free
+        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag, auto ev_tag) {
                 constexpr bool ST = decltype(st_tag)::value;
                 constexpr bool FULL = decltype(full_tag)::value;
                 constexpr int P = decltype(par_tag)::value;
+                constexpr bool EV = decltype(ev_tag)::value;
                 const int v = t - lane;
                 const bool inr = (ST && FULL) ? true : (ST ? actA : ((v >= 0) && (v <= ncols) && actA));
 
@@ -217,7 +220,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
                         col_terms<KIND>(S, 0, copen, cext, ctext);
-                        if ((t & 63) == 0) {
+                        if (EV && (t & 63) == 0) {
                                 const int vv = min(max(t + lane, 1), ncols);
                                 resb = S.s2[REC(vv) - 1];
                         } else {
@@ -239,7 +242,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         }
                         bta = inia; btga = iniga; btgb = inigb;
                 } else {
-                        if ((t & 63) == 0) {
+                        if (EV && (t & 63) == 0) {
                                 if (t <= ncols) {
                                         // the previous strip must have published columns t .. t+63
                                         const int need = min(t + 64, ncols + 1);
@@ -281,20 +284,31 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         acc.x += sp_tbl[(2 * lane) * KA_SP_STRIDE + res2];
                         acc.y += sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2];
                 } else {
-                        // fetch the next step's column record into the other half of q while this
-                        // step's dot products run
+                        // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
+                        // v_pk_add of the chain instead of an s_nop
+                        float2v prod;
+                        { const float sc = q[P][(NRES - 1) >> 2][(NRES - 1) & 3]; float2v w; w.x = sc; w.y = sc; prod = p1v[NRES - 1] * w; }
+#pragma unroll
+                        for (int c = NRES - 1; c >= 1; --c) {
+                                const float sc = q[P][(c - 1) >> 2][(c - 1) & 3];
+                                float2v w; w.x = sc; w.y = sc;
+                                const float2v nprod = p1v[c - 1] * w;
+                                acc = acc + prod;
+                                prod = nprod;
+                        }
+                        acc = acc + prod;
+                        // Fetch the next step's column record into the other half of q.  The loads are
+                        // pinned AFTER the dot products (sched_barrier): hoisted above them, the
+                        // compiler's s_waitcnt for this step's half (loaded one step ago) would also
+                        // wait for the fresh loads, exposing the whole LDS latency every step.
+                        __builtin_amdgcn_sched_barrier(0);
                         const int tn = t + 1;
-                        if ((tn & (KA_RING_BATCH - 1)) == 0) {
+                        if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
                                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
                                 ring_issue((tn >> 5) + 1);
                         }
                         ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols));
-#pragma unroll
-                        for (int c = NRES - 1; c >= 0; --c) {
-                                const float sc = q[P][c >> 2][c & 3];
-                                float2v w; w.x = sc; w.y = sc;
-                                acc = acc + p1v[c] * w;
-                        }
+                        __builtin_amdgcn_sched_barrier(0);
                 }
                 float nAa, nAga, nAgb, nBa, nBga, nBgb;
                 if (ST) {
@@ -335,7 +349,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 const float lgb = lane_bcast(last_is_b ? cBgb : cAgb, lastl);
                                 if (lane == (vL & 63)) { oba = la; obga = lga; obgb = lgb; }
                         }
-                        if ((vL & 63) == 63 || vL == ncols) {
+                        if (EV && ((vL & 63) == 63 || vL == ncols)) {
                                 // FULL: lane i holds column vL - 63 + i; partial: lane i holds column (vL & ~63) + i
                                 const int c0 = vL & ~63;
                                 const int col = FULL ? (vL - 63 + lane) : (c0 + lane);
@@ -357,20 +371,49 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 }
         };
 
+        auto fix_parity = [&]() {
+                if (KIND == KA_PP) {
+#pragma unroll
+                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) q[0][ch] = q[1][ch];
+                }
+        };
         // run steps [t, tend): pairs with alternating q halves; an odd leftover step is followed
         // by a copy so that every phase starts on half 0
         auto run = [&](int& t, const int tend, auto st_tag, auto full_tag) {
                 for (; t + 1 < tend; t += 2) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>());
-                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>());
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type());
+                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type());
                 }
                 if (t < tend) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>());
-                        if (KIND == KA_PP) {
-#pragma unroll
-                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) q[0][ch] = q[1][ch];
-                        }
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type());
+                        fix_parity();
                         ++t;
+                }
+        };
+        // steady state: the periodic events fall on known steps (ring hand-over at t = 31 mod 32,
+        // batch reloads at t = 0 mod 64, output flush at t = lastl-1 mod 64); everything between
+        // two event steps runs as branch-free step pairs
+        auto run_steady = [&](int& t, const int tend, auto full_tag) {
+                while (t < tend) {
+                        const int e1 = t | 31;
+                        const int e2 = (t + 63) & ~63;
+                        const int e3 = t + ((lastl - 1 - t) & 63);
+                        const int ev = min(e1, min(e2, e3));
+                        const int fend = min(ev, tend);
+                        for (; t + 1 < fend; t += 2) {
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type());
+                                step(t + 1, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type());
+                        }
+                        if (t < fend) {
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type());
+                                fix_parity();
+                                ++t;
+                        }
+                        if (t < tend && t == ev) {
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::true_type());
+                                fix_parity();
+                                ++t;
+                        }
                 }
         };
 
@@ -380,11 +423,11 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         int t = 0;
         if (nr == KA_STRIP_ROWS) {
                 run(t, t_steady0, std::false_type(), std::true_type());
-                run(t, t_steady1, std::true_type(), std::true_type());
+                run_steady(t, t_steady1, std::true_type());
                 run(t, nsteps, std::false_type(), std::true_type());
         } else {
                 run(t, t_steady0, std::false_type(), std::false_type());
-                run(t, t_steady1, std::true_type(), std::false_type());
+                run_steady(t, t_steady1, std::false_type());
                 run(t, nsteps, std::false_type(), std::false_type());
         }
 #undef REC

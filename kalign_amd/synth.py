@@ -47,3 +47,57 @@ def read_fasta(path):
             elif line and seqs:
                 seqs[-1].append(line)
     return names, ["".join(s) for s in seqs]
+
+
+# background frequencies used as the emission prior (Robinson & Robinson order ACDEFGHIKLMNPQRSTVWY)
+_PRIOR_AA = np.array([0.0755, 0.0170, 0.0530, 0.0632, 0.0407, 0.0685, 0.0224, 0.0573, 0.0594, 0.0934,
+                      0.0236, 0.0453, 0.0493, 0.0402, 0.0516, 0.0722, 0.0574, 0.0652, 0.0125, 0.0322])
+_AA_ORDER = "ACDEFGHIKLMNPQRSTVWY"
+
+
+def dssim(n_seq, length, dna=False, seed=1, n_obs=30, match_err=0.05, insert_err=0.25):
+    """Restatement of the reference's DSSim generator (tests/dssim.c:68-168, 333-431): n_seq
+    independent samples from ONE random profile HMM of `length` match states.  Every match /
+    insert state has a dominant residue observed n_obs times with an error rate, plus the
+    background prior; transitions M->M 1-p, M->I = M->D = p/2 with p = 0.02 (n_seq > 100) or
+    0.04, I->I = I->M = D->D = D->M = 0.5; uniform start state.  Output lengths ~ length +- 5 %."""
+    rng = np.random.RandomState(seed)
+    if dna:
+        alpha, prior = "ACGT", np.full(4, 0.25)
+    else:
+        alpha, prior = _AA_ORDER, _PRIOR_AA / _PRIOR_AA.sum()
+    L = len(alpha)
+    letters = np.frombuffer(alpha.encode(), np.uint8)
+
+    def emissions(err):
+        pick = rng.choice(L, size=length, p=prior)
+        e = np.tile(prior, (length, 1))
+        wrong = rng.random_sample((length, n_obs)) < err
+        rnd = rng.randint(0, L, size=(length, n_obs))
+        obs = np.where(wrong, rnd, pick[:, None])
+        for c in range(L):
+            e[:, c] += (obs == c).sum(1)
+        return np.cumsum(e / e.sum(1, keepdims=True), axis=1)
+
+    cm, ci = emissions(match_err), emissions(insert_err)
+    p = 0.02 if n_seq > 100 else 0.04
+    out = []
+    for _ in range(n_seq):
+        seq = []
+        i, state = 0, rng.randint(0, 3)          # 0 M, 1 I, 2 D
+        while i < length:
+            r = rng.random_sample()
+            if state == 0:
+                seq.append(letters[min(int(np.searchsorted(cm[i], rng.random_sample())), L - 1)])
+                i += 1
+                state = 0 if r < 1.0 - p else (1 if r < 1.0 - p / 2 else 2)
+            elif state == 1:
+                seq.append(letters[min(int(np.searchsorted(ci[i], rng.random_sample())), L - 1)])
+                state = 1 if r < 0.5 else 0
+            else:
+                i += 1
+                state = 2 if r < 0.5 else 0
+        if not seq:
+            seq.append(letters[0])
+        out.append(bytes(seq).decode())
+    return out
