@@ -100,6 +100,42 @@ def cpu_baseline(codes, tasks, dist, dna, cells):
                 "sample": "first %d sequences, oracle C restatement, 1 thread (%s)" % (n, e)}
 
 
+def pairwise_leg(ctx, codes, subm, scal, args, k_anchors=5):
+    """N x K independent seq-seq alignments (every sequence against K anchors), full Hirschberg +
+    path coding per pair.  Reports the kernel rate (HIP events) and the host-buffer wall rate."""
+    n = len(codes)
+    ia = np.repeat(np.arange(n), k_anchors).astype(np.int32)
+    ib = np.tile(np.arange(k_anchors), n).astype(np.int32)
+    keep = ia != ib
+    ia, ib = ia[keep], ib[keep]
+    lens = np.array([len(c) for c in codes], np.int64)
+    cells = float((lens[ia] * lens[ib]).sum())
+    ctx.pairwise_batch(codes, ia, ib, subm, scal[0], scal[1], scal[2])           # warm-up (allocations)
+    t0 = time.perf_counter()
+    ctx.pairwise_batch(codes, ia, ib, subm, scal[0], scal[1], scal[2])
+    wall = time.perf_counter() - t0
+    kms = ctx.pairwise_kernel_ms()
+    depth = math.ceil(math.log2(max(int(lens.min()), 2))) + 1
+    abytes = float((depth * (np.minimum(lens[ia], lens[ib]) + 49 * np.maximum(lens[ia], lens[ib])) + 4 * (lens[ia] + lens[ib] + 2)).sum())
+    info = {"pairs": int(len(ia)), "useful_cells": cells, "kernel_ms": kms, "gcups_kernel": cells / kms / 1e6,
+            "wall_ms_host_buffers": wall * 1e3, "gcups_wall_host_buffers": cells / wall / 1e9,
+            "roofline_frac_hbm": abytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if not args.no_cpu:
+        try:
+            from oracle import refdrv
+            m = min(len(ia), 256)
+            nt = min(os.cpu_count() or 1, 16)
+            _, secs = refdrv.pairwise_batch(codes, ia[:m], ib[:m], subm, float(scal[0]), float(scal[1]), float(scal[2]),
+                                            n_threads=nt, want_paths=False)
+            c = float((lens[ia[:m]] * lens[ib[:m]]).sum())
+            info["cpu_reference_gcups"] = c / secs / 1e9
+            info["cpu_reference_sample"] = "%d pairs, aln_runner of the reference, %d OpenMP threads (the reference itself runs this loop serially)" % (m, nt)
+        except Exception as e:      # pragma: no cover
+            info["cpu_reference_gcups"] = None
+            info["cpu_reference_sample"] = str(e)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +145,7 @@ def main():
     ap.add_argument("--len", type=int, default=400)
     ap.add_argument("--dna", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pairs", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -155,6 +192,12 @@ def main():
     kern_ms, n_launch = ctx.tree_kernel_ms()          # HIP events on the launch stream, last step
     total_cells = kd.reduce_scalar(cells, "sum", device="cuda")    # every rank aligned its own set
 
+    # secondary measurement (rank 0 only, outside the timed region): the N x K seq-seq batch of
+    # anchor consistency (anchor_consistency.c:246-267) through ka_pairwise_batch
+    pair_info = None
+    if rank == 0 and not args.no_pairs:
+        pair_info = pairwise_leg(ctx, codes, subm, scal, args)
+
     if rank == 0:
         abytes = algorithmic_bytes(recs)
         achieved = abytes / (kern_ms * 1e-3) / 1e9
@@ -187,6 +230,8 @@ def main():
                 "kernel_ms_per_step": kern_ms,
             },
         }
+        if pair_info:
+            out["seqseq_batch"] = pair_info
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
         print(json.dumps(out))

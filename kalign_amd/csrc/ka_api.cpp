@@ -86,6 +86,9 @@ struct ka_ctx {
         int n_launches = 0;
         double cells = 0.0;
         float pair_ms = 0.0f;                        // kernel time of the last ka_pairwise_batch
+        // grow-only device buffers of ka_pairwise_batch (no hipMalloc/hipFree per call)
+        DevBuf<uint8_t> p_codes; DevBuf<int> p_off, p_len, p_ia, p_ib, p_paths, p_err; DevBuf<float> p_subm, p_scores;
+        DevBuf<long long> p_poff; DevBuf<char> p_scr;
         std::vector<ka_task_rec> h_recs;
         unsigned long long h_counters[4] = {0, 0, 0, 0};
 };
@@ -120,6 +123,8 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
         c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release(); c->d_timing.release();
         c->d_ctl.release(); c->d_blocks.release();
+        c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
+        c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -538,18 +543,15 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
                 ptotal = std::max(ptotal, poff[k] + li + lj + 3);
         }
         stride = (stride + 255) / 256 * 256;
-        DevBuf<uint8_t> d_codes; DevBuf<int> d_off, d_len, d_ia, d_ib, d_paths; DevBuf<float> d_subm, d_scores;
-        DevBuf<long long> d_poff; DevBuf<char> d_scr; DevBuf<int> d_err;
-        int rc = KA_OK;
+        DevBuf<uint8_t>& d_codes = c->p_codes; DevBuf<int>& d_off = c->p_off; DevBuf<int>& d_len = c->p_len;
+        DevBuf<int>& d_ia = c->p_ia; DevBuf<int>& d_ib = c->p_ib; DevBuf<int>& d_paths = c->p_paths; DevBuf<int>& d_err = c->p_err;
+        DevBuf<float>& d_subm = c->p_subm; DevBuf<float>& d_scores = c->p_scores;
+        DevBuf<long long>& d_poff = c->p_poff; DevBuf<char>& d_scr = c->p_scr;
         if (d_codes.alloc((size_t)codes_bytes) || d_off.alloc(numseq) || d_len.alloc(numseq) || d_ia.alloc(npairs) ||
             d_ib.alloc(npairs) || d_paths.alloc((size_t)ptotal) || d_subm.alloc(23 * 23) || d_scores.alloc(npairs) ||
             d_poff.alloc(npairs) || d_scr.alloc((size_t)(stride * npairs)) || d_err.alloc(1))
-                rc = fail("hipMalloc failed");
-        auto cleanup = [&]() {
-                d_codes.release(); d_off.release(); d_len.release(); d_ia.release(); d_ib.release(); d_paths.release();
-                d_subm.release(); d_scores.release(); d_poff.release(); d_scr.release(); d_err.release();
-        };
-        if (rc) { cleanup(); return rc; }
+                return fail("hipMalloc failed");
+        auto cleanup = [&]() {};
 #define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
         PCHK(hipMemcpyAsync(d_codes.p, codes, (size_t)codes_bytes, hipMemcpyHostToDevice, c->stream));
         PCHK(hipMemcpyAsync(d_off.p, off, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
