@@ -18,7 +18,7 @@
 
 #include "ka_device.h"
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, hipStream_t stream);
 extern "C" long long ka_ctl_bytes_host(void);
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb);
@@ -62,6 +62,7 @@ struct ka_ctx {
         std::vector<int> level_ids_flat, level_off;
         std::vector<int2> blocks_flat;               // per level: (task, member | cluster size << 8) per workgroup
         std::vector<int> blocks_off;
+        std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
         int max_cluster = 4;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
         std::vector<long long> leaf_prof_off;
         long long leaf_prof_total = 0;
@@ -237,11 +238,15 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         // lengths how many of them it uses).  Workgroups of one cluster are spaced 8 blocks apart:
         // block b runs on XCD b % 8 (observed, not contractual -- used for L2 locality only).
         if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
-        c->blocks_flat.clear(); c->blocks_off.assign(1, 0);
+        c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
         for (auto& L : c->levels) {
                 const int nt = (int)L.size();
+                int lean = 1;
+                for (int t : L) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) lean = 0;
+                if (getenv("KA_NO_LEAN")) lean = 0;
+                c->level_lean.push_back(lean);
                 int G = 1;
-                while (G * 2 <= c->max_cluster && nt * G * 2 <= 256) G *= 2;
+                while (!lean && G * 2 <= c->max_cluster && nt * G * 2 <= 256) G *= 2;
                 const int groups = (nt + 7) / 8;
                 std::vector<int2> tbl((size_t)groups * 8 * G, make_int2(-1, 0));
                 for (int j = 0; j < nt; j++)
@@ -326,7 +331,7 @@ static int tree_launch(ka_ctx* c)
                 const int n = (int)c->levels[L].size();
                 if (!n) continue;
                 if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
-                ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->stream);
+                ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->level_lean[L], c->stream);
                 c->n_launches++;
         }
         HIPCHK(hipGetLastError());

@@ -692,7 +692,10 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ------------------------------------------------------------------------------------------
 // The task kernel: one workgroup per task of the current guide-tree level.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks)
+// LEAN = true: a level whose tasks are all seq-seq (the guide tree's leaf level): 4 waves, no LDS
+// ring, <=128 VGPRs -> four workgroups per CU instead of one.
+template <bool LEAN>
+__device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __restrict__ blocks)
 {
         // all LDS lives in the dynamic region (16-B aligned carve-outs, guide section 6 G17)
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
 
         // P2
-        if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23>(S, s_dbg, lds_waves, tss, D.trace);
+        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23>(S, s_dbg, lds_waves, tss, D.trace);
         else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23>(S, s_dbg, lds_waves, tss, D.trace);
         else if (D.nres <= 5) ka_hirschberg<KA_PP, 5>(S, s_dbg, lds_waves, tss, D.trace);
         else ka_hirschberg<KA_PP, 23>(S, s_dbg, lds_waves, tss, D.trace);
@@ -855,6 +858,16 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         }
 }
 
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks)
+{
+        ka_task_body<false>(D, blocks);
+}
+
+__global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks)
+{
+        ka_task_body<true>(D, blocks);
+}
+
 // ------------------------------------------------------------------------------------------
 // Batch of independent seq-seq alignments (pairwise_align_map, anchor_consistency.c:19-120)
 // ------------------------------------------------------------------------------------------
@@ -909,14 +922,17 @@ static hipError_t ka_lds_optin()
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)ka_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ka_task_kernel_lean, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
+        if (e != hipSuccess) return e;
         done = true;
         return hipSuccess;
 }
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream)
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, hipStream_t stream)
 {
         if (ka_lds_optin() != hipSuccess) return;
-        hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
+        if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
+        else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
 }
 
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
