@@ -1,0 +1,102 @@
+"""Full-size checks on the GPU box (BASELINE.json configs): the bench workload against the REAL
+reference's dispatcher (the prebuilt oracle/_ref travels with the repo; its create_msa_tree runs
+in well under a second on the host cores) and through size-independent properties."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def check_path_invariants(recs, paths):
+    """Every coded path consumes exactly len_a positions of a and len_b of b, has the declared
+    length and terminator, and only the op codes the reference can emit (0, 1, 2, 33, 34)."""
+    for r in recs:
+        p = paths[r.path_off:r.path_off + r.plen + 2]
+        assert p[0] == r.plen and p[-1] == 3
+        ops = p[1:-1]
+        assert np.isin(ops, [0, 1, 2, 33, 34]).all()
+        assert int((ops == 0).sum() + ((ops & 2) != 0).sum()) == r.len_a
+        assert int((ops == 0).sum() + ((ops & 1) != 0).sum()) == r.len_b
+        lead = np.flatnonzero(ops == 0)
+        if len(lead):
+            assert ((ops[:lead[0]] & 32) != 0).all() and ((ops[lead[-1] + 1:] & 32) != 0).all()
+            assert ((ops[lead[0]:lead[-1] + 1] & 32) == 0).all()
+
+
+def run_case(nseq, length, dna, seed=1, reference=True):
+    import bench
+    import kalign_amd
+    codes, tasks, dist = bench.make_workload(nseq, length, dna, seed)
+    subm, scal = bench.scoring(dna)
+    ctx = kalign_amd.Context(0)
+    recs, paths, gaps = ctx.msa_tree(codes, tasks, subm, scal, dist)
+    ctx.close()
+    check_path_invariants(recs, paths)
+    # all rows of the final alignment have the same length, residues are preserved by construction
+    lens = np.array([len(c) for c in codes])
+    total = np.array([int(g.sum()) for g in gaps]) + lens
+    assert (total == total[0]).all() and total[0] == recs[-1].plen
+    # parents consume their children's alignment lengths
+    plen = {r.c: r.plen for r in recs}
+    for r in recs:
+        assert r.len_a == (plen[r.a] if r.a in plen else lens[r.a])
+        assert r.len_b == (plen[r.b] if r.b in plen else lens[r.b])
+    if reference:
+        from oracle import refdrv
+        if not refdrv.available():
+            pytest.skip("oracle/_ref not built")
+        job = refdrv.EncodedJob(codes, tasks, dist, biotype=1 if dna else 0, type_=0 if dna else -1,
+                                n_threads=min(16, os.cpu_count() or 1))
+        ref_gaps, _ = job.run_tree()
+        job.close()
+        for got, want in zip(gaps, ref_gaps):
+            assert np.array_equal(got, want)
+
+
+def test_config1_protein_1024x400_matches_reference():
+    """BASELINE.json configs[1] shape (the bench.py default): bit-identical gap arrays."""
+    run_case(1024, 400, False)
+
+
+def test_config2_shape_dna_256x2000_matches_reference():
+    """configs[2] shape (--type dna, ~2000 nt, profile-profile dominated), scaled to 256 sequences
+    so the CPU reference finishes in seconds: long anti-diagonals, multi-strip passes, clusters."""
+    run_case(256, 2000, True)
+
+
+def test_two_sequences_and_tiny_inputs():
+    import kalign_amd
+    import bench
+    subm, scal = bench.scoring(False)
+    ctx = kalign_amd.Context(0)
+    from oracle import oracledrv
+    for lens in [(1, 1), (1, 7), (9, 1), (3, 2), (64, 65), (129, 128), (257, 300)]:
+        rng = np.random.RandomState(sum(lens))
+        codes = [rng.randint(0, 20, n).astype(np.uint8) for n in lens]
+        tasks = np.array([[0, 1, 2]], np.int32)
+        recs, paths, gaps = ctx.msa_tree(codes, tasks, subm, scal, None)
+        orecs, opaths, ogaps, _ = oracledrv.msa_tree(codes, tasks, subm, scal, None)
+        assert np.array_equal(paths[:recs[0].plen + 2], opaths[:orecs[0].plen + 2]), lens
+        assert recs[0].score == orecs[0].score
+    ctx.close()
+
+
+def test_error_behaviour():
+    """FAIL (non-zero + message) like the reference's convention, never a crash or a hang."""
+    import kalign_amd
+    import bench
+    subm, scal = bench.scoring(False)
+    ctx = kalign_amd.Context(0)
+    a = np.arange(5, dtype=np.uint8)
+    with pytest.raises(kalign_amd.KalignAmdError):          # parents before children
+        ctx.msa_tree([a, a, a], np.array([[3, 2, 4], [0, 1, 3]], np.int32), subm, scal)
+    with pytest.raises(kalign_amd.KalignAmdError):          # code outside the alphabet
+        ctx.msa_tree([a, (a + 30).astype(np.uint8)], np.array([[0, 1, 2]], np.int32), subm, scal)
+    with pytest.raises(kalign_amd.KalignAmdError):          # wrong task count
+        ctx.msa_tree([a, a, a], np.array([[0, 1, 3]], np.int32), subm, scal)
+    ctx.close()
