@@ -185,9 +185,17 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         return o;
 }
 
-template <int KIND>
-__device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub* qnext, const KaLevelOut& lout, const int lane, const bool is_top)
+// GL lanes per sub-problem (64 / GL sub-problems per wave): deep recursion levels have hundreds of
+// sub-problems with a handful of columns each.
+template <int KIND, int GL>
+__device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const int k0, const int ncur, KaSub* qnext,
+                                          const KaLevelOut& lout, const int wlane, const bool top_level)
 {
+        const int lane = wlane % GL;                                 // lane within the sub-problem's group
+        const int ksub = k0 + wlane / GL;
+        const bool valid = ksub < ncur;
+        const KaSub sb = qc[valid ? ksub : k0];
+        const bool is_top = top_level && ksub == 0;
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
         const KaState* f = S.fbuf + sb.roff;
@@ -206,7 +214,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub*
                 g6f = (endb == S.Lb) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
         }
         Best B = { -KA_F, -KA_F, 0x7fffffff };
-        for (int i = startb + lane; i <= endb; i += 64) {
+        for (int i = startb + lane; valid && i <= endb; i += GL) {
                 const KaState fi = f[i - startb], bi = b[i - startb];
                 float sub = fabsf(middle - (float)i);
                 sub = sub / 1000.0f;
@@ -226,14 +234,15 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub& sb, KaSub*
                         best_consider(B, fi.gb + bi.gb + g6f - sub, kb + 4);
                 }
         }
-        // wave reduction (butterfly); every lane ends with the same answer
-        for (int off = 32; off >= 1; off >>= 1) {
+        // group reduction (butterfly); every lane of the group ends with the same answer
+#pragma unroll
+        for (int off = GL / 2; off >= 1; off >>= 1) {
                 const float omx = __shfl_xor(B.mx, off, 64);
                 const float omx2 = __shfl_xor(B.mx2, off, 64);
                 const int okey = __shfl_xor(B.key, off, 64);
                 best_merge(B, omx, omx2, okey);
         }
-        if (lane != 0) return;
+        if (lane != 0 || !valid) return;
 
         int meet = -1, tr = -1;
         if (B.key != 0x7fffffff) {
@@ -419,9 +428,19 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const float* b = (const float*)S.bbuf;
                         for (int i = tid; i < n; i += KA_NT) { dbg_rows[i] = f[i]; dbg_rows[n + i] = b[i]; }
                 }
-                for (int k = S.member * KA_NW + wave; k < ncur; k += KA_NW * S.G) {
-                        const KaSub sb = qc[k];
-                        ka_meetup<KIND>(S, sb, qn, ka_level_out(S, (level + 1) & 1, true), lane, level == 0);
+                {
+                        const KaLevelOut lout = ka_level_out(S, (level + 1) & 1, true);
+                        const int est_cols = S.Lb >> level;          // typical columns per sub-problem at this depth
+                        if (est_cols > 48) {
+                                for (int k = S.member * KA_NW + wave; k < ncur; k += KA_NW * S.G)
+                                        ka_meetup<KIND, 64>(S, qc, k, ncur, qn, lout, lane, level == 0);
+                        } else if (est_cols > 6) {
+                                for (int k = (S.member * KA_NW + wave) * 4; k < ncur; k += KA_NW * S.G * 4)
+                                        ka_meetup<KIND, 16>(S, qc, k, ncur, qn, lout, lane, level == 0);
+                        } else {
+                                for (int k = (S.member * KA_NW + wave) * 16; k < ncur; k += KA_NW * S.G * 16)
+                                        ka_meetup<KIND, 4>(S, qc, k, ncur, qn, lout, lane, level == 0);
+                        }
                 }
                 ka_cluster_sync(S);
                 if (lead && tid == 0) {
