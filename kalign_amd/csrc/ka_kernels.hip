@@ -565,90 +565,119 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 if (k >= 27 && k <= 29) return leaf_b ? 0.0f : rec[k + 28] * sipa;
                 return rec[k];
         };
-        const long long total = (long long)(alnlen + 2) * 64;
-        for (long long x = (long long)S.member * KA_NT + threadIdx.x; x < total; x += (long long)S.G * KA_NT) {
-                const int c = (int)(x >> 6);
-                const int k = (int)(x & 63);
+        // one thread per (output column, 4 consecutive fields): the column's op code and source
+        // records are looked up once, the four field values are independent
+        const float* __restrict__ pa_r = pa;
+        const float* __restrict__ pb_r = pb;
+        float* __restrict__ np_r = np;
+        const int* __restrict__ coded = S.coded;
+        const int* __restrict__ srcA = S.srcA;
+        const int* __restrict__ srcB = S.srcB;
+        auto elem = [&](const int c, const int k, const int code, const float* __restrict__ ra, const float* __restrict__ rb) -> float {
                 float val;
                 if (c == 0 || c == alnlen + 1) {
-                        const float va = (c == 0) ? fa(pa, k) : fa(pa + ((long long)(S.len_a + 1) << 6), k);
-                        const float vb = (c == 0) ? fb(pb, k) : fb(pb + ((long long)(S.len_b + 1) << 6), k);
+                        const float va = fa(ra, k), vb = fb(rb, k);
                         val = (rebalance && k < 23) ? (va * sA + vb * sB) : (va + vb);
-                } else {
-                        const int code = S.coded[c];
-                        if (!code) {
-                                const float* ra = pa + ((long long)S.srcA[c] << 6);
-                                const float* rb = pb + ((long long)S.srcB[c] << 6);
-                                if (rebalance && k < 23) {
-                                        val = ra[k] * sA + rb[k] * sB;
-                                } else {
-                                        val = fa(ra, k) + fb(rb, k);
-                                        if (rebalance && k >= 32 && k < 55) {
-                                                const float dA = sA - 1.0f, dB = sB - 1.0f;
-                                                const int jj = k - 32;
-                                                float delta = 0.0f;
-                                                for (int aa = 0; aa < 23; ++aa) {
-                                                        delta += (ra[aa] * dA + rb[aa] * dB) * D.subm[23 * aa + jj];
-                                                }
-                                                val += delta;
+                } else if (!code) {
+                        if (rebalance && k < 23) {
+                                val = ra[k] * sA + rb[k] * sB;
+                        } else {
+                                val = fa(ra, k) + fb(rb, k);
+                                if (rebalance && k >= 32 && k < 55) {
+                                        const float dA = sA - 1.0f, dB = sB - 1.0f;
+                                        const int jj = k - 32;
+                                        float delta = 0.0f;
+                                        for (int aa = 0; aa < 23; ++aa) {
+                                                delta += (ra[aa] * dA + rb[aa] * dB) * D.subm[23 * aa + jj];
                                         }
+                                        val += delta;
+                                }
+                        }
+                } else {
+                        const bool gap_in_a = (code & 1) != 0;
+                        const float sip = gap_in_a ? sipa : sipb;
+                        val = gap_in_a ? fb(rb, k) : fa(ra, k);
+                        // as the reference: up to two successive adjustments (close, then open)
+                        if (!(code & 20)) {
+                                if (code & 32) {
+                                        if (k == 25) val += sip;
+                                        if (k >= 32 && k < 55) val -= D.tgpe0 * sip;
+                                } else {
+                                        if (k == 24) val += sip;
+                                        if (k >= 32 && k < 55) val -= D.gpe0 * sip;
                                 }
                         } else {
-                                const bool gap_in_a = (code & 1) != 0;
-                                const float* src = gap_in_a ? (pb + ((long long)S.srcB[c] << 6)) : (pa + ((long long)S.srcA[c] << 6));
-                                const float sip = gap_in_a ? sipa : sipb;
-                                val = gap_in_a ? fb(src, k) : fa(src, k);
-                                // as the reference: up to two successive adjustments (close, then open)
-                                if (!(code & 20)) {
+                                for (int pass = 0; pass < 2; ++pass) {
+                                        const int bit = pass == 0 ? 16 : 4;
+                                        if (!(code & bit)) continue;
+                                        float gp;
                                         if (code & 32) {
                                                 if (k == 25) val += sip;
-                                                if (k >= 32 && k < 55) val -= D.tgpe0 * sip;
+                                                gp = D.tgpe0 * sip;
+                                                if (k == 23) val += sip;
+                                                gp += D.gpo0 * sip;
                                         } else {
-                                                if (k == 24) val += sip;
-                                                if (k >= 32 && k < 55) val -= D.gpe0 * sip;
+                                                if (k == 23) val += sip;
+                                                gp = D.gpo0 * sip;
                                         }
-                                } else {
-                                        for (int pass = 0; pass < 2; ++pass) {
-                                                const int bit = pass == 0 ? 16 : 4;
-                                                if (!(code & bit)) continue;
-                                                float gp;
-                                                if (code & 32) {
-                                                        if (k == 25) val += sip;
-                                                        gp = D.tgpe0 * sip;
-                                                        if (k == 23) val += sip;
-                                                        gp += D.gpo0 * sip;
-                                                } else {
-                                                        if (k == 23) val += sip;
-                                                        gp = D.gpo0 * sip;
-                                                }
-                                                if (k >= 32 && k < 55) val -= gp;
-                                        }
+                                        if (k >= 32 && k < 55) val -= gp;
                                 }
                         }
                 }
-                np[x] = val;
+                return val;
+        };
+        const long long total4 = (long long)(alnlen + 2) * 16;
+        for (long long x4 = (long long)S.member * KA_NT + threadIdx.x; x4 < total4; x4 += (long long)S.G * KA_NT) {
+                const int c = (int)(x4 >> 4);
+                const int k4 = (int)(x4 & 15) << 2;
+                int code = 0;
+                const float* ra;
+                const float* rb;
+                if (c == 0) { ra = pa_r; rb = pb_r; }
+                else if (c == alnlen + 1) { ra = pa_r + ((long long)(S.len_a + 1) << 6); rb = pb_r + ((long long)(S.len_b + 1) << 6); }
+                else {
+                        code = coded[c];
+                        const int ia = srcA[c], ib = srcB[c];
+                        ra = pa_r + ((long long)(ia < 0 ? 0 : ia) << 6);
+                        rb = pb_r + ((long long)(ib < 0 ? 0 : ib) << 6);
+                }
+                float4v out;
+                out.x = elem(c, k4 + 0, code, ra, rb);
+                out.y = elem(c, k4 + 1, code, ra, rb);
+                out.z = elem(c, k4 + 2, code, ra, rb);
+                out.w = elem(c, k4 + 3, code, ra, rb);
+                *(float4v*)(np_r + (x4 << 2)) = out;
         }
 }
 
-// Leaf profile (make_profile_n, aln_setup.c:40-99).  Non-leaf operands need nothing here:
-// set_gap_penalties_n is folded into the loads (see col_terms).
-__device__ void ka_make_leaf_profile(const KaTreeDev& D, float* prof, int len, const uint8_t* seq,
-                                     float gpo, float gpe, float tgpe, float soff)
+// Leaf profile (make_profile_n, aln_setup.c:40-99), one float4 per thread.  The pre-summed
+// substitution scores subm[c][j] - soff come from the seq-seq table in LDS (same expression, same
+// bits).  Non-leaf operands need nothing here: set_gap_penalties_n is folded into the loads.
+__device__ void ka_make_leaf_profile(float* __restrict__ prof, int len, const uint8_t* __restrict__ seq,
+                                     float gpo, float gpe, float tgpe, const float* tss)
 {
-        const long long total = (long long)(len + 2) * 64;
-        for (long long x = threadIdx.x; x < total; x += KA_NT) {
-                const int r = (int)(x >> 6);
-                const int k = (int)(x & 63);
-                float val = 0.0f;
-                if (k == 55) val = -gpo;
-                else if (k == 56) val = -gpe;
-                else if (k == 57) val = -tgpe;
-                else if (r >= 1 && r <= len) {
-                        const int c = seq[r - 1];
-                        if (k == c) val = 1.0f;
-                        else if (k >= 32 && k < 55) val = D.subm[23 * c + (k - 32)] - soff;
+        const long long total4 = (long long)(len + 2) * 16;
+        for (long long x4 = threadIdx.x; x4 < total4; x4 += KA_NT) {
+                const int r = (int)(x4 >> 4);
+                const int k4 = (int)(x4 & 15) << 2;
+                const bool inner = (r >= 1 && r <= len);
+                const int c = inner ? seq[r - 1] : 0;
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                        const int k = k4 + u;
+                        float val = 0.0f;
+                        if (k == 55) val = -gpo;
+                        else if (k == 56) val = -gpe;
+                        else if (k == 57) val = -tgpe;
+                        else if (inner) {
+                                if (k == c) val = 1.0f;
+                                else if (k >= 32 && k < 55) val = tss[c * KA_T_STRIDE + (k - 32)];
+                        }
+                        v[u] = val;
                 }
-                prof[x] = val;
+                float4v out; out.x = v[0]; out.y = v[1]; out.z = v[2]; out.w = v[3];
+                *(float4v*)(prof + (x4 << 2)) = out;
         }
 }
 
@@ -797,11 +826,12 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
         if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b);
 
         // P1
-        if (S.member == 0) {
-                if (T.nsip_a == 1) ka_make_leaf_profile(D, S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, T.soff);
-                if (T.nsip_b == 1) ka_make_leaf_profile(D, S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, T.soff);
-        }
         ka_build_tss(tss, D.subm, T.soff);
+        __syncthreads();
+        if (S.member == 0) {
+                if (T.nsip_a == 1) ka_make_leaf_profile(S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, tss);
+                if (T.nsip_b == 1) ka_make_leaf_profile(S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, tss);
+        }
         ka_cluster_sync(S);
         tk1 = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
