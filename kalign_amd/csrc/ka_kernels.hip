@@ -51,9 +51,9 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane)
 // The mutable state of one task's recursion: lives in LDS when one workgroup owns the task, in
 // HBM (zeroed by the host before the run) when a cluster of workgroups on different CUs shares it.
 struct KaCtl {
-        int ncur, nnext, rowalloc;
-        int nitems_cur, nitems_next, next_item;
-        int npack_cur[2], npack_next[2];
+        // per-level counters, double-buffered by level parity: level L consumes lvl[L & 1] while its
+        // meetups fill lvl[(L + 1) & 1] (zeroed at the start of level L) -> two barriers per level
+        struct Lvl { int nsub, rowalloc, nitems, next_item, npack[2]; } lvl[2];
         int mcount;
         int top_meet, top_tr;
         float top_score;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
 // than 32 rows becomes strip items (its strips are contiguous and ascending, so strip k-1 is
 // always pulled before strip k); smaller passes go to the packed lists (16-lane slots for up
 // to 32 rows, 4-lane slots for up to 8 rows).
-struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; };
+struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; };
 
 __device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows)
 {
@@ -179,9 +179,12 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         KaLevelOut o;
         o.items = S.items[parity]; o.prog = S.prog[parity];
         o.pack16 = S.pack[parity][0]; o.pack4 = S.pack[parity][1];
-        o.nitems = next ? &S.ctl->nitems_next : &S.ctl->nitems_cur;
-        o.n16 = next ? &S.ctl->npack_next[0] : &S.ctl->npack_cur[0];
-        o.n4 = next ? &S.ctl->npack_next[1] : &S.ctl->npack_cur[1];
+        (void)next;
+        o.nitems = &S.ctl->lvl[parity].nitems;
+        o.n16 = &S.ctl->lvl[parity].npack[0];
+        o.n4 = &S.ctl->lvl[parity].npack[1];
+        o.nsub = &S.ctl->lvl[parity].nsub;
+        o.rowalloc = &S.ctl->lvl[parity].rowalloc;
         return o;
 }
 
@@ -297,14 +300,14 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 break;
         }
         if (c1.starta < c1.enda && c1.startb < c1.endb) {
-                const int slot = atomicAdd(&S.ctl->nnext, 1);
-                c1.roff = atomicAdd(&S.ctl->rowalloc, c1.endb - c1.startb + 1);
+                const int slot = atomicAdd(lout.nsub, 1);
+                c1.roff = atomicAdd(lout.rowalloc, c1.endb - c1.startb + 1);
                 qnext[slot] = c1;
                 ka_emit_items(lout, slot, c1.starta, c1.enda);
         }
         if (c2.starta < c2.enda && c2.startb < c2.endb) {
-                const int slot = atomicAdd(&S.ctl->nnext, 1);
-                c2.roff = atomicAdd(&S.ctl->rowalloc, c2.endb - c2.startb + 1);
+                const int slot = atomicAdd(lout.nsub, 1);
+                c2.roff = atomicAdd(lout.rowalloc, c2.endb - c2.startb + 1);
                 qnext[slot] = c2;
                 ka_emit_items(lout, slot, c2.starta, c2.enda);
         }
@@ -353,11 +356,13 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
                 root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
                 S.q[0][0] = root;
-                S.ctl->ncur = (S.La > 0 && S.Lb > 0) ? 1 : 0;
-                S.ctl->nnext = 0; S.ctl->rowalloc = 0;
-                S.ctl->nitems_cur = 0; S.ctl->nitems_next = 0; S.ctl->next_item = 0;
-                S.ctl->npack_cur[0] = 0; S.ctl->npack_cur[1] = 0; S.ctl->npack_next[0] = 0; S.ctl->npack_next[1] = 0;
-                if (S.ctl->ncur) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La);
+                for (int par = 0; par < 2; ++par) {
+                        S.ctl->lvl[par].nsub = 0; S.ctl->lvl[par].rowalloc = 0; S.ctl->lvl[par].nitems = 0;
+                        S.ctl->lvl[par].next_item = 0; S.ctl->lvl[par].npack[0] = 0; S.ctl->lvl[par].npack[1] = 0;
+                }
+                S.ctl->lvl[0].nsub = (S.La > 0 && S.Lb > 0) ? 1 : 0;
+                S.ctl->lvl[0].rowalloc = S.Lb + 1;
+                if (S.ctl->lvl[0].nsub) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La);
                 S.ctl->msum = 0.0; S.ctl->mcount = 0;
                 S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f;
                 S.t_pass = 0; S.t_meet = 0; S.n_levels = 0;
@@ -365,16 +370,23 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         ka_cluster_sync(S);
         int level = 0;
         while (true) {
-                const int ncur = S.ctl->ncur;
+                KaCtl::Lvl* const cur = &S.ctl->lvl[level & 1];
+                const int ncur = cur->nsub;
                 if (ncur == 0) break;
                 KaSub* qc = S.q[level & 1];
                 KaSub* qn = S.q[(level + 1) & 1];
+                if (lead && tid == 0 && level > 0) {
+                        // the other parity was consumed by level-1 and is idle until this level's meetups
+                        // (which start after the barrier below): reset it now
+                        KaCtl::Lvl* const nxt = &S.ctl->lvl[(level + 1) & 1];
+                        nxt->nsub = 0; nxt->rowalloc = 0; nxt->nitems = 0; nxt->next_item = 0; nxt->npack[0] = 0; nxt->npack[1] = 0;
+                }
                 const long long tp0 = __builtin_amdgcn_s_memtime();
                 {
                         const int2* items = S.items[level & 1];
                         int* prog = S.prog[level & 1];
-                        const int nitems = S.ctl->nitems_cur;
-                        const int n16 = S.ctl->npack_cur[0], n4 = S.ctl->npack_cur[1];
+                        const int nitems = cur->nitems;
+                        const int n16 = cur->npack[0], n4 = cur->npack[1];
                         const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
                         const int ntotal = nitems + njobs16 + njobs4;
                         const int2* pack16 = S.pack[level & 1][0];
@@ -388,7 +400,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 int puller = lane;
                                 asm volatile("" : "+v"(puller));
                                 int it = 0;
-                                if (puller == 0) it = atomicAdd(&S.ctl->next_item, 1);
+                                if (puller == 0) it = atomicAdd(&cur->next_item, 1);
                                 it = __builtin_amdgcn_readfirstlane(it);
                                 if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
@@ -444,15 +456,10 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 }
                 ka_cluster_sync(S);
                 if (lead && tid == 0) {
-                        S.ctl->ncur = S.ctl->nnext; S.ctl->nnext = 0; S.ctl->rowalloc = 0;
-                        S.ctl->nitems_cur = S.ctl->nitems_next; S.ctl->nitems_next = 0; S.ctl->next_item = 0;
-                        S.ctl->npack_cur[0] = S.ctl->npack_next[0]; S.ctl->npack_cur[1] = S.ctl->npack_next[1];
-                        S.ctl->npack_next[0] = 0; S.ctl->npack_next[1] = 0;
                         const long long tp2 = __builtin_amdgcn_s_memtime();
                         S.t_pass += tp1 - tp0; S.t_meet += tp2 - tp1; S.n_levels = level + 1;
                         if (level < 16) { S.lvl_n[level] = ncur; S.lvl_pass[level] = (int)(tp1 - tp0); S.lvl_meet[level] = (int)(tp2 - tp1); }
                 }
-                ka_cluster_sync(S);
                 ++level;
         }
 }
