@@ -404,11 +404,11 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 it = __builtin_amdgcn_readfirstlane(it);
                                 if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
-                                        ka_packed<KIND, NRES, 4>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss);
+                                        ka_packed<KIND, NRES, 4>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
                                 }
                                 if (it >= nitems) {
-                                        ka_packed<KIND, NRES, 16>(S, qc, pack16, n16, it - nitems, lane, tss);
+                                        ka_packed<KIND, NRES, 16>(S, qc, pack16, n16, it - nitems, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
                                 }
                                 // everything about the item is wave-uniform: keep it in SGPRs

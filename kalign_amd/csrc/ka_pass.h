@@ -445,7 +445,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 // ------------------------------------------------------------------------------------------
 template <int KIND, int NRES, int SLOT>
 __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, const int2* pack, const int nslots,
-                                          const int job, const int lane, const float* tss)
+                                          const int job, const int lane, const float* tss, char* wlds)
 {
         constexpr int SPW = 64 / SLOT;                                // slots per wave
         const int slot = job * SPW + lane / SLOT;
@@ -516,13 +516,46 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
         float4v q[2][KA_REC_CHUNKS];
         int resq[2] = {0, 0};
 
+        // Profile-profile: when the column records of all the job's slots fit into this wave's LDS
+        // region (128 records), stage them once (every slot's lanes copy their slot's columns) and
+        // read LDS per step; otherwise stream them from L2 one step ahead.
+        int lds_base = 0;                                             // first staged record of this lane's slot
+        bool staged = false;
+        if (KIND == KA_PP && wlds != nullptr) {
+                const int cnt = live ? (ncols + 1) : 0;               // identical in all lanes of a slot
+                int total = 0;
+#pragma unroll
+                for (int sidx = 0; sidx < SPW; ++sidx) {
+                        const int c = __shfl(cnt, sidx * SLOT, 64);
+                        if (sidx < lane / SLOT) lds_base += c;
+                        total += c;
+                }
+                staged = total <= KA_RING_SLOTS * KA_RING_BATCH;      // 128 records (wave-uniform)
+                if (staged) {
+                        for (int vv = ls; vv < cnt; vv += SLOT) {
+                                const float4v* g = (const float4v*)(S.p2 + ((long long)REC(vv) << 6) + 32);
+                                char* dst = wlds + (lds_base + vv) * 16;
+#pragma unroll
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) *(float4v*)(dst + ch * 2048) = g[ch];
+                        }
+                        // written and read by different lanes of this wave only
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_s_waitcnt(0);
+                }
+        }
         auto fetch = [&](float4v* dstq, int& dstres, int vcol) {
-                // column operand for column counter vcol (clamped), straight from L2
+                // column operand for column counter vcol (clamped)
                 const int vv = min(max(vcol, 0), ncols);
                 if (KIND == KA_PP) {
-                        const float4v* g = (const float4v*)(S.p2 + ((long long)REC(vv) << 6) + 32);
+                        if (staged) {
+                                const char* src = wlds + (lds_base + vv) * 16;
 #pragma unroll
-                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = g[ch];
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = *(const float4v*)(src + ch * 2048);
+                        } else {
+                                const float4v* g = (const float4v*)(S.p2 + ((long long)REC(vv) << 6) + 32);
+#pragma unroll
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = g[ch];
+                        }
                 } else {
                         dstres = S.s2[min(max(REC(max(vv, 1)) - 1, 0), S.Lb - 1)];
                 }
