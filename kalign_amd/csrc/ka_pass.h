@@ -186,10 +186,30 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 512), 16, 0, 0);
                 }
         };
-        auto ring_read = [&](float4v* dstq, int vcol) {
-                const char* src = wlds + ((vcol >> 5) & (KA_RING_SLOTS - 1)) * KA_SLOT_BYTES + (vcol & 31) * 16;
-#pragma unroll
-                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = *(const float4v*)(src + ch * 512);
+        // The ring reads are issued as inline asm so that the compiler does not track them: its
+        // own s_waitcnt for this step's half of q (loaded one step ago) would otherwise also wait
+        // for the loads just issued for the next step (lgkmcnt is a plain in-order counter), exposing
+        // the full LDS latency every step.  ring_wait() is the matching manual wait; it takes the
+        // registers as in/out operands so that no use can be scheduled above it.
+        auto ring_read = [&](float4v* dstq, int vcol, float2v& dep) {
+                const unsigned a = (unsigned)(unsigned long long)(wlds + ((vcol >> 5) & (KA_RING_SLOTS - 1)) * KA_SLOT_BYTES + (vcol & 31) * 16);
+                asm volatile("ds_read_b128 %0, %8\n\t"
+                             "ds_read_b128 %1, %8 offset:512\n\t"
+                             "ds_read_b128 %2, %8 offset:1024\n\t"
+                             "ds_read_b128 %3, %8 offset:1536\n\t"
+                             "ds_read_b128 %4, %8 offset:2048\n\t"
+                             "ds_read_b128 %5, %8 offset:2560\n\t"
+                             "ds_read_b128 %6, %8 offset:3072"
+                             : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "=&v"(dstq[3]), "=&v"(dstq[4]), "=&v"(dstq[5]), "=&v"(dstq[6]),
+                               "+v"(dep)                              // orders the loads after the value `dep` (see step())
+                             : "v"(a)
+                             : "memory");
+        };
+        auto ring_wait = [&](float4v* qq) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6])
+                             :
+                             : "memory");
         };
 
         if (KIND == KA_PP) {
@@ -197,7 +217,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 ring_issue(0);
                 ring_issue(1);
                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
-                ring_read(q[0], min(max(-lane, 0), ncols));
+                { float2v nodep = {0.0f, 0.0f}; ring_read(q[0], min(max(-lane, 0), ncols), nodep); }
         }
 
         // One wavefront step.
@@ -217,6 +237,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
                 if (KIND == KA_PP) {
+                        ring_wait(q[P]);                              // this step's column record (issued one step ago)
                         copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
                         col_terms<KIND>(S, 0, copen, cext, ctext);
@@ -297,17 +318,18 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 prod = nprod;
                         }
                         acc = acc + prod;
-                        // Fetch the next step's column record into the other half of q.  The loads are
-                        // pinned AFTER the dot products (sched_barrier): hoisted above them, the
-                        // compiler's s_waitcnt for this step's half (loaded one step ago) would also
-                        // wait for the fresh loads, exposing the whole LDS latency every step.
+                        // Fetch the next step's column record into the other half of q.  The loads must
+                        // stay AFTER the dot products: placed above them, the s_waitcnt for this step's
+                        // half (loaded one step ago) also waits for the fresh loads and exposes the whole
+                        // LDS latency every step.  sched_barrier pins the machine scheduler; the fake
+                        // dependency on acc keeps the IR passes from sinking the chain below the loads.
                         __builtin_amdgcn_sched_barrier(0);
                         const int tn = t + 1;
                         if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
                                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
                                 ring_issue((tn >> 5) + 1);
                         }
-                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols));
+                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
                         __builtin_amdgcn_sched_barrier(0);
                 }
                 float nAa, nAga, nAgb, nBa, nBga, nBgb;
@@ -373,6 +395,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 
         auto fix_parity = [&]() {
                 if (KIND == KA_PP) {
+                        ring_wait(q[1]);
 #pragma unroll
                         for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) q[0][ch] = q[1][ch];
                 }
