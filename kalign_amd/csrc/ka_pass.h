@@ -51,20 +51,32 @@ __device__ __forceinline__ int wave_shr1_i(int x)
 // lane l <- lane l-1 of src; lane 0 keeps its own `old` (used to splice the boundary state in)
 __device__ __forceinline__ float wave_shr1_old(float old, float src)
 {
+#if defined(KA_EXP) && (KA_EXP & 4)
+        return old + src;
+#endif
         return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x138, 0xf, 0xf, false));
 }
 // lane l <- lane l+1 of src; lane 63 keeps its own `old` (shift register fed at the top lane)
 __device__ __forceinline__ float wave_shl1_old(float old, float src)
 {
+#if defined(KA_EXP) && (KA_EXP & 4)
+        return old + src;
+#endif
         return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x130, 0xf, 0xf, false));
 }
 // rotate: lane l <- lane (l+1) mod 64
 __device__ __forceinline__ float wave_rol1(float x)
 {
+#if defined(KA_EXP) && (KA_EXP & 4)
+        return x + 1.0f;
+#endif
         const int xi = __float_as_int(x);
         return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x134, 0xf, 0xf, false));
 }
 
+#ifndef KA_EXP
+#define KA_EXP 0      // timing experiments only (scratch builds): 1 no dot chain, 2 no ring reads, 4 no DPP
+#endif
 __device__ __forceinline__ int ka_strips_of(int nrows) { return nrows <= 0 ? 1 : (nrows + KA_STRIP_ROWS - 1) / KA_STRIP_ROWS; }
 
 template <int KIND, int NRES>
@@ -237,7 +249,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
                 if (KIND == KA_PP) {
-                        ring_wait(q[P]);                              // this step's column record (issued one step ago)
+                        if (!(KA_EXP & 2)) ring_wait(q[P]);           // this step's column record (issued one step ago)
                         copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
                         col_terms<KIND>(S, 0, copen, cext, ctext);
@@ -310,7 +322,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         float2v prod;
                         { const float sc = q[P][(NRES - 1) >> 2][(NRES - 1) & 3]; float2v w; w.x = sc; w.y = sc; prod = p1v[NRES - 1] * w; }
 #pragma unroll
-                        for (int c = NRES - 1; c >= 1; --c) {
+                        for (int c = ((KA_EXP & 1) ? 2 : NRES - 1); c >= 1; --c) {
                                 const float sc = q[P][(c - 1) >> 2][(c - 1) & 3];
                                 float2v w; w.x = sc; w.y = sc;
                                 const float2v nprod = p1v[c - 1] * w;
@@ -329,7 +341,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
                                 ring_issue((tn >> 5) + 1);
                         }
-                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
+                        if (!(KA_EXP & 2)) ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
                         __builtin_amdgcn_sched_barrier(0);
                 }
                 float nAa, nAga, nAgb, nBa, nBga, nBgb;
