@@ -544,17 +544,219 @@ static float mean_distance(const float* dist, const int* ma, int na, const int* 
         return n ? sum / (float)n : 0.0f;
 }
 
+
+/* ---- anchor consistency (anchor_consistency.c) ------------------------------------- */
+typedef struct { int K, N; float weight; int* anchor_ids; int** maps; } ko_cons;
+
+/* farthest-first on |dist[i] - dist[anchor]| (anchor_consistency.c:122-192) */
+static void ko_select_anchors(const float* dist, int N, int K, int* ids)
+{
+        float* min_dist = malloc(sizeof(float) * (size_t)N);
+        float sum = 0.0f, mean, best_diff = FLT_MAX;
+        int best = 0;
+        for(int i = 0; i < N; i++) sum += dist[i];
+        mean = sum / (float)N;
+        for(int i = 0; i < N; i++){
+                float diff = dist[i] - mean;
+                if(diff < 0) diff = -diff;
+                if(diff < best_diff){ best_diff = diff; best = i; }
+        }
+        ids[0] = best;
+        for(int i = 0; i < N; i++){
+                float d = dist[i] - dist[ids[0]];
+                if(d < 0) d = -d;
+                min_dist[i] = d;
+        }
+        for(int k = 1; k < K; k++){
+                float best_min = -1.0f;
+                best = 0;
+                for(int i = 0; i < N; i++){
+                        int skip = 0;
+                        for(int j = 0; j < k; j++) if(ids[j] == i){ skip = 1; break; }
+                        if(skip) continue;
+                        if(min_dist[i] > best_min){ best_min = min_dist[i]; best = i; }
+                }
+                ids[k] = best;
+                for(int i = 0; i < N; i++){
+                        float d = dist[i] - dist[best];
+                        if(d < 0) d = -d;
+                        if(d < min_dist[i]) min_dist[i] = d;
+                }
+        }
+        free(min_dist);
+}
+
+/* coded path -> position map (anchor_consistency.c:86-114) */
+static void ko_posmap(const int* coded, int len_i, int* map)
+{
+        int pos_a = 0, pos_b = 0;
+        for(int c = 0; c < len_i; c++) map[c] = -1;
+        for(int c = 1; coded[c] != 3; c++){
+                if(coded[c] == 0){
+                        if(pos_a < len_i) map[pos_a] = pos_b;
+                        pos_a++; pos_b++;
+                }else if(coded[c] & 1){
+                        pos_b++;
+                }else if(coded[c] & 2){
+                        if(pos_a < len_i) map[pos_a] = -1;
+                        pos_a++;
+                }
+        }
+}
+
+static void ko_cons_free(ko_cons* ct)
+{
+        if(!ct) return;
+        if(ct->maps){ for(int i = 0; i < ct->N * ct->K; i++) free(ct->maps[i]); free(ct->maps); }
+        free(ct->anchor_ids);
+        free(ct);
+}
+
+/* anchor_consistency_build (anchor_consistency.c:194-275): NULL when it declines (K<=0, N<3, no distances) */
+static ko_cons* ko_cons_build(int N, const uint8_t* codes, const int* off, const int* lens, const float* dist,
+                              const float* subm, float gpo, float gpe, float tgpe, int K, float weight)
+{
+        ko_cons* ct;
+        if(K <= 0 || N < 3 || !dist) return NULL;
+        if(K > N) K = N;
+        ct = calloc(1, sizeof(ko_cons));
+        ct->K = K; ct->N = N; ct->weight = weight;
+        ct->anchor_ids = malloc(sizeof(int) * (size_t)K);
+        ct->maps = calloc((size_t)N * (size_t)K, sizeof(int*));
+        ko_select_anchors(dist, N, K, ct->anchor_ids);
+        for(int i = 0; i < N; i++){
+                for(int k = 0; k < K; k++){
+                        const int ak = ct->anchor_ids[k];
+                        int* map = malloc(sizeof(int) * (size_t)(lens[i] > 0 ? lens[i] : 1));
+                        if(i == ak){
+                                for(int p = 0; p < lens[i]; p++) map[p] = p;
+                        }else{
+                                const long long poff = 0;
+                                int* coded = malloc(sizeof(int) * (size_t)(lens[i] + lens[ak] + 3));
+                                ko_pairwise_batch(codes, off, lens, &i, &ak, 1, subm, gpo, gpe, tgpe, coded, &poff, NULL);
+                                ko_posmap(coded, lens[i], map);
+                                free(coded);
+                        }
+                        ct->maps[i * K + k] = map;
+                }
+        }
+        return ct;
+}
+
+/* get_node_anchor_positions (anchor_consistency.c:352-470) */
+static void ko_node_positions(const ko_cons* ct, int node, int nmem, const int* members, const int* lens,
+                              int** gaps, int dp_len, int k, int* positions, float* conf)
+{
+        const int K = ct->K;
+        if(nmem == 1){
+                const int* map = ct->maps[node * K + k];
+                const int seq_len = lens[node];
+                int i;
+                for(i = 0; i < dp_len && i < seq_len; i++){
+                        positions[i] = map[i];
+                        conf[i] = (map[i] >= 0) ? 1.0f : 0.0f;
+                }
+                for(; i < dp_len; i++){ positions[i] = -1; conf[i] = 0.0f; }
+                return;
+        }
+        {
+                int* c2u = malloc(sizeof(int) * (size_t)(dp_len + 1));
+                int* best = malloc(sizeof(int) * (size_t)dp_len);
+                int* agree = calloc((size_t)dp_len, sizeof(int));
+                int* total = calloc((size_t)dp_len, sizeof(int));
+                for(int c = 0; c < dp_len; c++) best[c] = -1;
+                for(int mi = 0; mi < nmem; mi++){
+                        const int si = members[mi];
+                        const int* map;
+                        const int* g;
+                        int seq_len, col = 0;
+                        if(si >= ct->N) continue;
+                        map = ct->maps[si * K + k];
+                        seq_len = lens[si];
+                        g = gaps[si];
+                        for(int p = 0; p <= seq_len && col < dp_len; p++){
+                                for(int q = 0; q < g[p] && col < dp_len; q++) c2u[col++] = -1;
+                                if(p < seq_len && col < dp_len) c2u[col++] = p;
+                        }
+                        while(col < dp_len) c2u[col++] = -1;
+                        for(int c = 0; c < dp_len; c++){
+                                const int ugp = c2u[c];
+                                int apos;
+                                if(ugp < 0 || ugp >= seq_len) continue;
+                                apos = map[ugp];
+                                if(apos < 0) continue;
+                                total[c]++;
+                                if(best[c] < 0){ best[c] = apos; agree[c] = 1; }
+                                else if(apos == best[c]) agree[c]++;
+                        }
+                }
+                for(int c = 0; c < dp_len; c++){
+                        if(total[c] > 0 && agree[c] > 0){
+                                positions[c] = best[c];
+                                conf[c] = (float)agree[c] / (float)total[c];
+                        }else{
+                                positions[c] = -1; conf[c] = 0.0f;
+                        }
+                }
+                free(c2u); free(best); free(agree); free(total);
+        }
+}
+
+/* anchor_consistency_get_bonus_profile (anchor_consistency.c:472-561): dense rows x cols matrix */
+static float* ko_bonus_profile(const ko_cons* ct, const int* lens, int** gaps,
+                               int rnode, int rn, const int* rmem, int rows,
+                               int cnode, int cn, const int* cmem, int cols)
+{
+        float* bonus = calloc((size_t)rows * (size_t)cols, sizeof(float));
+        int* apos_a = malloc(sizeof(int) * (size_t)rows);
+        float* conf_a = malloc(sizeof(float) * (size_t)rows);
+        int* apos_b = malloc(sizeof(int) * (size_t)cols);
+        float* conf_b = malloc(sizeof(float) * (size_t)cols);
+        const float paw = ct->weight / (float)ct->K;
+        for(int k = 0; k < ct->K; k++){
+                int anchor_len = 0;
+                int* inv_b;
+                float* inv_conf_b;
+                ko_node_positions(ct, rnode, rn, rmem, lens, gaps, rows, k, apos_a, conf_a);
+                ko_node_positions(ct, cnode, cn, cmem, lens, gaps, cols, k, apos_b, conf_b);
+                for(int i = 0; i < rows; i++) if(apos_a[i] >= anchor_len) anchor_len = apos_a[i] + 1;
+                for(int j = 0; j < cols; j++) if(apos_b[j] >= anchor_len) anchor_len = apos_b[j] + 1;
+                if(anchor_len == 0) continue;
+                inv_b = malloc(sizeof(int) * (size_t)anchor_len);
+                inv_conf_b = malloc(sizeof(float) * (size_t)anchor_len);
+                for(int j = 0; j < anchor_len; j++){ inv_b[j] = -1; inv_conf_b[j] = 0.0f; }
+                for(int j = 0; j < cols; j++){
+                        if(apos_b[j] >= 0 && apos_b[j] < anchor_len){
+                                inv_b[apos_b[j]] = j;
+                                inv_conf_b[apos_b[j]] = conf_b[j];
+                        }
+                }
+                for(int i = 0; i < rows; i++){
+                        const int ak = apos_a[i];
+                        if(ak >= 0 && ak < anchor_len){
+                                const int bj = inv_b[ak];
+                                if(bj >= 0) bonus[(size_t)i * (size_t)cols + (size_t)bj] += paw * conf_a[i] * inv_conf_b[ak];
+                        }
+                }
+                free(inv_b); free(inv_conf_b);
+        }
+        free(apos_a); free(conf_a); free(apos_b); free(conf_b);
+        return bonus;
+}
+
 /*
- * The dispatcher: create_msa_tree / do_align without consistency
- * (aln_run.c:43-124, :213-441).  Tasks must be in TASK_ORDER_TREE order
- * (children before parents; the last task is the root).
+ * The dispatcher: create_msa_tree / do_align (aln_run.c:43-124, :213-441), with the
+ * anchor-consistency bonus when n_anchors > 0 (aln_wrap.c:207-214, aln_run.c:262-295).
+ * Tasks must be in TASK_ORDER_TREE order (children before parents; the last task is the root).
  */
-int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* lens,
-                const float* seq_distances,
-                int n_tasks, const int* abc,
-                const float* subm, const float* scal,
-                ko_task_rec* recs, int* paths_out, long long paths_cap,
-                int* gaps_out, int dump_task, float* prof_dump)
+int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                     const float* seq_distances,
+                     int n_tasks, const int* abc,
+                     const float* subm, const float* scal,
+                     int n_anchors, float cons_weight,
+                     ko_task_rec* recs, int* paths_out, long long paths_cap,
+                     int* gaps_out, int dump_task, float* prof_dump,
+                     int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out)
 {
         const int nprof = 2 * numseq - 1;
         const float gpo0 = scal[0], gpe0 = scal[1], tgpe0 = scal[2];
@@ -566,7 +768,13 @@ int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* len
         int** gaps = calloc((size_t)numseq, sizeof(int*));
         long long poff = 0;
         int rc = 0;
+        ko_cons* ct = ko_cons_build(numseq, codes, off, lens, seq_distances, subm, gpo0, gpe0, tgpe0, n_anchors, cons_weight);
 
+        if(ct && anchor_ids_out) for(int k = 0; k < ct->K; k++) anchor_ids_out[k] = ct->anchor_ids[k];
+        if(ct && maps_out){
+                int o = 0;
+                for(int i = 0; i < numseq * ct->K; i++) for(int p = 0; p < lens[i / ct->K]; p++) maps_out[o++] = ct->maps[i][p];
+        }
         for(int i = 0; i < numseq; i++){
                 sip[i] = malloc(sizeof(int)); sip[i][0] = i; nsip[i] = 1;
                 gaps[i] = calloc((size_t)lens[i] + 1, sizeof(int));
@@ -580,6 +788,7 @@ int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* len
                 probe_t probe;
                 int *raw, *raw2, *coded;
                 float* merged;
+                float* bonus = NULL;
 
                 memset(&d, 0, sizeof(d));
                 memset(&probe, 0, sizeof(probe));
@@ -641,6 +850,15 @@ int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* len
                 }
                 d.len_a = swapped ? len_b : len_a;
                 d.len_b = swapped ? len_a : len_b;
+                if(ct){
+                        /* rows/cols of the bonus follow the DP operands (aln_run.c:262-295) */
+                        const int rn = swapped ? b : a, cn = swapped ? a : b;
+                        bonus = ko_bonus_profile(ct, lens, gaps, rn, nsip[rn], sip[rn], d.len_a, cn, nsip[cn], sip[cn], d.len_b);
+                        d.bonus = bonus; d.bstride = d.len_b;
+                        if(bonus_hash_out) bonus_hash_out[tid] = ko_fnv1a(bonus, sizeof(float) * (uint64_t)d.len_a * (uint64_t)d.len_b);
+                }else if(bonus_hash_out){
+                        bonus_hash_out[tid] = 0;
+                }
                 g = (len_a > len_b ? len_a : len_b) + 2;
                 d.f = malloc(sizeof(st) * (size_t)g);
                 d.b = malloc(sizeof(st) * (size_t)g);
@@ -692,8 +910,9 @@ int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* len
                 g = 0;
                 for(int j = nsip[a]; j--;) sip[c][g++] = sip[a][j];          /* aln_run.c:428-436 */
                 for(int j = nsip[b]; j--;) sip[c][g++] = sip[b][j];
-                free(d.f); free(d.b); free(raw); free(raw2); free(coded);
+                free(d.f); free(d.b); free(raw); free(raw2); free(coded); free(bonus);
         }
+        ko_cons_free(ct);
         if(gaps_out){
                 int o = 0;
                 for(int i = 0; i < numseq; i++) for(int j = 0; j <= lens[i]; j++) gaps_out[o++] = gaps[i][j];
@@ -702,6 +921,17 @@ int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* len
         for(int i = 0; i < numseq; i++) free(gaps[i]);
         free(prof); free(sip); free(nsip); free(plen); free(gaps);
         return rc;
+}
+
+int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                const float* seq_distances,
+                int n_tasks, const int* abc,
+                const float* subm, const float* scal,
+                ko_task_rec* recs, int* paths_out, long long paths_cap,
+                int* gaps_out, int dump_task, float* prof_dump)
+{
+        return ko_msa_tree_cons(numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, 0, 0.0f,
+                                recs, paths_out, paths_cap, gaps_out, dump_task, prof_dump, NULL, NULL, NULL);
 }
 
 /* N x seq-seq as pairwise_align_map runs them (anchor_consistency.c:19-120) */

@@ -43,6 +43,18 @@ int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* len
                 ko_task_rec* recs, int* paths_out, long long paths_cap,
                 int* gaps_out, int dump_task, float* prof_dump);
 
+/* The same with anchor consistency (n_anchors > 0: anchor_consistency_build + bonus in every DP).
+   Optional outputs: anchor_ids_out[K]; maps_out = all position maps concatenated in (i*K+k) order;
+   bonus_hash_out[n_tasks] = FNV-1a of each task's dense bonus matrix. */
+int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                     const float* seq_distances,
+                     int n_tasks, const int* tasks_abc,
+                     const float* subm, const float* scal,
+                     int n_anchors, float cons_weight,
+                     ko_task_rec* recs, int* paths_out, long long paths_cap,
+                     int* gaps_out, int dump_task, float* prof_dump,
+                     int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out);
+
 int ko_pairwise_batch(const uint8_t* codes, const int* off, const int* lens,
                       const int* ia, const int* ib, int npairs,
                       const float* subm, float gpo, float gpe, float tgpe,

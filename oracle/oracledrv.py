@@ -56,6 +56,8 @@ def lib():
         vp = C.c_void_p
         L.ko_msa_tree.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                   C.POINTER(TaskRec), vp, C.c_longlong, vp, C.c_int, vp]
+        L.ko_msa_tree_cons.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float,
+                                       C.POINTER(TaskRec), vp, C.c_longlong, vp, C.c_int, vp, vp, vp, vp]
         L.ko_pairwise_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, C.c_float,
                                         vp, vp, vp]
         L.ko_dp_single.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp,
@@ -108,6 +110,41 @@ def msa_tree(codes, tasks, subm, scal, seq_distances=None, dump_task=-1):
         g.append(gaps[o:o + int(n) + 1].copy())
         o += int(n) + 1
     return recs, paths, g, dump
+
+
+def msa_tree_cons(codes, tasks, subm, scal, seq_distances, n_anchors=5, weight=2.0):
+    """Oracle dispatcher in default mode (anchor consistency).  Returns
+    (recs, paths, gaps per seq, anchor_ids, maps[i][k], bonus_hash[n_tasks])."""
+    flat, off, lens = flatten(codes)
+    tasks = np.ascontiguousarray(tasks, np.int32)
+    nt = len(tasks)
+    recs = (TaskRec * nt)()
+    cap = (int(lens.max()) * 2 + 4) * nt + int(lens.sum()) * 2 * 40
+    paths = np.zeros(cap, np.int32)
+    gaps = np.zeros(int(lens.sum()) + len(codes), np.int32)
+    K = min(n_anchors, len(codes))
+    ids = np.full(max(K, 1), -1, np.int32)
+    mflat = np.zeros(max(1, int(lens.sum()) * max(K, 1)), np.int32)
+    bh = np.zeros(nt, np.uint64)
+    sd = None if seq_distances is None else np.ascontiguousarray(seq_distances, np.float32)
+    rc = lib().ko_msa_tree_cons(len(codes), _ptr(flat), _ptr(off), _ptr(lens), _ptr(sd), nt, _ptr(tasks),
+                                _ptr(np.ascontiguousarray(subm, np.float32).reshape(-1)),
+                                _ptr(np.ascontiguousarray(scal, np.float32)), n_anchors, weight,
+                                recs, _ptr(paths), cap, _ptr(gaps), -1, None, _ptr(ids), _ptr(mflat), _ptr(bh))
+    if rc:
+        raise RuntimeError("ko_msa_tree_cons rc=%d" % rc)
+    g, o = [], 0
+    for n in lens:
+        g.append(gaps[o:o + int(n) + 1].copy())
+        o += int(n) + 1
+    maps, o = [], 0
+    for i in range(len(codes)):
+        row = []
+        for k in range(K):
+            row.append(mflat[o:o + int(lens[i])].copy())
+            o += int(lens[i])
+        maps.append(row)
+    return recs, paths, g, ids[:K], maps, bh
 
 
 def pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe):

@@ -237,6 +237,71 @@ ERROR:
         return NULL;
 }
 
+
+/* ---- anchor consistency (aln_wrap.c:207-214) ---- */
+/* Builds msa->consistency_table with the reference's own anchor_consistency_build
+   (anchor selection + N x K pairwise_align_map).  From then on refh_run_tree and
+   refh_run_tree_traced run in "default mode" (bonus matrices in every DP). */
+int refh_build_consistency(void* hv, int n_anchors, float weight)
+{
+        struct refh* h = (struct refh*)hv;
+        if(h->msa->consistency_table){
+                anchor_consistency_free((struct consistency_table*)h->msa->consistency_table);
+                h->msa->consistency_table = NULL;
+        }
+        h->ap->consistency_anchors = n_anchors;
+        h->ap->consistency_weight = weight;
+        if(anchor_consistency_build(h->msa, h->ap, n_anchors, weight,
+                                    (struct consistency_table**)&h->msa->consistency_table) != OK) return 1;
+        return 0;
+}
+
+/* K (0 when no table), anchor ids, and all position maps concatenated in (i*K + k) order,
+   each of length len_i.  Pass NULL to query K only. */
+int refh_get_consistency(void* hv, int* anchor_ids, int* maps_out)
+{
+        struct refh* h = (struct refh*)hv;
+        struct consistency_table* ct = (struct consistency_table*)h->msa->consistency_table;
+        if(!ct) return 0;
+        if(anchor_ids) for(int k = 0; k < ct->n_anchors; k++) anchor_ids[k] = ct->anchor_ids[k];
+        if(maps_out){
+                int o = 0;
+                for(int i = 0; i < ct->numseq * ct->n_anchors; i++){
+                        for(int p = 0; p < ct->map_lengths[i]; p++) maps_out[o++] = ct->pos_maps[i][p];
+                }
+        }
+        return ct->n_anchors;
+}
+
+/* optional sink for the FNV hash of every task's bonus matrix (traced replay) */
+static uint64_t* g_bonus_hash_out = NULL;
+void refh_set_bonus_hash_out(uint64_t* out){ g_bonus_hash_out = out; }
+
+/* do_align's bonus block (aln_run.c:262-295): row/col node assignment mirrors the DP swap rules */
+static int attach_bonus(struct msa* msa, struct aln_mem* m, int a, int b, int len_a, int len_b, float** bonus)
+{
+        struct consistency_table* ct = (struct consistency_table*)msa->consistency_table;
+        int rn, cn, rows, cols;
+        *bonus = NULL;
+        m->consistency = NULL; m->consistency_stride = 0;
+        if(!ct) return 0;
+        if(msa->nsip[a] == 1 && msa->nsip[b] == 1){
+                if(len_a < len_b){ rn = a; rows = len_a; cn = b; cols = len_b; }
+                else{ rn = b; rows = len_b; cn = a; cols = len_a; }
+        }else if(msa->nsip[a] == 1){
+                rn = b; rows = len_b; cn = a; cols = len_a;
+        }else if(msa->nsip[b] == 1){
+                rn = a; rows = len_a; cn = b; cols = len_b;
+        }else{
+                if(len_a < len_b){ rn = a; rows = len_a; cn = b; cols = len_b; }
+                else{ rn = b; rows = len_b; cn = a; cols = len_a; }
+        }
+        if(anchor_consistency_get_bonus_profile(ct, msa, rn, rows, cn, cols, bonus) != OK) return 1;
+        m->consistency = *bonus;
+        m->consistency_stride = cols;
+        return 0;
+}
+
 static void collect_gaps(struct msa* msa, int* gaps_out)
 {
         int o = 0;
@@ -344,8 +409,8 @@ static void set_operands(struct msa* msa, struct aln_tasks* t, struct aln_mem* m
 }
 
 /* Replays do_align (aln_run.c:213-441) for every task, through the reference's
-   own functions, recording golden data.  Consistency is not used (library
-   default, aln_wrap.c:263-266).  paths_out must hold sum(len_a+len_b+3) ints.
+   own functions, recording golden data.  With a consistency table attached
+   (refh_build_consistency) every DP reads its bonus matrix as do_align does.  paths_out must hold sum(len_a+len_b+3) ints.
    prof_dump (optional): receives the merged profile of task `dump_task`
    ((plen+2)*64 floats). */
 int refh_run_tree_traced(void* hv, struct refh_task_rec* recs, int* paths_out,
@@ -362,7 +427,8 @@ int refh_run_tree_traced(void* hv, struct refh_task_rec* recs, int* paths_out,
                 struct aln_param scaled;
                 struct aln_param* ap = h->ap;
                 float* tmp = NULL;
-                int kind, swapped, len_a, len_b;
+                float* bonus = NULL;
+                int kind, swapped, len_a, len_b, bonus_stride = 0;
 
                 if(alloc_aln_mem(&m, 256) != OK) return 1;
                 m->run_parallel = 0;
@@ -398,7 +464,11 @@ int refh_run_tree_traced(void* hv, struct refh_task_rec* recs, int* paths_out,
                 {
                         int old_cor[5]; int meet = -1, tr = -1; float score = 0.0f;
                         if(init_alnmem(m) != OK) return 1;
-                        m->consistency = NULL; m->consistency_stride = 0;
+                        if(attach_bonus(msa, m, a, b, len_a, len_b, &bonus) != 0) return 1;
+                        bonus_stride = m->consistency_stride;
+                        if(g_bonus_hash_out){
+                                g_bonus_hash_out[tid] = bonus ? fnv1a(bonus, sizeof(float) * (size_t)len_a * (size_t)len_b, FNV_SEED) : 0;
+                        }
                         set_operands(msa, t, m, a, b, &kind, &swapped);
                         if(m->enda > m->starta && m->endb > m->startb){
                                 int mid = ((m->enda - m->starta) / 2) + m->starta;
@@ -427,10 +497,12 @@ int refh_run_tree_traced(void* hv, struct refh_task_rec* recs, int* paths_out,
                 /* ---- the real thing ---- */
                 if(init_alnmem(m) != OK) return 1;
                 m->margin_sum = 0.0F; m->margin_count = 0;
-                m->consistency = NULL; m->consistency_stride = 0;
+                m->consistency = bonus; m->consistency_stride = bonus_stride;
                 m->mode = ALN_MODE_FULL;
                 set_operands(msa, t, m, a, b, &kind, &swapped);
                 aln_runner(m);
+                if(bonus){ free(bonus); bonus = NULL; }
+                m->consistency = NULL;
                 if(swapped){
                         if(mirror_path_n(m, len_a, len_b) != OK) return 1;
                         m->len_a = len_a; m->len_b = len_b;

@@ -66,6 +66,10 @@ def lib():
         L.refh_prepare_encoded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, C.c_float, C.c_int,
                                            C.c_float, C.c_float, C.c_float]
+        L.refh_build_consistency.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.refh_get_consistency.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.refh_set_bonus_hash_out.argtypes = [C.c_void_p]
+        L.refh_set_bonus_hash_out.restype = None
         L.refh_kalign.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_float, C.c_float, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
         _lib = L
@@ -139,7 +143,31 @@ class RefJob:
             raise RuntimeError("create_msa_tree failed")
         return self.split_gaps(g), secs.value
 
-    def run_tree_traced(self, dump_task=-1):
+    def build_consistency(self, n_anchors=5, weight=2.0):
+        """anchor_consistency_build (aln_wrap.c:207-214): from now on the tree runs in default mode."""
+        if lib().refh_build_consistency(self.h, n_anchors, weight):
+            raise RuntimeError("anchor_consistency_build failed")
+
+    def consistency(self):
+        """(anchor_ids[K], maps[i][k] = int array of len_i) or None when no table is attached."""
+        K = lib().refh_get_consistency(self.h, None, None)
+        if K == 0:
+            return None
+        ids = np.zeros(K, np.int32)
+        flat = np.zeros(int(self.lens.sum()) * K, np.int32)
+        lib().refh_get_consistency(self.h, _ptr(ids), _ptr(flat))
+        maps, o = [], 0
+        for i in range(self.n):
+            row = []
+            for k in range(K):
+                row.append(flat[o:o + int(self.lens[i])].copy())
+                o += int(self.lens[i])
+            maps.append(row)
+        return ids, maps
+
+    def run_tree_traced(self, dump_task=-1, bonus_hash=None):
+        """bonus_hash: optional uint64[ntasks] array receiving the FNV hash of each task's bonus matrix."""
+        lib().refh_set_bonus_hash_out(_ptr(bonus_hash) if bonus_hash is not None else None)
         recs = (TaskRec * self.ntasks)()
         total = 0
         # upper bound on the path storage

@@ -48,6 +48,45 @@ def tree_case(name, seqs, **kw):
     print(name, "n=%d" % job.n, "alnlen=%d" % len(rows[0]))
 
 
+def cons_case(name, seqs, n_anchors=5, weight=2.0, **kw):
+    """Default mode: anchor_consistency_build + bonus matrices in every DP (aln_wrap.c:207-214)."""
+    job = refdrv.RefJob(seqs, **kw)
+    job.build_consistency(n_anchors, weight)
+    ids, maps = job.consistency()
+    bh = np.zeros(job.ntasks, np.uint64)
+    recs, paths, gaps, _ = job.run_tree_traced(bonus_hash=bh)
+    rows = job.finalise()
+    job2 = refdrv.RefJob(seqs, **kw)
+    job2.build_consistency(n_anchors, weight)
+    gaps2, _ = job2.run_tree()
+    assert all(np.array_equal(a, b) for a, b in zip(gaps, gaps2)), name
+    used = recs[-1].path_off + recs[-1].plen + 2
+    d = dict(
+        seqs=np.array(seqs), kw=np.array(repr(sorted(kw.items()))),
+        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes),
+        seq_distances=job.seq_distances, tasks=job.tasks, subm=job.subm,
+        scal=np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32),
+        biotype=np.int32(job.biotype),
+        paths=paths[:used], gaps=np.concatenate(gaps), rows=np.array(rows),
+        n_anchors=np.int32(n_anchors), weight=np.float32(weight), anchor_ids=ids,
+        maps=np.concatenate([m for row in maps for m in row]), bonus_hash=bh,
+    )
+    for k, v in oracledrv.recs_to_dict(recs).items():
+        d["rec_" + k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "n=%d" % job.n, "alnlen=%d" % len(rows[0]), "anchors", ids)
+
+
+def cons_cases():
+    data = os.path.join(HERE, "data")
+    cons_case("cons_BB11001", synth.read_fasta(os.path.join(data, "BB11001.tfa"))[1])
+    cons_case("cons_BB30014", synth.read_fasta(os.path.join(data, "BB30014.tfa"))[1])
+    cons_case("cons_prot32x200", synth.family(32, 200, seed=1))
+    cons_case("cons_dna16x300", synth.family(16, 300, dna=True, seed=1), type_=0)
+    cons_case("cons_prot48_k3", synth.family(48, 130, seed=21), n_anchors=3, weight=1.5)
+    cons_case("cons_ragged", ["ACDEFGHIKL", "AC", "ACDEFGHIKLMNPQRSTVWYACDEFGHIKLMNPQRSTVWY", "MKV", "ACDKL", "WYACDEFG"])
+
+
 def pairwise_case(name, seqs, type_):
     job = refdrv.RefJob(seqs, type_=type_)
     n = job.n
@@ -94,4 +133,8 @@ def main():
 if __name__ == "__main__":
     if not refdrv.available():
         sys.exit("oracle/_ref/libkalign_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cons":        # only the consistency cases
+        cons_cases()
+    else:
+        main()
+        cons_cases()

@@ -3,7 +3,7 @@ the REAL reference (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from util import Golden, compare_recs, pair_cases, tree_cases
+from util import Golden, compare_recs, cons_cases, pair_cases, tree_cases
 
 EXACT = ["a", "b", "c", "len_a", "len_b", "nsip_a", "nsip_b", "plen", "kind", "swapped",
          "meet", "transition", "gap_scale", "subm_off", "score", "prof_hash", "fhash", "bhash"]
@@ -20,6 +20,27 @@ def test_tree_matches_reference(oracle, name):
     n = len(g.dump)
     assert np.array_equal(dump[:n].view(np.uint32), g.dump.view(np.uint32))
     # finalise_alignment + rank order == the reference's aligned rows
+    rows_sorted = oracle.rows_from_gaps(g.sorted_seqs(), gaps)
+    rows = [None] * len(rows_sorted)
+    for i, r in enumerate(g.ranks):
+        rows[int(r)] = rows_sorted[i]
+    assert rows == [str(x) for x in g.rows]
+
+
+@pytest.mark.parametrize("name", cons_cases())
+def test_consistency_tree_matches_reference(oracle, name):
+    """default mode: anchor selection, N x K position maps, per-task bonus matrices, bonus-aware DP"""
+    g = Golden(name)
+    recs, paths, gaps, ids, maps, bh = oracle.msa_tree_cons(g.codes, g.tasks, g.subm, g.scal, g.seq_distances,
+                                                            int(g.n_anchors), float(g.weight))
+    assert np.array_equal(ids, g.anchor_ids)
+    for got_row, want_row in zip(maps, g.maps_list()):
+        for got, want in zip(got_row, want_row):
+            assert np.array_equal(got, want)
+    assert np.array_equal(bh, g.bonus_hash)
+    assert compare_recs(g, recs, paths, EXACT) == []
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
     rows_sorted = oracle.rows_from_gaps(g.sorted_seqs(), gaps)
     rows = [None] * len(rows_sorted)
     for i, r in enumerate(g.ranks):

@@ -11,6 +11,10 @@ def tree_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "tree_*.npz")))
 
 
+def cons_cases():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "cons_*.npz")))
+
+
 def pair_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pairs_*.npz")))
 
@@ -40,6 +44,18 @@ class Golden:
         for n in self.lens:
             out.append(self.gaps[o:o + int(n) + 1])
             o += int(n) + 1
+        return out
+
+    def maps_list(self):
+        """consistency goldens: maps[i][k] = position map of sequence i against anchor k"""
+        K = len(self.anchor_ids)
+        out, o = [], 0
+        for n in self.lens:
+            row = []
+            for _ in range(K):
+                row.append(self.maps[o:o + int(n)])
+                o += int(n)
+            out.append(row)
         return out
 
     def sorted_seqs(self):
