@@ -11,6 +11,8 @@
  *                              lib/src/aln_run.c:43-78, with do_align :213-441 per task
  *   ka_pairwise_batch()  <->  the N x K loop over pairwise_align_map() -> aln_runner()
  *                              lib/src/anchor_consistency.c:19-120, :246-267
+ *   ka_tree_build_consistency() <-> anchor_consistency_build(), lib/src/anchor_consistency.c:194-275, plus the
+ *                              per-task bonus of do_align (aln_run.c:262-295) inside ka_tree_run
  *   ka_tree_upload/run/download: the same dispatcher split so that a caller can
  *                              keep inputs resident in HBM (bench.py times ka_tree_run only)
  *
@@ -111,6 +113,21 @@ double ka_tree_cells(ka_ctx* ctx);
 /* Milliseconds spent in the DP kernels of the last ka_tree_run, measured with HIP events
    on the launch stream; n_launches receives the number of kernel launches. */
 int ka_tree_kernel_ms(ka_ctx* ctx, float* ms, int* n_launches);
+
+/*
+ * Anchor consistency = the reference's default mode (anchor_consistency_build, anchor_consistency.c:194-275,
+ * called from kalign_run_seeded, aln_wrap.c:207-214).  Call between ka_tree_upload and ka_tree_run:
+ * selects n_anchors anchors from seq_distances, aligns every sequence to every anchor on the device, keeps
+ * the position maps in HBM; from then on every DP of ka_tree_run adds the consistency bonus that do_align
+ * builds with anchor_consistency_get_bonus_profile (aln_run.c:262-295).  Like the reference it declines
+ * silently (returns OK, no table) when n_anchors <= 0, numseq < 3 or there are no seq_distances.
+ * n_anchors <= 5 (the reference's default is 5, src/parameters.c:72-73; weight 2.0).
+ * ka_tree_upload drops the table again.
+ */
+int ka_tree_build_consistency(ka_ctx* ctx, int n_anchors, float weight);
+/* Returns K (0: no table).  anchor_ids[K]; maps_out: all position maps concatenated in (i*K + k) order,
+   each lens[i] ints (pos_maps, anchor_consistency.h:17-24).  Either pointer may be NULL. */
+int ka_tree_get_consistency(ka_ctx* ctx, int* anchor_ids, int* maps_out);
 
 /*
  * npairs independent seq-seq alignments (pair k = sequences ia[k], ib[k]) with unscaled

@@ -36,7 +36,7 @@ class TaskRec(C.Structure):
 EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
-           "ka_pairwise_batch", "ka_pairwise_kernel_ms"]
+           "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency"]
 
 
 def lib_path():
@@ -78,6 +78,8 @@ def load_library():
     L.ka_tree_cells.argtypes = [vp]
     L.ka_tree_cells.restype = C.c_double
     L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
+    L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
     L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
                                     C.c_float, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
@@ -186,8 +188,32 @@ class Context:
         return out
 
     # ---- one-shot -----------------------------------------------------------------------
-    def msa_tree(self, codes, tasks, subm, scal, seq_distances=None, flags=0):
+    def tree_build_consistency(self, n_anchors=5, weight=2.0):
+        """anchor_consistency_build: call between tree_upload and tree_run (the reference's default mode)."""
+        self._chk(self.L.ka_tree_build_consistency(self.h, int(n_anchors), float(weight)))
+
+    def tree_consistency(self):
+        """(anchor_ids[K], maps[i][k]) or None when the job has no consistency table."""
+        K = self.L.ka_tree_get_consistency(self.h, None, None)
+        if K <= 0:
+            return None
+        lens = self._job["lens"]
+        ids = np.zeros(K, np.int32)
+        flat = np.zeros(int(lens.sum()) * K, np.int32)
+        self.L.ka_tree_get_consistency(self.h, _ptr(ids), _ptr(flat))
+        maps, o = [], 0
+        for n in lens:
+            row = []
+            for _ in range(K):
+                row.append(flat[o:o + int(n)].copy())
+                o += int(n)
+            maps.append(row)
+        return ids, maps
+
+    def msa_tree(self, codes, tasks, subm, scal, seq_distances=None, flags=0, n_anchors=0, weight=2.0):
         self.tree_upload(codes, tasks, subm, scal, seq_distances, flags)
+        if n_anchors > 0:
+            self.tree_build_consistency(n_anchors, weight)
         self.tree_run()
         return self.tree_download()
 

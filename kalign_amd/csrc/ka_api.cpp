@@ -21,7 +21,7 @@
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, hipStream_t stream);
 extern "C" long long ka_ctl_bytes_host(void);
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
-extern "C" long long ka_scratch_bytes_host(long long la, long long lb);
+extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen);
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return KA_FAIL; }
@@ -92,10 +92,22 @@ struct ka_ctx {
         DevBuf<long long> p_poff; DevBuf<char> p_scr;
         std::vector<ka_task_rec> h_recs;
         unsigned long long h_counters[4] = {0, 0, 0, 0};
+        // ---- anchor consistency (ka_tree_build_consistency) ----
+        std::vector<uint8_t> h_codes;                // host copy of the uploaded sequences
+        std::vector<float> seq_dist;                 // msa->seq_distances (empty: none)
+        std::vector<int> sip_flat;                   // member lists of every node, reference order
+        std::vector<long long> sip_off;
+        int cons_K = 0;
+        size_t colof_n = 0;
+        float cons_weight = 0.0f;
+        std::vector<int> cons_anchor_ids, cons_maps;
+        std::vector<long long> cons_map_off;
+        DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip;
+        DevBuf<long long> d_cons_map_off, d_sip_off;
 };
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
-extern "C" int ka_abi_version(void) { return 1; }
+extern "C" int ka_abi_version(void) { return 2; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
@@ -126,6 +138,8 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_ctl.release(); c->d_blocks.release();
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
+        c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
+        c->d_cons_map_off.release(); c->d_sip_off.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -158,6 +172,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         HIPCHK(hipSetDevice(c->device));
         const int nprof = 2 * numseq - 1;
         c->have_job = false; c->ran = false; c->synced = false;
+        c->cons_K = 0;                           // a new job starts without a consistency table
         c->numseq = numseq; c->n_tasks = n_tasks; c->flags = flags;
         c->lens.assign(lens, lens + numseq);
         c->off.assign(off, off + numseq);
@@ -177,6 +192,11 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 c->max_len = std::max(c->max_len, lens[i]);
                 codes_bytes = std::max<long long>(codes_bytes, (long long)off[i] + lens[i]);
         }
+
+        c->h_codes.assign(codes, codes + codes_bytes);
+        if (seq_distances) c->seq_dist.assign(seq_distances, seq_distances + numseq); else c->seq_dist.clear();
+        c->sip_flat.clear(); c->sip_off.assign(nprof, 0);
+        for (int i = 0; i < numseq; i++) { c->sip_off[i] = (long long)c->sip_flat.size(); c->sip_flat.push_back(i); }
 
         // ---- host-side task preparation: nsip, sip order, gap_scale / subm_offset, levels ----
         std::vector<int> nsip(nprof, 0), level(nprof, 0);
@@ -219,6 +239,8 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 sip[cc].reserve(nsip[cc]);
                 for (int j = nsip[a]; j--;) sip[cc].push_back(sip[a][j]);        // aln_run.c:428-436
                 for (int j = nsip[b]; j--;) sip[cc].push_back(sip[b][j]);
+                c->sip_off[cc] = (long long)c->sip_flat.size();
+                c->sip_flat.insert(c->sip_flat.end(), sip[cc].begin(), sip[cc].end());
                 std::vector<int>().swap(sip[a]);
                 std::vector<int>().swap(sip[b]);
                 made[cc] = 1;
@@ -271,7 +293,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         long long scr = 0;
         // per level every sequence is a member of at most one task; profile lengths never exceed
         // the sum of their members' lengths
-        scr = ka_scratch_bytes_host(c->sum_len, c->sum_len) / 2 + (long long)numseq * 2048 + 65536;
+        scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 4LL * c->max_len) + 65536;
         c->scratch_cap = std::max(c->scratch_cap, scr);
         c->dbg_cap = (flags & KA_FLAG_DEBUG_ROWS) ? std::max<long long>(c->dbg_cap, 6LL * (cols + 2LL * n_tasks + c->sum_len)) : c->dbg_cap;
 
@@ -324,6 +346,12 @@ static int tree_launch(ka_ctx* c)
         D.nres = c->nres;
         D.trace = c->h_trace;
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
+        D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;
+        D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
+        D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
+        D.colof = c->d_colof.p; D.sip = c->d_sip.p; D.sip_off = c->d_sip_off.p;
+        if (c->cons_K > 0)                           // every leaf starts with residue p in column p
+                HIPCHK(hipMemcpyAsync(c->d_colof.p, c->d_colof_init.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToDevice, c->stream));
 
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
@@ -364,6 +392,7 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                 }
                 if (err == 5) return fail("device watchdog: a strip pipeline stopped making progress");
                 if (err == 6) return fail("device watchdog: a cluster barrier was never completed (workgroups of one task not co-resident?)");
+                if (err == 7) return fail("consistency: a profile is too long for the LDS vote table");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)
                 if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
                 else if (err == 2) { c->scratch_cap *= 2; c->d_scratch.release(); }
@@ -519,6 +548,124 @@ extern "C" int ka_tree_kernel_ms(ka_ctx* c, float* ms, int* n_launches)
         return KA_OK;
 }
 
+
+// ---- anchor consistency: anchor_consistency_build (anchor_consistency.c:122-275) ----
+// Anchor selection (farthest-first over |seq_distances[i] - seq_distances[anchor]|) runs on the host, the
+// N x K seq-seq alignments on the device (ka_pairwise_batch), the paths become position maps on the host
+// (:86-114) and the maps go back to HBM for the per-task bonus construction inside the task kernels.
+static void select_anchors(const std::vector<float>& dist, int K, std::vector<int>& ids)
+{
+        const int N = (int)dist.size();
+        std::vector<float> min_dist(N);
+        float sum = 0.0f;
+        for (int i = 0; i < N; i++) sum += dist[i];
+        const float mean = sum / (float)N;
+        float best_diff = 3.402823466e+38f;
+        int best = 0;
+        for (int i = 0; i < N; i++) {
+                float diff = dist[i] - mean;
+                if (diff < 0) diff = -diff;
+                if (diff < best_diff) { best_diff = diff; best = i; }
+        }
+        ids.assign(K, 0);
+        ids[0] = best;
+        for (int i = 0; i < N; i++) {
+                float d = dist[i] - dist[ids[0]];
+                if (d < 0) d = -d;
+                min_dist[i] = d;
+        }
+        for (int k = 1; k < K; k++) {
+                float best_min = -1.0f;
+                best = 0;
+                for (int i = 0; i < N; i++) {
+                        bool skip = false;
+                        for (int j = 0; j < k; j++) if (ids[j] == i) { skip = true; break; }
+                        if (skip) continue;
+                        if (min_dist[i] > best_min) { best_min = min_dist[i]; best = i; }
+                }
+                ids[k] = best;
+                for (int i = 0; i < N; i++) {
+                        float d = dist[i] - dist[best];
+                        if (d < 0) d = -d;
+                        if (d < min_dist[i]) min_dist[i] = d;
+                }
+        }
+}
+
+extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        HIPCHK(hipSetDevice(c->device));
+        c->cons_K = 0;
+        const int N = c->numseq;
+        // the reference silently declines in these cases (anchor_consistency.c:206-217)
+        if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
+        int K = std::min(n_anchors, N);
+        if (K > KA_NB - 1) return fail("this build carries at most 5 consistency anchors per DP row");
+        select_anchors(c->seq_dist, K, c->cons_anchor_ids);
+
+        // N x K pairs (i, anchor_k), i != anchor_k
+        std::vector<int> ia, ib;
+        std::vector<long long> poff;
+        long long ptotal = 0;
+        for (int i = 0; i < N; i++)
+                for (int k = 0; k < K; k++) {
+                        const int ak = c->cons_anchor_ids[k];
+                        if (i == ak) continue;
+                        ia.push_back(i); ib.push_back(ak); poff.push_back(ptotal);
+                        ptotal += (long long)c->lens[i] + c->lens[ak] + 3;
+                }
+        std::vector<int> paths((size_t)std::max<long long>(ptotal, 1));
+        if (!ia.empty() &&
+            ka_pairwise_batch(c, c->h_codes.data(), c->off.data(), c->lens.data(), N, ia.data(), ib.data(), (int)ia.size(),
+                              c->subm, c->scal[0], c->scal[1], c->scal[2], paths.data(), poff.data(), nullptr))
+                return KA_FAIL;
+
+        c->cons_map_off.assign(N, 0);
+        long long mt = 0;
+        for (int i = 0; i < N; i++) { c->cons_map_off[i] = mt; mt += (long long)K * c->lens[i]; }
+        c->cons_maps.assign((size_t)mt, -1);
+        size_t pk = 0;
+        for (int i = 0; i < N; i++)
+                for (int k = 0; k < K; k++) {
+                        int* map = c->cons_maps.data() + c->cons_map_off[i] + (long long)k * c->lens[i];
+                        const int len_i = c->lens[i];
+                        if (i == c->cons_anchor_ids[k]) { for (int p = 0; p < len_i; p++) map[p] = p; continue; }
+                        const int* path = paths.data() + poff[pk++];
+                        int pos_a = 0, pos_b = 0;
+                        for (int x = 1; path[x] != 3; x++) {                 // anchor_consistency.c:86-114
+                                if (path[x] == 0) { if (pos_a < len_i) map[pos_a] = pos_b; pos_a++; pos_b++; }
+                                else if (path[x] & 1) pos_b++;
+                                else if (path[x] & 2) { if (pos_a < len_i) map[pos_a] = -1; pos_a++; }
+                        }
+                }
+
+        // device copies: maps, member lists, the identity residue->column table
+        std::vector<int> ident((size_t)c->h_codes.size(), 0);
+        for (int i = 0; i < N; i++) for (int p = 0; p < c->lens[i]; p++) ident[(size_t)c->off[i] + p] = p;
+        if (c->d_cons_maps.alloc(c->cons_maps.size()) || c->d_cons_map_off.alloc(N) || c->d_colof.alloc(ident.size()) ||
+            c->d_colof_init.alloc(ident.size()) || c->d_sip.alloc(c->sip_flat.size()) || c->d_sip_off.alloc(c->sip_off.size()))
+                return fail("hipMalloc failed");
+        c->colof_n = ident.size();
+        HIPCHK(hipMemcpy(c->d_cons_maps.p, c->cons_maps.data(), sizeof(int) * c->cons_maps.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_cons_map_off.p, c->cons_map_off.data(), sizeof(long long) * N, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_colof_init.p, ident.data(), sizeof(int) * ident.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_sip.p, c->sip_flat.data(), sizeof(int) * c->sip_flat.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_sip_off.p, c->sip_off.data(), sizeof(long long) * c->sip_off.size(), hipMemcpyHostToDevice));
+        c->cons_K = K; c->cons_weight = weight;
+        c->ran = false; c->synced = false;
+        return KA_OK;
+}
+
+extern "C" int ka_tree_get_consistency(ka_ctx* c, int* anchor_ids, int* maps_out)
+{
+        if (!c || !c->have_job) return -1;
+        if (c->cons_K <= 0) return 0;
+        if (anchor_ids) memcpy(anchor_ids, c->cons_anchor_ids.data(), sizeof(int) * c->cons_K);
+        if (maps_out) memcpy(maps_out, c->cons_maps.data(), sizeof(int) * c->cons_maps.size());
+        return c->cons_K;
+}
+
 extern "C" int ka_msa_tree(ka_ctx* c, int numseq, const uint8_t* codes, const int* off, const int* lens,
                            const float* seq_distances, int n_tasks, const int* abc,
                            const float* subm, const float* scal, int flags,
@@ -544,7 +691,7 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
                 if (ia[k] < 0 || ia[k] >= numseq || ib[k] < 0 || ib[k] >= numseq) return fail("pair index out of range");
                 const long long li = lens[ia[k]], lj = lens[ib[k]];
                 if (li < 1 || lj < 1) return fail("zero-length sequence");
-                stride = std::max(stride, ka_scratch_bytes_host(li, lj));
+                stride = std::max(stride, ka_scratch_bytes_host(li, lj, 0));
                 ptotal = std::max(ptotal, poff[k] + li + lj + 3);
         }
         stride = (stride + 255) / 256 * 256;

@@ -55,8 +55,20 @@ struct KaTreeDev {
         int nres;                      // alphabet size: 23 protein, 5 nucleotide (alphabet.c)
         long long* timing;             // [n_tasks][8] phase cycle counts (KA_FLAG_TIMING) or null
         int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
-        int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow
+        int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table
+        // ---- anchor consistency (anchor_consistency.c); cons_K == 0: off ----
+        int cons_K;                    // anchors
+        int cons_maxlen;               // longest sequence: bounds every anchor position
+        float cons_paw;                // weight / (float)K  (per_anchor_weight, anchor_consistency.c:487)
+        const int* cons_maps;          // position maps: (sequence i, anchor k) at cons_map_off[i] + k * len_i
+        const long long* cons_map_off; // [numseq]
+        int* colof;                    // [sum of lengths], indexed like codes: residue -> column of the profile of the
+                                       // node that currently contains the sequence (the device's form of gaps[])
+        const int* sip;                // member lists of every node in the reference's order (aln_run.c:428-436)
+        const long long* sip_off;      // [2N-1]
 };
+
+#define KA_NB 6                        // bonus entries a DP row carries: <= 5 anchors + the wrap-around entry
 
 struct KaPairDev {
         const uint8_t* codes;

@@ -90,6 +90,14 @@ struct TaskShared {
         int* coded;
         int* srcA;
         int* srcB;
+        // anchor consistency (only carved when the job has a consistency table)
+        int2* ent;                     // [La][KA_NB] bonus entries of every DP row: (column, value bits)
+        int* apos_r;                   // per anchor: anchor position / confidence of every DP row and column
+        float* conf_r;
+        int* apos_c;
+        float* conf_c;
+        int* invj;                     // anchor position -> DP column
+        char* vote;                    // HBM vote tables for profiles too long for LDS (16 B per column)
         KaCtl* ctl;                    // -> ctl_lds (one workgroup) or the task's block in HBM (cluster)
         KaCtl ctl_lds;
         int G, member;                 // cluster size / this workgroup's index in it
@@ -341,7 +349,7 @@ __device__ void ka_cluster_sync(TaskShared& S)
 // debug breadcrumbs into a host-pinned buffer (KA_TRACE=1): survives a hung kernel
 #define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
 
-template <int KIND, int NRES>
+template <int KIND, int NRES, int NB>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
@@ -404,11 +412,11 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 it = __builtin_amdgcn_readfirstlane(it);
                                 if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
-                                        ka_packed<KIND, NRES, 4>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
+                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
                                 }
                                 if (it >= nitems) {
-                                        ka_packed<KIND, NRES, 16>(S, qc, pack16, n16, it - nitems, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
+                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
                                 }
                                 // everything about the item is wave-uniform: keep it in SGPRs
@@ -425,7 +433,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 const float ja = ka_uniform_f(dir == KA_FWD ? sp->fin.a : sp->bin.a);
                                 const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
                                 const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
-                                ka_strip<KIND, NRES>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                ka_strip<KIND, NRES, NB>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                      (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
                                                      lds_waves + wave * KA_WAVE_LDS, tss);
                         }
@@ -688,6 +696,175 @@ __device__ void ka_make_leaf_profile(float* __restrict__ prof, int len, const ui
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Anchor consistency, per task (anchor_consistency.c:352-561 + do_align's bonus block,
+// aln_run.c:262-295).  The reference materialises a dense La x Lb bonus matrix on the host for
+// every task; per anchor every row has at most ONE non-zero entry, so the device keeps <= K
+// (column, value) entries per DP row instead and the passes carry them in registers.
+//
+// ka_node_positions = get_node_anchor_positions: for a leaf the position map itself; for a
+// profile a vote over its member sequences, where "best" is the anchor position of the FIRST
+// member (in the reference's sip order) that has one in the column.  Being first in a fixed
+// order is a min-reduction over the member index, and `agree` / `total` are counts, so the vote
+// runs in parallel over (member, residue) with LDS atomics: key = member_index << 32 | position.
+// Which column a residue sits in comes from D.colof (kept up to date by ka_update_colof).
+// ------------------------------------------------------------------------------------------
+template <bool LEAN>
+__device__ void ka_node_positions(const KaTreeDev& D, const int node, const int nmem, const int dp_len, const int k,
+                                  int* __restrict__ pos_out, float* __restrict__ conf_out, char* lds, const long long lds_bytes, char* vote_glb)
+{
+        const int tid = threadIdx.x;
+        if (nmem == 1) {
+                const int* map = D.cons_maps + D.cons_map_off[node] + (long long)k * dp_len;   // a leaf's dp_len is its length
+                for (int i = tid; i < dp_len; i += KA_NT) { const int a = map[i]; pos_out[i] = a; conf_out[i] = (a >= 0) ? 1.0f : 0.0f; }
+                __syncthreads();
+                return;
+        }
+        if (LEAN) return;                                        // lean levels hold leaf-leaf tasks only
+        // vote tables: LDS when the profile fits (16 B per column), else the task's HBM scratch
+        const bool in_lds = (long long)dp_len * 16 <= lds_bytes;
+        unsigned long long* key = in_lds ? (unsigned long long*)lds : (unsigned long long*)vote_glb;
+        unsigned int* total = (unsigned int*)(key + dp_len);
+        unsigned int* agree = total + dp_len;
+        for (int c = tid; c < dp_len; c += KA_NT) { key[c] = ~0ull; total[c] = 0u; agree[c] = 0u; }
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6;
+        const int* members = D.sip + D.sip_off[node];
+        for (int mi = wave; mi < nmem; mi += KA_NW) {
+                const int si = members[mi];
+                const int len = D.node_len[si];
+                const int* map = D.cons_maps + D.cons_map_off[si] + (long long)k * len;
+                const int* col = D.colof + D.seq_off[si];
+                for (int p = lane; p < len; p += 64) {
+                        const int a = map[p];
+                        if (a >= 0) {
+                                const int c = col[p];
+                                atomicMin(&key[c], ((unsigned long long)(unsigned int)mi << 32) | (unsigned int)a);
+                                atomicAdd(&total[c], 1u);
+                        }
+                }
+        }
+        __syncthreads();
+        // (HBM tables: the atomics above were performed at L2; read them back past the L1)
+        for (int mi = wave; mi < nmem; mi += KA_NW) {
+                const int si = members[mi];
+                const int len = D.node_len[si];
+                const int* map = D.cons_maps + D.cons_map_off[si] + (long long)k * len;
+                const int* col = D.colof + D.seq_off[si];
+                for (int p = lane; p < len; p += 64) {
+                        const int a = map[p];
+                        if (a >= 0) {
+                                const int c = col[p];
+                                const unsigned long long kk = in_lds ? key[c] : __hip_atomic_load(&key[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) atomicAdd(&agree[c], 1u);
+                        }
+                }
+        }
+        __syncthreads();
+        for (int c = tid; c < dp_len; c += KA_NT) {
+                unsigned long long kk;
+                unsigned int tot, ag;
+                if (in_lds) { kk = key[c]; tot = total[c]; ag = agree[c]; }
+                else {
+                        kk = __hip_atomic_load(&key[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tot = __hip_atomic_load(&total[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ag = __hip_atomic_load(&agree[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tot > 0u && ag > 0u) { pos_out[c] = (int)(unsigned int)(kk & 0xffffffffull); conf_out[c] = (float)(int)ag / (float)(int)tot; }
+                else { pos_out[c] = -1; conf_out[c] = 0.0f; }
+        }
+        __syncthreads();
+}
+
+// anchor_consistency_get_bonus_profile in sparse form.  After it S.ent[row][0..KA_NB) holds the row's
+// non-zero bonus cells with distinct columns: entries of different anchors that hit the same cell are
+// summed in anchor order (the dense matrix accumulates k = 0..K-1 into a zeroed cell), and slot
+// KA_NB-1 carries the cell the reference reaches when a forward pass indexes column Lb of row i --
+// flat index i*Lb + Lb is cell (i+1, 0) (aln_seqseq.c:83-85 uses the 1-based column).
+template <bool LEAN>
+__device__ void ka_cons_prepare(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const long long lds_bytes)
+{
+        const int tid = threadIdx.x;
+        const int K = D.cons_K;
+        const int rows = S.La, cols = S.Lb;
+        const int rnode = S.swapped ? T.b : T.a, cnode = S.swapped ? T.a : T.b;
+        const int rn = S.swapped ? T.nsip_b : T.nsip_a, cn = S.swapped ? T.nsip_a : T.nsip_b;
+        const float paw = D.cons_paw;
+        for (int k = 0; k < K; ++k) {
+                ka_node_positions<LEAN>(D, rnode, rn, rows, k, S.apos_r, S.conf_r, lds, lds_bytes, S.vote);
+                ka_node_positions<LEAN>(D, cnode, cn, cols, k, S.apos_c, S.conf_c, lds, lds_bytes, S.vote);
+                // inverse map anchor position -> column; of several columns the last one wins (:521-526)
+                for (int x = tid; x < D.cons_maxlen; x += KA_NT) S.invj[x] = -1;
+                __syncthreads();
+                for (int j = tid; j < cols; j += KA_NT) { const int a = S.apos_c[j]; if (a >= 0) atomicMax(&S.invj[a], j); }
+                __syncthreads();
+                for (int i = tid; i < rows; i += KA_NT) {
+                        const int a = S.apos_r[i];
+                        int col = -1;
+                        float val = 0.0f;
+                        if (a >= 0) {
+                                const int bj = __hip_atomic_load(&S.invj[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (bj >= 0) { col = bj; val = paw * S.conf_r[i] * S.conf_c[bj]; }        // :534-535
+                        }
+                        S.ent[(long long)i * KA_NB + k] = make_int2(col, __float_as_int(val));
+                }
+                __syncthreads();
+        }
+        // merge per row (anchor order), then the wrap-around entry from the row below
+        for (int i = tid; i < rows; i += KA_NT) {
+                int2* e = S.ent + (long long)i * KA_NB;
+                int mc[KA_NB];
+                float mv[KA_NB];
+                int n = 0;
+                for (int k = 0; k < K; ++k) {
+                        const int2 x = e[k];
+                        if (x.x < 0) continue;
+                        int hit = -1;
+                        for (int m = 0; m < n; ++m) if (mc[m] == x.x) hit = m;
+                        if (hit >= 0) mv[hit] += __int_as_float(x.y);
+                        else { mc[n] = x.x; mv[n] = 0.0f + __int_as_float(x.y); ++n; }
+                }
+                for (int m = 0; m < KA_NB - 1; ++m) e[m] = (m < n) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
+        }
+        __syncthreads();
+        for (int i = tid; i < rows; i += KA_NT) {
+                int2 w = make_int2(-1, 0);
+                if (i + 1 < rows) {
+                        const int2* nx = S.ent + (long long)(i + 1) * KA_NB;
+                        for (int m = 0; m < KA_NB - 1; ++m) if (nx[m].x == 0) w = make_int2(cols, nx[m].y);
+                }
+                S.ent[(long long)i * KA_NB + KA_NB - 1] = w;
+        }
+        __syncthreads();
+}
+
+// make_seq / update_gaps (weave_alignment.c:41-112) in the device's form: after the merge of a and
+// b, residue p of a member of a moves from column col to amap[col].  S.raw / S.raw2 (dead after the
+// path coding) receive amap / bmap.  All workgroups of the cluster share the members.
+__device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen)
+{
+        const int tid = threadIdx.x;
+        if (S.member == 0) {
+                for (int j = 1 + tid; j <= alnlen; j += KA_NT) {
+                        const int ia = S.srcA[j], ib = S.srcB[j];
+                        if (ia >= 1) S.raw[ia - 1] = j - 1;
+                        if (ib >= 1) S.raw2[ib - 1] = j - 1;
+                }
+        }
+        ka_cluster_sync(S);
+        const int lane = tid & 63, wave = tid >> 6;
+        const int na = T.nsip_a, nb = T.nsip_b;
+        const int* ma = D.sip + D.sip_off[T.a];
+        const int* mb = D.sip + D.sip_off[T.b];
+        for (int m = S.member * KA_NW + wave; m < na + nb; m += KA_NW * S.G) {
+                const int si = (m < na) ? ma[m] : mb[m - na];
+                const int* mp = (m < na) ? S.raw : S.raw2;
+                int* col = D.colof + D.seq_off[si];
+                const int len = D.node_len[si];
+                for (int p = lane; p < len; p += 64) col[p] = mp[col[p]];
+        }
+}
+
 // dynamic-LDS layout of a workgroup
 #define KA_LDS_DBG 768
 #define KA_LDS_TSS 784
@@ -708,8 +885,8 @@ __device__ void ka_build_tss(float* tss, const float* subm, float soff)
 
 __device__ __forceinline__ long long ka_align_up(long long x, long long a) { return (x + a - 1) / a * a; }
 
-// carve the per-task scratch region
-__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb)
+// carve the per-task scratch region (cons_maxlen > 0: the job has a consistency table)
+__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen)
 {
         const long long n = (long long)la + lb + 8;
         long long o = 0;
@@ -730,18 +907,30 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb)
         S.prog[1] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
         for (int par = 0; par < 2; ++par)
                 for (int cls = 0; cls < 2; ++cls) { S.pack[par][cls] = (int2*)(base + o); o += ka_align_up(2 * nq * 8, 16); }
+        S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
+        if (cons_maxlen > 0) {
+                S.ent = (int2*)(base + o);    o += ka_align_up(n * 8 * KA_NB, 16);
+                S.apos_r = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+                S.conf_r = (float*)(base + o); o += ka_align_up(n * 4, 16);
+                S.apos_c = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+                S.conf_c = (float*)(base + o); o += ka_align_up(n * 4, 16);
+                S.invj = (int*)(base + o);    o += ka_align_up(((long long)cons_maxlen + 8) * 4, 16);
+                S.vote = base + o;            o += ka_align_up(n * 16, 16);
+        }
         return o;
 }
 
-__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb)
+__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen)
 {
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 4;
         const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
-        return 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
+        long long b = 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
+        if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * ((n * 4 + 15) / 16 * 16) + ((cons_maxlen + 8) * 4 + 15) / 16 * 16 + n * 16;
+        return b;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -749,7 +938,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ------------------------------------------------------------------------------------------
 // LEAN = true: a level whose tasks are all seq-seq (the guide tree's leaf level): 4 waves, no LDS
 // ring, <=128 VGPRs -> four workgroups per CU instead of one.
-template <bool LEAN>
+template <bool LEAN, int NB>
 __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __restrict__ blocks)
 {
         // all LDS lives in the dynamic region (16-B aligned carve-outs, guide section 6 G17)
@@ -814,7 +1003,7 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
                 if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; }
                 s_dbg = nullptr;
                 if (member == 0) {
-                        const long long need = ka_scratch_bytes(len_a, len_b);
+                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0);
                         const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                         if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
                         S.ctl->scratch_off = (long long)so;
@@ -830,7 +1019,7 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
         if (S.member >= S.G) return;                         // surplus workgroup of an over-provisioned cluster
         ka_cluster_sync(S);
         if (S.ctl->fail) return;
-        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b);
+        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0);
 
         // P1
         ka_build_tss(tss, D.subm, T.soff);
@@ -839,15 +1028,21 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
                 if (T.nsip_a == 1) ka_make_leaf_profile(S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, tss);
                 if (T.nsip_b == 1) ka_make_leaf_profile(S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, tss);
         }
+        // P1b: the bonus entries of every DP row (the first workgroup of the cluster; the barrier
+        // below publishes them to the others)
+        if (NB && S.member == 0) {
+                __syncthreads();
+                ka_cons_prepare<LEAN>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_WAVES * KA_WAVE_LDS);
+        }
         ka_cluster_sync(S);
         tk1 = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
 
         // P2
-        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5>(S, s_dbg, lds_waves, tss, D.trace);
-        else ka_hirschberg<KA_PP, 23>(S, s_dbg, lds_waves, tss, D.trace);
+        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB>(S, s_dbg, lds_waves, tss, D.trace);
+        else ka_hirschberg<KA_PP, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         tk2 = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 3);
@@ -896,6 +1091,7 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
         const int alnlen = S.ctl->alnlen;
         if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T, alnlen);
+        if (NB && !T.is_root) ka_update_colof(S, D, T, alnlen);
         if (D.timing && S.member == 0) {
                 __syncthreads();
                 if (tid == 0) {
@@ -916,12 +1112,23 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
 
 __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks)
 {
-        ka_task_body<false>(D, blocks);
+        ka_task_body<false, 0>(D, blocks);
 }
 
 __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks)
 {
-        ka_task_body<true>(D, blocks);
+        ka_task_body<true, 0>(D, blocks);
+}
+
+// the same two with the anchor-consistency bonus (default mode of the reference's CLI)
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks)
+{
+        ka_task_body<false, KA_NB>(D, blocks);
+}
+
+__global__ __launch_bounds__(KA_PAIR_BLOCK, 3) void ka_task_kernel_lean_cons(const KaTreeDev D, const int2* __restrict__ blocks)
+{
+        ka_task_body<true, KA_NB>(D, blocks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -953,11 +1160,11 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 S.gpo = P.gpo; S.gpe = P.gpe; S.tgpe = P.tgpe; S.soff = 0.0f;
                 S.sp_open = 0.0f; S.sp_ext = 0.0f; S.sp_text = 0.0f;
                 S.p1_mult = 1.0f; S.p2_mult = 1.0f;
-                ka_carve(S, P.scratch + (long long)k * P.scratch_stride, len_i, len_j);
+                ka_carve(S, P.scratch + (long long)k * P.scratch_stride, len_i, len_j, 0);
         }
         ka_build_tss(tss, P.subm, 0.0f);
         __syncthreads();
-        ka_hirschberg<KA_SS, 23>(S, nullptr, lds_waves, tss, nullptr);
+        ka_hirschberg<KA_SS, 23, 0>(S, nullptr, lds_waves, tss, nullptr);
         __syncthreads();
         ka_code_path(S, (int*)lds_waves);
         if (tid == 0 && P.scores) P.scores[k] = S.ctl->top_score;
@@ -980,6 +1187,10 @@ static hipError_t ka_lds_optin()
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)ka_task_kernel_lean, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ka_task_kernel_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ka_task_kernel_lean_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
+        if (e != hipSuccess) return e;
         done = true;
         return hipSuccess;
 }
@@ -987,8 +1198,13 @@ static hipError_t ka_lds_optin()
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, hipStream_t stream)
 {
         if (ka_lds_optin() != hipSuccess) return;
-        if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
-        else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
+        if (D->cons_K > 0) {
+                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
+                else hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
+        } else {
+                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
+                else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
+        }
 }
 
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
@@ -997,5 +1213,5 @@ extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
         hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *P);
 }
 
-extern "C" long long ka_scratch_bytes_host(long long la, long long lb) { return ka_scratch_bytes(la, lb); }
+extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen) { return ka_scratch_bytes(la, lb, cons_maxlen); }
 extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }

@@ -79,7 +79,28 @@ __device__ __forceinline__ float wave_rol1(float x)
 #endif
 __device__ __forceinline__ int ka_strips_of(int nrows) { return nrows <= 0 ? 1 : (nrows + KA_STRIP_ROWS - 1) / KA_STRIP_ROWS; }
 
-template <int KIND, int NRES>
+// NB > 0: anchor-consistency build -- every DP row carries NB (column, value) bonus entries with distinct
+// columns (ka_cons_prepare); the cell at s-index j adds the value of the entry whose column is j, which
+// is what the reference's dense `pa += consistency[i*stride + j]` adds (aln_seqseq.c:83-85,199-201).
+template <int NB>
+struct KaBonus {
+        int col[NB > 0 ? NB : 1];
+        float val[NB > 0 ? NB : 1];
+        __device__ __forceinline__ void load(const int2* ent, int row)
+        {
+#pragma unroll
+                for (int e = 0; e < NB; ++e) { const int2 x = ent[(long long)row * NB + e]; col[e] = x.x; val[e] = __int_as_float(x.y); }
+        }
+        __device__ __forceinline__ float at(int j) const
+        {
+                float b = 0.0f;
+#pragma unroll
+                for (int e = 0; e < NB; ++e) b = (col[e] == j) ? val[e] : b;
+                return b;
+        }
+};
+
+template <int KIND, int NRES, int NB>
 __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
                                          const float inj_a, const float inj_ga, const float inj_gb,
                                          const int dir, const int k, KaState* rows, int* prog,
@@ -172,6 +193,9 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         for (int c = 0; c < 23; ++c) { tA_[c] = pA[32 + c]; tB_[c] = pB[32 + c]; }
                 }
         }
+
+        KaBonus<NB> bonA, bonB;
+        if (NB) { bonA.load(S.ent, iA); bonB.load(S.ent, iB); }
 
         // cell states as plain scalars (a struct here ends up in scratch memory)
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
@@ -313,9 +337,11 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 if (KIND == KA_SS) {
                         acc.x += tss[res1A + res2];
                         acc.y += tss[res1B + res2];
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
                 } else if (KIND == KA_SP) {
                         acc.x += sp_tbl[(2 * lane) * KA_SP_STRIDE + res2];
                         acc.y += sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2];
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
                 } else {
                         // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
                         // v_pk_add of the chain instead of an s_nop
@@ -330,6 +356,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 prod = nprod;
                         }
                         acc = acc + prod;
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
                         // Fetch the next step's column record into the other half of q.  The loads must
                         // stay AFTER the dot products: placed above them, the s_waitcnt for this step's
                         // half (loaded one step ago) also waits for the fresh loads and exposes the whole
@@ -478,7 +505,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 // record comes straight from L2 one step ahead instead of the LDS ring, and the slot's last
 // lane writes the last row state by state.
 // ------------------------------------------------------------------------------------------
-template <int KIND, int NRES, int SLOT>
+template <int KIND, int NRES, int SLOT, int NB>
 __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, const int2* pack, const int nslots,
                                           const int job, const int lane, const float* tss, char* wlds)
 {
@@ -542,6 +569,9 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                         }
                 }
         }
+
+        KaBonus<NB> bonA, bonB;
+        if (NB) { bonA.load(S.ent, min(max(iA, 0), S.La - 1)); bonB.load(S.ent, min(max(iB, 0), S.La - 1)); }
 
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
         float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
@@ -640,6 +670,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                                 acc = acc + p1v[c] * w;
                         }
                 }
+                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
                 const bool at0 = (v == 0), atN = (v == ncols);
                 const bool edge = at0 || atN;
                 const bool term = (at0 && near_t) || (atN && far_t);

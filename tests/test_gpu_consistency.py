@@ -1,0 +1,102 @@
+"""GPU parity in the reference's DEFAULT mode (anchor consistency): anchor selection, the N x K
+position maps, and the whole guide tree with the per-task consistency bonus -- against golden
+vectors of the real reference and against the oracle on seeded inputs.  Everything the bonus
+touches must still be bit-exact: paths, gap arrays, meetups, scores, f/b rows, merged profiles."""
+import os
+
+import numpy as np
+import pytest
+
+from util import GOLDEN, Golden, compare_recs, cons_cases
+
+pytestmark = pytest.mark.gpu
+
+EXACT = ["a", "b", "c", "len_a", "len_b", "nsip_a", "nsip_b", "plen", "kind", "swapped",
+         "meet", "transition", "gap_scale", "subm_off", "score", "fhash", "bhash"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kalign_amd
+    c = kalign_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", cons_cases())
+def test_consistency_tree_matches_reference_golden(ctx, oracle, name):
+    from kalign_amd import api
+    g = Golden(name)
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, flags=api.FLAG_DEBUG_ROWS)
+    ctx.tree_build_consistency(int(g.n_anchors), float(g.weight))
+    ids, maps = ctx.tree_consistency()
+    assert np.array_equal(ids, g.anchor_ids)
+    for got_row, want_row in zip(maps, g.maps_list()):
+        for got, want in zip(got_row, want_row):
+            assert np.array_equal(got, want)
+    ctx.tree_run()
+    recs, paths, gaps = ctx.tree_download()
+    assert compare_recs(g, recs, paths, EXACT) == []
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    L = oracle.lib()
+    for t, r in enumerate(recs[:-1]):
+        prof = ctx.tree_profile(r.c, r.plen)
+        assert L.ko_fnv1a(prof.ctypes.data, 4 * 64 * (r.plen + 2)) == int(g.rec("prof_hash")[t]), (name, t)
+    # running the same job twice gives the same answer (the residue->column table is reset per run)
+    ctx.tree_run()
+    recs2, paths2, gaps2 = ctx.tree_download()
+    assert compare_recs(g, recs2, paths2, EXACT) == []
+
+
+def _random_tree(n, rng):
+    nodes = list(range(n))
+    tasks, nxt = [], n
+    while len(nodes) > 1:
+        i, j = rng.choice(len(nodes), 2, replace=False)
+        tasks.append((nodes[i], nodes[j], nxt))
+        nodes = [x for k, x in enumerate(nodes) if k not in (i, j)] + [nxt]
+        nxt += 1
+    return np.array(tasks, np.int32)
+
+
+@pytest.mark.parametrize("n,length,dna,seed,k", [(40, 260, False, 13, 5), (16, 900, True, 14, 5), (80, 100, False, 15, 2), (10, 1300, False, 16, 4)])
+def test_consistency_tree_matches_oracle_seeded(ctx, oracle, n, length, dna, seed, k):
+    """random guide trees (unbalanced: long chains of seq-profile merges), strips + packed passes + clusters"""
+    from kalign_amd import api, synth
+    rng = np.random.RandomState(seed)
+    seqs = synth.family(n, length, dna=dna, seed=seed)
+    alpha = "ACGT" if dna else "ARNDCQEGHILKMFPSTWYV"
+    codes = [np.array([alpha.index(ch) for ch in s], np.uint8) for s in seqs]
+    tasks = _random_tree(n, rng)
+    z = np.load(os.path.join(GOLDEN, "param_tables.npz"))
+    subm = z["subm_1_0"] if dna else z["subm_0_3"]
+    scal = (z["scal_1_0"] if dna else z["scal_0_3"]).copy()
+    dist = rng.uniform(0.2, 1.2, size=n).astype(np.float32)
+    recs, paths, gaps = ctx.msa_tree(codes, tasks, subm, scal, dist, flags=api.FLAG_DEBUG_ROWS, n_anchors=k, weight=2.0)
+    ids, maps = ctx.tree_consistency()
+    orecs, opaths, ogaps, oids, omaps, _ = oracle.msa_tree_cons(codes, tasks, subm, scal, dist, k, 2.0)
+    assert np.array_equal(ids, oids)
+    for ra, rb in zip(maps, omaps):
+        for a, b in zip(ra, rb):
+            assert np.array_equal(a, b)
+    for t, (r, o) in enumerate(zip(recs, orecs)):
+        for f in EXACT:
+            assert getattr(r, f) == getattr(o, f), (t, f, getattr(r, f), getattr(o, f))
+        assert abs(r.confidence - o.confidence) <= 1e-5 * max(1.0, abs(o.confidence))
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], opaths[o.path_off:o.path_off + o.plen + 2]), t
+    for a, b in zip(gaps, ogaps):
+        assert np.array_equal(a, b)
+
+
+def test_consistency_declines_like_the_reference(ctx):
+    """no seq_distances / fewer than 3 sequences / K <= 0: no table, plain tree (anchor_consistency.c:206-217)"""
+    g = Golden("tree_prot32x200")
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, None)
+    ctx.tree_build_consistency(5, 2.0)
+    assert ctx.tree_consistency() is None
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    ctx.tree_build_consistency(0, 2.0)
+    assert ctx.tree_consistency() is None
+    with pytest.raises(RuntimeError):
+        ctx.tree_build_consistency(6, 2.0)
