@@ -150,6 +150,51 @@ def pairwise_leg(ctx, codes, subm, scal, args, k_anchors=5):
     return info
 
 
+def default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args, k_anchors=5, weight=2.0):
+    """The reference CLI's default mode: anchor_consistency_build (N x K seq-seq alignments -> position
+    maps) followed by the guide tree with the consistency bonus in every DP.  Outside the timed region
+    of the headline metric; reports wall times with host buffers for the build and HBM-resident runs
+    for the tree, next to the reference doing the same on the host cores."""
+    lens = np.array([len(c) for c in codes], np.int64)
+    ctx.tree_upload(codes, tasks, subm, scal, seq_dist)
+    ctx.tree_build_consistency(k_anchors, weight)                  # warm-up (allocations)
+    t0 = time.perf_counter()
+    ctx.tree_build_consistency(k_anchors, weight)
+    build_s = time.perf_counter() - t0
+    ids, _ = ctx.tree_consistency()
+    pair_cells = float(sum(int(lens[i]) * int(lens[a]) for i in range(len(codes)) for a in ids if a != i))
+    ctx.tree_run(); ctx.tree_sync()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.tree_run()
+    ctx.tree_sync()
+    tree_s = (time.perf_counter() - t0) / reps
+    recs, _, _ = ctx.tree_download(want_gaps=False)
+    tree_cells = float(sum(r.len_a * r.len_b for r in recs))
+    info = {"anchors": k_anchors, "weight": weight,
+            "build_consistency_ms_host_buffers": build_s * 1e3, "tree_ms": tree_s * 1e3,
+            "useful_cells": pair_cells + tree_cells,
+            "gcups_tree": tree_cells / tree_s / 1e9,
+            "gcups_total": (pair_cells + tree_cells) / (build_s + tree_s) / 1e9}
+    if not args.no_cpu:
+        try:
+            from oracle import refdrv
+            nt = min(os.cpu_count() or 1, 16)
+            job = refdrv.EncodedJob(codes, tasks, seq_dist, biotype=1 if args.dna else 0, type_=0 if args.dna else -1, n_threads=nt)
+            t0 = time.perf_counter()
+            job.build_consistency(k_anchors, weight)
+            cb = time.perf_counter() - t0
+            _, ct = job.run_tree()
+            job.close()
+            info["cpu_reference"] = {"build_consistency_ms": cb * 1e3, "tree_ms": ct * 1e3,
+                                     "gcups_total": (pair_cells + tree_cells) / (cb + ct) / 1e9, "threads": nt,
+                                     "note": "the reference builds the position maps serially (anchor_consistency.c:246-267); the tree uses OpenMP tasks"}
+        except Exception as e:      # pragma: no cover
+            info["cpu_reference"] = str(e)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +205,7 @@ def main():
     ap.add_argument("--dna", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pairs", action="store_true")
+    ap.add_argument("--no-default-mode", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -211,6 +257,9 @@ def main():
     pair_info = None
     if rank == 0 and not args.no_pairs:
         pair_info = pairwise_leg(ctx, codes, subm, scal, args)
+    dm_info = None
+    if rank == 0 and not args.no_default_mode and not args.no_pairs:
+        dm_info = default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args)
 
     if rank == 0:
         abytes = algorithmic_bytes(recs)
@@ -246,6 +295,8 @@ def main():
         }
         if pair_info:
             out["seqseq_batch"] = pair_info
+        if dm_info:
+            out["default_mode"] = dm_info
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
         print(json.dumps(out))

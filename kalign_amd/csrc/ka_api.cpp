@@ -293,7 +293,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         long long scr = 0;
         // per level every sequence is a member of at most one task; profile lengths never exceed
         // the sum of their members' lengths
-        scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 4LL * c->max_len) + 65536;
+        scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
         c->scratch_cap = std::max(c->scratch_cap, scr);
         c->dbg_cap = (flags & KA_FLAG_DEBUG_ROWS) ? std::max<long long>(c->dbg_cap, 6LL * (cols + 2LL * n_tasks + c->sum_len)) : c->dbg_cap;
 

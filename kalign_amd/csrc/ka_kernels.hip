@@ -702,129 +702,172 @@ __device__ void ka_make_leaf_profile(float* __restrict__ prof, int len, const ui
 // every task; per anchor every row has at most ONE non-zero entry, so the device keeps <= K
 // (column, value) entries per DP row instead and the passes carry them in registers.
 //
-// ka_node_positions = get_node_anchor_positions: for a leaf the position map itself; for a
-// profile a vote over its member sequences, where "best" is the anchor position of the FIRST
-// member (in the reference's sip order) that has one in the column.  Being first in a fixed
-// order is a min-reduction over the member index, and `agree` / `total` are counts, so the vote
-// runs in parallel over (member, residue) with LDS atomics: key = member_index << 32 | position.
-// Which column a residue sits in comes from D.colof (kept up to date by ka_update_colof).
+// ka_cons_votes = get_node_anchor_positions for both operands and all anchors: for a leaf the
+// position map itself; for a profile a vote over its member sequences, where "best" is the anchor
+// position of the FIRST member (in the reference's sip order) that has one in the column.  Being
+// first in a fixed order is a min-reduction over the member index, and `agree` / `total` are
+// counts, so the vote runs in parallel over (member, residue) with LDS atomics:
+// key = member_index << 32 | position, counts = total | agree << 16.  Which column a residue sits
+// in comes from D.colof (kept up to date by ka_update_colof).  The workgroups of a cluster share
+// the work by operand and by anchor; tables that do not fit into LDS live in the task's HBM scratch.
 // ------------------------------------------------------------------------------------------
 template <bool LEAN>
-__device__ void ka_node_positions(const KaTreeDev& D, const int node, const int nmem, const int dp_len, const int k,
-                                  int* __restrict__ pos_out, float* __restrict__ conf_out, char* lds, const long long lds_bytes, char* vote_glb)
+__device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const long long lds_bytes)
 {
-        const int tid = threadIdx.x;
-        if (nmem == 1) {
-                const int* map = D.cons_maps + D.cons_map_off[node] + (long long)k * dp_len;   // a leaf's dp_len is its length
-                for (int i = tid; i < dp_len; i += KA_NT) { const int a = map[i]; pos_out[i] = a; conf_out[i] = (a >= 0) ? 1.0f : 0.0f; }
-                __syncthreads();
-                return;
-        }
-        if (LEAN) return;                                        // lean levels hold leaf-leaf tasks only
-        // vote tables: LDS when the profile fits (16 B per column), else the task's HBM scratch
-        const bool in_lds = (long long)dp_len * 16 <= lds_bytes;
-        unsigned long long* key = in_lds ? (unsigned long long*)lds : (unsigned long long*)vote_glb;
-        unsigned int* total = (unsigned int*)(key + dp_len);
-        unsigned int* agree = total + dp_len;
-        for (int c = tid; c < dp_len; c += KA_NT) { key[c] = ~0ull; total[c] = 0u; agree[c] = 0u; }
-        __syncthreads();
-        const int lane = tid & 63, wave = tid >> 6;
-        const int* members = D.sip + D.sip_off[node];
-        for (int mi = wave; mi < nmem; mi += KA_NW) {
-                const int si = members[mi];
-                const int len = D.node_len[si];
-                const int* map = D.cons_maps + D.cons_map_off[si] + (long long)k * len;
-                const int* col = D.colof + D.seq_off[si];
-                for (int p = lane; p < len; p += 64) {
-                        const int a = map[p];
-                        if (a >= 0) {
-                                const int c = col[p];
-                                atomicMin(&key[c], ((unsigned long long)(unsigned int)mi << 32) | (unsigned int)a);
-                                atomicAdd(&total[c], 1u);
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int K = D.cons_K;
+        const long long n = (long long)S.len_a + S.len_b + 8;           // stride of the per-anchor arrays
+        const int half = (S.G >= 2) ? (S.G >> 1) : 1;
+        for (int side = 0; side < 2; ++side) {
+                if (S.G >= 2 && side != S.member / half) continue;
+                const int sub = (S.G >= 2) ? (S.member % half) : 0;
+                const bool is_rows = (side == 0);
+                const int node = (is_rows != (S.swapped != 0)) ? T.a : T.b;  // rows: a unless swapped
+                const int nmem = (node == T.a) ? T.nsip_a : T.nsip_b;
+                const int dp_len = is_rows ? S.La : S.Lb;
+                int* apos = is_rows ? S.apos_r : S.apos_c;
+                float* conf = is_rows ? S.conf_r : S.conf_c;
+                // this workgroup's anchors: sub, sub + half, ...  (closed form: an indexed array would live in scratch
+                // memory and put a scratch load in front of every gather)
+                const int nk = (K - sub + half - 1) / half;
+#define KS(b_) (sub + (b_) * half)
+                if (nmem == 1) {
+                        // leaf: direct lookup (a leaf's dp_len is its length)
+                        for (int b = 0; b < nk; ++b) {
+                                const int* map = D.cons_maps + D.cons_map_off[node] + (long long)KS(b) * dp_len;
+                                for (int i = tid; i < dp_len; i += KA_NT) {
+                                        const int a = map[i];
+                                        apos[KS(b) * n + i] = a; conf[KS(b) * n + i] = (a >= 0) ? 1.0f : 0.0f;
+                                }
                         }
+                        continue;
                 }
-        }
-        __syncthreads();
-        // (HBM tables: the atomics above were performed at L2; read them back past the L1)
-        for (int mi = wave; mi < nmem; mi += KA_NW) {
-                const int si = members[mi];
-                const int len = D.node_len[si];
-                const int* map = D.cons_maps + D.cons_map_off[si] + (long long)k * len;
-                const int* col = D.colof + D.seq_off[si];
-                for (int p = lane; p < len; p += 64) {
-                        const int a = map[p];
-                        if (a >= 0) {
-                                const int c = col[p];
-                                const unsigned long long kk = in_lds ? key[c] : __hip_atomic_load(&key[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) atomicAdd(&agree[c], 1u);
+                if (LEAN) continue;                                      // lean levels hold leaf-leaf tasks only
+                if (nmem >= 65536) { if (tid == 0) atomicExch(D.error, 7); continue; }
+                const int* members = D.sip + D.sip_off[node];
+                int fit = (int)(lds_bytes / (12ll * dp_len));             // anchors whose tables fit into LDS together
+                const bool in_lds = fit >= 1;
+                if (!in_lds) fit = nk;
+                for (int b0 = 0; b0 < nk; b0 += fit) {
+                        const int nb = min(fit, nk - b0);
+                        unsigned long long* key = in_lds ? (unsigned long long*)lds : (unsigned long long*)S.vote;
+                        unsigned int* cnt = (unsigned int*)(key + (long long)nb * dp_len);
+                        for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; }
+                        __syncthreads();
+                        // Two sweeps over (member, residue): [0] first-member key + total, [1] agreement with the
+                        // winner.  Latency-bound gathers, so each wave pre-loads the metadata of 64 of its
+                        // members lane-parallel and keeps 4 x 64 residues of loads in flight before the atomics.
+                        for (int sweep = 0; sweep < 2; ++sweep) {
+                                const int mine = (nmem - wave + KA_NW - 1) / KA_NW;          // members of this wave
+                                for (int base = 0; base < mine; base += 64) {
+                                        const int ml = min(base + lane, mine - 1);
+                                        const int mi_l = wave + KA_NW * ml;
+                                        const int si_l = members[mi_l];
+                                        const int len_l = D.node_len[si_l];
+                                        const long long mo_l = D.cons_map_off[si_l];
+                                        const int so_l = D.seq_off[si_l];
+                                        const int cntm = min(64, mine - base);
+                                        for (int jm = 0; jm < cntm; ++jm) {
+                                                const int mi = wave + KA_NW * (base + jm);
+                                                const int len = __shfl(len_l, jm, 64);
+                                                const long long mo = __shfl(mo_l, jm, 64);
+                                                const int* map = D.cons_maps + mo;
+                                                const int* col = D.colof + __shfl(so_l, jm, 64);
+                                                for (int p0 = lane; p0 < len; p0 += 256) {
+                                                        int cc[4], aa[4][KA_NB - 1];
+#pragma unroll
+                                                        for (int u = 0; u < 4; ++u) {
+                                                                const int pp = p0 + 64 * u;
+                                                                const bool ok = pp < len;
+                                                                cc[u] = ok ? col[pp] : 0;
+#pragma unroll
+                                                                for (int b = 0; b < KA_NB - 1; ++b)
+                                                                        aa[u][b] = (ok && b < nb) ? map[(long long)KS(b0 + b) * len + pp] : -1;
+                                                        }
+#pragma unroll
+                                                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                                                                for (int b = 0; b < KA_NB - 1; ++b) {
+                                                                        const int a = aa[u][b];
+                                                                        if (a < 0) continue;
+                                                                        const int x = b * dp_len + cc[u];
+                                                                        if (sweep == 0) {
+                                                                                atomicMin(&key[x], ((unsigned long long)(unsigned int)mi << 32) | (unsigned int)a);
+                                                                                atomicAdd(&cnt[x], 1u);
+                                                                        } else {
+                                                                                // (HBM tables: the atomics were performed at L2; read them back past the L1)
+                                                                                const unsigned long long kk = in_lds ? key[x]
+                                                                                        : __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) atomicAdd(&cnt[x], 0x10000u);
+                                                                        }
+                                                                }
+                                                        }
+                                                }
+                                        }
+                                }
+                                __syncthreads();
                         }
+                        for (int x = tid; x < nb * dp_len; x += KA_NT) {
+                                const int b = x / dp_len, c = x - b * dp_len;
+                                unsigned long long kk;
+                                unsigned int cc;
+                                if (in_lds) { kk = key[x]; cc = cnt[x]; }
+                                else {
+                                        kk = __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        cc = __hip_atomic_load(&cnt[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                const int tot = (int)(cc & 0xffffu), ag = (int)(cc >> 16);
+                                const long long o = KS(b0 + b) * n + c;
+                                if (tot > 0 && ag > 0) { apos[o] = (int)(unsigned int)(kk & 0xffffffffull); conf[o] = (float)ag / (float)tot; }
+                                else { apos[o] = -1; conf[o] = 0.0f; }
+                        }
+                        __syncthreads();
                 }
         }
-        __syncthreads();
-        for (int c = tid; c < dp_len; c += KA_NT) {
-                unsigned long long kk;
-                unsigned int tot, ag;
-                if (in_lds) { kk = key[c]; tot = total[c]; ag = agree[c]; }
-                else {
-                        kk = __hip_atomic_load(&key[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        tot = __hip_atomic_load(&total[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ag = __hip_atomic_load(&agree[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (tot > 0u && ag > 0u) { pos_out[c] = (int)(unsigned int)(kk & 0xffffffffull); conf_out[c] = (float)(int)ag / (float)(int)tot; }
-                else { pos_out[c] = -1; conf_out[c] = 0.0f; }
-        }
-        __syncthreads();
 }
 
-// anchor_consistency_get_bonus_profile in sparse form.  After it S.ent[row][0..KA_NB) holds the row's
-// non-zero bonus cells with distinct columns: entries of different anchors that hit the same cell are
-// summed in anchor order (the dense matrix accumulates k = 0..K-1 into a zeroed cell), and slot
-// KA_NB-1 carries the cell the reference reaches when a forward pass indexes column Lb of row i --
-// flat index i*Lb + Lb is cell (i+1, 0) (aln_seqseq.c:83-85 uses the 1-based column).
-template <bool LEAN>
-__device__ void ka_cons_prepare(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const long long lds_bytes)
+#undef KS
+
+// anchor_consistency_get_bonus_profile in sparse form (first workgroup of the cluster, after the votes).
+// After it S.ent[row][0..KA_NB) holds the row's non-zero bonus cells with distinct columns: entries of
+// different anchors that hit the same cell are summed in anchor order (the dense matrix accumulates
+// k = 0..K-1 into a zeroed cell), and slot KA_NB-1 carries the cell the reference reaches when a forward
+// pass indexes column Lb of row i -- flat index i*Lb + Lb is cell (i+1, 0) (aln_seqseq.c:83-85 uses the
+// 1-based column).
+__device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
 {
         const int tid = threadIdx.x;
         const int K = D.cons_K;
         const int rows = S.La, cols = S.Lb;
-        const int rnode = S.swapped ? T.b : T.a, cnode = S.swapped ? T.a : T.b;
-        const int rn = S.swapped ? T.nsip_b : T.nsip_a, cn = S.swapped ? T.nsip_a : T.nsip_b;
+        const long long n = (long long)S.len_a + S.len_b + 8;
+        const int ml = D.cons_maxlen + 8;
         const float paw = D.cons_paw;
-        for (int k = 0; k < K; ++k) {
-                ka_node_positions<LEAN>(D, rnode, rn, rows, k, S.apos_r, S.conf_r, lds, lds_bytes, S.vote);
-                ka_node_positions<LEAN>(D, cnode, cn, cols, k, S.apos_c, S.conf_c, lds, lds_bytes, S.vote);
-                // inverse map anchor position -> column; of several columns the last one wins (:521-526)
-                for (int x = tid; x < D.cons_maxlen; x += KA_NT) S.invj[x] = -1;
-                __syncthreads();
-                for (int j = tid; j < cols; j += KA_NT) { const int a = S.apos_c[j]; if (a >= 0) atomicMax(&S.invj[a], j); }
-                __syncthreads();
-                for (int i = tid; i < rows; i += KA_NT) {
-                        const int a = S.apos_r[i];
-                        int col = -1;
-                        float val = 0.0f;
-                        if (a >= 0) {
-                                const int bj = __hip_atomic_load(&S.invj[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (bj >= 0) { col = bj; val = paw * S.conf_r[i] * S.conf_c[bj]; }        // :534-535
-                        }
-                        S.ent[(long long)i * KA_NB + k] = make_int2(col, __float_as_int(val));
-                }
-                __syncthreads();
+        // inverse maps anchor position -> column; of several columns the last one wins (:521-526)
+        for (int x = tid; x < K * ml; x += KA_NT) S.invj[x] = -1;
+        __syncthreads();
+        for (int x = tid; x < K * cols; x += KA_NT) {
+                const int k = x / cols, j = x - k * cols;
+                const int a = S.apos_c[k * n + j];
+                if (a >= 0) atomicMax(&S.invj[k * ml + a], j);
         }
-        // merge per row (anchor order), then the wrap-around entry from the row below
+        __syncthreads();
         for (int i = tid; i < rows; i += KA_NT) {
-                int2* e = S.ent + (long long)i * KA_NB;
                 int mc[KA_NB];
                 float mv[KA_NB];
-                int n = 0;
+                int cnt = 0;
                 for (int k = 0; k < K; ++k) {
-                        const int2 x = e[k];
-                        if (x.x < 0) continue;
+                        const int a = S.apos_r[k * n + i];
+                        if (a < 0) continue;
+                        const int bj = __hip_atomic_load(&S.invj[k * ml + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (bj < 0) continue;
+                        const float val = paw * S.conf_r[k * n + i] * S.conf_c[k * n + bj];                // :534-535
                         int hit = -1;
-                        for (int m = 0; m < n; ++m) if (mc[m] == x.x) hit = m;
-                        if (hit >= 0) mv[hit] += __int_as_float(x.y);
-                        else { mc[n] = x.x; mv[n] = 0.0f + __int_as_float(x.y); ++n; }
+                        for (int m = 0; m < cnt; ++m) if (mc[m] == bj) hit = m;
+                        if (hit >= 0) mv[hit] += val;
+                        else { mc[cnt] = bj; mv[cnt] = 0.0f + val; ++cnt; }
                 }
-                for (int m = 0; m < KA_NB - 1; ++m) e[m] = (m < n) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
+                int2* e = S.ent + (long long)i * KA_NB;
+                for (int m = 0; m < KA_NB - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
         }
         __syncthreads();
         for (int i = tid; i < rows; i += KA_NT) {
@@ -910,12 +953,13 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
         if (cons_maxlen > 0) {
                 S.ent = (int2*)(base + o);    o += ka_align_up(n * 8 * KA_NB, 16);
-                S.apos_r = (int*)(base + o);  o += ka_align_up(n * 4, 16);
-                S.conf_r = (float*)(base + o); o += ka_align_up(n * 4, 16);
-                S.apos_c = (int*)(base + o);  o += ka_align_up(n * 4, 16);
-                S.conf_c = (float*)(base + o); o += ka_align_up(n * 4, 16);
-                S.invj = (int*)(base + o);    o += ka_align_up(((long long)cons_maxlen + 8) * 4, 16);
-                S.vote = base + o;            o += ka_align_up(n * 16, 16);
+                const long long KM = KA_NB - 1;                      // anchors
+                S.apos_r = (int*)(base + o);  o += ka_align_up(KM * n * 4, 16);
+                S.conf_r = (float*)(base + o); o += ka_align_up(KM * n * 4, 16);
+                S.apos_c = (int*)(base + o);  o += ka_align_up(KM * n * 4, 16);
+                S.conf_c = (float*)(base + o); o += ka_align_up(KM * n * 4, 16);
+                S.invj = (int*)(base + o);    o += ka_align_up(KM * ((long long)cons_maxlen + 8) * 4, 16);
+                S.vote = base + o;            o += ka_align_up(KM * n * 12, 16);
         }
         return o;
 }
@@ -929,7 +973,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
-        if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * ((n * 4 + 15) / 16 * 16) + ((cons_maxlen + 8) * 4 + 15) / 16 * 16 + n * 16;
+        if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 12 + 15) / 16 * 16;
         return b;
 }
 
@@ -1028,11 +1072,13 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
                 if (T.nsip_a == 1) ka_make_leaf_profile(S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, tss);
                 if (T.nsip_b == 1) ka_make_leaf_profile(S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, tss);
         }
-        // P1b: the bonus entries of every DP row (the first workgroup of the cluster; the barrier
-        // below publishes them to the others)
-        if (NB && S.member == 0) {
+        // P1b: anchor positions of both operands (all workgroups of the cluster), then the bonus entries
+        // of every DP row (the first one); the barrier below publishes them
+        if (NB) {
                 __syncthreads();
-                ka_cons_prepare<LEAN>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_WAVES * KA_WAVE_LDS);
+                ka_cons_votes<LEAN>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_WAVES * KA_WAVE_LDS);
+                ka_cluster_sync(S);
+                if (S.member == 0) ka_cons_entries(S, D);
         }
         ka_cluster_sync(S);
         tk1 = __builtin_amdgcn_s_memtime();

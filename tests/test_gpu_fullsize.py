@@ -28,13 +28,13 @@ def check_path_invariants(recs, paths):
             assert ((ops[lead[0]:lead[-1] + 1] & 32) == 0).all()
 
 
-def run_case(nseq, length, dna, seed=1, reference=True):
+def run_case(nseq, length, dna, seed=1, reference=True, n_anchors=0):
     import bench
     import kalign_amd
     codes, tasks, dist = bench.make_workload(nseq, length, dna, seed)
     subm, scal = bench.scoring(dna)
     ctx = kalign_amd.Context(0)
-    recs, paths, gaps = ctx.msa_tree(codes, tasks, subm, scal, dist)
+    recs, paths, gaps = ctx.msa_tree(codes, tasks, subm, scal, dist, n_anchors=n_anchors, weight=2.0)
     ctx.close()
     check_path_invariants(recs, paths)
     # all rows of the final alignment have the same length, residues are preserved by construction
@@ -52,6 +52,8 @@ def run_case(nseq, length, dna, seed=1, reference=True):
             pytest.skip("oracle/_ref not built")
         job = refdrv.EncodedJob(codes, tasks, dist, biotype=1 if dna else 0, type_=0 if dna else -1,
                                 n_threads=min(16, os.cpu_count() or 1))
+        if n_anchors:
+            job.build_consistency(n_anchors, 2.0)
         ref_gaps, _ = job.run_tree()
         job.close()
         for got, want in zip(gaps, ref_gaps):
@@ -67,6 +69,12 @@ def test_config2_shape_dna_256x2000_matches_reference():
     """configs[2] shape (--type dna, ~2000 nt, profile-profile dominated), scaled to 256 sequences
     so the CPU reference finishes in seconds: long anti-diagonals, multi-strip passes, clusters."""
     run_case(256, 2000, True)
+
+
+def test_config1_default_mode_512x400_matches_reference():
+    """The CLI's default mode (5 consistency anchors, weight 2.0) at the configs[1] shape, scaled to 512
+    sequences because the reference builds its N x K position maps serially (~1 ms per pair)."""
+    run_case(512, 400, False, n_anchors=5)
 
 
 def test_two_sequences_and_tiny_inputs():
