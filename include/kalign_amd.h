@@ -98,7 +98,29 @@ int ka_tree_run(ka_ctx* ctx);
 int ka_tree_sync(ka_ctx* ctx);
 long long ka_tree_paths_size(ka_ctx* ctx);      /* ints needed for paths_out (valid after run+sync) */
 int ka_tree_download(ka_ctx* ctx, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
-/* Merged profile of node `node` ((plen+2)*64 floats) after a run; for tests. */
+/*
+ * Partial runs -- what single-tree multi-GPU sharding is made of (kalign_amd/dist.py:sharded_tree
+ * drives them with one process per GPU): a rank runs the tasks of its subtree, the profile of a subtree root moves
+ * to the rank that runs its parent (ka_tree_get_profile -> send/recv -> ka_tree_set_profile), rank 0 gathers all
+ * records and paths and weaves the gap arrays.  Results do not depend on the number of ranks.
+ *   ka_tree_run_tasks: run the listed tasks (children must be available here: leaves, earlier tasks, injected
+ *     profiles); does not reset the device state (ka_tree_upload / ka_tree_run do).
+ *   ka_tree_reset: forget every computed / injected node (a new sharded run over the same upload).
+ *   ka_tree_node_len: alignment length of a node on this context (-1 on error).
+ *   ka_tree_set_profile: inject the merged profile of an internal node, (plen+2)*64 floats.
+ *   ka_tree_download_tasks: records + coded paths of the listed tasks, paths packed in list order.
+ *   ka_weave_gaps: host-only make_seq/update_gaps over all tasks in tree order (weave_alignment.c:41-112);
+ *     recs[t] needs a, b, c, path_off.
+ */
+int ka_tree_run_tasks(ka_ctx* ctx, const int* task_ids, int n);
+int ka_tree_reset(ka_ctx* ctx);
+int ka_tree_node_len(ka_ctx* ctx, int node);
+int ka_tree_set_profile(ka_ctx* ctx, int node, const float* prof, int plen);
+int ka_tree_download_tasks(ka_ctx* ctx, const int* task_ids, int n, ka_task_rec* recs, int* paths_out,
+                           long long paths_cap, long long* used_out);
+int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_task_rec* recs, const int* paths, int* gaps_out);
+
+/* Merged profile of node `node` ((plen+2)*64 floats) after a run. */
 int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats);
 /* Per-task phase timings of the last run (KA_FLAG_TIMING): out[8*t + k], shader-clock cycles:
    0 operand prep, 1 Hirschberg, 2 path coding, 3 profile merge, 4 passes, 5 meetups, 6 recursion

@@ -36,7 +36,8 @@ class TaskRec(C.Structure):
 EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
-           "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency"]
+           "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
+           "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps"]
 
 
 def lib_path():
@@ -78,6 +79,12 @@ def load_library():
     L.ka_tree_cells.argtypes = [vp]
     L.ka_tree_cells.restype = C.c_double
     L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ka_tree_run_tasks.argtypes = [vp, vp, C.c_int]
+    L.ka_tree_reset.argtypes = [vp]
+    L.ka_tree_node_len.argtypes = [vp, C.c_int]
+    L.ka_tree_set_profile.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.ka_tree_download_tasks.argtypes = [vp, vp, C.c_int, C.POINTER(TaskRec), vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.ka_weave_gaps.argtypes = [C.c_int, vp, C.c_int, C.POINTER(TaskRec), vp, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
     L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
     L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
@@ -188,6 +195,40 @@ class Context:
         return out
 
     # ---- one-shot -----------------------------------------------------------------------
+    # ---- partial runs (single-tree multi-GPU sharding, kalign_amd/dist.py:sharded_tree) ----
+    def tree_run_tasks(self, task_ids):
+        ids = np.ascontiguousarray(task_ids, np.int32)
+        self._chk(self.L.ka_tree_run_tasks(self.h, _ptr(ids), len(ids)))
+
+    def tree_reset(self):
+        self._chk(self.L.ka_tree_reset(self.h))
+
+    def tree_node_len(self, node):
+        n = self.L.ka_tree_node_len(self.h, int(node))
+        if n < 0:
+            raise KalignAmdError("ka_tree_node_len failed")
+        return n
+
+    def tree_get_node(self, node):
+        """merged profile of an internal node, float32[(plen+2)*64]"""
+        self.tree_sync()
+        return self.tree_profile(node, self.tree_node_len(node))
+
+    def tree_set_node(self, node, prof):
+        prof = np.ascontiguousarray(prof, np.float32).reshape(-1)
+        self._chk(self.L.ka_tree_set_profile(self.h, int(node), _ptr(prof), len(prof) // 64 - 2))
+
+    def tree_download_tasks(self, task_ids):
+        """(recs, paths) of the listed tasks; recs[i].path_off indexes `paths`."""
+        ids = np.ascontiguousarray(task_ids, np.int32)
+        recs = (TaskRec * max(len(ids), 1))()
+        cap = int(self._job["lens"].sum()) * 2 * max(len(ids), 1) + 8 * len(ids) + 16
+        cap = min(cap, (int(self._job["lens"].sum()) + 2) * (len(ids) + 1) + 16)
+        paths = np.zeros(cap, np.int32)
+        used = C.c_longlong(0)
+        self._chk(self.L.ka_tree_download_tasks(self.h, _ptr(ids), len(ids), recs, _ptr(paths), cap, C.byref(used)))
+        return list(recs)[:len(ids)], paths[:used.value]
+
     def tree_build_consistency(self, n_anchors=5, weight=2.0):
         """anchor_consistency_build: call between tree_upload and tree_run (the reference's default mode)."""
         self._chk(self.L.ka_tree_build_consistency(self.h, int(n_anchors), float(weight)))
@@ -231,6 +272,23 @@ class Context:
                                            _ptr(ia), _ptr(ib), len(ia), _ptr(sub),
                                            float(gpo), float(gpe), float(tgpe), _ptr(paths), _ptr(poff), _ptr(scores)))
         return [paths[poff[k]:poff[k] + paths[poff[k]] + 2].copy() for k in range(len(ia))], scores
+
+
+def weave_gaps(lens, recs, paths):
+    """Host-only make_seq/update_gaps over all tasks in tree order (ka_weave_gaps); needs the library but no GPU.
+    recs: sequence of TaskRec in task order with path_off into `paths`.  Returns the gap array per sequence."""
+    L = load_library()
+    lens = np.ascontiguousarray(lens, np.int32)
+    arr = (TaskRec * len(recs))(*recs)
+    paths = np.ascontiguousarray(paths, np.int32)
+    gaps = np.zeros(int(lens.sum()) + len(lens), np.int32)
+    if L.ka_weave_gaps(len(lens), _ptr(lens), len(recs), arr, _ptr(paths), _ptr(gaps)):
+        raise KalignAmdError(L.ka_last_error().decode())
+    out, o = [], 0
+    for n in lens:
+        out.append(gaps[o:o + int(n) + 1].copy())
+        o += int(n) + 1
+    return out
 
 
 def msa_tree(codes, tasks, subm, scal, seq_distances=None, flags=0, device=0):

@@ -84,6 +84,12 @@ struct ka_ctx {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         int* h_trace = nullptr;       // pinned, device-visible breadcrumbs (KA_TRACE=1)
         bool ran = false, synced = false;
+        bool state_valid = false;      // device state reset and consistent with task_done
+        bool partial = false;          // last launch was ka_tree_run_tasks (no automatic grow + re-run)
+        std::vector<char> task_done;
+        std::vector<int> injected;       // nodes whose profile came from ka_tree_set_profile
+        std::vector<int> task_level;
+        DevBuf<int2> d_blocks_tmp;
         int n_launches = 0;
         double cells = 0.0;
         float pair_ms = 0.0f;                        // kernel time of the last ka_pairwise_batch
@@ -105,6 +111,8 @@ struct ka_ctx {
         DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip;
         DevBuf<long long> d_cons_map_off, d_sip_off;
 };
+
+static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
 extern "C" int ka_abi_version(void) { return 2; }
@@ -135,7 +143,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_path_arena.release(); c->d_error.release(); c->d_node_prof.release(); c->d_dbg_off.release();
         c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
         c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release(); c->d_timing.release();
-        c->d_ctl.release(); c->d_blocks.release();
+        c->d_ctl.release(); c->d_blocks.release(); c->d_blocks_tmp.release();
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
@@ -171,7 +179,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (numseq < 2 || n_tasks != numseq - 1) return fail("need numseq >= 2 and n_tasks == numseq-1");
         HIPCHK(hipSetDevice(c->device));
         const int nprof = 2 * numseq - 1;
-        c->have_job = false; c->ran = false; c->synced = false;
+        c->have_job = false; c->ran = false; c->synced = false; c->state_valid = false;
         c->cons_K = 0;                           // a new job starts without a consistency table
         c->numseq = numseq; c->n_tasks = n_tasks; c->flags = flags;
         c->lens.assign(lens, lens + numseq);
@@ -255,25 +263,16 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 c->level_off.push_back((int)c->level_ids_flat.size());
         }
 
-        // ---- workgroup tables: near the top of the tree there are fewer tasks than CUs, so a task
-        // gets a cluster of up to max_cluster workgroups (the kernel decides from the actual operand
-        // lengths how many of them it uses).  Workgroups of one cluster are spaced 8 blocks apart:
-        // block b runs on XCD b % 8 (observed, not contractual -- used for L2 locality only).
+        // ---- workgroup tables, one per dependency level (build_blocks) ----
         if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
+        c->task_level.assign(n_tasks, 0);
+        for (int t = 0; t < n_tasks; t++) c->task_level[t] = level[abc[3 * t + 2]] - 1;
         for (auto& L : c->levels) {
-                const int nt = (int)L.size();
-                int lean = 1;
-                for (int t : L) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) lean = 0;
-                if (getenv("KA_NO_LEAN")) lean = 0;
+                std::vector<int2> tbl;
+                int lean = 0;
+                build_blocks(c, L, tbl, &lean);
                 c->level_lean.push_back(lean);
-                int G = 1;
-                while (!lean && G * 2 <= c->max_cluster && nt * G * 2 <= 256) G *= 2;
-                const int groups = (nt + 7) / 8;
-                std::vector<int2> tbl((size_t)groups * 8 * G, make_int2(-1, 0));
-                for (int j = 0; j < nt; j++)
-                        for (int m = 0; m < G; m++)
-                                tbl[(size_t)(j % 8) + 8 * ((size_t)m + (size_t)G * (j / 8))] = make_int2(L[j], m | (G << 8));
                 c->blocks_flat.insert(c->blocks_flat.end(), tbl.begin(), tbl.end());
                 c->blocks_off.push_back((int)c->blocks_flat.size());
         }
@@ -316,10 +315,10 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         return KA_OK;
 }
 
-static int tree_launch(ka_ctx* c)
+// reset the device state so that a run is repeatable
+static int tree_reset(ka_ctx* c)
 {
         const int numseq = c->numseq, nprof = 2 * numseq - 1;
-        // reset the device state so that run() is repeatable
         std::vector<int> node_len(nprof, 0);
         std::vector<long long> node_prof(nprof, -1);
         for (int i = 0; i < numseq; i++) { node_len[i] = c->lens[i]; node_prof[i] = c->leaf_prof_off[i]; }
@@ -330,8 +329,18 @@ static int tree_launch(ka_ctx* c)
         HIPCHK(hipMemcpyAsync(c->d_counters.p, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_error.p, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemsetAsync(c->d_ctl.p, 0, (size_t)ka_ctl_bytes_host() * c->n_tasks, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_recs.p, 0, sizeof(ka_task_rec) * c->n_tasks, c->stream));
+        if (c->cons_K > 0)                           // every leaf starts with residue p in column p
+                HIPCHK(hipMemcpyAsync(c->d_colof.p, c->d_colof_init.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));          // the staging vectors above are stack/heap temporaries
+        c->state_valid = true;
+        c->task_done.assign(c->n_tasks, 0);
+        c->injected.clear();
+        return KA_OK;
+}
 
+static KaTreeDev tree_dev(ka_ctx* c)
+{
         KaTreeDev D;
         D.codes = c->d_codes.p; D.seq_off = c->d_seq_off.p;
         D.node_len = c->d_node_len.p; D.node_prof = c->d_node_prof.p;
@@ -342,7 +351,7 @@ static int tree_launch(ka_ctx* c)
         D.tasks = c->d_tasks.p; D.recs = c->d_recs.p; D.subm = c->d_subm.p;
         D.ctl = (KaCtl*)c->d_ctl.p;
         D.gpo0 = c->scal[0]; D.gpe0 = c->scal[1]; D.tgpe0 = c->scal[2]; D.usw = c->scal[5];
-        D.numseq = numseq; D.flags = c->flags; D.error = c->d_error.p;
+        D.numseq = c->numseq; D.flags = c->flags; D.error = c->d_error.p;
         D.nres = c->nres;
         D.trace = c->h_trace;
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
@@ -350,9 +359,34 @@ static int tree_launch(ka_ctx* c)
         D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
         D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
         D.colof = c->d_colof.p; D.sip = c->d_sip.p; D.sip_off = c->d_sip_off.p;
-        if (c->cons_K > 0)                           // every leaf starts with residue p in column p
-                HIPCHK(hipMemcpyAsync(c->d_colof.p, c->d_colof_init.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToDevice, c->stream));
+        return D;
+}
 
+// Workgroup table of one launch: near the top of the tree there are fewer tasks than CUs, so a task
+// gets a cluster of up to max_cluster workgroups (the kernel decides from the actual operand
+// lengths how many of them it uses).  Workgroups of one cluster are spaced 8 blocks apart:
+// block b runs on XCD b % 8 (observed, not contractual -- used for L2 locality only).
+static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out)
+{
+        const int nt = (int)L.size();
+        int lean = 1;
+        for (int t : L) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) lean = 0;
+        if (getenv("KA_NO_LEAN")) lean = 0;
+        int G = 1;
+        while (!lean && G * 2 <= c->max_cluster && nt * G * 2 <= 256) G *= 2;
+        const int groups = (nt + 7) / 8;
+        tbl.assign((size_t)groups * 8 * G, make_int2(-1, 0));
+        for (int j = 0; j < nt; j++)
+                for (int m = 0; m < G; m++)
+                        tbl[(size_t)(j % 8) + 8 * ((size_t)m + (size_t)G * (j / 8))] = make_int2(L[j], m | (G << 8));
+        *lean_out = lean;
+}
+
+static int tree_launch(ka_ctx* c)
+{
+        if (tree_reset(c)) return KA_FAIL;
+        const KaTreeDev D = tree_dev(c);
+        c->partial = false;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
         for (size_t L = 0; L < c->levels.size(); L++) {
@@ -364,6 +398,7 @@ static int tree_launch(ka_ctx* c)
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev1, c->stream));
+        std::fill(c->task_done.begin(), c->task_done.end(), 1);
         return KA_OK;
 }
 
@@ -393,6 +428,7 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                 if (err == 5) return fail("device watchdog: a strip pipeline stopped making progress");
                 if (err == 6) return fail("device watchdog: a cluster barrier was never completed (workgroups of one task not co-resident?)");
                 if (err == 7) return fail("consistency: a profile is too long for the LDS vote table");
+                if (c->partial) return fail("a device arena overflowed during a partial run (ka_tree_run_tasks does not re-run)");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)
                 if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
                 else if (err == 2) { c->scratch_cap *= 2; c->d_scratch.release(); }
@@ -423,6 +459,41 @@ static void fold_gaps(int len, int* gis, const int* newgaps)
                 rel += gis[i] + 1;
                 gis[i] += add;
         }
+}
+
+// make_seq + update_gaps for every task in tree order (weave_alignment.c:41-112): host-only, needs
+// only (a, b, c, path_off) of every task and the coded paths.
+extern "C" int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_task_rec* recs, const int* paths, int* gaps_out)
+{
+        if (numseq < 1 || n_tasks != numseq - 1 || !lens || !recs || !paths || !gaps_out) return fail("ka_weave_gaps: bad arguments");
+        const int nprof = 2 * numseq - 1;
+        std::vector<int> goff(numseq);
+        long long g = 0;
+        for (int i = 0; i < numseq; i++) { goff[i] = (int)g; g += lens[i] + 1; }
+        memset(gaps_out, 0, sizeof(int) * (size_t)g);
+        std::vector<std::vector<int>> sip(nprof);
+        for (int i = 0; i < numseq; i++) sip[i] = {i};
+        std::vector<int> ga, gb;
+        for (int t = 0; t < n_tasks; t++) {
+                const ka_task_rec& r = recs[t];
+                if (r.a < 0 || r.b < 0 || r.c < numseq || r.a >= nprof || r.b >= nprof || r.c >= nprof) return fail("ka_weave_gaps: bad task record");
+                const int* p = paths + r.path_off;
+                ga.assign(p[0] + 1, 0); gb.assign(p[0] + 1, 0);
+                int posa = 0, posb = 0;
+                for (int k = 1; p[k] != 3; k++) {
+                        if (!p[k]) { posa++; posb++; }
+                        else if (p[k] & 1) { ga[posa] += 1; posb++; }
+                        else if (p[k] & 2) { gb[posb] += 1; posa++; }
+                }
+                for (int x : sip[r.a]) fold_gaps(lens[x], gaps_out + goff[x], ga.data());
+                for (int x : sip[r.b]) fold_gaps(lens[x], gaps_out + goff[x], gb.data());
+                sip[r.c].reserve(sip[r.a].size() + sip[r.b].size());
+                sip[r.c].insert(sip[r.c].end(), sip[r.a].begin(), sip[r.a].end());
+                sip[r.c].insert(sip[r.c].end(), sip[r.b].begin(), sip[r.b].end());
+                std::vector<int>().swap(sip[r.a]);
+                std::vector<int>().swap(sip[r.b]);
+        }
+        return KA_OK;
 }
 
 extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
@@ -472,34 +543,129 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
         }
         if (recs) memcpy(recs, c->h_recs.data(), sizeof(ka_task_rec) * c->n_tasks);
 
-        if (gaps_out) {
-                const int numseq = c->numseq, nprof = 2 * numseq - 1;
-                std::vector<int> goff(numseq);
-                long long g = 0;
-                for (int i = 0; i < numseq; i++) { goff[i] = (int)g; g += c->lens[i] + 1; }
-                memset(gaps_out, 0, sizeof(int) * (size_t)g);
-                std::vector<std::vector<int>> sip(nprof);
-                for (int i = 0; i < numseq; i++) sip[i] = {i};
-                std::vector<int> ga, gb;
-                for (int t = 0; t < c->n_tasks; t++) {
-                        const ka_task_rec& r = c->h_recs[t];
-                        const int* p = paths_out + r.path_off;
-                        ga.assign(p[0] + 1, 0); gb.assign(p[0] + 1, 0);
-                        int posa = 0, posb = 0;
-                        for (int k = 1; p[k] != 3; k++) {
-                                if (!p[k]) { posa++; posb++; }
-                                else if (p[k] & 1) { ga[posa] += 1; posb++; }
-                                else if (p[k] & 2) { gb[posb] += 1; posa++; }
-                        }
-                        for (int x : sip[r.a]) fold_gaps(c->lens[x], gaps_out + goff[x], ga.data());
-                        for (int x : sip[r.b]) fold_gaps(c->lens[x], gaps_out + goff[x], gb.data());
-                        sip[r.c].reserve(sip[r.a].size() + sip[r.b].size());
-                        sip[r.c].insert(sip[r.c].end(), sip[r.a].begin(), sip[r.a].end());
-                        sip[r.c].insert(sip[r.c].end(), sip[r.b].begin(), sip[r.b].end());
-                        std::vector<int>().swap(sip[r.a]);
-                        std::vector<int>().swap(sip[r.b]);
-                }
+        if (gaps_out && ka_weave_gaps(c->numseq, c->lens.data(), c->n_tasks, c->h_recs.data(), paths_out, gaps_out)) return KA_FAIL;
+        return KA_OK;
+}
+
+
+// ---- partial runs: the pieces single-tree multi-GPU sharding is made of ----
+// Run the listed tasks only, level by level.  Their children must already be available on this context:
+// leaves, tasks run earlier (ka_tree_run_tasks does not reset the device state), or injected profiles.
+extern "C" int ka_tree_run_tasks(ka_ctx* c, const int* task_ids, int n)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (c->cons_K > 0) return fail("partial runs do not carry the consistency state yet");
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->state_valid && tree_reset(c)) return KA_FAIL;
+        c->synced = false;
+        std::vector<std::vector<int>> by_level(c->levels.size());
+        std::vector<char> have(2 * c->numseq - 1, 0);
+        for (int i = 0; i < c->numseq; i++) have[i] = 1;
+        for (int t = 0; t < c->n_tasks; t++) if (c->task_done[t]) have[c->descs[t].c] = 1;
+        for (int node : c->injected) have[node] = 1;
+        for (int i = 0; i < n; i++) {
+                const int t = task_ids[i];
+                if (t < 0 || t >= c->n_tasks) return fail("task id out of range");
+                if (c->task_done[t]) return fail("task already run");
+                by_level[c->task_level[t]].push_back(t);
         }
+        for (auto& L : by_level)                                   // dependency check in level order
+                for (int t : L) {
+                        if (!have[c->descs[t].a] || !have[c->descs[t].b]) return fail("a task's operand is neither computed nor injected on this context");
+                        have[c->descs[t].c] = 1;
+                }
+        const KaTreeDev D = tree_dev(c);
+        c->partial = true;
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        c->n_launches = 0;
+        for (auto& L : by_level) {
+                if (L.empty()) continue;
+                std::vector<int2> tbl;
+                int lean = 0;
+                build_blocks(c, L, tbl, &lean);
+                if (c->d_blocks_tmp.alloc(tbl.size())) return fail("hipMalloc failed");
+                // the table is consumed by the launch below; stream order makes the reuse of the buffer safe
+                HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                HIPCHK(hipMemcpyAsync(c->d_blocks_tmp.p, tbl.data(), sizeof(int2) * tbl.size(), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                ka_launch_task_level(&D, c->d_blocks_tmp.p, (int)tbl.size(), lean, c->stream);
+                HIPCHK(hipStreamSynchronize(c->stream));
+                c->n_launches++;
+                for (int t : L) c->task_done[t] = 1;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        c->ran = true;
+        return KA_OK;
+}
+
+// Forget every computed / injected node: the next ka_tree_run_tasks starts from the leaves again.
+extern "C" int ka_tree_reset(ka_ctx* c)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        HIPCHK(hipSetDevice(c->device));
+        c->ran = false; c->synced = false;
+        return tree_reset(c);
+}
+
+extern "C" int ka_tree_node_len(ka_ctx* c, int node)
+{
+        if (!c || !c->have_job || !c->state_valid) return -1;
+        if (node < 0 || node >= 2 * c->numseq - 1) return -1;
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        int len = 0;
+        if (hipMemcpy(&len, c->d_node_len.p + node, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return len;
+}
+
+// Make the merged profile of an internal node available on this context without running its task
+// (it was computed on another GPU): (plen+2)*64 floats as ka_tree_get_profile returns them.
+extern "C" int ka_tree_set_profile(ka_ctx* c, int node, const float* prof, int plen)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (node < c->numseq || node >= 2 * c->numseq - 1 || plen < 1 || !prof) return fail("bad node / profile");
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->state_valid && tree_reset(c)) return KA_FAIL;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        unsigned long long top = 0;
+        HIPCHK(hipMemcpy(&top, c->d_counters.p, sizeof(top), hipMemcpyDeviceToHost));
+        const unsigned long long need = (unsigned long long)(plen + 2) * KA_REC;
+        if ((long long)(top + need) > c->prof_cap) return fail("profile arena too small for the injected profile");
+        const long long po = (long long)top;
+        top += need;
+        HIPCHK(hipMemcpy(c->d_prof_arena.p + po, prof, sizeof(float) * (size_t)need, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_counters.p, &top, sizeof(top), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_node_len.p + node, &plen, sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_node_prof.p + node, &po, sizeof(long long), hipMemcpyHostToDevice));
+        c->injected.push_back(node);
+        return KA_OK;
+}
+
+// Records and coded paths of the listed tasks (they must have been run on this context), paths packed
+// in the order of the list; *used receives the number of ints written.
+extern "C" int ka_tree_download_tasks(ka_ctx* c, const int* task_ids, int n, ka_task_rec* recs, int* paths_out, long long paths_cap, long long* used_out)
+{
+        if (!c || !c->ran) return fail("nothing to download");
+        if (!c->synced && ka_tree_sync(c)) return KA_FAIL;
+        HIPCHK(hipSetDevice(c->device));
+        const long long used = (long long)c->h_counters[2];
+        std::vector<ka_task_rec> all(c->n_tasks);
+        HIPCHK(hipMemcpy(all.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
+        std::vector<int> arena((size_t)std::max<long long>(used, 1));
+        HIPCHK(hipMemcpy(arena.data(), c->d_path_arena.p, sizeof(int) * (size_t)used, hipMemcpyDeviceToHost));
+        long long o = 0;
+        for (int i = 0; i < n; i++) {
+                const int t = task_ids[i];
+                if (t < 0 || t >= c->n_tasks || !c->task_done[t]) return fail("task was not run on this context");
+                ka_task_rec r = all[t];
+                const int cnt = r.plen + 2;
+                if (o + cnt > paths_cap) { g_err = "paths_out too small"; return KA_ERR_PATHS_CAP; }
+                memcpy(paths_out + o, arena.data() + r.path_off, sizeof(int) * cnt);
+                r.path_off = (int)o;
+                o += cnt;
+                recs[i] = r;
+        }
+        if (used_out) *used_out = o;
         return KA_OK;
 }
 
@@ -653,7 +819,7 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
         HIPCHK(hipMemcpy(c->d_sip.p, c->sip_flat.data(), sizeof(int) * c->sip_flat.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_sip_off.p, c->sip_off.data(), sizeof(long long) * c->sip_off.size(), hipMemcpyHostToDevice));
         c->cons_K = K; c->cons_weight = weight;
-        c->ran = false; c->synced = false;
+        c->ran = false; c->synced = false; c->state_valid = false;
         return KA_OK;
 }
 

@@ -6,8 +6,11 @@ What shards:
     contiguous, cost-balanced slices per rank, no data-path collective, results gathered at the
     end (paths are small: 4*(La+Lb+2) bytes per pair);
   * independent sequence sets / ensemble members: one per rank (what bench.py scales).
-A single guide tree is NOT sharded in this round (its top is a serial chain of big tasks); see
-DESIGN.md "Multi-GPU".
+  * a single guide tree (sharded_tree): cut into one subtree per rank balanced by estimated DP
+    cells; every rank runs its subtree with profiles resident in its own HBM; the remaining
+    top merges form a reduction in which one child profile moves point-to-point (send/recv,
+    <= ~1 MB) to the rank that runs the parent; rank-independent results are gathered at the end.
+See DESIGN.md "Multi-GPU".
 """
 import os
 
@@ -108,3 +111,150 @@ def sharded_pairwise(compute, lens, ia, ib, rank, world, device="cpu"):
             o += s
         all_scores.append(g_scores[r][:n])
     return all_paths, np.concatenate(all_scores) if all_scores else np.zeros(0, np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# single guide tree over several GPUs
+# ------------------------------------------------------------------------------------------------
+def plan_subtrees(tasks, lens, world):
+    """Cut the guide tree into at most `world` subtrees balanced by estimated DP cells.
+
+    tasks: (n_tasks, 3) array of (a, b, c) in TASK_ORDER_TREE order.  Returns (run_rank, top) where
+    run_rank[t] is the rank that runs task t and top is the list of task ids above the cut, in
+    tree order.  Deterministic: every rank computes the same plan from the same inputs."""
+    tasks = np.asarray(tasks)
+    numseq = len(lens)
+    nt = len(tasks)
+    task_of = {int(c): t for t, (_, _, c) in enumerate(tasks)}
+    est_len = {i: float(lens[i]) for i in range(numseq)}
+    work = {i: 0.0 for i in range(numseq)}
+    members = {i: 1 for i in range(numseq)}
+    for a, b, c in tasks:
+        a, b, c = int(a), int(b), int(c)
+        est_len[c] = 1.05 * max(est_len[a], est_len[b])
+        work[c] = work[a] + work[b] + est_len[a] * est_len[b]
+        members[c] = members[a] + members[b]
+    root = int(tasks[-1][2])
+    frontier, top = [root], []
+    while len([x for x in frontier if x >= numseq]) < world:
+        cand = [x for x in frontier if x >= numseq]
+        if not cand:
+            break
+        x = max(cand, key=lambda v: (work[v], -v))
+        t = task_of[x]
+        if len(cand) - 1 + sum(1 for y in (int(tasks[t][0]), int(tasks[t][1])) if y >= numseq) < len(cand):
+            break                                              # splitting would not add a subtree (both children are leaves)
+        frontier.remove(x)
+        frontier += [int(tasks[t][0]), int(tasks[t][1])]
+        top.append(t)
+    top.sort()
+    roots = sorted([x for x in frontier if x >= numseq], key=lambda v: (-work[v], v))
+    run_rank = np.full(nt, -1, np.int64)
+    holder = {}
+
+    def assign(node, r):
+        stack = [node]
+        while stack:
+            v = stack.pop()
+            if v < numseq:
+                continue
+            t = task_of[v]
+            run_rank[t] = r
+            stack += [int(tasks[t][0]), int(tasks[t][1])]
+
+    for r, x in enumerate(roots):
+        assign(x, r % world)
+        holder[x] = r % world
+    for t in top:                                              # tree order: children first
+        a, b, c = (int(v) for v in tasks[t])
+        ha, hb = holder.get(a), holder.get(b)
+        if ha is None and hb is None:
+            r = 0
+        elif ha is None or (hb is not None and members[b] > members[a]):
+            r = hb
+        else:
+            r = ha
+        run_rank[t] = r
+        holder[c] = r
+    return run_rank, top
+
+
+def _gather_bytes(arr, world, device):
+    """all_gather of ragged uint8 arrays -> list of numpy uint8 arrays, one per rank"""
+    import torch
+    import torch.distributed as dist
+    n = torch.tensor([len(arr)], dtype=torch.int64, device=device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    mx = max(int(x.item()) for x in ns)
+    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
+    if len(arr):
+        buf[:len(arr)] = torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.uint8, device=device)
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return [o.cpu().numpy()[:int(k.item())] for o, k in zip(out, ns)]
+
+
+def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
+    """One guide tree over `world` ranks (one process per GPU).
+
+    ex: this rank's executor over an uploaded job -- kalign_amd.Context after tree_upload, or anything
+    with the same four methods: tree_run_tasks(ids), tree_get_node(node) -> float32[(plen+2)*64],
+    tree_set_node(node, prof), tree_download_tasks(ids) -> (recs, paths).
+    rec_type: the ctypes record class (kalign_amd.api.TaskRec) used to move records between ranks.
+    Returns (recs in task order with path_off into paths, paths) on every rank; identical for any world."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    tasks = np.asarray(tasks)
+    numseq = len(lens)
+    run_rank, top = plan_subtrees(tasks, lens, world)
+    top_set = set(top)
+    mine = [t for t in range(len(tasks)) if run_rank[t] == rank and t not in top_set]
+    if mine:
+        ex.tree_run_tasks(mine)
+    holder = {}
+    for t in range(len(tasks)):
+        if t not in top_set:
+            holder[int(tasks[t][2])] = int(run_rank[t])
+    for t in top:
+        a, b, c = (int(v) for v in tasks[t])
+        dst = int(run_rank[t])
+        for child in (a, b):
+            src = holder.get(child)
+            if child < numseq or src is None or src == dst or world == 1:
+                continue
+            if rank == src:
+                prof = ex.tree_get_node(child)
+                dist.send(torch.tensor([len(prof)], dtype=torch.int64, device=device), dst)
+                dist.send(torch.as_tensor(prof, dtype=torch.float32, device=device), dst)
+            elif rank == dst:
+                n = torch.zeros(1, dtype=torch.int64, device=device)
+                dist.recv(n, src)
+                buf = torch.zeros(int(n.item()), dtype=torch.float32, device=device)
+                dist.recv(buf, src)
+                ex.tree_set_node(child, buf.cpu().numpy())
+        if rank == dst:
+            ex.tree_run_tasks([t])
+        holder[c] = dst
+    ran = [t for t in range(len(tasks)) if run_rank[t] == rank]
+    recs, paths = ex.tree_download_tasks(ran) if ran else ([], np.zeros(0, np.int32))
+    if world == 1:
+        return list(recs), np.asarray(paths, np.int32)
+    rec_bytes = np.frombuffer(b"".join(bytes(r) for r in recs), np.uint8) if recs else np.zeros(0, np.uint8)
+    g_ids = _gather_bytes(np.asarray(ran, np.int32).view(np.uint8), world, device)
+    g_recs = _gather_bytes(rec_bytes, world, device)
+    g_paths = _gather_bytes(np.asarray(paths, np.int32).view(np.uint8), world, device)
+    rs = C.sizeof(rec_type)
+    all_recs = [None] * len(tasks)
+    chunks, off = [], 0
+    for r in range(world):
+        ids = g_ids[r].view(np.int32)
+        rp = g_paths[r].view(np.int32)
+        for i, t in enumerate(ids):
+            rec = rec_type.from_buffer_copy(g_recs[r][i * rs:(i + 1) * rs].tobytes())
+            rec.path_off += off
+            all_recs[int(t)] = rec
+        chunks.append(rp)
+        off += len(rp)
+    return all_recs, (np.concatenate(chunks) if chunks else np.zeros(0, np.int32))

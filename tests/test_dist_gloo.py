@@ -64,3 +64,77 @@ def test_sharded_pairwise_world2_gloo(tmp_path):
     assert int(z["n"]) == len(g.ia)
     assert np.array_equal(z["flat"], g.paths)          # identical to the reference's paths, in pair order
     assert float(z["tmax"]) == 2.0 and float(z["tsum"]) == 20.0
+
+
+# ------------------------------------------------------------------------------------------------
+# one guide tree over two ranks (kalign_amd.dist.sharded_tree)
+# ------------------------------------------------------------------------------------------------
+def _tree_worker(rank, world, port, out, case):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from kalign_amd import dist as kd
+    from oracle import oracledrv
+    from oracle_executor import OracleExecutor
+    from util import Golden
+    kd.init(backend="gloo")
+    g = Golden(case)
+    ex = OracleExecutor(g.codes, g.tasks, g.subm, g.scal, g.rec("gap_scale"), g.rec("subm_off"))
+    recs, paths = kd.sharded_tree(ex, g.tasks, g.lens, rank, world, oracledrv.TaskRec)
+    ran_here = len(ex.done)
+    dist.barrier()
+    np.savez(out % rank, plen=[r.plen for r in recs], path_off=[r.path_off for r in recs],
+             score=np.array([r.score for r in recs], np.float32), abc=[[r.a, r.b, r.c] for r in recs],
+             paths=paths, ran_here=ran_here)
+    dist.destroy_process_group()
+
+
+def test_plan_subtrees_is_a_partition():
+    from kalign_amd.dist import plan_subtrees
+    from util import Golden
+    for case in ("tree_prot64_gon", "tree_ragged", "tree_BB11001"):
+        g = Golden(case)
+        for world in (1, 2, 3, 8):
+            run_rank, top = plan_subtrees(g.tasks, g.lens, world)
+            assert ((run_rank >= 0) & (run_rank < world)).all()
+            assert sorted(top) == top and (not top or top[-1] == len(g.tasks) - 1 or world == 1)
+            # below the cut a task runs where its children ran (no transfers inside a subtree)
+            where = {int(c): int(run_rank[t]) for t, (_, _, c) in enumerate(g.tasks)}
+            for t, (a, b, c) in enumerate(g.tasks):
+                if t in top:
+                    continue
+                for child in (int(a), int(b)):
+                    if child >= len(g.lens):
+                        assert where[child] == run_rank[t]
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("case", ["tree_prot32x200", "tree_prot24_scaled"])
+def test_sharded_tree_world2_gloo(tmp_path, case):
+    """Two ranks, one subtree each, the profile of one subtree root crosses ranks for the root task:
+    records, coded paths and gap arrays identical to the single-process reference run."""
+    import torch.multiprocessing as mp
+    from kalign_amd import api
+    from util import Golden
+    out = str(tmp_path / "r%d.npz")
+    port = 29500 + ((os.getpid() + 77) % 500)
+    mp.spawn(_tree_worker, args=(2, port, out, case), nprocs=2, join=True)
+    g = Golden(case)
+    z0, z1 = np.load(out % 0), np.load(out % 1)
+    assert int(z0["ran_here"]) > 0 and int(z1["ran_here"]) > 0           # both ranks did work
+    assert int(z0["ran_here"]) + int(z1["ran_here"]) == len(g.tasks)
+    for z in (z0, z1):                                                    # every rank holds the full result
+        assert np.array_equal(z["plen"], g.rec("plen"))
+        assert np.array_equal(z["score"], g.rec("score"))
+        assert np.array_equal(z["abc"], g.tasks)
+        recs = []
+        for t in range(len(g.tasks)):
+            o, n = int(z["path_off"][t]), int(z["plen"][t])
+            assert np.array_equal(z["paths"][o:o + n + 2], g.path(t)), t
+            r = api.TaskRec()
+            r.a, r.b, r.c = (int(v) for v in g.tasks[t])
+            r.path_off, r.plen = o, n
+            recs.append(r)
+        gaps = api.weave_gaps(g.lens, recs, z["paths"])                   # host-only C function, no GPU needed
+        for got, want in zip(gaps, g.gaps_list()):
+            assert np.array_equal(got, want)

@@ -1,0 +1,63 @@
+"""The partial-run C ABI that single-tree multi-GPU sharding is built from (ka_tree_run_tasks,
+ka_tree_set_profile, ka_tree_download_tasks, ka_weave_gaps): two contexts on one GPU play two ranks
+through kalign_amd.dist.sharded_tree's plan; results must equal the whole-tree goldens bit for bit."""
+import numpy as np
+import pytest
+
+from util import Golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case,world", [("tree_prot32x200", 2), ("tree_prot64_gon", 4), ("tree_dna16x300", 3)])
+def test_subtrees_on_separate_contexts_match_golden(case, world):
+    import kalign_amd
+    from kalign_amd import api, dist as kd
+    g = Golden(case)
+    ctxs = [kalign_amd.Context(0) for _ in range(world)]
+    for c in ctxs:
+        c.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    run_rank, top = kd.plan_subtrees(g.tasks, g.lens, world)
+    top_set = set(top)
+    n = len(g.lens)
+    for r, c in enumerate(ctxs):
+        mine = [t for t in range(len(g.tasks)) if run_rank[t] == r and t not in top_set]
+        if mine:
+            c.tree_run_tasks(mine)
+    holder = {int(g.tasks[t][2]): int(run_rank[t]) for t in range(len(g.tasks)) if t not in top_set}
+    for t in top:
+        a, b, cnode = (int(v) for v in g.tasks[t])
+        dst = int(run_rank[t])
+        for child in (a, b):
+            if child >= n and holder[child] != dst:
+                ctxs[dst].tree_set_node(child, ctxs[holder[child]].tree_get_node(child))
+        ctxs[dst].tree_run_tasks([t])
+        holder[cnode] = dst
+    recs_all = [None] * len(g.tasks)
+    chunks, off = [], 0
+    for r, c in enumerate(ctxs):
+        ran = [t for t in range(len(g.tasks)) if run_rank[t] == r]
+        if not ran:
+            continue
+        recs, paths = c.tree_download_tasks(ran)
+        for t, rec in zip(ran, recs):
+            rec.path_off += off
+            recs_all[t] = rec
+        chunks.append(paths)
+        off += len(paths)
+    paths = np.concatenate(chunks)
+    for t, r in enumerate(recs_all):
+        assert r.plen == g.rec("plen")[t] and r.score == g.rec("score")[t] and r.meet == g.rec("meet")[t]
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
+    gaps = api.weave_gaps(g.lens, recs_all, paths)
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    # misuse fails loudly: running a task twice, or a task whose operand is not on this context
+    with pytest.raises(kalign_amd.KalignAmdError):
+        ctxs[int(run_rank[0])].tree_run_tasks([0])
+    if world > 1:
+        other = [c for r, c in enumerate(ctxs) if r != int(run_rank[top[-1]])][0]
+        with pytest.raises(kalign_amd.KalignAmdError):
+            other.tree_run_tasks([top[-1]])
+    for c in ctxs:
+        c.close()
