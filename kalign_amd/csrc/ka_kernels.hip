@@ -25,6 +25,7 @@
 #define KA_BLOCK 512                     // task kernel: 8 waves, one workgroup per CU (LDS ring per wave)
 #define KA_WAVES (KA_BLOCK / 64)
 #define KA_PAIR_BLOCK 256                // seq-seq pair kernel: 4 waves, no ring -> several workgroups per CU
+#define KA_LEAN_BLOCK 512                // seq-seq levels of the tree: 8 waves (a 400-row task has 8 strips at level 2), two workgroups per CU
 #define KA_NT ((int)blockDim.x)          // threads / waves of the running workgroup
 #define KA_NW ((int)blockDim.x >> 6)
 
@@ -412,11 +413,11 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 it = __builtin_amdgcn_readfirstlane(it);
                                 if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
-                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
+                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
                                 }
                                 if (it >= nitems) {
-                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND == KA_PP ? lds_waves + wave * KA_WAVE_LDS : nullptr);
+                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
                                 }
                                 // everything about the item is wave-uniform: keep it in SGPRs
@@ -914,6 +915,7 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 #define KA_LDS_WAVES (KA_LDS_TSS + 23 * KA_T_STRIDE * 4)          // 2736, multiple of 16
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
 #define KA_LDS_PAIR (KA_LDS_WAVES + (2 * KA_PAIR_BLOCK + 16) * 4)   // seq-seq: only the path-coding scratch follows the table
+#define KA_LDS_LEAN (KA_LDS_WAVES + (2 * KA_LEAN_BLOCK + 16) * 4)
 static_assert(sizeof(TaskShared) <= KA_LDS_DBG, "TaskShared outgrew its LDS slot");
 static_assert(KA_LDS_WAVES % 16 == 0, "wave regions must be 16-B aligned");
 
@@ -1161,7 +1163,8 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, co
         ka_task_body<false, 0>(D, blocks);
 }
 
-__global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks)
+// (the second launch-bound is waves per SIMD: 4 -> <=128 VGPRs -> two 8-wave workgroups per CU)
+__global__ __launch_bounds__(KA_LEAN_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks)
 {
         ka_task_body<true, 0>(D, blocks);
 }
@@ -1172,6 +1175,7 @@ __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev 
         ka_task_body<false, KA_NB>(D, blocks);
 }
 
+// the bonus entries cost ~40 VGPRs: 4 waves, 3 waves per SIMD (<=168 VGPRs) -> three workgroups per CU
 __global__ __launch_bounds__(KA_PAIR_BLOCK, 3) void ka_task_kernel_lean_cons(const KaTreeDev D, const int2* __restrict__ blocks)
 {
         ka_task_body<true, KA_NB>(D, blocks);
@@ -1231,7 +1235,7 @@ static hipError_t ka_lds_optin()
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)ka_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_task_kernel_lean, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
+        e = hipFuncSetAttribute((const void*)ka_task_kernel_lean, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_LEAN);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)ka_task_kernel_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
         if (e != hipSuccess) return e;
@@ -1248,7 +1252,7 @@ extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev,
                 if (lean) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
                 else hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
         } else {
-                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
+                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev);
                 else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
         }
 }

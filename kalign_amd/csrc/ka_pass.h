@@ -567,6 +567,13 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                                 p1v[c].x = pA[c];
                                 p1v[c].y = actB ? pB[c] : 0.0f;
                         }
+                } else {
+                        // seq-profile: score = P1[row][32 + residue] with a different residue every step ->
+                        // this lane's two score rows go to its private LDS lines (as in ka_strip)
+                        float* tA_ = (float*)wlds + (2 * lane) * KA_SP_STRIDE;
+                        float* tB_ = tA_ + KA_SP_STRIDE;
+#pragma unroll
+                        for (int c = 0; c < 23; ++c) { tA_[c] = pA[32 + c]; tB_[c] = pB[32 + c]; }
                 }
         }
 
@@ -579,7 +586,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
         float inia = inj_a, iniga = inj_ga, inigb = inj_gb;
         float copen_prev = 0.0f;
         float4v q[2][KA_REC_CHUNKS];
-        int resq[2] = {0, 0};
+        int resq[4] = {0, 0, 0, 0};                                   // sequence columns: residues 3 steps ahead (L2 latency)
 
         // Profile-profile: when the column records of all the job's slots fit into this wave's LDS
         // region (128 records), stage them once (every slot's lanes copy their slot's columns) and
@@ -626,16 +633,21 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 }
         };
         fetch(q[0], resq[0], -ls);
+        if (KIND != KA_PP) { fetch(q[0], resq[1], 1 - ls); fetch(q[0], resq[2], 2 - ls); }
 
         int nsteps = live ? (ncols + max(nl, 1)) : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, off, 64));
 
+        // P4 = t mod 4: register-ring slot of this step's residue (sequence columns, fetched 3 steps ahead);
+        // profile columns ping-pong between the two halves of q
         auto step = [&](const int t, auto par_tag) {
-                constexpr int P = decltype(par_tag)::value;
+                constexpr int P4 = decltype(par_tag)::value;
+                constexpr int P = P4 & 1;
                 const int v = t - ls;
                 const bool vin = live && (v >= 0) && (v <= ncols);
-                fetch(q[1 - P], resq[1 - P], v + 1);
+                if (KIND == KA_PP) fetch(q[1 - P], resq[0], v + 1);
+                else fetch(q[0], resq[(P4 + 3) & 3], v + 3);
 
                 float copen, cext, ctext;
                 if (KIND == KA_PP) { copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2; }
@@ -657,11 +669,11 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
                 acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
                 if (KIND == KA_SS) {
-                        acc.x += tss[res1A + resq[P]];
-                        acc.y += tss[res1B + resq[P]];
+                        acc.x += tss[res1A + resq[P4]];
+                        acc.y += tss[res1B + resq[P4]];
                 } else if (KIND == KA_SP) {
-                        acc.x += pA[32 + resq[P]];
-                        acc.y += pB[32 + resq[P]];
+                        acc.x += ((const float*)wlds)[(2 * lane) * KA_SP_STRIDE + resq[P4]];
+                        acc.y += ((const float*)wlds)[(2 * lane + 1) * KA_SP_STRIDE + resq[P4]];
                 } else {
 #pragma unroll
                         for (int c = NRES - 1; c >= 0; --c) {
@@ -697,11 +709,15 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 }
         };
         int t = 0;
-        for (; t + 1 < nsteps; t += 2) {
+        for (; t + 3 < nsteps; t += 4) {
                 step(t, std::integral_constant<int, 0>());
                 step(t + 1, std::integral_constant<int, 1>());
+                step(t + 2, std::integral_constant<int, 2>());
+                step(t + 3, std::integral_constant<int, 3>());
         }
         if (t < nsteps) step(t, std::integral_constant<int, 0>());
+        if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>());
+        if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2>());
 #undef REC
 #undef IDX
 }

@@ -77,6 +77,19 @@ def test_config1_default_mode_512x400_matches_reference():
     run_case(512, 400, False, n_anchors=5)
 
 
+def test_config2_full_size_dna_4096x2000_properties():
+    """configs[2] at its full size (4096 DNA x ~2000, 2e10 useful cells, root profile > 10k columns): no CPU
+    run of this size fits a test, so the size-independent properties decide: every coded path consumes
+    exactly its operands, parents consume their children's lengths, all rows of the woven alignment
+    have the root's length."""
+    run_case(4096, 2000, True, reference=False)
+
+
+def test_config3_shape_protein_16384x500_properties():
+    """configs[3] shape on ONE GPU (the 8-GPU form shards it by subtree, kalign_amd/dist.py)."""
+    run_case(16384, 500, False, reference=False)
+
+
 def test_two_sequences_and_tiny_inputs():
     import kalign_amd
     import bench
