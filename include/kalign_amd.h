@@ -125,7 +125,8 @@ int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats)
 /* Per-task phase timings of the last run (KA_FLAG_TIMING): out[8*t + k], shader-clock cycles:
    0 operand prep, 1 Hirschberg, 2 path coding, 3 profile merge, 4 passes, 5 meetups, 6 recursion
    levels, 7 DP rows*cols; followed by 16 x (sub-problems, pass cycles, meetup cycles) per
-   recursion level of the root task: out must hold 8*n_tasks + 48 values. */
+   recursion level of the root task, followed by 512 values that only profiling builds (-DKA_PROF) fill:
+   out must hold 8*n_tasks + 48 + 512 values. */
 int ka_tree_get_timing(ka_ctx* ctx, long long* out);
 /* Debug: 64 breadcrumb words written by workgroup 0 (context created with KA_TRACE=1 in the
    environment); readable while a kernel is still running. */

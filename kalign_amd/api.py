@@ -176,9 +176,10 @@ class Context:
 
     def tree_timing(self):
         n = self._job["ntasks"]
-        out = np.zeros(8 * n + 48, np.int64)
+        out = np.zeros(8 * n + 48 + 512, np.int64)
         self._chk(self.L.ka_tree_get_timing(self.h, _ptr(out)))
-        self.root_levels = out[8 * n:].reshape(16, 3)      # per recursion level of the root task: n, pass, meetup
+        self.root_levels = out[8 * n:8 * n + 48].reshape(16, 3)      # per recursion level of the root task: n, pass, meetup
+        self.prof = out[8 * n + 48:].reshape(8, 8, 8)                 # KA_PROF builds: [level][wave][slot]
         return out[:8 * n].reshape(n, 8)
 
     def pairwise_kernel_ms(self):

@@ -299,7 +299,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
             c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
             c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
-            c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 64) ||
+            c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 48 + 512) ||
             c->d_ctl.alloc((size_t)ka_ctl_bytes_host() * n_tasks) || c->d_blocks.alloc(c->blocks_flat.size()) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
             c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
             c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
@@ -691,7 +691,7 @@ extern "C" int ka_tree_get_timing(ka_ctx* c, long long* out)
         if (!c || !c->synced) return fail("run + sync first");
         if (!(c->flags & KA_FLAG_TIMING)) return fail("KA_FLAG_TIMING was not set");
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpy(out, c->d_timing.p, sizeof(long long) * (8 * c->n_tasks + 48), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, c->d_timing.p, sizeof(long long) * (8 * c->n_tasks + 48 + 512), hipMemcpyDeviceToHost));
         return KA_OK;
 }
 

@@ -113,6 +113,7 @@ struct TaskShared {
         int* watchdog;                 // device error word: a bounded spin that expired writes 5 here
         long long t_pass, t_meet;      // KA_FLAG_TIMING: shader-clock cycles spent in passes / meetups
         int n_levels;
+        long long* prof;               // KA_PROF builds: per (level, wave) timestamps of the root task
         int lvl_n[16];                 // per recursion level: sub-problems, pass / meetup cycles
         int lvl_pass[16], lvl_meet[16];
 };
@@ -391,6 +392,10 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         nxt->nsub = 0; nxt->rowalloc = 0; nxt->nitems = 0; nxt->next_item = 0; nxt->npack[0] = 0; nxt->npack[1] = 0;
                 }
                 const long long tp0 = __builtin_amdgcn_s_memtime();
+                long long* pslot = nullptr;
+#ifdef KA_PROF
+                if (S.prof && lead && level < 8) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; } }
+#endif
                 {
                         const int2* items = S.items[level & 1];
                         int* prog = S.prog[level & 1];
@@ -411,6 +416,9 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 int it = 0;
                                 if (puller == 0) it = atomicAdd(&cur->next_item, 1);
                                 it = __builtin_amdgcn_readfirstlane(it);
+#ifdef KA_PROF
+                                if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
+#endif
                                 if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
                                         ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr);
@@ -436,10 +444,16 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
                                 ka_strip<KIND, NRES, NB>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                      (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
-                                                     lds_waves + wave * KA_WAVE_LDS, tss);
+                                                     lds_waves + wave * KA_WAVE_LDS, tss, pslot);
                         }
                 }
+#ifdef KA_PROF
+                if (pslot && lane == 0) pslot[3] = __builtin_amdgcn_s_memtime();
+#endif
                 ka_cluster_sync(S);
+#ifdef KA_PROF
+                if (pslot && lane == 0) pslot[4] = __builtin_amdgcn_s_memtime();
+#endif
                 if (tid == 0 && blockIdx.x == 0) KA_CRUMB(trace, 3, 1000 * level + 1);
                 const long long tp1 = __builtin_amdgcn_s_memtime();
                 if (level == 0 && dbg_rows && lead) {
@@ -1008,6 +1022,7 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
                 S.watchdog = D.error; S.trace = D.trace; S.dbgskip = D.flags >> 16;
+                S.prof = (D.timing && T.is_root) ? (D.timing + 8ll * (D.numseq - 1) + 48) : nullptr;
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
                 S.profb = D.prof_arena + D.node_prof[T.b];
@@ -1198,7 +1213,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
-                S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0;
+                S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;
                 S.kind = KA_SS; S.swapped = swapped;
                 S.len_a = len_i; S.len_b = len_j;
                 S.La = swapped ? len_j : len_i;

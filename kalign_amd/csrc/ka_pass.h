@@ -104,7 +104,7 @@ template <int KIND, int NRES, int NB>
 __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
                                          const float inj_a, const float inj_ga, const float inj_gb,
                                          const int dir, const int k, KaState* rows, int* prog,
-                                         const int lane, char* wlds, const float* tss)
+                                         const int lane, char* wlds, const float* tss, long long* pslot = nullptr)
 {
         const int ncols = endb - startb;
         const int mid = ((enda - starta) / 2) + starta;
@@ -197,6 +197,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         KaBonus<NB> bonA, bonB;
         if (NB) { bonA.load(S.ent, iA); bonB.load(S.ent, iB); }
 
+        // sequence columns: the three column gap terms are task constants.  Read them from the LDS-resident
+        // TaskShared ONCE -- inside the step the compiler re-loads them (ds_read + s_waitcnt) every step.
+        float kc_open = 0.0f, kc_ext = 0.0f, kc_text = 0.0f;
+        if (KIND != KA_PP) {
+                col_terms<KIND>(S, 0, kc_open, kc_ext, kc_text);
+                kc_open = ka_uniform_f(kc_open); kc_ext = ka_uniform_f(kc_ext); kc_text = ka_uniform_f(kc_text);
+        }
+
         // cell states as plain scalars (a struct here ends up in scratch memory)
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
         float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
@@ -208,7 +216,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // partial strips: lane j holds column 64*b + j
         float oba = -KA_F, obga = -KA_F, obgb = -KA_F;
         float copen_prev = 0.0f;
-        int res2 = 0, resb = 0;
+        int res2 = 0, resb = 0, resn = 0;
+        float scA = 0.0f, scB = 0.0f;                                 // sequence columns: this step's two scores, looked up one step ahead
         float4v q[2][KA_REC_CHUNKS];                                  // column record: current / next step (ping-pong)
 
         auto ring_issue = [&](int nb) {
@@ -254,8 +263,19 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 ring_issue(1);
                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
                 { float2v nodep = {0.0f, 0.0f}; ring_read(q[0], min(max(-lane, 0), ncols), nodep); }
+        } else {
+                // Sequence columns run one step ahead: at step t the residue and the two score look-ups of
+                // step t+1 are prepared (the LDS latency of the look-up and, every 64 steps, the L2 latency
+                // of the residue batch would otherwise sit in every step of a lone wave).  resn = batch of
+                // columns 64m+1+lane, fetched 64 steps before it is rotated in.
+                resn = S.s2[REC(min(1 + lane, ncols)) - 1];
+                if (KIND == KA_SS) { scA = tss[res1A]; scB = tss[res1B]; }        // step 0: no lane is at a real column yet
+                else { scA = sp_tbl[(2 * lane) * KA_SP_STRIDE]; scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE]; }
         }
 
+#ifdef KA_PROF
+        if (pslot && lane == 0 && pslot[2] == 0) pslot[2] = __builtin_amdgcn_s_memtime();
+#endif
         // One wavefront step.
         //   ST   : steady state, every active lane is strictly inside the column range (no edge cases)
         //   FULL : the strip has all 128 rows (64 active lanes, last row = row B of lane 63)
@@ -276,15 +296,20 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         if (!(KA_EXP & 2)) ring_wait(q[P]);           // this step's column record (issued one step ago)
                         copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
-                        col_terms<KIND>(S, 0, copen, cext, ctext);
+                        copen = kc_open; cext = kc_ext; ctext = kc_text;
+                }
+                const float scA_cur = scA, scB_cur = scB;
+                if (KIND != KA_PP) {
+                        // prepare step t+1: lane 0 takes column t+1 from the batch, lanes > 0 their upper neighbour's residue
                         if (EV && (t & 63) == 0) {
-                                const int vv = min(max(t + lane, 1), ncols);
-                                resb = S.s2[REC(vv) - 1];
+                                resb = resn;
+                                resn = S.s2[REC(min(t + 65 + lane, ncols)) - 1];
                         } else {
                                 resb = __builtin_amdgcn_update_dpp(resb, resb, 0x134, 0xf, 0xf, false);   // wave_rol:1
                         }
-                        // lanes > 0 take their upper neighbour's residue, lane 0 the next one of the batch
                         res2 = __builtin_amdgcn_update_dpp(resb, res2, 0x138, 0xf, 0xf, false);
+                        if (KIND == KA_SS) { scA = tss[res1A + res2]; scB = tss[res1B + res2]; }
+                        else { scA = sp_tbl[(2 * lane) * KA_SP_STRIDE + res2]; scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2]; }
                 }
 
                 // ---- state of the row above A: lane l-1's row B, lane 0 takes the boundary ----
@@ -335,12 +360,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
                 acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
                 if (KIND == KA_SS) {
-                        acc.x += tss[res1A + res2];
-                        acc.y += tss[res1B + res2];
+                        acc.x += scA_cur;
+                        acc.y += scB_cur;
                         if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
                 } else if (KIND == KA_SP) {
-                        acc.x += sp_tbl[(2 * lane) * KA_SP_STRIDE + res2];
-                        acc.y += sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2];
+                        acc.x += scA_cur;
+                        acc.y += scB_cur;
                         if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
                 } else {
                         // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
@@ -579,6 +604,11 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
 
         KaBonus<NB> bonA, bonB;
         if (NB) { bonA.load(S.ent, min(max(iA, 0), S.La - 1)); bonB.load(S.ent, min(max(iB, 0), S.La - 1)); }
+        float kc_open = 0.0f, kc_ext = 0.0f, kc_text = 0.0f;           // see ka_strip
+        if (KIND != KA_PP) {
+                col_terms<KIND>(S, 0, kc_open, kc_ext, kc_text);
+                kc_open = ka_uniform_f(kc_open); kc_ext = ka_uniform_f(kc_ext); kc_text = ka_uniform_f(kc_text);
+        }
 
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
         float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
@@ -651,7 +681,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
 
                 float copen, cext, ctext;
                 if (KIND == KA_PP) { copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2; }
-                else col_terms<KIND>(S, 0, copen, cext, ctext);
+                else { copen = kc_open; cext = kc_ext; ctext = kc_text; }
 
                 // "row -1" of the pass, generated by the slot's first lane (v == t there)
                 if (v == 0) {
