@@ -18,7 +18,8 @@
 
 #include "ka_device.h"
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, hipStream_t stream);
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream);
+extern "C" int ka_max_g_host(void);
 extern "C" long long ka_ctl_bytes_host(void);
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen);
@@ -77,6 +78,10 @@ struct ka_ctx {
         DevBuf<float> d_prof_arena, d_subm, d_dbg_arena;
         DevBuf<unsigned long long> d_counters;
         DevBuf<char> d_scratch, d_ctl;
+        DevBuf<KaJoin> d_join;
+        int chain_level = -1;          // first level of the chained launch (-1: every level is its own launch)
+        std::vector<int2> chain_blocks;
+        int chain_blocks_off = 0;
         DevBuf<int2> d_blocks;
         DevBuf<KaTaskDesc> d_tasks;
         DevBuf<ka_task_rec> d_recs;
@@ -143,7 +148,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_path_arena.release(); c->d_error.release(); c->d_node_prof.release(); c->d_dbg_off.release();
         c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
         c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release(); c->d_timing.release();
-        c->d_ctl.release(); c->d_blocks.release(); c->d_blocks_tmp.release();
+        c->d_ctl.release(); c->d_blocks.release(); c->d_blocks_tmp.release(); c->d_join.release();
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
@@ -242,7 +247,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 d.gpo = gpo0; d.gpe = gpe0; d.tgpe = tgpe0;
                 if (gap_scale < 1.0f || soff > 0.0f) { d.gpo *= gap_scale; d.gpe *= gap_scale; d.tgpe *= gap_scale; }
                 else soff = 0.0f;
-                d.soff = soff; d.gap_scale = gap_scale; d.pad = 0;
+                d.soff = soff; d.gap_scale = gap_scale; d.parent = -1; d.chain_need = 0;
                 nsip[cc] = nsip[a] + nsip[b];
                 sip[cc].reserve(nsip[cc]);
                 for (int j = nsip[a]; j--;) sip[cc].push_back(sip[a][j]);        // aln_run.c:428-436
@@ -263,6 +268,39 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 c->level_off.push_back((int)c->level_ids_flat.size());
         }
 
+        // ---- parents, and the level from which the rest of the tree runs as ONE chained launch: the first
+        // non-leaf level with at most one task per CU (all its workgroups resident at once; levels only get
+        // narrower above it).  KA_NO_CHAIN=1 keeps one launch per level.
+        {
+                std::vector<int> task_of(nprof, -1);
+                for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
+                for (int t = 0; t < n_tasks; t++) { c->descs[t].parent = -1; c->descs[t].chain_need = 0; }
+                for (int t = 0; t < n_tasks; t++) {
+                        const int a = abc[3 * t], b = abc[3 * t + 1];
+                        if (a >= numseq) c->descs[task_of[a]].parent = t;
+                        if (b >= numseq) c->descs[task_of[b]].parent = t;
+                }
+                c->chain_level = -1;
+                if (!getenv("KA_NO_CHAIN")) {
+                        for (int L = 0; L + 1 < max_level; L++) {
+                                bool all_ss = true;
+                                for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
+                                if (!all_ss && (int)c->levels[L].size() <= 248) { c->chain_level = L; break; }
+                        }
+                }
+                if (c->chain_level >= 0) {
+                        for (int t = 0; t < n_tasks; t++) {
+                                if (level[abc[3 * t + 2]] - 1 <= c->chain_level) continue;
+                                int need = 0;
+                                for (int k = 0; k < 2; k++) {
+                                        const int ch = abc[3 * t + k];
+                                        if (ch >= numseq && level[ch] - 1 >= c->chain_level) need++;
+                                }
+                                c->descs[t].chain_need = need;
+                        }
+                }
+        }
+
         // ---- workgroup tables, one per dependency level (build_blocks) ----
         if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
@@ -275,6 +313,29 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 c->level_lean.push_back(lean);
                 c->blocks_flat.insert(c->blocks_flat.end(), tbl.begin(), tbl.end());
                 c->blocks_off.push_back((int)c->blocks_flat.size());
+        }
+
+        if (c->chain_level >= 0) {
+                // Every task of the chain's first level starts on a single workgroup; clusters form on the way up.
+                // Entries are laid out in depth-first order of the upper tree, one contiguous run per XCD
+                // (block b runs on XCD b % 8 -- observed, not contractual): subtrees that merge early share an
+                // L2, only the top three levels cross XCDs.
+                std::vector<int> task_of(nprof, -1), order;
+                for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
+                std::vector<int> stack(1, n_tasks - 1);
+                while (!stack.empty()) {
+                        const int t = stack.back(); stack.pop_back();
+                        if (c->task_level[t] == c->chain_level) { order.push_back(t); continue; }
+                        for (int k = 1; k >= 0; k--) {
+                                const int ch = abc[3 * t + k];
+                                if (ch >= numseq && c->task_level[task_of[ch]] >= c->chain_level) stack.push_back(task_of[ch]);
+                        }
+                }
+                const int m = ((int)order.size() + 7) / 8;
+                c->chain_blocks.assign((size_t)8 * m, make_int2(-1, 0));
+                for (int r = 0; r < (int)order.size(); r++) c->chain_blocks[(size_t)(r % m) * 8 + (r / m)] = make_int2(order[r], 0 | (1 << 8));
+                c->chain_blocks_off = (int)c->blocks_flat.size();
+                c->blocks_flat.insert(c->blocks_flat.end(), c->chain_blocks.begin(), c->chain_blocks.end());
         }
 
         // ---- arenas ----
@@ -293,6 +354,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         // per level every sequence is a member of at most one task; profile lengths never exceed
         // the sum of their members' lengths
         scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
+        if (c->chain_level >= 0) scr *= (long long)std::min(max_level - c->chain_level, 8);   // the chained launch never resets the scratch counter; grows on demand
         c->scratch_cap = std::max(c->scratch_cap, scr);
         c->dbg_cap = (flags & KA_FLAG_DEBUG_ROWS) ? std::max<long long>(c->dbg_cap, 6LL * (cols + 2LL * n_tasks + c->sum_len)) : c->dbg_cap;
 
@@ -300,7 +362,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
             c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
             c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
             c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 48 + 512) ||
-            c->d_ctl.alloc((size_t)ka_ctl_bytes_host() * n_tasks) || c->d_blocks.alloc(c->blocks_flat.size()) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
+            c->d_ctl.alloc((size_t)ka_ctl_bytes_host() * n_tasks) || c->d_join.alloc(n_tasks) || c->d_blocks.alloc(c->blocks_flat.size()) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
             c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
             c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
                 return fail("hipMalloc failed");
@@ -330,6 +392,7 @@ static int tree_reset(ka_ctx* c)
         HIPCHK(hipMemcpyAsync(c->d_error.p, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemsetAsync(c->d_ctl.p, 0, (size_t)ka_ctl_bytes_host() * c->n_tasks, c->stream));
         HIPCHK(hipMemsetAsync(c->d_recs.p, 0, sizeof(ka_task_rec) * c->n_tasks, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_join.p, 0, sizeof(KaJoin) * c->n_tasks, c->stream));
         if (c->cons_K > 0)                           // every leaf starts with residue p in column p
                 HIPCHK(hipMemcpyAsync(c->d_colof.p, c->d_colof_init.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));          // the staging vectors above are stack/heap temporaries
@@ -350,6 +413,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.dbg_arena = c->d_dbg_arena.p; D.dbg_off = c->d_dbg_off.p;
         D.tasks = c->d_tasks.p; D.recs = c->d_recs.p; D.subm = c->d_subm.p;
         D.ctl = (KaCtl*)c->d_ctl.p;
+        D.join = c->d_join.p;
         D.gpo0 = c->scal[0]; D.gpe0 = c->scal[1]; D.tgpe0 = c->scal[2]; D.usw = c->scal[5];
         D.numseq = c->numseq; D.flags = c->flags; D.error = c->d_error.p;
         D.nres = c->nres;
@@ -393,7 +457,13 @@ static int tree_launch(ka_ctx* c)
                 const int n = (int)c->levels[L].size();
                 if (!n) continue;
                 if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
-                ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->level_lean[L], c->stream);
+                if ((int)L == c->chain_level) {
+                        // this level and everything above it: one launch, tasks chained through their join points
+                        ka_launch_task_level(&D, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, c->stream);
+                        c->n_launches++;
+                        break;
+                }
+                ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->level_lean[L], 0, c->stream);
                 c->n_launches++;
         }
         HIPCHK(hipGetLastError());
@@ -588,7 +658,7 @@ extern "C" int ka_tree_run_tasks(ka_ctx* c, const int* task_ids, int n)
                 HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
                 HIPCHK(hipMemcpyAsync(c->d_blocks_tmp.p, tbl.data(), sizeof(int2) * tbl.size(), hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
-                ka_launch_task_level(&D, c->d_blocks_tmp.p, (int)tbl.size(), lean, c->stream);
+                ka_launch_task_level(&D, c->d_blocks_tmp.p, (int)tbl.size(), lean, 0, c->stream);
                 HIPCHK(hipStreamSynchronize(c->stream));
                 c->n_launches++;
                 for (int t : L) c->task_done[t] = 1;

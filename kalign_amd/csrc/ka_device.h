@@ -20,7 +20,19 @@ struct KaTaskDesc {
         float gpo, gpe, tgpe;          // scaled by gap_scale when scaling applies
         float soff;                    // subm_offset
         float gap_scale;
-        int pad;
+        int parent;                    // task that consumes node c (-1: root)
+        int chain_need;                // chained launch: how many children of this task run inside the same launch (0: entry task)
+};
+
+// Join point of a task in a chained launch (see ka_task_entry): the clusters that computed its children meet here.
+struct KaJoin {
+        unsigned int arrive;           // clusters arrived so far
+        unsigned int sum_g;            // workgroups they bring
+        unsigned int go;               // set by the last arriver once join_base / join_g are valid
+        int join_base;                 // member index of the first joining workgroup (= size of the leading cluster)
+        int join_g;                    // workgroups offered to this task (the kernel may use fewer)
+        int role;                      // written by the child's first workgroup for its own cluster: 1 leads the parent, 2 joins
+        int pad[2];
 };
 
 // One Hirschberg sub-problem: window + injected boundary states (aln_controller.c:194-436)
@@ -47,6 +59,7 @@ struct KaTreeDev {
         long long* dbg_off;            // [n_tasks] offset of the task's debug rows, -1 if none
         const KaTaskDesc* tasks;
         KaCtl* ctl;                    // [n_tasks] cluster control blocks, zeroed before every run
+        KaJoin* join;                  // [n_tasks] join points of the chained launch, zeroed before every run
         ka_task_rec* recs;
         const float* subm;             // 23*23
         float gpo0, gpe0, tgpe0, usw;  // unscaled penalties for update_n, use_seq_weights

@@ -44,6 +44,18 @@ __device__ __forceinline__ float ka_uniform_f(float x)
         return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
+// Bounded spin: gives up when the limit is reached, reporting `code` unless an error is already set.
+// other_tasks: the wait depends on ANOTHER task (a join point of the chained launch): also give up, checked
+// every 256 iterations, as soon as any workgroup has reported an error -- a failed task (arena overflow)
+// never signals its consumers, and the run is going to be repeated anyway.  Waits inside a task must not do
+// that: the task itself is healthy and has to run to its end.
+__device__ __forceinline__ bool ka_spin_expired(int* err, int spins, int limit, int code, bool other_tasks = false)
+{
+        if (spins > limit) { atomicCAS(err, 0, code); return true; }
+        if (other_tasks && (spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        return false;
+}
+
 __device__ __forceinline__ float lane_bcast(float x, int src_lane)
 {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
@@ -113,6 +125,7 @@ struct TaskShared {
         int* watchdog;                 // device error word: a bounded spin that expired writes 5 here
         long long t_pass, t_meet;      // KA_FLAG_TIMING: shader-clock cycles spent in passes / meetups
         int n_levels;
+        int next_member, next_g;       // chained launch: this workgroup's place in the parent task's cluster
         long long* prof;               // KA_PROF builds: per (level, wave) timestamps of the root task
         int lvl_n[16];                 // per recursion level: sub-problems, pass / meetup cycles
         int lvl_pass[16], lvl_meet[16];
@@ -341,7 +354,7 @@ __device__ void ka_cluster_sync(TaskShared& S)
                 int spins = 0;
                 while (__hip_atomic_load(&S.ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1 << 24)) { *S.watchdog = 6; break; }
+                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 24, 6)) break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -998,8 +1011,10 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ------------------------------------------------------------------------------------------
 // LEAN = true: a level whose tasks are all seq-seq (the guide tree's leaf level): 4 waves, no LDS
 // ring, <=128 VGPRs -> four workgroups per CU instead of one.
+// Returns 0 when this workgroup took part in the task to its end, 1 when it was surplus to the
+// task's cluster or the task failed (arena overflow).
 template <bool LEAN, int NB>
-__device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __restrict__ blocks)
+__device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, const int member, const int g_launch)
 {
         // all LDS lives in the dynamic region (16-B aligned carve-outs, guide section 6 G17)
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
@@ -1008,11 +1023,6 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
         float* tss = (float*)(ka_smem + KA_LDS_TSS);
         char* lds_waves = ka_smem + KA_LDS_WAVES;
 #define s_dbg (*s_dbg_p)
-        // blocks[b] = (task, member | launched cluster size << 8); task < 0: padding block
-        const int2 blk = blocks[blockIdx.x];
-        const int task = blk.x;
-        if (task < 0) return;
-        const int member = blk.y & 0xff, g_launch = blk.y >> 8;
         const KaTaskDesc T = D.tasks[task];
         const int tid = threadIdx.x;
         const long long tk0 = __builtin_amdgcn_s_memtime();
@@ -1020,12 +1030,14 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
 
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 1);
         if (tid == 0) {
-                const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
+                // (a chained launch reads what other workgroups of the SAME launch wrote: go past L1 / scalar cache)
+                const int len_a = __hip_atomic_load(&D.node_len[T.a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int len_b = __hip_atomic_load(&D.node_len[T.b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 S.watchdog = D.error; S.trace = D.trace; S.dbgskip = D.flags >> 16;
                 S.prof = (D.timing && T.is_root) ? (D.timing + 8ll * (D.numseq - 1) + 48) : nullptr;
                 S.len_a = len_a; S.len_b = len_b;
-                S.profa = D.prof_arena + D.node_prof[T.a];
-                S.profb = D.prof_arena + D.node_prof[T.b];
+                S.profa = D.prof_arena + __hip_atomic_load(&D.node_prof[T.a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                S.profb = D.prof_arena + __hip_atomic_load(&D.node_prof[T.b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 S.subm = D.subm;
                 S.gpo = T.gpo; S.gpe = T.gpe; S.tgpe = T.tgpe; S.soff = T.soff;
                 S.s1 = nullptr; S.s2 = nullptr; S.p1 = nullptr; S.p2 = nullptr;
@@ -1077,9 +1089,9 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
                 }
         }
         __syncthreads();
-        if (S.member >= S.G) return;                         // surplus workgroup of an over-provisioned cluster
+        if (S.member >= S.G) return 1;                       // surplus workgroup of an over-provisioned cluster
         ka_cluster_sync(S);
-        if (S.ctl->fail) return;
+        if (S.ctl->fail) return 1;
         if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0);
 
         // P1
@@ -1143,7 +1155,7 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
         }
         ka_cluster_sync(S);
         tk3 = __builtin_amdgcn_s_memtime();
-        if (S.ctl->fail) return;
+        if (S.ctl->fail) return 1;
 
         // P4 (all workgroups of the cluster)
         if (tid == 0) {
@@ -1171,29 +1183,101 @@ __device__ __forceinline__ void ka_task_body(const KaTreeDev& D, const int2* __r
                         }
                 }
         }
+        return 0;
 }
 
-__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks)
+// Entry of the task kernels.  blocks[b] = (task, member | launched cluster size << 8); task < 0: padding.
+//
+// chain != 0: the launch covers the first guide-tree level with at most one task per CU AND everything above
+// it.  Every workgroup starts as a one-workgroup cluster on a task of that level; when a task is done its
+// cluster moves up the tree: the clusters of the two children meet at the parent's KaJoin -- the first to
+// arrive waits, the last one leads, and both together (up to KA_MAX_G workgroups) run the parent.  Tasks start
+// as soon as both operands exist instead of at the next launch, clusters grow as the tree narrows, and the
+// whole upper tree is one launch.  All workgroups are resident from the start (<= one per CU), so the waits
+// cannot starve anybody; they are bounded all the same (device watchdog).
+#define KA_MAX_G 4
+template <bool LEAN, int NB>
+__device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __restrict__ blocks, const int chain)
 {
-        ka_task_body<false, 0>(D, blocks);
+        extern __shared__ __attribute__((aligned(16))) char ka_smem[];
+        TaskShared& S = *(TaskShared*)ka_smem;
+        const int2 blk = blocks[blockIdx.x];
+        int task = blk.x;
+        if (task < 0) return;
+        int member = blk.y & 0xff, g = blk.y >> 8;
+        const int tid = threadIdx.x;
+        while (true) {
+                const int st = ka_task_body<LEAN, NB>(D, task, member, g);
+                if (!chain || st != 0) return;
+                const int parent = D.tasks[task].parent;
+                if (parent < 0) return;
+                // everything this cluster wrote for the task (profile, node_len, colof) is released ...
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                ka_cluster_sync(S);
+                KaJoin* J = D.join + parent;
+                KaJoin* Jc = D.join + task;
+                if (S.member == 0 && tid == 0) {
+                        const unsigned int need = (unsigned int)D.tasks[parent].chain_need;
+                        __hip_atomic_fetch_add(&J->sum_g, (unsigned int)S.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned int slot = __hip_atomic_fetch_add(&J->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                        if (slot + 1 == need) {
+                                const unsigned int tot = __hip_atomic_load(&J->sum_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const int gp = (int)(tot < KA_MAX_G ? tot : KA_MAX_G);
+                                J->join_base = S.G; J->join_g = gp;
+                                __hip_atomic_store(&J->go, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&Jc->role, 1 | (gp << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                                __hip_atomic_store(&Jc->role, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                }
+                // ... and the role of this cluster at the parent is published to all of its workgroups
+                ka_cluster_sync(S);
+                if (tid == 0) {
+                        const int role = __hip_atomic_load(&Jc->role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int nm, ng;
+                        if ((role & 0xff) == 1) {
+                                nm = S.member; ng = role >> 8;
+                        } else {
+                                int spins = 0;
+                                while (__hip_atomic_load(&J->go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                        __builtin_amdgcn_s_sleep(32);
+                                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 24, 6, true)) break;
+                                }
+                                nm = __hip_atomic_load(&J->join_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + S.member;
+                                ng = __hip_atomic_load(&J->join_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        S.next_member = nm; S.next_g = ng;
+                }
+                __syncthreads();
+                member = S.next_member; g = S.next_g;
+                __syncthreads();
+                if (member >= g || __hip_atomic_load(S.watchdog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                task = parent;
+        }
+}
+
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<false, 0>(D, blocks, chain);
 }
 
 // (the second launch-bound is waves per SIMD: 4 -> <=128 VGPRs -> two 8-wave workgroups per CU)
-__global__ __launch_bounds__(KA_LEAN_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks)
+__global__ __launch_bounds__(KA_LEAN_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
-        ka_task_body<true, 0>(D, blocks);
+        ka_task_entry<true, 0>(D, blocks, 0);
 }
 
 // the same two with the anchor-consistency bonus (default mode of the reference's CLI)
-__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks)
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
-        ka_task_body<false, KA_NB>(D, blocks);
+        ka_task_entry<false, KA_NB>(D, blocks, chain);
 }
 
 // the bonus entries cost ~40 VGPRs: 4 waves, 3 waves per SIMD (<=168 VGPRs) -> three workgroups per CU
-__global__ __launch_bounds__(KA_PAIR_BLOCK, 3) void ka_task_kernel_lean_cons(const KaTreeDev D, const int2* __restrict__ blocks)
+__global__ __launch_bounds__(KA_PAIR_BLOCK, 3) void ka_task_kernel_lean_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
-        ka_task_body<true, KA_NB>(D, blocks);
+        ka_task_entry<true, KA_NB>(D, blocks, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1260,15 +1344,15 @@ static hipError_t ka_lds_optin()
         return hipSuccess;
 }
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, hipStream_t stream)
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream)
 {
         if (ka_lds_optin() != hipSuccess) return;
         if (D->cons_K > 0) {
-                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev);
-                else hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
+                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+                else hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
         } else {
-                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev);
-                else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev);
+                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev, 0);
+                else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
         }
 }
 
@@ -1280,3 +1364,4 @@ extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen) { return ka_scratch_bytes(la, lb, cons_maxlen); }
 extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }
+extern "C" int ka_max_g_host(void) { return KA_MAX_G; }

@@ -334,12 +334,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                                 if (clustered) {
                                                         while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                                                                 __builtin_amdgcn_s_sleep(4);
-                                                                if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                                                                if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
                                                         }
                                                 } else {
                                                         while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
                                                                 __builtin_amdgcn_s_sleep(2);
-                                                                if (++spins > (1 << 22)) { *S.watchdog = 5; break; }
+                                                                if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
                                                         }
                                                 }
                                         }

@@ -20,6 +20,12 @@ def rows(path):
         return list(csv.DictReader(f))
 
 
+LAUNCHES_FOR_TRACE = 13
+_b = os.path.join(d, "bench.json")
+if os.path.exists(_b):
+    for _l in open(_b).read().splitlines():
+        if _l.startswith("{"):
+            LAUNCHES_FOR_TRACE = int(json.loads(_l)["roofline"]["launches_per_step"])
 # ---- kernel trace: stats + the launches of the last timed step ----
 st = find("kt", "kernel_stats.csv")
 if st:
@@ -29,7 +35,7 @@ tr = find("kt", "kernel_trace.csv")
 if tr:
     r = [x for x in rows(tr) if x["Kernel_Name"].startswith("ka_task_kernel")]
     r.sort(key=lambda x: int(x["Start_Timestamp"]))
-    last = r[-13:]
+    last = r[-LAUNCHES_FOR_TRACE:]
     with open(os.path.join(here, tag + "_last_step_launches.csv"), "w") as g:
         g.write("kernel,grid,workgroup,lds_bytes,vgprs,sgprs,duration_us\n")
         for x in last:
@@ -51,6 +57,11 @@ def pmc_sum(sub, counter):
 fetch, nf = pmc_sum("pmc_fetch", "FETCH_SIZE")
 write, nw = pmc_sum("pmc_write", "WRITE_SIZE")
 LAUNCHES = 13
+b0 = os.path.join(d, "bench.json")
+if os.path.exists(b0):
+    for l in open(b0).read().splitlines():
+        if l.startswith("{"):
+            LAUNCHES = int(json.loads(l)["roofline"]["launches_per_step"])
 if fetch is not None and write is not None and nf and nw:
     steps_f, steps_w = nf / LAUNCHES, nw / LAUNCHES
     fkb, wkb = fetch / steps_f, write / steps_w
