@@ -108,6 +108,8 @@ int ka_tree_download(ka_ctx* ctx, ka_task_rec* recs, int* paths_out, long long p
  *   ka_tree_reset: forget every computed / injected node (a new sharded run over the same upload).
  *   ka_tree_node_len: alignment length of a node on this context (-1 on error).
  *   ka_tree_set_profile: inject the merged profile of an internal node, (plen+2)*64 floats.
+ *   ka_tree_get_node_cols / ka_tree_set_node_cols: with a consistency table, the residue -> column table of the
+ *     node's member sequences (ka_tree_node_cols_size ints) travels with the profile.
  *   ka_tree_download_tasks: records + coded paths of the listed tasks, paths packed in list order.
  *   ka_weave_gaps: host-only make_seq/update_gaps over all tasks in tree order (weave_alignment.c:41-112);
  *     recs[t] needs a, b, c, path_off.
@@ -116,6 +118,9 @@ int ka_tree_run_tasks(ka_ctx* ctx, const int* task_ids, int n);
 int ka_tree_reset(ka_ctx* ctx);
 int ka_tree_node_len(ka_ctx* ctx, int node);
 int ka_tree_set_profile(ka_ctx* ctx, int node, const float* prof, int plen);
+long long ka_tree_node_cols_size(ka_ctx* ctx, int node);
+int ka_tree_get_node_cols(ka_ctx* ctx, int node, int* out);
+int ka_tree_set_node_cols(ka_ctx* ctx, int node, const int* cols);
 int ka_tree_download_tasks(ka_ctx* ctx, const int* task_ids, int n, ka_task_rec* recs, int* paths_out,
                            long long paths_cap, long long* used_out);
 int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_task_rec* recs, const int* paths, int* gaps_out);

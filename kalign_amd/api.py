@@ -37,7 +37,8 @@ EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_erro
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
-           "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps"]
+           "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
+           "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols"]
 
 
 def lib_path():
@@ -83,6 +84,10 @@ def load_library():
     L.ka_tree_reset.argtypes = [vp]
     L.ka_tree_node_len.argtypes = [vp, C.c_int]
     L.ka_tree_set_profile.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.ka_tree_node_cols_size.argtypes = [vp, C.c_int]
+    L.ka_tree_node_cols_size.restype = C.c_longlong
+    L.ka_tree_get_node_cols.argtypes = [vp, C.c_int, vp]
+    L.ka_tree_set_node_cols.argtypes = [vp, C.c_int, vp]
     L.ka_tree_download_tasks.argtypes = [vp, vp, C.c_int, C.POINTER(TaskRec), vp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.ka_weave_gaps.argtypes = [C.c_int, vp, C.c_int, C.POINTER(TaskRec), vp, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
@@ -211,13 +216,27 @@ class Context:
         return n
 
     def tree_get_node(self, node):
-        """merged profile of an internal node, float32[(plen+2)*64]"""
+        """State of an internal node as one float32 array: the merged profile [(plen+2)*64] followed, when the job
+        has a consistency table, by the residue->column table of its members (ints viewed as float32)."""
         self.tree_sync()
-        return self.tree_profile(node, self.tree_node_len(node))
+        prof = self.tree_profile(node, self.tree_node_len(node))
+        if self.L.ka_tree_get_consistency(self.h, None, None) > 0:
+            n = int(self.L.ka_tree_node_cols_size(self.h, int(node)))
+            cols = np.zeros(n, np.int32)
+            self._chk(self.L.ka_tree_get_node_cols(self.h, int(node), _ptr(cols)))
+            return np.concatenate([prof, cols.view(np.float32)])
+        return prof
 
-    def tree_set_node(self, node, prof):
-        prof = np.ascontiguousarray(prof, np.float32).reshape(-1)
+    def tree_set_node(self, node, state):
+        state = np.ascontiguousarray(state, np.float32).reshape(-1)
+        ncols = 0
+        if self.L.ka_tree_get_consistency(self.h, None, None) > 0:
+            ncols = int(self.L.ka_tree_node_cols_size(self.h, int(node)))
+        prof = np.ascontiguousarray(state[:len(state) - ncols])
         self._chk(self.L.ka_tree_set_profile(self.h, int(node), _ptr(prof), len(prof) // 64 - 2))
+        if ncols:
+            cols = np.ascontiguousarray(state[len(state) - ncols:]).view(np.int32)
+            self._chk(self.L.ka_tree_set_node_cols(self.h, int(node), _ptr(cols)))
 
     def tree_download_tasks(self, task_ids):
         """(recs, paths) of the listed tasks; recs[i].path_off indexes `paths`."""

@@ -624,7 +624,6 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
 extern "C" int ka_tree_run_tasks(ka_ctx* c, const int* task_ids, int n)
 {
         if (!c || !c->have_job) return fail("no uploaded job");
-        if (c->cons_K > 0) return fail("partial runs do not carry the consistency state yet");
         HIPCHK(hipSetDevice(c->device));
         if (!c->state_valid && tree_reset(c)) return KA_FAIL;
         c->synced = false;
@@ -708,6 +707,60 @@ extern "C" int ka_tree_set_profile(ka_ctx* c, int node, const float* prof, int p
         HIPCHK(hipMemcpy(c->d_node_len.p + node, &plen, sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_node_prof.p + node, &po, sizeof(long long), hipMemcpyHostToDevice));
         c->injected.push_back(node);
+        return KA_OK;
+}
+
+// Consistency state of a node for partial runs: the residue -> column table of its member sequences, concatenated
+// in the node's member order (sum of their lengths ints).  Moves with the profile when a node changes GPUs.
+static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi)
+{
+        // sip_flat holds the leaves first (one entry each), then every internal node in task order
+        *lo = c->sip_off[node];
+        if (node < c->numseq) { *hi = *lo + 1; return; }
+        long long best = (long long)c->sip_flat.size();
+        for (size_t k = 0; k < c->sip_off.size(); k++) if (c->sip_off[k] > *lo && c->sip_off[k] < best) best = c->sip_off[k];
+        *hi = best;
+}
+
+extern "C" long long ka_tree_node_cols_size(ka_ctx* c, int node)
+{
+        if (!c || !c->have_job || node < 0 || node >= 2 * c->numseq - 1) return -1;
+        long long lo, hi, n = 0;
+        node_members(c, node, &lo, &hi);
+        for (long long k = lo; k < hi; k++) n += c->lens[c->sip_flat[k]];
+        return n;
+}
+
+extern "C" int ka_tree_get_node_cols(ka_ctx* c, int node, int* out)
+{
+        if (!c || !c->have_job || c->cons_K <= 0) return fail("no consistency table on this context");
+        if (node < 0 || node >= 2 * c->numseq - 1) return fail("bad node");
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        long long lo, hi, o = 0;
+        node_members(c, node, &lo, &hi);
+        for (long long k = lo; k < hi; k++) {
+                const int si = c->sip_flat[k];
+                HIPCHK(hipMemcpy(out + o, c->d_colof.p + c->off[si], sizeof(int) * c->lens[si], hipMemcpyDeviceToHost));
+                o += c->lens[si];
+        }
+        return KA_OK;
+}
+
+extern "C" int ka_tree_set_node_cols(ka_ctx* c, int node, const int* cols)
+{
+        if (!c || !c->have_job || c->cons_K <= 0) return fail("no consistency table on this context");
+        if (node < 0 || node >= 2 * c->numseq - 1) return fail("bad node");
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->state_valid && tree_reset(c)) return KA_FAIL;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        long long lo, hi, o = 0;
+        node_members(c, node, &lo, &hi);
+        for (long long k = lo; k < hi; k++) {
+                const int si = c->sip_flat[k];
+                HIPCHK(hipMemcpy(c->d_colof.p + c->off[si], cols + o, sizeof(int) * c->lens[si], hipMemcpyHostToDevice));
+                o += c->lens[si];
+        }
         return KA_OK;
 }
 

@@ -9,14 +9,19 @@ from util import Golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case,world", [("tree_prot32x200", 2), ("tree_prot64_gon", 4), ("tree_dna16x300", 3)])
+@pytest.mark.parametrize("case,world", [("tree_prot32x200", 2), ("tree_prot64_gon", 4), ("tree_dna16x300", 3),
+                                        ("cons_prot32x200", 2), ("cons_BB30014", 4), ("cons_prot48_k3", 3)])
 def test_subtrees_on_separate_contexts_match_golden(case, world):
+    """cons_* cases: default mode -- every context builds the same consistency table and the residue->column
+    state of a subtree travels with its root profile."""
     import kalign_amd
     from kalign_amd import api, dist as kd
     g = Golden(case)
     ctxs = [kalign_amd.Context(0) for _ in range(world)]
     for c in ctxs:
         c.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+        if case.startswith("cons_"):
+            c.tree_build_consistency(int(g.n_anchors), float(g.weight))
     run_rank, top = kd.plan_subtrees(g.tasks, g.lens, world)
     top_set = set(top)
     n = len(g.lens)
