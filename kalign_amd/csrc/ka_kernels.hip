@@ -66,7 +66,7 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane)
 struct KaCtl {
         // per-level counters, double-buffered by level parity: level L consumes lvl[L & 1] while its
         // meetups fill lvl[(L + 1) & 1] (zeroed at the start of level L) -> two barriers per level
-        struct Lvl { int nsub, rowalloc, nitems, next_item, npack[2]; } lvl[2];
+        struct Lvl { int nsub, rowalloc, nitems, next_item, npack[2], next_job, pad; } lvl[2];
         int mcount;
         int top_meet, top_tr;
         float top_score;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 S.q[0][0] = root;
                 for (int par = 0; par < 2; ++par) {
                         S.ctl->lvl[par].nsub = 0; S.ctl->lvl[par].rowalloc = 0; S.ctl->lvl[par].nitems = 0;
-                        S.ctl->lvl[par].next_item = 0; S.ctl->lvl[par].npack[0] = 0; S.ctl->lvl[par].npack[1] = 0;
+                        S.ctl->lvl[par].next_item = 0; S.ctl->lvl[par].next_job = 0; S.ctl->lvl[par].npack[0] = 0; S.ctl->lvl[par].npack[1] = 0;
                 }
                 S.ctl->lvl[0].nsub = (S.La > 0 && S.Lb > 0) ? 1 : 0;
                 S.ctl->lvl[0].rowalloc = S.Lb + 1;
@@ -402,7 +402,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         // the other parity was consumed by level-1 and is idle until this level's meetups
                         // (which start after the barrier below): reset it now
                         KaCtl::Lvl* const nxt = &S.ctl->lvl[(level + 1) & 1];
-                        nxt->nsub = 0; nxt->rowalloc = 0; nxt->nitems = 0; nxt->next_item = 0; nxt->npack[0] = 0; nxt->npack[1] = 0;
+                        nxt->nsub = 0; nxt->rowalloc = 0; nxt->nitems = 0; nxt->next_item = 0; nxt->next_job = 0; nxt->npack[0] = 0; nxt->npack[1] = 0;
                 }
                 const long long tp0 = __builtin_amdgcn_s_memtime();
                 long long* pslot = nullptr;
@@ -418,6 +418,13 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const int ntotal = nitems + njobs16 + njobs4;
                         const int2* pack16 = S.pack[level & 1][0];
                         const int2* pack4 = S.pack[level & 1][1];
+                        // A wave64 VALU instruction occupies its SIMD for 4 cycles and a strip is almost pure VALU:
+                        // two strip waves on one SIMD run at half speed each.  While the level has no more strips
+                        // than the cluster has SIMDs, only waves 0..3 of a workgroup (one per SIMD) take strips;
+                        // the others serve the packed jobs.  (Strip k-1 is still always pulled before strip k.)
+                        const bool can_strip = (wave < 4) || (nitems > 4 * S.G);
+                        bool strips_left = can_strip && nitems > 0;
+                        const int njobs = njobs16 + njobs4;
                         while (true) {
                                 // One lane takes the next item, then it is broadcast.  The puller lane is
                                 // compared through an opaque copy: with a plain `lane == 0` the optimiser
@@ -427,12 +434,22 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 int puller = lane;
                                 asm volatile("" : "+v"(puller));
                                 int it = 0;
-                                if (puller == 0) it = atomicAdd(&cur->next_item, 1);
-                                it = __builtin_amdgcn_readfirstlane(it);
+                                if (strips_left) {
+                                        if (puller == 0) it = atomicAdd(&cur->next_item, 1);
+                                        it = __builtin_amdgcn_readfirstlane(it);
+                                        if (it >= nitems) strips_left = false;
+                                }
+                                if (!strips_left) {
+                                        if (njobs == 0) break;
+                                        int jb = 0;
+                                        if (puller == 0) jb = atomicAdd(&cur->next_job, 1);
+                                        jb = __builtin_amdgcn_readfirstlane(jb);
+                                        if (jb >= njobs) break;
+                                        it = nitems + jb;
+                                }
 #ifdef KA_PROF
                                 if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
 #endif
-                                if (it >= ntotal) break;
                                 if (it >= nitems + njobs16) {
                                         ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr);
                                         continue;
