@@ -956,7 +956,8 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 // dynamic-LDS layout of a workgroup
 #define KA_LDS_DBG 768
 #define KA_LDS_TSS 784
-#define KA_LDS_WAVES (KA_LDS_TSS + 23 * KA_T_STRIDE * 4)          // 2736, multiple of 16
+#define KA_LDS_WAVES 4096                                           // per-wave regions: 2048-B aligned (ring addressing ORs the column offset in)
+static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table overlaps the wave regions");
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
 #define KA_LDS_PAIR (KA_LDS_WAVES + (2 * KA_PAIR_BLOCK + 16) * 4)   // seq-seq: only the path-coding scratch follows the table
 #define KA_LDS_LEAN (KA_LDS_WAVES + (2 * KA_LEAN_BLOCK + 16) * 4)

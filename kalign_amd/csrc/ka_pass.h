@@ -220,15 +220,18 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         float scA = 0.0f, scB = 0.0f;                                 // sequence columns: this step's two scores, looked up one step ahead
         float4v q[2][KA_REC_CHUNKS];                                  // column record: current / next step (ping-pong)
 
+        const unsigned wlds_u = (unsigned)(unsigned long long)wlds;
         auto ring_issue = [&](int nb) {
                 // start the global->LDS copy of column batch nb (32 columns x 7 chunks)
                 if (lane < KA_RING_BATCH && nb * KA_RING_BATCH <= ncols) {
                         const int vv = min(nb * KA_RING_BATCH + lane, ncols);
                         const float* g = S.p2 + ((long long)REC(vv) << 6) + 32;
-                        char* dst = wlds + (nb & (KA_RING_SLOTS - 1)) * KA_SLOT_BYTES;
+                        // ring layout: chunk-major, 128 columns per chunk row (2048 B): column v of chunk ch at
+                        // ch * 2048 + (v & 127) * 16 -- the read address is one AND + one shift-OR
+                        char* dst = wlds + (nb & (KA_RING_SLOTS - 1)) * (KA_RING_BATCH * 16);
 #pragma unroll
                         for (int ch = 0; ch < KA_REC_CHUNKS; ++ch)
-                                __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 512), 16, 0, 0);
+                                __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 2048), 16, 0, 0);
                 }
         };
         // The ring reads are issued as inline asm so that the compiler does not track them: its
@@ -237,14 +240,15 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // the full LDS latency every step.  ring_wait() is the matching manual wait; it takes the
         // registers as in/out operands so that no use can be scheduled above it.
         auto ring_read = [&](float4v* dstq, int vcol, float2v& dep) {
-                const unsigned a = (unsigned)(unsigned long long)(wlds + ((vcol >> 5) & (KA_RING_SLOTS - 1)) * KA_SLOT_BYTES + (vcol & 31) * 16);
+                // (the wave's LDS region is 2048-B aligned: OR instead of ADD)
+                const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
                 asm volatile("ds_read_b128 %0, %8\n\t"
-                             "ds_read_b128 %1, %8 offset:512\n\t"
-                             "ds_read_b128 %2, %8 offset:1024\n\t"
-                             "ds_read_b128 %3, %8 offset:1536\n\t"
-                             "ds_read_b128 %4, %8 offset:2048\n\t"
-                             "ds_read_b128 %5, %8 offset:2560\n\t"
-                             "ds_read_b128 %6, %8 offset:3072"
+                             "ds_read_b128 %1, %8 offset:2048\n\t"
+                             "ds_read_b128 %2, %8 offset:4096\n\t"
+                             "ds_read_b128 %3, %8 offset:6144\n\t"
+                             "ds_read_b128 %4, %8 offset:8192\n\t"
+                             "ds_read_b128 %5, %8 offset:10240\n\t"
+                             "ds_read_b128 %6, %8 offset:12288"
                              : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "=&v"(dstq[3]), "=&v"(dstq[4]), "=&v"(dstq[5]), "=&v"(dstq[6]),
                                "+v"(dep)                              // orders the loads after the value `dep` (see step())
                              : "v"(a)
@@ -282,7 +286,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         //   P    : which half of q[] holds this step's column record (the other half receives the next)
         //   EV   : this step may carry a periodic event (ring batch hand-over, boundary / residue batch
         //          reload, flush of the output batch); EV = false steps are branch-free
-        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag, auto ev_tag) {
+        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag, auto ev_tag, auto first_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;             // strip 0 of its pass: the row above is the pass's generated row -1
                 constexpr bool ST = decltype(st_tag)::value;
                 constexpr bool FULL = decltype(full_tag)::value;
                 constexpr int P = decltype(par_tag)::value;
@@ -313,11 +318,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 }
 
                 // ---- state of the row above A: lane l-1's row B, lane 0 takes the boundary ----
-                if (first) {
+                if (FIRST) {
                         if (t == 0) {
                                 inia = inj_a; iniga = inj_ga; inigb = inj_gb;
                         } else if (ST || t < ncols) {
-                                const float g = near_t ? kmax(iniga, inia) + ctext : kmax(iniga + cext, inia + copen);
+                                // max(x, y) + c == max(x + c, y + c) bit for bit (rounding is monotonic): one select-free form
+                                // for the terminal and the inner case instead of a branch per step
+                                const float gx = near_t ? ctext : cext, gy = near_t ? ctext : copen;
+                                const float g = kmax(iniga + gx, inia + gy);
                                 inia = -KA_F; iniga = g; inigb = -KA_F;
                         } else {
                                 inia = -KA_F; iniga = -KA_F; inigb = -KA_F;
@@ -466,13 +474,13 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         };
         // run steps [t, tend): pairs with alternating q halves; an odd leftover step is followed
         // by a copy so that every phase starts on half 0
-        auto run = [&](int& t, const int tend, auto st_tag, auto full_tag) {
+        auto run = [&](int& t, const int tend, auto st_tag, auto full_tag, auto first_tag) {
                 for (; t + 1 < tend; t += 2) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type());
-                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type());
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag);
+                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag);
                 }
                 if (t < tend) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type());
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag);
                         fix_parity();
                         ++t;
                 }
@@ -480,7 +488,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // steady state: the periodic events fall on known steps (ring hand-over at t = 31 mod 32,
         // batch reloads at t = 0 mod 64, output flush at t = lastl-1 mod 64); everything between
         // two event steps runs as branch-free step pairs
-        auto run_steady = [&](int& t, const int tend, auto full_tag) {
+        auto run_steady = [&](int& t, const int tend, auto full_tag, auto first_tag) {
                 while (t < tend) {
                         const int e1 = t | 31;
                         const int e2 = (t + 63) & ~63;
@@ -488,16 +496,16 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         const int ev = min(e1, min(e2, e3));
                         const int fend = min(ev, tend);
                         for (; t + 1 < fend; t += 2) {
-                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type());
-                                step(t + 1, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type());
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag);
+                                step(t + 1, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag);
                         }
                         if (t < fend) {
-                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type());
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag);
                                 fix_parity();
                                 ++t;
                         }
                         if (t < tend && t == ev) {
-                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::true_type());
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag);
                                 fix_parity();
                                 ++t;
                         }
@@ -507,15 +515,18 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const int nsteps = ncols + nl;                                // t = 0 .. ncols + nl - 1
         const int t_steady0 = min(nl, nsteps);                        // first step with every active lane at v >= 1
         const int t_steady1 = ncols;                                  // one past the last step with every lane at v <= ncols-1
-        int t = 0;
+        auto phases = [&](auto full_tag, auto first_tag) {
+                int t = 0;
+                run(t, t_steady0, std::false_type(), full_tag, first_tag);
+                run_steady(t, t_steady1, full_tag, first_tag);
+                run(t, nsteps, std::false_type(), full_tag, first_tag);
+        };
         if (nr == KA_STRIP_ROWS) {
-                run(t, t_steady0, std::false_type(), std::true_type());
-                run_steady(t, t_steady1, std::true_type());
-                run(t, nsteps, std::false_type(), std::true_type());
+                if (first) phases(std::true_type(), std::true_type());
+                else phases(std::true_type(), std::false_type());
         } else {
-                run(t, t_steady0, std::false_type(), std::false_type());
-                run_steady(t, t_steady1, std::false_type());
-                run(t, nsteps, std::false_type(), std::false_type());
+                if (first) phases(std::false_type(), std::true_type());
+                else phases(std::false_type(), std::false_type());
         }
 #undef REC
 #undef IDX
