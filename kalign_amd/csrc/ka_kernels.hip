@@ -415,7 +415,6 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const int nitems = cur->nitems;
                         const int n16 = cur->npack[0], n4 = cur->npack[1];
                         const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
-                        const int ntotal = nitems + njobs16 + njobs4;
                         const int2* pack16 = S.pack[level & 1][0];
                         const int2* pack4 = S.pack[level & 1][1];
                         // A wave64 VALU instruction occupies its SIMD for 4 cycles and a strip is almost pure VALU:

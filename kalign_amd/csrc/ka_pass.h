@@ -154,7 +154,6 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const bool last_is_b = (nr & 1) == 0;
         const bool first = (k == 0);
         const bool clustered = __builtin_amdgcn_readfirstlane(S.G) > 1;
-        const bool actA = 2 * lane < nr;
         const bool actB = 2 * lane + 1 < nr;
         const int uA = u0 + min(2 * lane, nr - 1);
         const int uB = u0 + min(2 * lane + 1, nr - 1);
@@ -293,7 +292,6 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 constexpr int P = decltype(par_tag)::value;
                 constexpr bool EV = decltype(ev_tag)::value;
                 const int v = t - lane;
-                const bool inr = (ST && FULL) ? true : (ST ? actA : ((v >= 0) && (v <= ncols) && actA));
 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
@@ -424,10 +422,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
                         nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
                 }
-                if (inr) {
-                        cAa = nAa; cAga = nAga; cAgb = nAgb;
-                        cBa = nBa; cBga = nBga; cBgb = nBgb;
-                }
+                // No predication on "this lane is inside its row/column range": state only flows DOWN the lanes
+                // (lane l -> l+1) and a lane's first real column (v = 0) rebuilds all six states from the lane above,
+                // so whatever lanes outside the range compute is never consumed by a lane inside it; the last-row
+                // collection below reads an active lane and is range-checked itself.
+                cAa = nAa; cAga = nAga; cAgb = nAgb;
+                cBa = nBa; cBga = nBga; cBgb = nBgb;
                 dga = upa; dgga = upga; dggb = upgb;
                 copen_prev = copen;
 
