@@ -569,7 +569,6 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
 #define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
 #define IDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
 
-        const bool actA = live && (2 * ls < nrows);
         const bool actB = live && (2 * ls + 1 < nrows);
         const bool writer = live && (ls == (nl > 0 ? nl - 1 : 0));    // owner of the pass's last row (or of the init row)
         const bool last_is_b = (nrows & 1) == 0;
@@ -733,10 +732,10 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 const float nBa = at0 ? -KA_F : acc.y;
                 const float nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
                 const float nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
-                if (vin && actA) {
-                        cAa = nAa; cAga = nAga; cAgb = nAgb;
-                        cBa = nBa; cBga = nBga; cBgb = nBgb;
-                }
+                // (no range predication, as in ka_strip: state flows down the lanes of a slot only, lane 0 of every
+                // slot takes the generated row, and v == 0 rebuilds all six states)
+                cAa = nAa; cAga = nAga; cAgb = nAgb;
+                cBa = nBa; cBga = nBga; cBgb = nBgb;
                 dga = upa; dgga = upga; dggb = upgb;
                 copen_prev = copen;
                 if (vin && writer) {
