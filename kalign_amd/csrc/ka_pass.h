@@ -355,11 +355,19 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                         const ka_gfloat* r = grows + 3 * IDX(min(t + lane, ncols));
                                         bta = r[0]; btga = r[1]; btgb = r[2];
                                 }
-                        } else {
-                                bta = wave_rol1(bta); btga = wave_rol1(btga); btgb = wave_rol1(btgb);
                         }
                 }
-                const float upa = wave_shr1_old(bta, cBa), upga = wave_shr1_old(btga, cBga), upgb = wave_shr1_old(btgb, cBgb);
+                // lanes > 0 take lane l-1's row B, lane 0 the boundary state of column t (lane 0 of the batch).  The
+                // batch is rotated for the NEXT step before it is used: its registers then die at the DPP that
+                // splices lane 0 in (the `old` operand is tied to the destination) and no copy is needed.
+                float upa, upga, upgb;
+                if (FIRST) {
+                        upa = wave_shr1_old(bta, cBa); upga = wave_shr1_old(btga, cBga); upgb = wave_shr1_old(btgb, cBgb);
+                } else {
+                        const float nbta = wave_rol1(bta), nbtga = wave_rol1(btga), nbtgb = wave_rol1(btgb);
+                        upa = wave_shr1_old(bta, cBa); upga = wave_shr1_old(btga, cBga); upgb = wave_shr1_old(btgb, cBgb);
+                        bta = nbta; btga = nbtga; btgb = nbtgb;
+                }
 
                 // ---- the two cells of this lane ----
                 float2v acc;
