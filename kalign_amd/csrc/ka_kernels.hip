@@ -177,9 +177,13 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
 // to 32 rows, 4-lane slots for up to 8 rows).
 struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; };
 
-__device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows)
+// A thin but long pass (few rows, many columns -- gap-rich regions of deep profiles produce them) also runs
+// as a strip: its ncols + nrows/2 dependent steps are the level's critical path, a strip step costs about
+// 60 % of a packed step, and the other waves of the cluster are idle at that depth anyway.
+#define KA_LONG_COLS 96
+__device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows, int ncols)
 {
-        if (nrows > 32) {
+        if (nrows > 32 || (nrows > 2 && ncols >= KA_LONG_COLS)) {
                 const int ns = ka_strips_of(nrows);
                 const int base = atomicAdd(o.nitems, ns);
                 for (int k = 0; k < ns; ++k) { o.items[base + k] = make_int2(slot, (dir << 16) | k); o.prog[base + k] = 0; }
@@ -190,11 +194,11 @@ __device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int 
         }
 }
 
-__device__ __forceinline__ void ka_emit_items(const KaLevelOut& o, int slot, int starta, int enda)
+__device__ __forceinline__ void ka_emit_items(const KaLevelOut& o, int slot, int starta, int enda, int ncols)
 {
         const int mid = ((enda - starta) / 2) + starta;
-        ka_emit_pass(o, slot, KA_FWD, mid - starta);
-        ka_emit_pass(o, slot, KA_BWD, enda - mid);
+        ka_emit_pass(o, slot, KA_FWD, mid - starta, ncols);
+        ka_emit_pass(o, slot, KA_BWD, enda - mid, ncols);
 }
 
 __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bool next)
@@ -326,13 +330,13 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 const int slot = atomicAdd(lout.nsub, 1);
                 c1.roff = atomicAdd(lout.rowalloc, c1.endb - c1.startb + 1);
                 qnext[slot] = c1;
-                ka_emit_items(lout, slot, c1.starta, c1.enda);
+                ka_emit_items(lout, slot, c1.starta, c1.enda, c1.endb - c1.startb);
         }
         if (c2.starta < c2.enda && c2.startb < c2.endb) {
                 const int slot = atomicAdd(lout.nsub, 1);
                 c2.roff = atomicAdd(lout.rowalloc, c2.endb - c2.startb + 1);
                 qnext[slot] = c2;
-                ka_emit_items(lout, slot, c2.starta, c2.enda);
+                ka_emit_items(lout, slot, c2.starta, c2.enda, c2.endb - c2.startb);
         }
 }
 
@@ -385,7 +389,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 }
                 S.ctl->lvl[0].nsub = (S.La > 0 && S.Lb > 0) ? 1 : 0;
                 S.ctl->lvl[0].rowalloc = S.Lb + 1;
-                if (S.ctl->lvl[0].nsub) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La);
+                if (S.ctl->lvl[0].nsub) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La, S.Lb);
                 S.ctl->msum = 0.0; S.ctl->mcount = 0;
                 S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f;
                 S.t_pass = 0; S.t_meet = 0; S.n_levels = 0;
@@ -417,35 +421,32 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
                         const int2* pack16 = S.pack[level & 1][0];
                         const int2* pack4 = S.pack[level & 1][1];
-                        // A wave64 VALU instruction occupies its SIMD for 4 cycles and a strip is almost pure VALU:
-                        // two strip waves on one SIMD run at half speed each.  While the level has no more strips
-                        // than the cluster has SIMDs, only waves 0..3 of a workgroup (one per SIMD) take strips;
-                        // the others serve the packed jobs.  (Strip k-1 is still always pulled before strip k.)
-                        const bool can_strip = (wave < 4) || (nitems > 4 * S.G);
-                        bool strips_left = can_strip && nitems > 0;
-                        const int njobs = njobs16 + njobs4;
+                        // A wave64 VALU instruction occupies its SIMD for 4 cycles and both strips and packed jobs are
+                        // almost pure VALU: two of them on one SIMD run at half speed each.  The first 8*G work items
+                        // are therefore dealt out statically, spread first over the workgroups of the cluster and
+                        // over waves 0..3 of each (one per SIMD), then over waves 4..7; whatever is left is pulled
+                        // dynamically.  (Item i only ever waits for items < i, and every wave takes its items in
+                        // increasing order, so the dealing cannot deadlock the strip pipelines.)
+                        const int ntotal = nitems + njobs16 + njobs4;
+                        const int nslots = __builtin_amdgcn_readfirstlane(KA_NW * S.G);
+                        int it = __builtin_amdgcn_readfirstlane(wave * S.G + S.member);   // this wave's statically dealt item
+                        bool dealt = true;
                         while (true) {
                                 // One lane takes the next item, then it is broadcast.  The puller lane is
                                 // compared through an opaque copy: with a plain `lane == 0` the optimiser
                                 // threads this test with the `lane == 0` regions inside ka_strip, splits the
                                 // loop per lane set and runs readfirstlane without lane 0 (observed: lanes
                                 // 1..63 spinning on item 0 forever).
-                                int puller = lane;
-                                asm volatile("" : "+v"(puller));
-                                int it = 0;
-                                if (strips_left) {
-                                        if (puller == 0) it = atomicAdd(&cur->next_item, 1);
-                                        it = __builtin_amdgcn_readfirstlane(it);
-                                        if (it >= nitems) strips_left = false;
+                                if (!dealt) {
+                                        if (ntotal <= nslots) break;
+                                        int puller = lane;
+                                        asm volatile("" : "+v"(puller));
+                                        int x = 0;
+                                        if (puller == 0) x = atomicAdd(&cur->next_item, 1);
+                                        it = nslots + __builtin_amdgcn_readfirstlane(x);
                                 }
-                                if (!strips_left) {
-                                        if (njobs == 0) break;
-                                        int jb = 0;
-                                        if (puller == 0) jb = atomicAdd(&cur->next_job, 1);
-                                        jb = __builtin_amdgcn_readfirstlane(jb);
-                                        if (jb >= njobs) break;
-                                        it = nitems + jb;
-                                }
+                                dealt = false;
+                                if (it >= ntotal) break;
 #ifdef KA_PROF
                                 if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
 #endif
