@@ -181,9 +181,11 @@ struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pac
 // as a strip: its ncols + nrows/2 dependent steps are the level's critical path, a strip step costs about
 // 60 % of a packed step, and the other waves of the cluster are idle at that depth anyway.
 #define KA_LONG_COLS 96
+__device__ __forceinline__ bool ka_pass_is_strip(int nrows, int ncols) { return nrows > 32 || (nrows > 2 && ncols >= KA_LONG_COLS); }
+
 __device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows, int ncols)
 {
-        if (nrows > 32 || (nrows > 2 && ncols >= KA_LONG_COLS)) {
+        if (ka_pass_is_strip(nrows, ncols)) {
                 const int ns = ka_strips_of(nrows);
                 const int base = atomicAdd(o.nitems, ns);
                 for (int k = 0; k < ns; ++k) { o.items[base + k] = make_int2(slot, (dir << 16) | k); o.prog[base + k] = 0; }
@@ -272,20 +274,18 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 const int okey = __shfl_xor(B.key, off, 64);
                 best_merge(B, omx, omx2, okey);
         }
-        if (lane != 0 || !valid) return;
-
+        // ---- aln_continue for the group's sub-problem (its lane 0 = "leader"), wave-cooperatively: the level's
+        // counters live in HBM when a cluster shares the task, and per-sub-problem atomics on five addresses
+        // serialise in L2 (a level with 250 sub-problems spent 30 us there).  Leaders only compute what they
+        // need; the wave adds it up and makes ONE atomic per counter.
+        const bool leader = (lane == 0) && valid;
         int meet = -1, tr = -1;
-        if (B.key != 0x7fffffff) {
+        if (leader && B.key != 0x7fffffff) {
                 const int ord = B.key & 7;                           // candidate order 0..5 -> codes 1,2,3,5,6,7
                 meet = startb + (B.key >> 3);
                 tr = ord + 1 + (ord >= 3 ? 1 : 0);
         }
-        if (B.mx2 > -KA_F) {
-                atomicAdd(&S.ctl->msum, (double)(B.mx - B.mx2));
-                atomicAdd(&S.ctl->mcount, 1);
-        }
-        if (is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
-        if (tr < 0) return;
+        if (leader && is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
 
         const KaState Z = { 0.0f, -KA_F, -KA_F };
         const KaState GA = { -KA_F, 0.0f, -KA_F };
@@ -293,50 +293,113 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         KaSub c1, c2;
         c1.starta = sb.starta; c1.startb = startb; c1.fin = sb.fin;
         c2.enda = sb.enda; c2.endb = endb; c2.bin = sb.bin;
-        c1.pad = 0; c2.pad = 0;
-        int* path = S.raw;
-        switch (tr) {
-        case 1:
-                path[mid] = meet; path[mid + 1] = meet + 1;
-                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
-                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
-                break;
-        case 2:
-                path[mid] = meet;
-                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
-                c2.starta = mid; c2.startb = meet + 1; c2.fin = GA;
-                break;
-        case 3:
-                path[mid] = meet;
-                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
-                c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
-                break;
-        case 5:
-                path[mid + 1] = meet + 1;
-                c1.enda = mid; c1.endb = meet - 1; c1.bin = GA;
-                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
-                break;
-        case 6:
-                c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
-                c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
-                break;
-        default: /* 7 */
-                path[mid + 1] = meet + 1;
-                c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
-                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
-                break;
+        c1.enda = c1.starta; c1.endb = c1.startb; c1.bin = Z;          // empty unless a transition fills them in
+        c2.starta = c2.enda; c2.startb = c2.endb; c2.fin = Z;
+        c1.pad = 0; c2.pad = 0; c1.roff = 0; c2.roff = 0;
+        if (tr > 0) {
+                int* path = S.raw;
+                switch (tr) {
+                case 1:
+                        path[mid] = meet; path[mid + 1] = meet + 1;
+                        c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                        c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                        break;
+                case 2:
+                        path[mid] = meet;
+                        c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                        c2.starta = mid; c2.startb = meet + 1; c2.fin = GA;
+                        break;
+                case 3:
+                        path[mid] = meet;
+                        c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                        c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
+                        break;
+                case 5:
+                        path[mid + 1] = meet + 1;
+                        c1.enda = mid; c1.endb = meet - 1; c1.bin = GA;
+                        c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                        break;
+                case 6:
+                        c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
+                        c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
+                        break;
+                default: /* 7 */
+                        path[mid + 1] = meet + 1;
+                        c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
+                        c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                        break;
+                }
         }
-        if (c1.starta < c1.enda && c1.startb < c1.endb) {
-                const int slot = atomicAdd(lout.nsub, 1);
-                c1.roff = atomicAdd(lout.rowalloc, c1.endb - c1.startb + 1);
-                qnext[slot] = c1;
-                ka_emit_items(lout, slot, c1.starta, c1.enda, c1.endb - c1.startb);
+        const bool v1 = (tr > 0) && c1.starta < c1.enda && c1.startb < c1.endb;
+        const bool v2 = (tr > 0) && c2.starta < c2.enda && c2.startb < c2.endb;
+        // what this leader needs: sub-problem slots, row-buffer cells, strip items, 16-lane and 4-lane packed entries
+        int need[5] = {0, 0, 0, 0, 0};
+        int pr[4], pc[4];                                            // rows / columns of the (up to) four passes
+        {
+                const int m1 = ((c1.enda - c1.starta) / 2) + c1.starta, m2 = ((c2.enda - c2.starta) / 2) + c2.starta;
+                pr[0] = m1 - c1.starta; pr[1] = c1.enda - m1; pr[2] = m2 - c2.starta; pr[3] = c2.enda - m2;
+                pc[0] = pc[1] = c1.endb - c1.startb; pc[2] = pc[3] = c2.endb - c2.startb;
         }
-        if (c2.starta < c2.enda && c2.startb < c2.endb) {
-                const int slot = atomicAdd(lout.nsub, 1);
-                c2.roff = atomicAdd(lout.rowalloc, c2.endb - c2.startb + 1);
-                qnext[slot] = c2;
-                ka_emit_items(lout, slot, c2.starta, c2.enda, c2.endb - c2.startb);
+        if (v1) { need[0] += 1; need[1] += c1.endb - c1.startb + 1; }
+        if (v2) { need[0] += 1; need[1] += c2.endb - c2.startb + 1; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+                if (!((x < 2) ? v1 : v2)) continue;
+                if (ka_pass_is_strip(pr[x], pc[x])) need[2] += ka_strips_of(pr[x]);
+                else if (pr[x] > 8) need[3] += 1;
+                else need[4] += 1;
+        }
+        float marg = 0.0f;
+        int mc = 0;
+        if (leader && B.mx2 > -KA_F) { marg = B.mx - B.mx2; mc = 1; }
+        // exclusive scans over the wave (non-leaders contribute nothing)
+        int off[5], tot[5];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+                int sc = need[x];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sc, d, 64); if (wlane >= d) sc += y; }
+                tot[x] = __shfl(sc, 63, 64);
+                off[x] = sc - need[x];
+        }
+        double msum_w = (double)marg;
+        int mcnt_w = mc;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { msum_w += __shfl_xor(msum_w, d, 64); mcnt_w += __shfl_xor(mcnt_w, d, 64); }
+        int base[5] = {0, 0, 0, 0, 0};
+        if (wlane == 0) {
+                if (tot[0]) base[0] = atomicAdd(lout.nsub, tot[0]);
+                if (tot[1]) base[1] = atomicAdd(lout.rowalloc, tot[1]);
+                if (tot[2]) base[2] = atomicAdd(lout.nitems, tot[2]);
+                if (tot[3]) base[3] = atomicAdd(lout.n16, tot[3]);
+                if (tot[4]) base[4] = atomicAdd(lout.n4, tot[4]);
+                if (mcnt_w) { atomicAdd(&S.ctl->msum, msum_w); atomicAdd(&S.ctl->mcount, mcnt_w); }
+        }
+#pragma unroll
+        for (int x = 0; x < 5; ++x) base[x] = __shfl(base[x], 0, 64) + off[x];
+        if (!leader || tr < 0) return;
+        // the leader's own ranges, filled in the order children / passes are numbered
+        int slot = base[0], row = base[1], ip = base[2], p16 = base[3], p4 = base[4];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+                KaSub& cs = ch ? c2 : c1;
+                if (!(ch ? v2 : v1)) continue;
+                cs.roff = row; row += cs.endb - cs.startb + 1;
+                qnext[slot] = cs;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                        const int nrows = pr[2 * ch + x], ncols = pc[2 * ch + x], dir = x ? KA_BWD : KA_FWD;
+                        if (ka_pass_is_strip(nrows, ncols)) {
+                                const int ns = ka_strips_of(nrows);
+                                for (int k = 0; k < ns; ++k) { lout.items[ip + k] = make_int2(slot, (dir << 16) | k); lout.prog[ip + k] = 0; }
+                                ip += ns;
+                        } else if (nrows > 8) {
+                                lout.pack16[p16++] = make_int2(slot, dir);
+                        } else {
+                                lout.pack4[p4++] = make_int2(slot, dir);
+                        }
+                }
+                ++slot;
         }
 }
 
