@@ -356,6 +356,12 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
         if (c->chain_level >= 0) scr *= (long long)std::min(max_level - c->chain_level, 8);   // the chained launch never resets the scratch counter; grows on demand
         c->scratch_cap = std::max(c->scratch_cap, scr);
+        if (getenv("KA_SMALL_ARENAS")) {
+                // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run
+                // path of ka_tree_sync is exercised (also across the join points of the chained launch)
+                c->prof_cap = top + 64LL * KA_REC; c->path_cap = 64; c->scratch_cap = 1 << 16;
+                c->d_prof_arena.release(); c->d_path_arena.release(); c->d_scratch.release();
+        }
         c->dbg_cap = (flags & KA_FLAG_DEBUG_ROWS) ? std::max<long long>(c->dbg_cap, 6LL * (cols + 2LL * n_tasks + c->sum_len)) : c->dbg_cap;
 
         if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
@@ -486,7 +492,7 @@ extern "C" int ka_tree_sync(ka_ctx* c)
 {
         if (!c || !c->ran) return fail("nothing running");
         HIPCHK(hipSetDevice(c->device));
-        for (int attempt = 0; attempt < 6; attempt++) {
+        for (int attempt = 0; attempt < 24; attempt++) {
                 int err = 0;
                 HIPCHK(hipStreamSynchronize(c->stream));
                 HIPCHK(hipMemcpy(&err, c->d_error.p, sizeof(int), hipMemcpyDeviceToHost));

@@ -1160,6 +1160,9 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0);
                         const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                         if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
+                        // an earlier task of this run already failed (arena overflow): its outputs -- possibly this
+                        // task's operands -- do not exist, and the host is going to repeat the run anyway
+                        if (__hip_atomic_load(D.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.ctl->fail = 1;
                         S.ctl->scratch_off = (long long)so;
                         if (D.flags & KA_FLAG_DEBUG_ROWS) {
                                 const unsigned long long nd = 6ull * (unsigned long long)(S.Lb + 1);

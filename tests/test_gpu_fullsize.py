@@ -121,3 +121,21 @@ def test_error_behaviour():
     with pytest.raises(kalign_amd.KalignAmdError):          # wrong task count
         ctx.msa_tree([a, a, a], np.array([[0, 1, 3]], np.int32), subm, scal)
     ctx.close()
+
+
+def test_arena_overflow_grows_and_reruns(monkeypatch):
+    """Device arenas (profiles, paths, scratch) are bump-allocated by the kernels; when one overflows the run is
+    repeated with a bigger arena (ka_tree_sync).  Start with arenas that are far too small: the result must be
+    the reference's, and a failed task must not leave the clusters waiting at its parent's join point hanging."""
+    import kalign_amd
+    from util import Golden
+    monkeypatch.setenv("KA_SMALL_ARENAS", "1")
+    g = Golden("tree_prot64_gon")
+    ctx = kalign_amd.Context(0)
+    recs, paths, gaps = ctx.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    ctx.close()
+    for t, r in enumerate(recs):
+        assert r.plen == g.rec("plen")[t]
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
