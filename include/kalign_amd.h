@@ -168,7 +168,18 @@ int ka_pairwise_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const i
                       const float* subm, float gpo, float gpe, float tgpe,
                       int* paths_out, const long long* poff, float* scores_out);
 
-/* Kernel time (HIP events on the launch stream) of the last ka_pairwise_batch, milliseconds. */
+/*
+ * Distance estimation for the guide tree: for every pair (ia[k], ib[k]) the value of
+ * calc_distance() -> bpm_block() (lib/src/sequence_distance.c:150-162, lib/src/bpm.c:356-582): block-wise Myers
+ * bit-vector edit distance of the shorter sequence against the longer one, integer-exact, at most 1024 pattern
+ * positions.  Sequence codes must be < 13 (the reduced alphabet kalign_run converts to before tree building,
+ * aln_wrap.c:155-160, or nucleotides).  d_estimation's length term is left to the caller:
+ * dm = dist + min(10000, (len_a + len_b) / 2) / 10000 (sequence_distance.c:66-69,118-120).
+ */
+int ka_bpm_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                 const int* ia, const int* ib, int npairs, int* dist_out);
+
+/* Kernel time (HIP events on the launch stream) of the last ka_pairwise_batch / ka_bpm_batch, milliseconds. */
 float ka_pairwise_kernel_ms(ka_ctx* ctx);
 
 #ifdef __cplusplus

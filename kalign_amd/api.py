@@ -38,7 +38,7 @@ EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_erro
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
-           "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols"]
+           "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch"]
 
 
 def lib_path():
@@ -90,6 +90,7 @@ def load_library():
     L.ka_tree_set_node_cols.argtypes = [vp, C.c_int, vp]
     L.ka_tree_download_tasks.argtypes = [vp, vp, C.c_int, C.POINTER(TaskRec), vp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.ka_weave_gaps.argtypes = [C.c_int, vp, C.c_int, C.POINTER(TaskRec), vp, vp]
+    L.ka_bpm_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
     L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
     L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
@@ -292,6 +293,19 @@ class Context:
                                            _ptr(ia), _ptr(ib), len(ia), _ptr(sub),
                                            float(gpo), float(gpe), float(tgpe), _ptr(paths), _ptr(poff), _ptr(scores)))
         return [paths[poff[k]:poff[k] + paths[poff[k]] + 2].copy() for k in range(len(ia))], scores
+
+
+def _bpm_batch(self, codes, ia, ib):
+    """calc_distance / bpm_block for a list of pairs (codes < 13): int32 distances."""
+    flat, off, lens = _flatten(codes)
+    ia = np.ascontiguousarray(ia, np.int32)
+    ib = np.ascontiguousarray(ib, np.int32)
+    out = np.zeros(len(ia), np.int32)
+    self._chk(self.L.ka_bpm_batch(self.h, _ptr(flat), _ptr(off), _ptr(lens), len(codes), _ptr(ia), _ptr(ib), len(ia), _ptr(out)))
+    return out
+
+
+Context.bpm_batch = _bpm_batch
 
 
 def weave_gaps(lens, recs, paths):

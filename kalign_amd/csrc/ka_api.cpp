@@ -20,6 +20,8 @@
 
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream);
 extern "C" int ka_max_g_host(void);
+extern "C" void ka_launch_bpm(const uint8_t* codes, const int* off, const int* lens, int numseq, unsigned long long* peq,
+                              const int* ia, const int* ib, int npairs, int* dist, hipStream_t stream);
 extern "C" long long ka_ctl_bytes_host(void);
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen);
@@ -101,6 +103,7 @@ struct ka_ctx {
         // grow-only device buffers of ka_pairwise_batch (no hipMalloc/hipFree per call)
         DevBuf<uint8_t> p_codes; DevBuf<int> p_off, p_len, p_ia, p_ib, p_paths, p_err; DevBuf<float> p_subm, p_scores;
         DevBuf<long long> p_poff; DevBuf<char> p_scr;
+        DevBuf<unsigned long long> b_peq; DevBuf<int> b_dist;   // ka_bpm_batch
         std::vector<ka_task_rec> h_recs;
         unsigned long long h_counters[4] = {0, 0, 0, 0};
         // ---- anchor consistency (ka_tree_build_consistency) ----
@@ -151,6 +154,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_ctl.release(); c->d_blocks.release(); c->d_blocks_tmp.release(); c->d_join.release();
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
+        c->b_peq.release(); c->b_dist.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1029,5 +1033,38 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
         if (scores_out) PCHK(hipMemcpy(scores_out, d_scores.p, sizeof(float) * npairs, hipMemcpyDeviceToHost));
 #undef PCHK
         cleanup();
+        return KA_OK;
+}
+
+// ---- distance estimation: calc_distance / bpm_block for a batch of pairs ----
+extern "C" int ka_bpm_batch(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                            const int* ia, const int* ib, int npairs, int* dist_out)
+{
+        if (!c) return fail("null ctx");
+        if (npairs <= 0) return KA_OK;
+        HIPCHK(hipSetDevice(c->device));
+        long long codes_bytes = 0;
+        for (int i = 0; i < numseq; i++) {
+                if (lens[i] < 1) return fail("zero-length sequence");
+                codes_bytes = std::max<long long>(codes_bytes, (long long)off[i] + lens[i]);
+                for (int j = 0; j < lens[i]; j++) if (codes[off[i] + j] >= 13) return fail("bpm: sequence code out of range (the distance alphabet has 13 letters, bpm.c:11)");
+        }
+        for (int k = 0; k < npairs; k++)
+                if (ia[k] < 0 || ia[k] >= numseq || ib[k] < 0 || ib[k] >= numseq) return fail("pair index out of range");
+        if (c->p_codes.alloc((size_t)codes_bytes) || c->p_off.alloc(numseq) || c->p_len.alloc(numseq) || c->p_ia.alloc(npairs) ||
+            c->p_ib.alloc(npairs) || c->b_peq.alloc((size_t)numseq * 13 * 16) || c->b_dist.alloc(npairs))
+                return fail("hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(c->p_codes.p, codes, (size_t)codes_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->p_off.p, off, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->p_len.p, lens, sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->p_ia.p, ia, sizeof(int) * npairs, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->p_ib.p, ib, sizeof(int) * npairs, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        ka_launch_bpm(c->p_codes.p, c->p_off.p, c->p_len.p, numseq, c->b_peq.p, c->p_ia.p, c->p_ib.p, npairs, c->b_dist.p, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipEventElapsedTime(&c->pair_ms, c->ev0, c->ev1));
+        HIPCHK(hipMemcpy(dist_out, c->b_dist.p, sizeof(int) * npairs, hipMemcpyDeviceToHost));
         return KA_OK;
 }

@@ -998,3 +998,95 @@ int ko_dp_single(int kind, const uint8_t* seq1, const uint8_t* seq2,
         free(d.f); free(d.b); free(d.path);
         return 0;
 }
+
+/* ---- distance estimation: block-wise Myers bit-vector edit distance (bpm_block, lib/src/bpm.c:356-582) ----
+ * Semi-global: the pattern p (length m, at most 1024 positions are used) against every end position of the
+ * text t; 64-bit blocks with Ukkonen's band: y = last active block.  Alphabet codes < 13 (bpm.c:11).
+ * Restated with the reference's exact update order, including its band rules: the band starts with ALL
+ * blocks active (maxd = m), shrinks while the last block's score is >= m + 64 and re-opens a block with
+ * P = ~0, M = 0 (bpm.c:505-560).  Text positions n .. n+W-1 are padding with code 0 (W = 64*b_max - m). */
+int ko_bpm_block(const uint8_t* t, const uint8_t* p, int n, int m)
+{
+        enum { W64 = 64, SIG = 13 };
+        uint64_t peq[13][16];
+        uint64_t P[16], M[16];
+        int32_t score[16];
+        const uint64_t ONE = 1, HIGH = ONE << 63;
+        int b_max, Wpad, k, maxd, y;
+        if(m > 1024) m = 1024;
+        b_max = (m == 0) ? 1 : (m / W64 + ((m % W64) ? 1 : 0));
+        Wpad = W64 * b_max - m;
+        k = m; maxd = m;
+        memset(peq, 0, sizeof(peq));
+        for(int c = 0; c < SIG; c++){
+                for(int b = 0; b < b_max; b++){
+                        uint64_t bit = 1;
+                        for(int i = b * W64; i < (b + 1) * W64; i++){
+                                if(i >= m || p[i] == c) peq[c][b] |= bit;      /* beyond m: matches anything */
+                                bit <<= 1;
+                        }
+                }
+        }
+        y = ((maxd == 0) ? 1 : (maxd / W64 + ((maxd % W64) ? 1 : 0))) - 1;
+        for(int b = 0; b < 16; b++){ P[b] = 0; M[b] = 0; score[b] = 0; }
+        for(int b = 0; b <= y; b++){ P[b] = ~(uint64_t)0; M[b] = 0; score[b] = (b + 1) * W64; }
+        for(int i = 0; i < n + Wpad; i++){
+                const int c = (i >= n) ? 0 : t[i];
+                int carry = 0;
+                for(int b = 0; b <= y; b++){
+                        uint64_t Pv = P[b], Mv = M[b], Eq = peq[c][b], Xv, Xh, Ph, Mh;
+                        const int hin = carry;
+                        int hout = 0;
+                        Xv = Eq | Mv;
+                        if(hin < 0) Eq |= ONE;
+                        Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                        Ph = Mv | ~(Xh | Pv);
+                        Mh = Pv & Xh;
+                        if(Ph & HIGH) hout += 1;
+                        if(Mh & HIGH) hout -= 1;
+                        Ph <<= 1; Mh <<= 1;
+                        if(hin < 0) Mh |= ONE; else if(hin > 0) Ph |= ONE;
+                        P[b] = Mh | ~(Xv | Ph);
+                        M[b] = Ph & Xv;
+                        carry = hout;
+                        score[b] += carry;
+                }
+                if((score[y] - carry <= maxd) && (y < b_max - 1) && ((peq[c][y + 1] & ONE) || (carry < 0))){
+                        uint64_t Pv, Mv, Eq, Xv, Xh, Ph, Mh;
+                        const int hin = carry;
+                        int hout = 0;
+                        y += 1;
+                        Pv = ~(uint64_t)0; Mv = 0; Eq = peq[c][y];
+                        Xv = Eq | Mv;
+                        if(hin < 0) Eq |= ONE;
+                        Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                        Ph = Mv | ~(Xh | Pv);
+                        Mh = Pv & Xh;
+                        if(Ph & HIGH) hout += 1;
+                        if(Mh & HIGH) hout -= 1;
+                        Ph <<= 1; Mh <<= 1;
+                        if(hin < 0) Mh |= ONE; else if(hin > 0) Ph |= ONE;
+                        P[y] = Mh | ~(Xv | Ph);
+                        M[y] = Ph & Xv;
+                        score[y] = score[y - 1] + W64 - carry + hout;
+                }else{
+                        while(score[y] >= maxd + W64){
+                                if(y == 0) break;
+                                y -= 1;
+                        }
+                }
+                if(score[y] < k) k = score[y];
+        }
+        return k;
+}
+
+/* calc_distance (sequence_distance.c:150-162) for a list of pairs: the longer sequence is the text */
+int ko_bpm_batch(const uint8_t* codes, const int* off, const int* lens, const int* ia, const int* ib, int npairs, int* dist_out)
+{
+        for(int k = 0; k < npairs; k++){
+                const int a = ia[k], b = ib[k];
+                if(lens[a] > lens[b]) dist_out[k] = ko_bpm_block(codes + off[a], codes + off[b], lens[a], lens[b]);
+                else dist_out[k] = ko_bpm_block(codes + off[b], codes + off[a], lens[b], lens[a]);
+        }
+        return 0;
+}

@@ -82,6 +82,11 @@ int ko_update_profile(const float* pa, const float* pb, float* out, const int* c
 
 uint64_t ko_fnv1a(const void* p, uint64_t n);
 
+/* distance estimation: bpm_block (lib/src/bpm.c:356-582) and calc_distance's pair rule
+   (sequence_distance.c:150-162: the longer sequence is the text).  Codes < 13. */
+int ko_bpm_block(const uint8_t* t, const uint8_t* p, int n, int m);
+int ko_bpm_batch(const uint8_t* codes, const int* off, const int* lens, const int* ia, const int* ib, int npairs, int* dist_out);
+
 #ifdef __cplusplus
 }
 #endif

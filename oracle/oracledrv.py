@@ -70,6 +70,7 @@ def lib():
         L.ko_mirror_path.argtypes = [vp, C.c_int, C.c_int, vp]
         L.ko_update_profile.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp,
                                         C.c_float, C.c_float, C.c_float, C.c_float]
+        L.ko_bpm_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
         L.ko_fnv1a.argtypes = [vp, C.c_uint64]
         L.ko_fnv1a.restype = C.c_uint64
         _lib = L
@@ -189,3 +190,13 @@ def rows_from_gaps(seqs_sorted, gaps):
         out.append("-" * int(g[len(s)]))
         rows.append("".join(out))
     return rows
+
+
+def bpm_batch(codes, ia, ib):
+    """calc_distance / bpm_block restatement for a list of pairs (codes < 13)."""
+    flat, off, lens = flatten(codes)
+    ia = np.ascontiguousarray(ia, np.int32)
+    ib = np.ascontiguousarray(ib, np.int32)
+    out = np.zeros(len(ia), np.int32)
+    lib().ko_bpm_batch(_ptr(flat), _ptr(off), _ptr(lens), _ptr(ia), _ptr(ib), len(ia), _ptr(out))
+    return out

@@ -47,6 +47,8 @@
 #include "aln_run.h"
 #include "weave_alignment.h"
 #include "anchor_consistency.h"
+#include "bpm.h"
+#include "sequence_distance.h"
 
 struct refh {
         struct msa* msa;
@@ -619,5 +621,14 @@ int refh_kalign(char** seqs, int* lens, int numseq, int n_threads, int type,
                 free(aligned[i]);
         }
         free(aligned);
+        return 0;
+}
+
+/* calc_distance (sequence_distance.c:150-162 -> bpm_block, bpm.c:356) for a list of pairs; codes < 13 */
+int refh_bpm_batch(const uint8_t* codes, const int* off, const int* lens, const int* ia, const int* ib, int npairs, int* dist_out)
+{
+        for(int k = 0; k < npairs; k++){
+                dist_out[k] = (int)calc_distance((uint8_t*)(codes + off[ia[k]]), (uint8_t*)(codes + off[ib[k]]), lens[ia[k]], lens[ib[k]]);
+        }
         return 0;
 }

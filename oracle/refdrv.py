@@ -70,6 +70,7 @@ def lib():
         L.refh_get_consistency.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.refh_set_bonus_hash_out.argtypes = [C.c_void_p]
         L.refh_set_bonus_hash_out.restype = None
+        L.refh_bpm_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.refh_kalign.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                   C.c_float, C.c_float, C.c_float, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
         _lib = L
@@ -270,3 +271,16 @@ def pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe, n_threads=1, want_paths=
     if want_paths:
         out = [paths[poff[k]:poff[k] + paths[poff[k]] + 2].copy() for k in range(len(ia))]
     return out, secs.value
+
+
+def bpm_batch(codes, ia, ib):
+    """calc_distance -> bpm_block of the reference for a list of pairs (codes < 13)."""
+    lens = np.array([len(c) for c in codes], np.int32)
+    off = np.zeros(len(codes), np.int32)
+    off[1:] = np.cumsum(lens)[:-1]
+    flat = np.ascontiguousarray(np.concatenate(codes), np.uint8)
+    ia = np.ascontiguousarray(ia, np.int32)
+    ib = np.ascontiguousarray(ib, np.int32)
+    out = np.zeros(len(ia), np.int32)
+    lib().refh_bpm_batch(_ptr(flat), _ptr(off), _ptr(lens), _ptr(ia), _ptr(ib), len(ia), _ptr(out))
+    return out

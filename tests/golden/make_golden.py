@@ -101,6 +101,30 @@ def pairwise_case(name, seqs, type_):
     print(name, "pairs=%d" % len(ia))
 
 
+def bpm_case(name, seed):
+    """Distance estimation: bpm_block through calc_distance on sequences over the 13-letter reduced alphabet
+    (what kalign_run converts to before tree building, aln_wrap.c:155-160) -- related and unrelated pairs,
+    lengths from 1 to beyond the 1024-position cap of the pattern."""
+    rng = np.random.RandomState(seed)
+    codes = []
+    for L in (1, 2, 63, 64, 65, 127, 128, 129, 300, 301, 400, 640, 1023, 1024, 1025, 1500):
+        base = rng.randint(0, 13, L).astype(np.uint8)
+        codes.append(base)
+        mut = base.copy()
+        idx = rng.rand(L) < 0.2
+        mut[idx] = rng.randint(0, 13, int(idx.sum()))
+        cut = rng.randint(0, max(1, L // 10) + 1)
+        codes.append(np.concatenate([mut[cut:], rng.randint(0, 13, rng.randint(0, 20)).astype(np.uint8)]) if L > 4 else mut)
+    codes = [c for c in codes if len(c) > 0]
+    n = len(codes)
+    ia, ib = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    ia, ib = ia.ravel().astype(np.int32), ib.ravel().astype(np.int32)
+    dist = refdrv.bpm_batch(codes, ia, ib)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), lens=np.array([len(c) for c in codes], np.int32),
+                        codes=np.concatenate(codes), ia=ia, ib=ib, dist=dist)
+    print(name, "pairs=%d" % len(ia), "max dist", int(dist.max()))
+
+
 def param_tables():
     out = {}
     for biotype, types in ((0, (3, 4, 5, 6, 8)), (1, (0, 1, 2, 8))):
@@ -135,6 +159,9 @@ if __name__ == "__main__":
         sys.exit("oracle/_ref/libkalign_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
     if len(sys.argv) > 1 and sys.argv[1] == "cons":        # only the consistency cases
         cons_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "bpm":
+        bpm_case("bpm_mixed", 31)
     else:
         main()
         cons_cases()
+        bpm_case("bpm_mixed", 31)

@@ -73,3 +73,9 @@ def test_code_path_edge_cases(oracle):
         out = np.zeros(la + lb + 3, np.int32)
         L.ko_code_path(r.ctypes.data_as(C.c_void_p), la, lb, out.ctypes.data_as(C.c_void_p))
         assert out[:len(want)].tolist() == want
+
+
+def test_bpm_distances_match_reference(oracle):
+    """distance estimation: bpm_block through calc_distance, 1024 pairs, lengths 1..1500"""
+    g = Golden("bpm_mixed")
+    assert np.array_equal(oracle.bpm_batch(g.codes, g.ia, g.ib), g.dist)
