@@ -43,6 +43,10 @@ extern "C" {
 /* flags for ka_msa_tree / ka_tree_upload */
 #define KA_FLAG_DEBUG_ROWS 1    /* also keep each task's top-level f/b rows (tests: row hashes) */
 #define KA_FLAG_TIMING 2        /* record per-task phase cycle counts (ka_tree_get_timing) */
+#define KA_FLAG_DEVICE_GAPS 4   /* keep every residue's alignment column on the device (make_seq / update_gaps,
+                                   weave_alignment.c:41-112): ka_tree_download derives gaps_out from it in O(sum of
+                                   lengths) instead of folding every task's path on the host; ka_msa_tree sets it
+                                   when gaps_out is requested */
 
 typedef struct ka_ctx ka_ctx;
 

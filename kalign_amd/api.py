@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 FLAG_DEBUG_ROWS = 1
 FLAG_TIMING = 2
+FLAG_DEVICE_GAPS = 4
 
 
 class KalignAmdError(RuntimeError):
@@ -273,7 +274,8 @@ class Context:
         return ids, maps
 
     def msa_tree(self, codes, tasks, subm, scal, seq_distances=None, flags=0, n_anchors=0, weight=2.0):
-        self.tree_upload(codes, tasks, subm, scal, seq_distances, flags)
+        # like ka_msa_tree: the gap arrays are wanted, so let the device keep every residue's column
+        self.tree_upload(codes, tasks, subm, scal, seq_distances, flags | FLAG_DEVICE_GAPS)
         if n_anchors > 0:
             self.tree_build_consistency(n_anchors, weight)
         self.tree_run()

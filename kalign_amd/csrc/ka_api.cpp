@@ -113,6 +113,7 @@ struct ka_ctx {
         std::vector<long long> sip_off;
         int cons_K = 0;
         size_t colof_n = 0;
+        bool have_colof = false;       // residue->column tables + member lists are on the device
         float cons_weight = 0.0f;
         std::vector<int> cons_anchor_ids, cons_maps;
         std::vector<long long> cons_map_off;
@@ -121,6 +122,7 @@ struct ka_ctx {
 };
 
 static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out);
+static int setup_colof(ka_ctx* c);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
 extern "C" int ka_abi_version(void) { return 2; }
@@ -190,6 +192,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         const int nprof = 2 * numseq - 1;
         c->have_job = false; c->ran = false; c->synced = false; c->state_valid = false;
         c->cons_K = 0;                           // a new job starts without a consistency table
+        c->have_colof = false;
         c->numseq = numseq; c->n_tasks = n_tasks; c->flags = flags;
         c->lens.assign(lens, lens + numseq);
         c->off.assign(off, off + numseq);
@@ -384,6 +387,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         HIPCHK(hipMemcpyAsync(c->d_subm.p, subm, sizeof(float) * 23 * 23, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_job = true;
+        if ((flags & KA_FLAG_DEVICE_GAPS) && setup_colof(c)) { c->have_job = false; return KA_FAIL; }
         return KA_OK;
 }
 
@@ -403,7 +407,7 @@ static int tree_reset(ka_ctx* c)
         HIPCHK(hipMemsetAsync(c->d_ctl.p, 0, (size_t)ka_ctl_bytes_host() * c->n_tasks, c->stream));
         HIPCHK(hipMemsetAsync(c->d_recs.p, 0, sizeof(ka_task_rec) * c->n_tasks, c->stream));
         HIPCHK(hipMemsetAsync(c->d_join.p, 0, sizeof(KaJoin) * c->n_tasks, c->stream));
-        if (c->cons_K > 0)                           // every leaf starts with residue p in column p
+        if (c->have_colof)                           // every leaf starts with residue p in column p
                 HIPCHK(hipMemcpyAsync(c->d_colof.p, c->d_colof_init.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));          // the staging vectors above are stack/heap temporaries
         c->state_valid = true;
@@ -623,6 +627,23 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
         }
         if (recs) memcpy(recs, c->h_recs.data(), sizeof(ka_task_rec) * c->n_tasks);
 
+        if (gaps_out && (c->flags & KA_FLAG_DEVICE_GAPS) && c->have_colof && !c->partial) {
+                // the kernels kept every residue's column (make_seq / update_gaps in the device's form): the gap
+                // arrays are its first differences, O(sum of lengths) instead of O(N L log N) folding on the host
+                std::vector<int> col(c->colof_n);
+                HIPCHK(hipMemcpy(col.data(), c->d_colof.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToHost));
+                const int alnlen = c->h_recs[c->n_tasks - 1].plen;
+                long long g = 0;
+                for (int i = 0; i < c->numseq; i++) {
+                        const int* cc = col.data() + c->off[i];
+                        const int len = c->lens[i];
+                        gaps_out[g] = cc[0];
+                        for (int p = 1; p < len; p++) gaps_out[g + p] = cc[p] - cc[p - 1] - 1;
+                        gaps_out[g + len] = alnlen - 1 - cc[len - 1];
+                        g += len + 1;
+                }
+                return KA_OK;
+        }
         if (gaps_out && ka_weave_gaps(c->numseq, c->lens.data(), c->n_tasks, c->h_recs.data(), paths_out, gaps_out)) return KA_FAIL;
         return KA_OK;
 }
@@ -848,6 +869,23 @@ extern "C" int ka_tree_kernel_ms(ka_ctx* c, float* ms, int* n_launches)
 }
 
 
+// residue -> column tables and member lists on the device (consistency votes, device-side gap arrays)
+static int setup_colof(ka_ctx* c)
+{
+        const int N = c->numseq;
+        std::vector<int> ident((size_t)c->h_codes.size(), 0);
+        for (int i = 0; i < N; i++) for (int p = 0; p < c->lens[i]; p++) ident[(size_t)c->off[i] + p] = p;
+        if (c->d_colof.alloc(ident.size()) || c->d_colof_init.alloc(ident.size()) || c->d_sip.alloc(c->sip_flat.size()) ||
+            c->d_sip_off.alloc(c->sip_off.size()))
+                return fail("hipMalloc failed");
+        c->colof_n = ident.size();
+        HIPCHK(hipMemcpy(c->d_colof_init.p, ident.data(), sizeof(int) * ident.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_sip.p, c->sip_flat.data(), sizeof(int) * c->sip_flat.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_sip_off.p, c->sip_off.data(), sizeof(long long) * c->sip_off.size(), hipMemcpyHostToDevice));
+        c->have_colof = true;
+        return KA_OK;
+}
+
 // ---- anchor consistency: anchor_consistency_build (anchor_consistency.c:122-275) ----
 // Anchor selection (farthest-first over |seq_distances[i] - seq_distances[anchor]|) runs on the host, the
 // N x K seq-seq alignments on the device (ka_pairwise_batch), the paths become position maps on the host
@@ -940,17 +978,10 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
                 }
 
         // device copies: maps, member lists, the identity residue->column table
-        std::vector<int> ident((size_t)c->h_codes.size(), 0);
-        for (int i = 0; i < N; i++) for (int p = 0; p < c->lens[i]; p++) ident[(size_t)c->off[i] + p] = p;
-        if (c->d_cons_maps.alloc(c->cons_maps.size()) || c->d_cons_map_off.alloc(N) || c->d_colof.alloc(ident.size()) ||
-            c->d_colof_init.alloc(ident.size()) || c->d_sip.alloc(c->sip_flat.size()) || c->d_sip_off.alloc(c->sip_off.size()))
-                return fail("hipMalloc failed");
-        c->colof_n = ident.size();
+        if (c->d_cons_maps.alloc(c->cons_maps.size()) || c->d_cons_map_off.alloc(N)) return fail("hipMalloc failed");
         HIPCHK(hipMemcpy(c->d_cons_maps.p, c->cons_maps.data(), sizeof(int) * c->cons_maps.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_cons_map_off.p, c->cons_map_off.data(), sizeof(long long) * N, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_colof_init.p, ident.data(), sizeof(int) * ident.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_sip.p, c->sip_flat.data(), sizeof(int) * c->sip_flat.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_sip_off.p, c->sip_off.data(), sizeof(long long) * c->sip_off.size(), hipMemcpyHostToDevice));
+        if (!c->have_colof && setup_colof(c)) return KA_FAIL;
         c->cons_K = K; c->cons_weight = weight;
         c->ran = false; c->synced = false; c->state_valid = false;
         return KA_OK;
@@ -970,7 +1001,7 @@ extern "C" int ka_msa_tree(ka_ctx* c, int numseq, const uint8_t* codes, const in
                            const float* subm, const float* scal, int flags,
                            ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
 {
-        if (ka_tree_upload(c, numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, flags)) return KA_FAIL;
+        if (ka_tree_upload(c, numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, flags | (gaps_out ? KA_FLAG_DEVICE_GAPS : 0))) return KA_FAIL;
         if (ka_tree_run(c)) return KA_FAIL;
         if (ka_tree_sync(c)) return KA_FAIL;
         return ka_tree_download(c, recs, paths_out, paths_cap, gaps_out);

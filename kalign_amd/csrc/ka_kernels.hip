@@ -1250,7 +1250,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         const int alnlen = S.ctl->alnlen;
         if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T, alnlen);
-        if (NB && !T.is_root) ka_update_colof(S, D, T, alnlen);
+        if ((NB && !T.is_root) || (D.flags & KA_FLAG_DEVICE_GAPS)) ka_update_colof(S, D, T, alnlen);
         if (D.timing && S.member == 0) {
                 __syncthreads();
                 if (tid == 0) {
