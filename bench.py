@@ -195,6 +195,38 @@ def default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args, k_anchors=5,
     return info
 
 
+def concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank, nsets=8, reps=3):
+    """Throughput when independent alignments are available (ensemble members, a batch of families): `nsets`
+    copies of the workload in flight at once on one GPU, each on its own stream and its own `shared` context
+    (one workgroup per task, one launch per level -- no workgroup ever waits for another context's).
+    Reported next to the headline value, never instead of it."""
+    import torch
+    import kalign_amd
+    streams = [torch.cuda.Stream() for _ in range(nsets)]
+    ctxs = [kalign_amd.Context(local_rank, stream=s.cuda_stream, shared=True) for s in streams]
+    for c in ctxs:
+        c.tree_upload(codes, tasks, subm, scal, seq_dist)
+    for c in ctxs:                                    # warm-up
+        c.tree_run()
+    for c in ctxs:
+        c.tree_sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for c in ctxs:
+            c.tree_run()
+    for c in ctxs:
+        c.tree_sync()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    recs, _, _ = ctxs[0].tree_download(want_gaps=False)
+    cells = float(sum(r.len_a * r.len_b for r in recs))
+    for c in ctxs:
+        c.close()
+    return {"sets_in_flight": nsets, "ms_per_round": dt * 1e3, "gcups": nsets * cells / dt / 1e9,
+            "note": "independent copies of the workload on separate streams; shared contexts (no clusters, no chained launch)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +292,9 @@ def main():
     dm_info = None
     if rank == 0 and not args.no_default_mode and not args.no_pairs:
         dm_info = default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args)
+    cs_info = None
+    if rank == 0 and not args.no_pairs:
+        cs_info = concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank)
 
     if rank == 0:
         abytes = algorithmic_bytes(recs)
@@ -297,6 +332,8 @@ def main():
             out["seqseq_batch"] = pair_info
         if dm_info:
             out["default_mode"] = dm_info
+        if cs_info:
+            out["concurrent_sets"] = cs_info
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
         print(json.dumps(out))

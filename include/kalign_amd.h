@@ -73,6 +73,11 @@ int  ka_ctx_create(int device, ka_ctx** out);
 void ka_ctx_destroy(ka_ctx* ctx);
 /* Launch on the caller's HIP stream (a hipStream_t, e.g. torch's current stream). NULL = default stream. */
 int  ka_ctx_set_stream(ka_ctx* ctx, void* hip_stream);
+/* Tell the context that it does NOT have the GPU to itself (several alignments in flight on different streams /
+   processes).  Multi-workgroup tasks and the chained launch make workgroups wait for each other and need all of
+   them resident; a shared context runs every task on one workgroup, one launch per guide-tree level -- slower for
+   a single tree, safe under any co-scheduling.  Takes effect at the next ka_tree_upload. */
+int  ka_ctx_set_shared(ka_ctx* ctx, int shared);
 const char* ka_last_error(void);
 /* number of exported entry points, for the "library loads" test */
 int  ka_abi_version(void);

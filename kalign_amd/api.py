@@ -34,7 +34,7 @@ class TaskRec(C.Structure):
     ]
 
 
-EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_last_error", "ka_abi_version",
+EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
@@ -63,6 +63,7 @@ def load_library():
     L.ka_ctx_destroy.argtypes = [vp]
     L.ka_ctx_destroy.restype = None
     L.ka_ctx_set_stream.argtypes = [vp, vp]
+    L.ka_ctx_set_shared.argtypes = [vp, C.c_int]
     L.ka_last_error.restype = C.c_char_p
     L.ka_abi_version.restype = C.c_int
     L.ka_msa_tree.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
@@ -115,7 +116,8 @@ def _flatten(codes):
 class Context:
     """One GPU context (ka_ctx)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, shared=False):
+        """shared=True: other streams / processes use the GPU at the same time (ka_ctx_set_shared)."""
         self.L = load_library()
         h = C.c_void_p()
         if self.L.ka_ctx_create(device, C.byref(h)):
@@ -123,6 +125,8 @@ class Context:
         self.h = h
         if stream is not None:
             self.L.ka_ctx_set_stream(self.h, C.c_void_p(stream))
+        if shared:
+            self.L.ka_ctx_set_shared(self.h, 1)
         self._job = None
 
     def close(self):

@@ -67,6 +67,7 @@ struct ka_ctx {
         std::vector<int> blocks_off;
         std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
         int max_cluster = 4;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
+        bool shared_gpu = false;                     // ka_ctx_set_shared: no multi-workgroup tasks, no chained launch
         std::vector<long long> leaf_prof_off;
         long long leaf_prof_total = 0;
         long long sum_len = 0;
@@ -162,6 +163,17 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
+}
+
+// Clusters of workgroups and the chained launch let workgroups wait for each other, which is only safe while
+// all of them are resident -- true when this context has the GPU to itself.  A context that shares the GPU
+// with other streams or processes (several alignments in flight at once) must say so: every task then runs on
+// one workgroup and every guide-tree level is its own launch.  Takes effect at the next ka_tree_upload.
+extern "C" int ka_ctx_set_shared(ka_ctx* c, int shared)
+{
+        if (!c) return fail("null ctx");
+        c->shared_gpu = shared != 0;
+        return KA_OK;
 }
 
 extern "C" int ka_ctx_set_stream(ka_ctx* c, void* s)
@@ -288,7 +300,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                         if (b >= numseq) c->descs[task_of[b]].parent = t;
                 }
                 c->chain_level = -1;
-                if (!getenv("KA_NO_CHAIN")) {
+                if (!getenv("KA_NO_CHAIN") && !c->shared_gpu) {
                         for (int L = 0; L + 1 < max_level; L++) {
                                 bool all_ss = true;
                                 for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
@@ -310,6 +322,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
 
         // ---- workgroup tables, one per dependency level (build_blocks) ----
         if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
+        if (c->shared_gpu) c->max_cluster = 1;
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
         c->task_level.assign(n_tasks, 0);
         for (int t = 0; t < n_tasks; t++) c->task_level[t] = level[abc[3 * t + 2]] - 1;

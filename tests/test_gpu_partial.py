@@ -66,3 +66,25 @@ def test_subtrees_on_separate_contexts_match_golden(case, world):
             other.tree_run_tasks([top[-1]])
     for c in ctxs:
         c.close()
+
+
+def test_shared_contexts_run_concurrently_and_match_golden():
+    """ka_ctx_set_shared: several alignments in flight on one GPU (separate streams).  Shared contexts use neither
+    multi-workgroup tasks nor the chained launch, so no workgroup ever waits for one that is not resident."""
+    import torch
+    import kalign_amd
+    g = Golden("tree_prot64_gon")
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    ctxs = [kalign_amd.Context(0, stream=s.cuda_stream, shared=True) for s in streams]
+    for c in ctxs:
+        c.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    for _ in range(2):
+        for c in ctxs:
+            c.tree_run()
+    for c in ctxs:
+        recs, paths, gaps = c.tree_download()
+        for t, r in enumerate(recs):
+            assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
+        for got, want in zip(gaps, g.gaps_list()):
+            assert np.array_equal(got, want)
+        c.close()
