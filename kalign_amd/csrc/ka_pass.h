@@ -64,14 +64,34 @@ __device__ __forceinline__ float wave_shl1_old(float old, float src)
 #endif
         return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x130, 0xf, 0xf, false));
 }
+// (e, e) of a float4 as a shuffle: selects straight into the op_sel broadcast of v_pk_mul_f32 (built from a scalar
+// extract, the .w elements went through a v_mov_b32 first)
+// a * (v[E], v[E]): one v_pk_mul_f32 with an op_sel broadcast.  The compiler finds the broadcast for elements 0..2
+// but routes .w through a v_mov_b32 first, so that one is spelled out: src1 = the (z, w) half of the float4,
+// op_sel:[0,1] takes its high half for the low lane (op_sel_hi defaults to [1,1]).
+template <int E>
+__device__ __forceinline__ float2v ka_mul_bcast(const float2v a, const float4v& v)
+{
+        if (E == 3) {
+                const float2v zw = __builtin_shufflevector(v, v, 2, 3);
+                float2v r;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(zw));
+                return r;
+        }
+        const float sc = v[E];
+        float2v w; w.x = sc; w.y = sc;
+        return a * w;
+}
+
 // rotate: lane l <- lane (l+1) mod 64
 __device__ __forceinline__ float wave_rol1(float x)
 {
 #if defined(KA_EXP) && (KA_EXP & 4)
         return x + 1.0f;
 #endif
-        const int xi = __float_as_int(x);
-        return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x134, 0xf, 0xf, false));
+        // a rotation writes every lane: no `old` operand (which would be tied to the destination and cost a copy
+        // whenever the source stays live)
+        return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x134, 0xf, 0xf, true));
 }
 
 #ifndef KA_EXP
@@ -385,12 +405,16 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
                         // v_pk_add of the chain instead of an s_nop
                         float2v prod;
-                        { const float sc = q[P][(NRES - 1) >> 2][(NRES - 1) & 3]; float2v w; w.x = sc; w.y = sc; prod = p1v[NRES - 1] * w; }
+                        prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
 #pragma unroll
                         for (int c = ((KA_EXP & 1) ? 2 : NRES - 1); c >= 1; --c) {
-                                const float sc = q[P][(c - 1) >> 2][(c - 1) & 3];
-                                float2v w; w.x = sc; w.y = sc;
-                                const float2v nprod = p1v[c - 1] * w;
+                                float2v nprod;
+                                switch ((c - 1) & 3) {                  // (compile-time after unrolling)
+                                case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                case 1: nprod = ka_mul_bcast<1>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                case 2: nprod = ka_mul_bcast<2>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                default: nprod = ka_mul_bcast<3>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                }
                                 acc = acc + prod;
                                 prod = nprod;
                         }
