@@ -67,6 +67,7 @@ struct ka_ctx {
         std::vector<int> blocks_off;
         std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
         int max_cluster = 4;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
+        int n_cus = 256;                             // compute units of the device (hipDeviceProp)
         bool shared_gpu = false;                     // ka_ctx_set_shared: no multi-workgroup tasks, no chained launch
         std::vector<long long> leaf_prof_off;
         long long leaf_prof_total = 0;
@@ -136,6 +137,10 @@ extern "C" int ka_ctx_create(int device, ka_ctx** out)
         HIPCHK(hipSetDevice(device));
         ka_ctx* c = new ka_ctx();
         c->device = device;
+        {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+        }
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
         if (getenv("KA_TRACE")) {
@@ -304,7 +309,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                         for (int L = 0; L + 1 < max_level; L++) {
                                 bool all_ss = true;
                                 for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
-                                if (!all_ss && (int)c->levels[L].size() <= 248) { c->chain_level = L; break; }
+                                if (!all_ss && (int)c->levels[L].size() <= c->n_cus - 8) { c->chain_level = L; break; }   // one workgroup per CU, all resident
                         }
                 }
                 if (c->chain_level >= 0) {
@@ -464,7 +469,7 @@ static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector
         for (int t : L) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) lean = 0;
         if (getenv("KA_NO_LEAN")) lean = 0;
         int G = 1;
-        while (!lean && G * 2 <= c->max_cluster && nt * G * 2 <= 256) G *= 2;
+        while (!lean && G * 2 <= c->max_cluster && nt * G * 2 <= c->n_cus) G *= 2;
         const int groups = (nt + 7) / 8;
         tbl.assign((size_t)groups * 8 * G, make_int2(-1, 0));
         for (int j = 0; j < nt; j++)
