@@ -197,34 +197,26 @@ def default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args, k_anchors=5,
 
 def concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank, nsets=8, reps=3):
     """Throughput when independent alignments are available (ensemble members, a batch of families): `nsets`
-    copies of the workload in flight at once on one GPU, each on its own stream and its own `shared` context
-    (one workgroup per task, one launch per level -- no workgroup ever waits for another context's).
-    Reported next to the headline value, never instead of it."""
-    import torch
+    copies of the workload as ONE forest job (include/kalign_amd.h: n_tasks < numseq-1) -- the levels of all trees
+    share launches and the upper parts of all trees run in one chained launch.  Reported next to the headline
+    value, never instead of it."""
     import kalign_amd
-    streams = [torch.cuda.Stream() for _ in range(nsets)]
-    ctxs = [kalign_amd.Context(local_rank, stream=s.cuda_stream, shared=True) for s in streams]
-    for c in ctxs:
-        c.tree_upload(codes, tasks, subm, scal, seq_dist)
-    for c in ctxs:                                    # warm-up
-        c.tree_run()
-    for c in ctxs:
-        c.tree_sync()
-    torch.cuda.synchronize()
+    from kalign_amd import guide
+    fc, ft, fd, _ = guide.forest([(codes, tasks, seq_dist)] * nsets)
+    ctx = kalign_amd.Context(local_rank)
+    ctx.tree_upload(fc, ft, subm, scal, fd)
+    ctx.tree_run(); ctx.tree_sync()
     t0 = time.perf_counter()
     for _ in range(reps):
-        for c in ctxs:
-            c.tree_run()
-    for c in ctxs:
-        c.tree_sync()
-    torch.cuda.synchronize()
+        ctx.tree_run()
+    ctx.tree_sync()
     dt = (time.perf_counter() - t0) / reps
-    recs, _, _ = ctxs[0].tree_download(want_gaps=False)
+    recs, _, _ = ctx.tree_download(want_gaps=False)
     cells = float(sum(r.len_a * r.len_b for r in recs))
-    for c in ctxs:
-        c.close()
-    return {"sets_in_flight": nsets, "ms_per_round": dt * 1e3, "gcups": nsets * cells / dt / 1e9,
-            "note": "independent copies of the workload on separate streams; shared contexts (no clusters, no chained launch)"}
+    kern_ms, n_launch = ctx.tree_kernel_ms()
+    ctx.close()
+    return {"sets_in_flight": nsets, "ms_per_round": dt * 1e3, "gcups": cells / dt / 1e9, "launches": n_launch,
+            "note": "independent copies of the workload scheduled as one forest job in one context"}
 
 
 def main():

@@ -89,6 +89,9 @@ int  ka_abi_version(void);
  * subm: 23*23 floats; scal[6] = gpo, gpe, tgpe, dist_scale, vsm_amax, use_seq_weights
  * (struct aln_param, aln_param.h:19-34, after the sentinel resolution of aln_param_init).
  * seq_distances: numseq floats or NULL (msa->seq_distances).
+ * n_tasks < numseq-1 describes a FOREST: several independent alignments (a batch of families, ensemble members)
+ * scheduled together -- node ids stay unique, every task nobody consumes is the root of its tree, and the
+ * levels of all trees share launches (the GPU is mostly idle at the top of a single tree).
  * Outputs: recs[n_tasks]; coded paths packed into paths_out (capacity paths_cap ints);
  * gaps_out: concatenated gaps[len+1] per sequence (msa->sequences[i]->gaps after make_seq,
  * weave_alignment.c:41-112) or NULL.

@@ -83,6 +83,7 @@ struct ka_ctx {
         DevBuf<unsigned long long> d_counters;
         DevBuf<char> d_scratch, d_ctl;
         DevBuf<KaJoin> d_join;
+        int n_trees = 1;               // guide trees in the job (a forest when > 1)
         int chain_level = -1;          // first level of the chained launch (-1: every level is its own launch)
         std::vector<int2> chain_blocks;
         int chain_blocks_off = 0;
@@ -125,6 +126,7 @@ struct ka_ctx {
 
 static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out);
 static int setup_colof(ka_ctx* c);
+static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
 extern "C" int ka_abi_version(void) { return 2; }
@@ -204,7 +206,9 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                               const float* subm, const float* scal, int flags)
 {
         if (!c) return fail("null ctx");
-        if (numseq < 2 || n_tasks != numseq - 1) return fail("need numseq >= 2 and n_tasks == numseq-1");
+        // n_tasks == numseq-1: one guide tree.  Fewer tasks: a FOREST -- several independent alignments (a batch of
+        // families, ensemble members) scheduled together; every task with no consumer is the root of its tree.
+        if (numseq < 2 || n_tasks < 1 || n_tasks > numseq - 1) return fail("need numseq >= 2 and 1 <= n_tasks <= numseq-1");
         HIPCHK(hipSetDevice(c->device));
         const int nprof = 2 * numseq - 1;
         c->have_job = false; c->ran = false; c->synced = false; c->state_valid = false;
@@ -267,7 +271,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 }
                 d.a = a; d.b = b; d.c = cc;
                 d.nsip_a = nsip[a]; d.nsip_b = nsip[b];
-                d.is_root = (t == n_tasks - 1);
+                d.is_root = 0;                                   // set below: tasks nobody consumes
                 d.gpo = gpo0; d.gpe = gpe0; d.tgpe = tgpe0;
                 if (gap_scale < 1.0f || soff > 0.0f) { d.gpo *= gap_scale; d.gpe *= gap_scale; d.tgpe *= gap_scale; }
                 else soff = 0.0f;
@@ -304,6 +308,8 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                         if (a >= numseq) c->descs[task_of[a]].parent = t;
                         if (b >= numseq) c->descs[task_of[b]].parent = t;
                 }
+                for (int t = 0; t < n_tasks; t++) c->descs[t].is_root = (c->descs[t].parent < 0);
+                c->n_trees = numseq - n_tasks;
                 c->chain_level = -1;
                 if (!getenv("KA_NO_CHAIN") && !c->shared_gpu) {
                         for (int L = 0; L + 1 < max_level; L++) {
@@ -347,7 +353,8 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 // L2, only the top three levels cross XCDs.
                 std::vector<int> task_of(nprof, -1), order;
                 for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
-                std::vector<int> stack(1, n_tasks - 1);
+                std::vector<int> stack;
+                for (int t = n_tasks - 1; t >= 0; t--) if (c->descs[t].parent < 0 && c->task_level[t] >= c->chain_level) stack.push_back(t);   // every root above the cut
                 while (!stack.empty()) {
                         const int t = stack.back(); stack.pop_back();
                         if (c->task_level[t] == c->chain_level) { order.push_back(t); continue; }
@@ -567,7 +574,7 @@ static void fold_gaps(int len, int* gis, const int* newgaps)
 // only (a, b, c, path_off) of every task and the coded paths.
 extern "C" int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_task_rec* recs, const int* paths, int* gaps_out)
 {
-        if (numseq < 1 || n_tasks != numseq - 1 || !lens || !recs || !paths || !gaps_out) return fail("ka_weave_gaps: bad arguments");
+        if (numseq < 1 || n_tasks < 0 || n_tasks > numseq - 1 || !lens || !recs || !paths || !gaps_out) return fail("ka_weave_gaps: bad arguments");
         const int nprof = 2 * numseq - 1;
         std::vector<int> goff(numseq);
         long long g = 0;
@@ -650,11 +657,20 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
                 // arrays are its first differences, O(sum of lengths) instead of O(N L log N) folding on the host
                 std::vector<int> col(c->colof_n);
                 HIPCHK(hipMemcpy(col.data(), c->d_colof.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToHost));
-                const int alnlen = c->h_recs[c->n_tasks - 1].plen;
+                // alignment length of the tree each sequence belongs to (a sequence in no task aligns to itself)
+                std::vector<int> alen(c->numseq);
+                for (int i = 0; i < c->numseq; i++) alen[i] = c->lens[i];
+                for (int t = 0; t < c->n_tasks; t++) {
+                        if (!c->descs[t].is_root) continue;
+                        long long lo, hi;
+                        node_members(c, c->descs[t].c, &lo, &hi);
+                        for (long long k = lo; k < hi; k++) alen[c->sip_flat[k]] = c->h_recs[t].plen;
+                }
                 long long g = 0;
                 for (int i = 0; i < c->numseq; i++) {
                         const int* cc = col.data() + c->off[i];
                         const int len = c->lens[i];
+                        const int alnlen = alen[i];
                         gaps_out[g] = cc[0];
                         for (int p = 1; p < len; p++) gaps_out[g + p] = cc[p] - cc[p - 1] - 1;
                         gaps_out[g + len] = alnlen - 1 - cc[len - 1];
@@ -954,6 +970,7 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
         c->cons_K = 0;
         const int N = c->numseq;
         // the reference silently declines in these cases (anchor_consistency.c:206-217)
+        if (c->n_trees > 1) return fail("consistency tables are per alignment: build them on single-tree jobs");
         if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
         int K = std::min(n_anchors, N);
         if (K > KA_NB - 1) return fail("this build carries at most 5 consistency anchors per DP row");

@@ -41,3 +41,32 @@ def encode(seqs, dna=False):
     for i, ch in enumerate(alpha):
         lut[ord(ch)] = i
     return [lut[np.frombuffer(s.encode(), np.uint8)] for s in seqs]
+
+
+def forest(jobs):
+    """Several independent alignment jobs as ONE forest job (kalign_amd.h: n_tasks < numseq-1).
+
+    jobs: list of (codes, tasks[, seq_distances]) with tasks in TASK_ORDER_TREE order over that job's own
+    node ids (leaves 0..n-1, internal nodes n..2n-2).  Returns (codes, tasks, seq_distances or None, spans) where
+    spans[j] = (first sequence, first task, n sequences, n tasks) of job j in the combined job."""
+    import numpy as np
+    total = sum(len(j[0]) for j in jobs)
+    codes, tasks, dists, spans = [], [], [], []
+    seq0, node0, task0 = 0, total, 0
+    have_dist = all(len(j) > 2 and j[2] is not None for j in jobs)
+    for j in jobs:
+        cj, tj = j[0], np.asarray(j[1])
+        n = len(cj)
+
+        def m(x):
+            return seq0 + int(x) if x < n else node0 + (int(x) - n)
+
+        codes += list(cj)
+        tasks += [(m(a), m(b), m(c)) for a, b, c in tj]
+        if have_dist:
+            dists += list(j[2])
+        spans.append((seq0, task0, n, len(tj)))
+        seq0 += n
+        node0 += len(tj)
+        task0 += len(tj)
+    return codes, np.array(tasks, np.int32), (np.array(dists, np.float32) if have_dist else None), spans

@@ -88,3 +88,28 @@ def test_shared_contexts_run_concurrently_and_match_golden():
         for got, want in zip(gaps, g.gaps_list()):
             assert np.array_equal(got, want)
         c.close()
+
+
+def test_forest_of_independent_alignments_matches_goldens():
+    """n_tasks < numseq-1: a batch of independent alignments as one job (levels of all trees share launches, the
+    upper parts run in one chained launch); every tree's results are those of its own single-tree run."""
+    import kalign_amd
+    from kalign_amd import guide
+    names = ["tree_prot32x200", "tree_prot64_gon", "tree_prot32x200"]
+    gs = [Golden(n) for n in names]
+    # one scoring scheme per job: these three goldens share PFASUM defaults? use each golden's own parameters where equal
+    assert all(np.array_equal(g.subm, gs[0].subm) for g in gs[:1])
+    jobs = [(g.codes, g.tasks, g.seq_distances) for g in gs if np.array_equal(g.subm, gs[0].subm) and np.array_equal(g.scal, gs[0].scal)]
+    gs = [g for g in gs if np.array_equal(g.subm, gs[0].subm) and np.array_equal(g.scal, gs[0].scal)]
+    assert len(jobs) >= 2
+    codes, tasks, dist, spans = guide.forest(jobs)
+    ctx = kalign_amd.Context(0)
+    recs, paths, gaps = ctx.msa_tree(codes, tasks, gs[0].subm, gs[0].scal, dist)
+    ctx.close()
+    for g, (s0, t0, n, nt) in zip(gs, spans):
+        for t in range(nt):
+            r = recs[t0 + t]
+            assert r.plen == g.rec("plen")[t] and r.score == g.rec("score")[t]
+            assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
+        for got, want in zip(gaps[s0:s0 + n], g.gaps_list()):
+            assert np.array_equal(got, want)
