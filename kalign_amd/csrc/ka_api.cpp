@@ -472,11 +472,12 @@ static KaTreeDev tree_dev(ka_ctx* c)
 static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out)
 {
         const int nt = (int)L.size();
-        int lean = 1;
+        int lean = 1;                                    // launch kind: 0 = 8 waves, 1 = lean, 2 = half
         for (int t : L) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) lean = 0;
         if (getenv("KA_NO_LEAN")) lean = 0;
+        if (!lean && nt > c->n_cus && !getenv("KA_NO_HALF")) lean = 2;   // more tasks than CUs: two 4-wave workgroups per CU
         int G = 1;
-        while (!lean && G * 2 <= c->max_cluster && nt * G * 2 <= c->n_cus) G *= 2;
+        while (lean == 0 && G * 2 <= c->max_cluster && nt * G * 2 <= c->n_cus) G *= 2;
         const int groups = (nt + 7) / 8;
         tbl.assign((size_t)groups * 8 * G, make_int2(-1, 0));
         for (int j = 0; j < nt; j++)

@@ -1022,6 +1022,8 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 #define KA_LDS_WAVES 4096                                           // per-wave regions: 2048-B aligned (ring addressing ORs the column offset in)
 static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table overlaps the wave regions");
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
+#define KA_HALF_BLOCK 256
+#define KA_LDS_HALF (KA_LDS_WAVES + (KA_HALF_BLOCK / 64) * KA_WAVE_LDS)   // 4 rings: two workgroups per CU
 #define KA_LDS_PAIR (KA_LDS_WAVES + (2 * KA_PAIR_BLOCK + 16) * 4)   // seq-seq: only the path-coding scratch follows the table
 #define KA_LDS_LEAN (KA_LDS_WAVES + (2 * KA_LEAN_BLOCK + 16) * 4)
 static_assert(sizeof(TaskShared) <= KA_LDS_DBG, "TaskShared outgrew its LDS slot");
@@ -1189,7 +1191,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         // of every DP row (the first one); the barrier below publishes them
         if (NB) {
                 __syncthreads();
-                ka_cons_votes<LEAN>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_WAVES * KA_WAVE_LDS);
+                ka_cons_votes<LEAN>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_NW * KA_WAVE_LDS);
                 ka_cluster_sync(S);
                 if (S.member == 0) ka_cons_entries(S, D);
         }
@@ -1352,6 +1354,20 @@ __global__ __launch_bounds__(KA_LEAN_BLOCK, 4) void ka_task_kernel_lean(const Ka
         ka_task_entry<true, 0>(D, blocks, 0);
 }
 
+// Throughput variant for levels with more tasks than CUs (big trees, forests): 4 waves, 4 rings -> TWO workgroups per
+// CU.  The four strip waves of one task keep a CU's SIMDs busy only part of the time (pipeline fill and drain, deep
+// recursion levels, meetups); a second resident task fills the holes.  Latency per task is no better -- levels
+// with at most one task per CU use the 8-wave kernel.
+__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<false, 0>(D, blocks, 0);
+}
+
+__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<false, KA_NB>(D, blocks, 0);
+}
+
 // the same two with the anchor-consistency bonus (default mode of the reference's CLI)
 __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
@@ -1422,20 +1438,27 @@ static hipError_t ka_lds_optin()
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)ka_task_kernel_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ka_task_kernel_half, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_HALF);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)ka_task_kernel_half_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_HALF);
+        if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)ka_task_kernel_lean_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
         if (e != hipSuccess) return e;
         done = true;
         return hipSuccess;
 }
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream)
+// kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
+extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
 {
         if (ka_lds_optin() != hipSuccess) return;
         if (D->cons_K > 0) {
-                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+                if (kind == 1) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+                else if (kind == 2) hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
                 else hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
         } else {
-                if (lean) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev, 0);
+                if (kind == 1) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev, 0);
+                else if (kind == 2) hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
                 else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
         }
 }

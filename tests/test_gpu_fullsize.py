@@ -118,8 +118,11 @@ def test_error_behaviour():
         ctx.msa_tree([a, a, a], np.array([[3, 2, 4], [0, 1, 3]], np.int32), subm, scal)
     with pytest.raises(kalign_amd.KalignAmdError):          # code outside the alphabet
         ctx.msa_tree([a, (a + 30).astype(np.uint8)], np.array([[0, 1, 2]], np.int32), subm, scal)
-    with pytest.raises(kalign_amd.KalignAmdError):          # wrong task count
-        ctx.msa_tree([a, a, a], np.array([[0, 1, 3]], np.int32), subm, scal)
+    with pytest.raises(kalign_amd.KalignAmdError):          # more tasks than a tree over 3 sequences can have
+        ctx.msa_tree([a, a, a], np.array([[0, 1, 3], [3, 2, 4], [4, 0, 5]], np.int32), subm, scal)
+    # fewer tasks than numseq-1 is a forest (here: one pair plus a sequence that stays alone)
+    recs, paths, gaps = ctx.msa_tree([a, a, a], np.array([[0, 1, 3]], np.int32), subm, scal)
+    assert recs[0].plen == 5 and all(int(g.sum()) == 0 for g in gaps)
     ctx.close()
 
 
