@@ -111,11 +111,14 @@ struct KaBonus {
 #pragma unroll
                 for (int e = 0; e < NB; ++e) { const int2 x = ent[(long long)row * NB + e]; col[e] = x.x; val[e] = __int_as_float(x.y); }
         }
+        // EDGE = false: the wrap-around entry (slot NB-1, column Lb) is left out -- it can only match in the last column
+        // of a pass, which steady-state steps never are
+        template <bool EDGE>
         __device__ __forceinline__ float at(int j) const
         {
                 float b = 0.0f;
 #pragma unroll
-                for (int e = 0; e < NB; ++e) b = (col[e] == j) ? val[e] : b;
+                for (int e = 0; e < (EDGE ? NB : NB - 1); ++e) b = (col[e] == j) ? val[e] : b;
                 return b;
         }
 };
@@ -396,11 +399,11 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 if (KIND == KA_SS) {
                         acc.x += scA_cur;
                         acc.y += scB_cur;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
                 } else if (KIND == KA_SP) {
                         acc.x += scA_cur;
                         acc.y += scB_cur;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
                 } else {
                         // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
                         // v_pk_add of the chain instead of an s_nop
@@ -419,7 +422,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 prod = nprod;
                         }
                         acc = acc + prod;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
                         // Fetch the next step's column record into the other half of q.  The loads must
                         // stay AFTER the dot products: placed above them, the s_waitcnt for this step's
                         // half (loaded one step ago) also waits for the fresh loads and exposes the whole
@@ -754,7 +757,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                                 acc = acc + p1v[c] * w;
                         }
                 }
-                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.at(jb); acc.y += bonB.at(jb); }
+                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<true>(jb); acc.y += bonB.template at<true>(jb); }
                 const bool at0 = (v == 0), atN = (v == ncols);
                 const bool edge = at0 || atN;
                 const bool term = (at0 && near_t) || (atN && far_t);
