@@ -79,7 +79,7 @@ int  ka_ctx_set_stream(ka_ctx* ctx, void* hip_stream);
    a single tree, safe under any co-scheduling.  Takes effect at the next ka_tree_upload. */
 int  ka_ctx_set_shared(ka_ctx* ctx, int shared);
 const char* ka_last_error(void);
-/* number of exported entry points, for the "library loads" test */
+/* ABI revision of this header (bumped when entry points are added) */
 int  ka_abi_version(void);
 
 /*

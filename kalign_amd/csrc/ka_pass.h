@@ -51,17 +51,11 @@ __device__ __forceinline__ int wave_shr1_i(int x)
 // lane l <- lane l-1 of src; lane 0 keeps its own `old` (used to splice the boundary state in)
 __device__ __forceinline__ float wave_shr1_old(float old, float src)
 {
-#if defined(KA_EXP) && (KA_EXP & 4)
-        return old + src;
-#endif
         return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x138, 0xf, 0xf, false));
 }
 // lane l <- lane l+1 of src; lane 63 keeps its own `old` (shift register fed at the top lane)
 __device__ __forceinline__ float wave_shl1_old(float old, float src)
 {
-#if defined(KA_EXP) && (KA_EXP & 4)
-        return old + src;
-#endif
         return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), 0x130, 0xf, 0xf, false));
 }
 // (e, e) of a float4 as a shuffle: selects straight into the op_sel broadcast of v_pk_mul_f32 (built from a scalar
@@ -86,17 +80,11 @@ __device__ __forceinline__ float2v ka_mul_bcast(const float2v a, const float4v& 
 // rotate: lane l <- lane (l+1) mod 64
 __device__ __forceinline__ float wave_rol1(float x)
 {
-#if defined(KA_EXP) && (KA_EXP & 4)
-        return x + 1.0f;
-#endif
         // a rotation writes every lane: no `old` operand (which would be tied to the destination and cost a copy
         // whenever the source stays live)
         return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x134, 0xf, 0xf, true));
 }
 
-#ifndef KA_EXP
-#define KA_EXP 0      // timing experiments only (scratch builds): 1 no dot chain, 2 no ring reads, 4 no DPP
-#endif
 __device__ __forceinline__ int ka_strips_of(int nrows) { return nrows <= 0 ? 1 : (nrows + KA_STRIP_ROWS - 1) / KA_STRIP_ROWS; }
 
 // NB > 0: anchor-consistency build -- every DP row carries NB (column, value) bonus entries with distinct
@@ -319,7 +307,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
                 if (KIND == KA_PP) {
-                        if (!(KA_EXP & 2)) ring_wait(q[P]);           // this step's column record (issued one step ago)
+                        ring_wait(q[P]);                              // this step's column record (issued one step ago)
                         copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
                         copen = kc_open; cext = kc_ext; ctext = kc_text;
@@ -410,7 +398,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         float2v prod;
                         prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
 #pragma unroll
-                        for (int c = ((KA_EXP & 1) ? 2 : NRES - 1); c >= 1; --c) {
+                        for (int c = NRES - 1; c >= 1; --c) {
                                 float2v nprod;
                                 switch ((c - 1) & 3) {                  // (compile-time after unrolling)
                                 case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
@@ -434,7 +422,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
                                 ring_issue((tn >> 5) + 1);
                         }
-                        if (!(KA_EXP & 2)) ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
+                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
                         __builtin_amdgcn_sched_barrier(0);
                 }
                 float nAa, nAga, nAgb, nBa, nBga, nBgb;
