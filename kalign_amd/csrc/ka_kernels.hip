@@ -622,30 +622,38 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
                 nops += g + 1;
                 nb += g + (cur != -1 ? 1 : 0);
         }
-        tot_ops[tid] = nops; tot_b[tid] = nb;
+        // exclusive prefix sums of (ops, b positions) over the threads: wave scan + one pass over the wave totals
+        const int lane_ = tid & 63, wave_ = tid >> 6;
+        int sc_ops = nops, sc_b = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+                const int y1 = __shfl_up(sc_ops, d, 64), y2 = __shfl_up(sc_b, d, 64);
+                if (lane_ >= d) { sc_ops += y1; sc_b += y2; }
+        }
+        if (lane_ == 63) { tot_ops[wave_] = sc_ops; tot_b[wave_] = sc_b; }
         if (tid == 0) { *zmin = 0x7fffffff; *zmax = 0; }
         __syncthreads();
-        int off = 0, offb = 0, all_ops = 0;
-        for (int k = 0; k < KA_NT; ++k) {
-                const int a = tot_ops[k];
-                if (k < tid) { off += a; offb += tot_b[k]; }
-                all_ops += a;
+        int off = sc_ops - nops, offb = sc_b - nb, all_ops = 0, total_b = 0;
+        for (int k = 0; k < KA_NW; ++k) {
+                const int a = tot_ops[k], b2 = tot_b[k];
+                if (k < wave_) { off += a; offb += b2; }
+                all_ops += a; total_b += b2;
         }
         // trailing gap-in-a run (aln_setup.c:180-186)
         const int last = raw[len_a];
         const int tail = (last != -1 && last < len_b) ? (len_b - last) : 0;
         const int alnlen = all_ops + tail;
-        int total_b = 0;
-        for (int k = 0; k < KA_NT; ++k) total_b += tot_b[k];
+        int my_zmin = 0x7fffffff, my_zmax = 0;
         int j = 1 + off, rb = 1 + offb;
         for (int i = lo; i < hi; ++i) {
                 const int cur = raw[i], prev = (i > 1) ? raw[i - 1] : -1;
                 const int g = row_gaps(i, cur, prev);
                 for (int k = 0; k < g; ++k) { o[j] = 1; S.srcA[j] = -1; S.srcB[j] = rb++; ++j; }
                 if (cur == -1) { o[j] = 2; S.srcA[j] = i; S.srcB[j] = -1; }
-                else { o[j] = 0; S.srcA[j] = i; S.srcB[j] = rb++; atomicMin(zmin, j); atomicMax(zmax, j); }
+                else { o[j] = 0; S.srcA[j] = i; S.srcB[j] = rb++; my_zmin = min(my_zmin, j); my_zmax = max(my_zmax, j); }
                 ++j;
         }
+        if (my_zmax > 0) { atomicMin(zmin, my_zmin); atomicMax(zmax, my_zmax); }
         for (int k = tid; k < tail; k += KA_NT) { o[1 + all_ops + k] = 1; S.srcA[1 + all_ops + k] = -1; S.srcB[1 + all_ops + k] = 1 + total_b + k; }
         if (tid == 0) { o[0] = alnlen; o[alnlen + 1] = 3; S.ctl->alnlen = alnlen; }
         __syncthreads();
