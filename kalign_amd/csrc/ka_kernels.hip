@@ -758,6 +758,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 return val;
         };
         const long long total4 = (long long)(alnlen + 2) * 16;
+        const float gpe_a = D.gpe0 * sipa, gpe_b = D.gpe0 * sipb, tgpe_a = D.tgpe0 * sipa, tgpe_b = D.tgpe0 * sipb;
         for (long long x4 = (long long)S.member * KA_NT + threadIdx.x; x4 < total4; x4 += (long long)S.G * KA_NT) {
                 const int c = (int)(x4 >> 4);
                 const int k4 = (int)(x4 & 15) << 2;
@@ -773,10 +774,35 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                         rb = pb_r + ((long long)(ib < 0 ? 0 : ib) << 6);
                 }
                 float4v out;
-                out.x = elem(c, k4 + 0, code, ra, rb);
-                out.y = elem(c, k4 + 1, code, ra, rb);
-                out.z = elem(c, k4 + 2, code, ra, rb);
-                out.w = elem(c, k4 + 3, code, ra, rb);
+                if (!rebalance && !(code & 20)) {
+                        // The common case (no sequence weights; the coded path carries only the flags the reference
+                        // really sets), four fields at a time -- same operations as elem() below, without the per-field
+                        // branching: a match / boundary column is the sum of the two records, a gap column the present
+                        // side with its gap counter bumped and the scores lowered by (t)gpe * members of the absent side.
+                        float4v A = *(const float4v*)(ra + k4), B = *(const float4v*)(rb + k4);
+                        if (k4 == 24) {                                  // field 27 (see fa / fb)
+                                A.w = leaf_a ? 0.0f : ra[55] * sipb; B.w = leaf_b ? 0.0f : rb[55] * sipa;
+                        } else if (k4 == 28) {                           // fields 28, 29
+                                A.x = leaf_a ? 0.0f : ra[56] * sipb; A.y = leaf_a ? 0.0f : ra[57] * sipb;
+                                B.x = leaf_b ? 0.0f : rb[56] * sipa; B.y = leaf_b ? 0.0f : rb[57] * sipa;
+                        }
+                        if (c == 0 || c == alnlen + 1 || !code) {
+                                out = A + B;
+                        } else {
+                                const bool gap_in_a = (code & 1) != 0, term = (code & 32) != 0;
+                                const float sip = gap_in_a ? sipa : sipb;
+                                const float g = term ? (gap_in_a ? tgpe_a : tgpe_b) : (gap_in_a ? gpe_a : gpe_b);
+                                out = gap_in_a ? B : A;
+                                if (k4 == 24) { if (term) out.y += sip; else out.x += sip; }        // [25] / [24]
+                                else if (k4 >= 32 && k4 < 52) { out.x -= g; out.y -= g; out.z -= g; out.w -= g; }
+                                else if (k4 == 52) { out.x -= g; out.y -= g; out.z -= g; }           // [55] is not a score
+                        }
+                } else {
+                        out.x = elem(c, k4 + 0, code, ra, rb);
+                        out.y = elem(c, k4 + 1, code, ra, rb);
+                        out.z = elem(c, k4 + 2, code, ra, rb);
+                        out.w = elem(c, k4 + 3, code, ra, rb);
+                }
                 *(float4v*)(np_r + (x4 << 2)) = out;
         }
 }
