@@ -201,6 +201,88 @@ static float mean_distance(const float* dist, const std::vector<int>& ma, const 
         return n ? sum / (float)n : 0.0f;
 }
 
+// Launch plan of the uploaded job: parents and join counts of the chained launch, workgroup tables per level.
+// Depends on c->shared_gpu (no clusters, no chain), so ka_tree_sync can re-plan after a residency failure.
+static int plan_launches(ka_ctx* c)
+{
+        const int numseq = c->numseq, n_tasks = c->n_tasks;
+        const int* abc = c->abc.data();
+        const int max_level = (int)c->levels.size();
+        // ---- parents, and the level from which the rest of the tree runs as ONE chained launch: the first
+        // non-leaf level with at most one task per CU (all its workgroups resident at once; levels only get
+        // narrower above it).  KA_NO_CHAIN=1 keeps one launch per level.
+        {
+                std::vector<int> task_of((2 * numseq - 1), -1);
+                for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
+                for (int t = 0; t < n_tasks; t++) { c->descs[t].parent = -1; c->descs[t].chain_need = 0; }
+                for (int t = 0; t < n_tasks; t++) {
+                        const int a = abc[3 * t], b = abc[3 * t + 1];
+                        if (a >= numseq) c->descs[task_of[a]].parent = t;
+                        if (b >= numseq) c->descs[task_of[b]].parent = t;
+                }
+                for (int t = 0; t < n_tasks; t++) c->descs[t].is_root = (c->descs[t].parent < 0);
+                c->n_trees = numseq - n_tasks;
+                c->chain_level = -1;
+                if (!getenv("KA_NO_CHAIN") && !c->shared_gpu) {
+                        for (int L = 0; L + 1 < max_level; L++) {
+                                bool all_ss = true;
+                                for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
+                                if (!all_ss && (int)c->levels[L].size() <= c->n_cus - 8) { c->chain_level = L; break; }   // one workgroup per CU, all resident
+                        }
+                }
+                if (c->chain_level >= 0) {
+                        for (int t = 0; t < n_tasks; t++) {
+                                if (c->task_level[t] <= c->chain_level) continue;
+                                int need = 0;
+                                for (int k = 0; k < 2; k++) {
+                                        const int ch = abc[3 * t + k];
+                                        if (ch >= numseq && c->task_level[task_of[ch]] >= c->chain_level) need++;
+                                }
+                                c->descs[t].chain_need = need;
+                        }
+                }
+        }
+
+        // ---- workgroup tables, one per dependency level (build_blocks) ----
+        if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
+        if (c->shared_gpu) c->max_cluster = 1;
+        c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
+        for (auto& L : c->levels) {
+                std::vector<int2> tbl;
+                int lean = 0;
+                build_blocks(c, L, tbl, &lean);
+                c->level_lean.push_back(lean);
+                c->blocks_flat.insert(c->blocks_flat.end(), tbl.begin(), tbl.end());
+                c->blocks_off.push_back((int)c->blocks_flat.size());
+        }
+
+        if (c->chain_level >= 0) {
+                // Every task of the chain's first level starts on a single workgroup; clusters form on the way up.
+                // Entries are laid out in depth-first order of the upper tree, one contiguous run per XCD
+                // (block b runs on XCD b % 8 -- observed, not contractual): subtrees that merge early share an
+                // L2, only the top three levels cross XCDs.
+                std::vector<int> task_of((2 * numseq - 1), -1), order;
+                for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
+                std::vector<int> stack;
+                for (int t = n_tasks - 1; t >= 0; t--) if (c->descs[t].parent < 0 && c->task_level[t] >= c->chain_level) stack.push_back(t);   // every root above the cut
+                while (!stack.empty()) {
+                        const int t = stack.back(); stack.pop_back();
+                        if (c->task_level[t] == c->chain_level) { order.push_back(t); continue; }
+                        for (int k = 1; k >= 0; k--) {
+                                const int ch = abc[3 * t + k];
+                                if (ch >= numseq && c->task_level[task_of[ch]] >= c->chain_level) stack.push_back(task_of[ch]);
+                        }
+                }
+                const int m = ((int)order.size() + 7) / 8;
+                c->chain_blocks.assign((size_t)8 * m, make_int2(-1, 0));
+                for (int r = 0; r < (int)order.size(); r++) c->chain_blocks[(size_t)(r % m) * 8 + (r / m)] = make_int2(order[r], 0 | (1 << 8));
+                c->chain_blocks_off = (int)c->blocks_flat.size();
+                c->blocks_flat.insert(c->blocks_flat.end(), c->chain_blocks.begin(), c->chain_blocks.end());
+        }
+
+        return KA_OK;
+}
+
 extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const int* off, const int* lens,
                               const float* seq_distances, int n_tasks, const int* abc,
                               const float* subm, const float* scal, int flags)
@@ -296,79 +378,9 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 c->level_off.push_back((int)c->level_ids_flat.size());
         }
 
-        // ---- parents, and the level from which the rest of the tree runs as ONE chained launch: the first
-        // non-leaf level with at most one task per CU (all its workgroups resident at once; levels only get
-        // narrower above it).  KA_NO_CHAIN=1 keeps one launch per level.
-        {
-                std::vector<int> task_of(nprof, -1);
-                for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
-                for (int t = 0; t < n_tasks; t++) { c->descs[t].parent = -1; c->descs[t].chain_need = 0; }
-                for (int t = 0; t < n_tasks; t++) {
-                        const int a = abc[3 * t], b = abc[3 * t + 1];
-                        if (a >= numseq) c->descs[task_of[a]].parent = t;
-                        if (b >= numseq) c->descs[task_of[b]].parent = t;
-                }
-                for (int t = 0; t < n_tasks; t++) c->descs[t].is_root = (c->descs[t].parent < 0);
-                c->n_trees = numseq - n_tasks;
-                c->chain_level = -1;
-                if (!getenv("KA_NO_CHAIN") && !c->shared_gpu) {
-                        for (int L = 0; L + 1 < max_level; L++) {
-                                bool all_ss = true;
-                                for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
-                                if (!all_ss && (int)c->levels[L].size() <= c->n_cus - 8) { c->chain_level = L; break; }   // one workgroup per CU, all resident
-                        }
-                }
-                if (c->chain_level >= 0) {
-                        for (int t = 0; t < n_tasks; t++) {
-                                if (level[abc[3 * t + 2]] - 1 <= c->chain_level) continue;
-                                int need = 0;
-                                for (int k = 0; k < 2; k++) {
-                                        const int ch = abc[3 * t + k];
-                                        if (ch >= numseq && level[ch] - 1 >= c->chain_level) need++;
-                                }
-                                c->descs[t].chain_need = need;
-                        }
-                }
-        }
-
-        // ---- workgroup tables, one per dependency level (build_blocks) ----
-        if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
-        if (c->shared_gpu) c->max_cluster = 1;
-        c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
         c->task_level.assign(n_tasks, 0);
         for (int t = 0; t < n_tasks; t++) c->task_level[t] = level[abc[3 * t + 2]] - 1;
-        for (auto& L : c->levels) {
-                std::vector<int2> tbl;
-                int lean = 0;
-                build_blocks(c, L, tbl, &lean);
-                c->level_lean.push_back(lean);
-                c->blocks_flat.insert(c->blocks_flat.end(), tbl.begin(), tbl.end());
-                c->blocks_off.push_back((int)c->blocks_flat.size());
-        }
-
-        if (c->chain_level >= 0) {
-                // Every task of the chain's first level starts on a single workgroup; clusters form on the way up.
-                // Entries are laid out in depth-first order of the upper tree, one contiguous run per XCD
-                // (block b runs on XCD b % 8 -- observed, not contractual): subtrees that merge early share an
-                // L2, only the top three levels cross XCDs.
-                std::vector<int> task_of(nprof, -1), order;
-                for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
-                std::vector<int> stack;
-                for (int t = n_tasks - 1; t >= 0; t--) if (c->descs[t].parent < 0 && c->task_level[t] >= c->chain_level) stack.push_back(t);   // every root above the cut
-                while (!stack.empty()) {
-                        const int t = stack.back(); stack.pop_back();
-                        if (c->task_level[t] == c->chain_level) { order.push_back(t); continue; }
-                        for (int k = 1; k >= 0; k--) {
-                                const int ch = abc[3 * t + k];
-                                if (ch >= numseq && c->task_level[task_of[ch]] >= c->chain_level) stack.push_back(task_of[ch]);
-                        }
-                }
-                const int m = ((int)order.size() + 7) / 8;
-                c->chain_blocks.assign((size_t)8 * m, make_int2(-1, 0));
-                for (int r = 0; r < (int)order.size(); r++) c->chain_blocks[(size_t)(r % m) * 8 + (r / m)] = make_int2(order[r], 0 | (1 << 8));
-                c->chain_blocks_off = (int)c->blocks_flat.size();
-                c->blocks_flat.insert(c->blocks_flat.end(), c->chain_blocks.begin(), c->chain_blocks.end());
-        }
+        if (plan_launches(c)) return KA_FAIL;
 
         // ---- arenas ----
         c->leaf_prof_off.assign(numseq, 0);
@@ -413,6 +425,16 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_job = true;
         if ((flags & KA_FLAG_DEVICE_GAPS) && setup_colof(c)) { c->have_job = false; return KA_FAIL; }
+        return KA_OK;
+}
+
+// (re)upload the launch plan: task descriptors (parents, join counts) and workgroup tables
+static int upload_plan(ka_ctx* c)
+{
+        if (c->d_blocks.alloc(c->blocks_flat.size())) return fail("hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(c->d_tasks.p, c->descs.data(), sizeof(KaTaskDesc) * c->n_tasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_blocks.p, c->blocks_flat.data(), sizeof(int2) * c->blocks_flat.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
         return KA_OK;
 }
 
@@ -536,7 +558,15 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         return KA_OK;
                 }
                 if (err == 5) return fail("device watchdog: a strip pipeline stopped making progress");
-                if (err == 6) return fail("device watchdog: a cluster barrier was never completed (workgroups of one task not co-resident?)");
+                if (err == 6) {
+                        // workgroups that wait for each other were not all resident: somebody else is using the GPU.
+                        // Fall back to the plan that needs no co-residency (ka_ctx_set_shared) and run again.
+                        if (c->shared_gpu || c->partial) return fail("device watchdog: a wait between workgroups never completed");
+                        c->shared_gpu = true;
+                        if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
+                        if (tree_launch(c)) return KA_FAIL;
+                        continue;
+                }
                 if (err == 7) return fail("consistency: a profile is too long for the LDS vote table");
                 if (c->partial) return fail("a device arena overflowed during a partial run (ka_tree_run_tasks does not re-run)");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)

@@ -1361,7 +1361,7 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
                                 int spins = 0;
                                 while (__hip_atomic_load(&J->go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                                         __builtin_amdgcn_s_sleep(32);
-                                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 24, 6, true)) break;
+                                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 21, 6, true)) break;   // ~2 s: then the host re-plans without joins
                                 }
                                 nm = __hip_atomic_load(&J->join_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + S.member;
                                 ng = __hip_atomic_load(&J->join_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

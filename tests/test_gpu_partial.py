@@ -113,3 +113,32 @@ def test_forest_of_independent_alignments_matches_goldens():
             assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
         for got, want in zip(gaps[s0:s0 + n], g.gaps_list()):
             assert np.array_equal(got, want)
+
+
+def test_unshared_contexts_in_flight_together_fall_back():
+    """Two contexts that did NOT declare the GPU shared run their chained launches at the same time: together they
+    want more resident workgroups than there are CUs.  Whether the joins of one of them starve depends on how the
+    dispatcher interleaves the two kernels; if they do, the bounded waits report it and ka_tree_sync re-plans
+    without joins / clusters (what ka_ctx_set_shared would have chosen) and runs again.  Either way: the
+    reference's result, never a hang."""
+    import torch
+    import bench
+    import kalign_amd
+    codes, tasks, dist = bench.make_workload(1024, 400, False, 1)
+    subm, scal = bench.scoring(False)
+    ref = kalign_amd.Context(0)
+    want_recs, want_paths, want_gaps = ref.msa_tree(codes, tasks, subm, scal, dist)
+    ref.close()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    ctxs = [kalign_amd.Context(0, stream=s.cuda_stream) for s in streams]
+    for c in ctxs:
+        c.tree_upload(codes, tasks, subm, scal, dist)
+    for _ in range(3):
+        for c in ctxs:
+            c.tree_run()
+    for c in ctxs:
+        recs, paths, gaps = c.tree_download()
+        assert all(r.plen == w.plen for r, w in zip(recs, want_recs))
+        for got, want in zip(gaps, want_gaps):
+            assert np.array_equal(got, want)
+        c.close()
