@@ -240,6 +240,9 @@ static int plan_launches(ka_ctx* c)
                                 }
                                 c->descs[t].chain_need = need;
                         }
+                        // tests: make the last join wait for a workgroup that never comes (a residency failure as seen
+                        // from the device) -- the bounded wait must report it and ka_tree_sync must re-plan and re-run
+                        if (getenv("KA_TEST_STARVE")) c->descs[n_tasks - 1].chain_need += 1;
                 }
         }
 

@@ -142,3 +142,19 @@ def test_arena_overflow_grows_and_reruns(monkeypatch):
         assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
     for got, want in zip(gaps, g.gaps_list()):
         assert np.array_equal(got, want)
+
+
+def test_starved_join_is_reported_and_the_run_replanned(monkeypatch):
+    """A join of the chained launch whose sibling never arrives (what a non-resident workgroup looks like from the
+    device): the wait is bounded (~2 s), the run is re-planned without joins / clusters and repeated."""
+    import kalign_amd
+    from util import Golden
+    monkeypatch.setenv("KA_TEST_STARVE", "1")
+    g = Golden("tree_prot64_gon")
+    ctx = kalign_amd.Context(0)
+    recs, paths, gaps = ctx.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    ctx.close()
+    for t, r in enumerate(recs):
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
