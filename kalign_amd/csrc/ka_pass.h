@@ -42,6 +42,8 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* ka_lds_ptr;
 typedef const __attribute__((address_space(1))) void* ka_glb_ptr;
 typedef __attribute__((address_space(1))) float ka_gfloat;
+typedef const __attribute__((address_space(1))) float4v ka_gfloat4c;          // global (not flat) loads: a flat load counts on
+typedef const __attribute__((address_space(1))) unsigned char ka_gbytec;       // lgkmcnt too and is caught by every LDS wait
 
 __device__ __forceinline__ int wave_shr1_i(int x)
 {
@@ -282,7 +284,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // step t+1 are prepared (the LDS latency of the look-up and, every 64 steps, the L2 latency
                 // of the residue batch would otherwise sit in every step of a lone wave).  resn = batch of
                 // columns 64m+1+lane, fetched 64 steps before it is rotated in.
-                resn = S.s2[REC(min(1 + lane, ncols)) - 1];
+                resn = ((ka_gbytec*)S.s2)[REC(min(1 + lane, ncols)) - 1];
                 if (KIND == KA_SS) { scA = tss[res1A]; scB = tss[res1B]; }        // step 0: no lane is at a real column yet
                 else { scA = sp_tbl[(2 * lane) * KA_SP_STRIDE]; scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE]; }
         }
@@ -317,7 +319,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         // prepare step t+1: lane 0 takes column t+1 from the batch, lanes > 0 their upper neighbour's residue
                         if (EV && (t & 63) == 0) {
                                 resb = resn;
-                                resn = S.s2[REC(min(t + 65 + lane, ncols)) - 1];
+                                resn = ((ka_gbytec*)S.s2)[REC(min(t + 65 + lane, ncols)) - 1];
                         } else {
                                 resb = __builtin_amdgcn_update_dpp(resb, resb, 0x134, 0xf, 0xf, false);   // wave_rol:1
                         }
@@ -668,7 +670,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 staged = total <= KA_RING_SLOTS * KA_RING_BATCH;      // 128 records (wave-uniform)
                 if (staged) {
                         for (int vv = ls; vv < cnt; vv += SLOT) {
-                                const float4v* g = (const float4v*)(S.p2 + ((long long)REC(vv) << 6) + 32);
+                                ka_gfloat4c* g = (ka_gfloat4c*)(S.p2 + ((long long)REC(vv) << 6) + 32);
                                 char* dst = wlds + (lds_base + vv) * 16;
 #pragma unroll
                                 for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) *(float4v*)(dst + ch * 2048) = g[ch];
@@ -678,25 +680,28 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                         __builtin_amdgcn_s_waitcnt(0);
                 }
         }
-        auto fetch = [&](float4v* dstq, int& dstres, int vcol) {
+        // (STG is a template tag, not a run-time test: with both sources in one step the loaded values meet in a phi
+        // and the compiler waits for the global loads right where they are issued -- no prefetch at all)
+        auto fetch = [&](float4v* dstq, int& dstres, int vcol, auto stg_tag) {
+                constexpr bool STG = decltype(stg_tag)::value;
                 // column operand for column counter vcol (clamped)
                 const int vv = min(max(vcol, 0), ncols);
                 if (KIND == KA_PP) {
-                        if (staged) {
+                        if (STG) {
                                 const char* src = wlds + (lds_base + vv) * 16;
 #pragma unroll
                                 for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = *(const float4v*)(src + ch * 2048);
                         } else {
-                                const float4v* g = (const float4v*)(S.p2 + ((long long)REC(vv) << 6) + 32);
+                                ka_gfloat4c* g = (ka_gfloat4c*)(S.p2 + ((long long)REC(vv) << 6) + 32);
 #pragma unroll
                                 for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = g[ch];
                         }
                 } else {
-                        dstres = S.s2[min(max(REC(max(vv, 1)) - 1, 0), S.Lb - 1)];
+                        dstres = ((ka_gbytec*)S.s2)[min(max(REC(max(vv, 1)) - 1, 0), S.Lb - 1)];
                 }
         };
-        fetch(q[0], resq[0], -ls);
-        if (KIND != KA_PP) { fetch(q[0], resq[1], 1 - ls); fetch(q[0], resq[2], 2 - ls); }
+        if (staged) fetch(q[0], resq[0], -ls, std::true_type()); else fetch(q[0], resq[0], -ls, std::false_type());
+        if (KIND != KA_PP) { fetch(q[0], resq[1], 1 - ls, std::false_type()); fetch(q[0], resq[2], 2 - ls, std::false_type()); }
 
         int nsteps = live ? (ncols + max(nl, 1)) : 0;
 #pragma unroll
@@ -704,26 +709,27 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
 
         // P4 = t mod 4: register-ring slot of this step's residue (sequence columns, fetched 3 steps ahead);
         // profile columns ping-pong between the two halves of q
-        auto step = [&](const int t, auto par_tag) {
+        auto step = [&](const int t, auto par_tag, auto stg_tag) {
                 constexpr int P4 = decltype(par_tag)::value;
                 constexpr int P = P4 & 1;
                 const int v = t - ls;
                 const bool vin = live && (v >= 0) && (v <= ncols);
-                if (KIND == KA_PP) fetch(q[1 - P], resq[0], v + 1);
-                else fetch(q[0], resq[(P4 + 3) & 3], v + 3);
+                if (KIND == KA_PP) fetch(q[1 - P], resq[0], v + 1, stg_tag);
+                else fetch(q[0], resq[(P4 + 3) & 3], v + 3, stg_tag);
 
                 float copen, cext, ctext;
                 if (KIND == KA_PP) { copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2; }
                 else { copen = kc_open; cext = kc_ext; ctext = kc_text; }
 
                 // "row -1" of the pass, generated by the slot's first lane (v == t there)
-                if (v == 0) {
-                        inia = inj_a; iniga = inj_ga; inigb = inj_gb;
-                } else if (v < ncols) {
-                        const float g = near_t ? kmax(iniga, inia) + ctext : kmax(iniga + cext, inia + copen);
-                        inia = -KA_F; iniga = g; inigb = -KA_F;
-                } else {
-                        inia = -KA_F; iniga = -KA_F; inigb = -KA_F;
+                // (selects, not branches: the three cases differ per lane; max(x, y) + c == max(x + c, y + c) bit for bit)
+                {
+                        const float gx = near_t ? ctext : cext, gy = near_t ? ctext : copen;
+                        const float g = kmax(iniga + gx, inia + gy);
+                        const bool v0 = (v == 0), vmid = (v < ncols);
+                        inia = v0 ? inj_a : -KA_F;
+                        iniga = v0 ? inj_ga : (vmid ? g : -KA_F);
+                        inigb = v0 ? inj_gb : -KA_F;
                 }
                 float upa = wave_shr1(cBa), upga = wave_shr1(cBga), upgb = wave_shr1(cBgb);
                 if (ls == 0) { upa = inia; upga = iniga; upgb = inigb; }
@@ -771,16 +777,19 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                         }
                 }
         };
-        int t = 0;
-        for (; t + 3 < nsteps; t += 4) {
-                step(t, std::integral_constant<int, 0>());
-                step(t + 1, std::integral_constant<int, 1>());
-                step(t + 2, std::integral_constant<int, 2>());
-                step(t + 3, std::integral_constant<int, 3>());
-        }
-        if (t < nsteps) step(t, std::integral_constant<int, 0>());
-        if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>());
-        if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2>());
+        auto loop = [&](auto stg_tag) {
+                int t = 0;
+                for (; t + 3 < nsteps; t += 4) {
+                        step(t, std::integral_constant<int, 0>(), stg_tag);
+                        step(t + 1, std::integral_constant<int, 1>(), stg_tag);
+                        step(t + 2, std::integral_constant<int, 2>(), stg_tag);
+                        step(t + 3, std::integral_constant<int, 3>(), stg_tag);
+                }
+                if (t < nsteps) step(t, std::integral_constant<int, 0>(), stg_tag);
+                if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>(), stg_tag);
+                if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2>(), stg_tag);
+        };
+        if (KIND == KA_PP && staged) loop(std::true_type()); else loop(std::false_type());
 #undef REC
 #undef IDX
 }
