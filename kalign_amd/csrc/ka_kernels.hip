@@ -492,6 +492,15 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         // increasing order, so the dealing cannot deadlock the strip pipelines.)
                         const int ntotal = nitems + njobs16 + njobs4;
                         const int nslots = __builtin_amdgcn_readfirstlane(KA_NW * S.G);
+                        // a level that keeps only waves 0 .. NW/2-1 (or NW/4-1) of every workgroup busy: its packed jobs may
+                        // stage their columns in the idle waves' LDS regions too (ka_packed)
+                        int nreg = 1;
+                        if (ntotal <= nslots) {
+                                const int per_wg = (ntotal + S.G - 1) / S.G;
+                                if (per_wg <= KA_NW / 4) nreg = 4; else if (per_wg <= KA_NW / 2) nreg = 2;
+                        }
+                        nreg = __builtin_amdgcn_readfirstlane(nreg);
+                        const int reg_stride = (KA_NW / nreg) * KA_WAVE_LDS;
                         int it = __builtin_amdgcn_readfirstlane(wave * S.G + S.member);   // this wave's statically dealt item
                         bool dealt = true;
                         while (true) {
@@ -514,11 +523,11 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
 #endif
                                 if (it >= nitems + njobs16) {
-                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr);
+                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
                                         continue;
                                 }
                                 if (it >= nitems) {
-                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr);
+                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
                                         continue;
                                 }
                                 // everything about the item is wave-uniform: keep it in SGPRs

@@ -568,7 +568,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 // ------------------------------------------------------------------------------------------
 template <int KIND, int NRES, int SLOT, int NB>
 __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, const int2* pack, const int nslots,
-                                          const int job, const int lane, const float* tss, char* wlds)
+                                          const int job, const int lane, const float* tss, char* wlds,
+                                          const int nreg = 1, const int reg_stride = 0)
 {
         constexpr int SPW = 64 / SLOT;                                // slots per wave
         const int slot = job * SPW + lane / SLOT;
@@ -653,9 +654,12 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
         float4v q[2][KA_REC_CHUNKS];
         int resq[4] = {0, 0, 0, 0};                                   // sequence columns: residues 3 steps ahead (L2 latency)
 
-        // Profile-profile: when the column records of all the job's slots fit into this wave's LDS
-        // region (128 records), stage them once (every slot's lanes copy their slot's columns) and
-        // read LDS per step; otherwise stream them from L2 one step ahead.
+        // Profile-profile: when the column records of all the job's slots fit into LDS, stage them once (every
+        // slot's lanes copy their slot's columns) and read LDS per step; otherwise stream them from L2 one step
+        // ahead (a packed step then costs ~2000 cycles instead of ~800: the per-lane gathers cannot be run far
+        // enough ahead without spilling).  The wave's own region holds 128 records; on levels that keep only
+        // a half / a quarter of the workgroup's waves busy the caller lends it the idle waves' regions as well
+        // (nreg regions, reg_stride bytes apart).
         int lds_base = 0;                                             // first staged record of this lane's slot
         bool staged = false;
         if (KIND == KA_PP && wlds != nullptr) {
@@ -667,11 +671,12 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                         if (sidx < lane / SLOT) lds_base += c;
                         total += c;
                 }
-                staged = total <= KA_RING_SLOTS * KA_RING_BATCH;      // 128 records (wave-uniform)
+                staged = total <= nreg * KA_RING_SLOTS * KA_RING_BATCH;   // 128 records per region (wave-uniform)
                 if (staged) {
                         for (int vv = ls; vv < cnt; vv += SLOT) {
                                 ka_gfloat4c* g = (ka_gfloat4c*)(S.p2 + ((long long)REC(vv) << 6) + 32);
-                                char* dst = wlds + (lds_base + vv) * 16;
+                                const int idx = lds_base + vv;
+                                char* dst = wlds + (idx >> 7) * reg_stride + (idx & 127) * 16;
 #pragma unroll
                                 for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) *(float4v*)(dst + ch * 2048) = g[ch];
                         }
@@ -688,7 +693,8 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 const int vv = min(max(vcol, 0), ncols);
                 if (KIND == KA_PP) {
                         if (STG) {
-                                const char* src = wlds + (lds_base + vv) * 16;
+                                const int idx = lds_base + vv;
+                                const char* src = wlds + (idx >> 7) * reg_stride + (idx & 127) * 16;
 #pragma unroll
                                 for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = *(const float4v*)(src + ch * 2048);
                         } else {
