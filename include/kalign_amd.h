@@ -162,10 +162,12 @@ int ka_tree_kernel_ms(ka_ctx* ctx, float* ms, int* n_launches);
  * builds with anchor_consistency_get_bonus_profile (aln_run.c:262-295).  Like the reference it declines
  * silently (returns OK, no table) when n_anchors <= 0, numseq < 3 or there are no seq_distances.
  * n_anchors <= 5 (the reference's default is 5, src/parameters.c:72-73; weight 2.0).
+ * In a forest job every alignment gets its own table (its own anchors among its own sequences).
  * ka_tree_upload drops the table again.
  */
 int ka_tree_build_consistency(ka_ctx* ctx, int n_anchors, float weight);
-/* Returns K (0: no table).  anchor_ids[K]; maps_out: all position maps concatenated in (i*K + k) order,
+/* Returns K (0: no table).  anchor_ids[K] (a forest job: K per alignment that has a table, in order of the
+   alignments' first sequences); maps_out: all position maps concatenated in (i*K + k) order,
    each lens[i] ints (pos_maps, anchor_consistency.h:17-24).  Either pointer may be NULL. */
 int ka_tree_get_consistency(ka_ctx* ctx, int* anchor_ids, int* maps_out);
 

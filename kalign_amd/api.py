@@ -265,9 +265,10 @@ class Context:
         if K <= 0:
             return None
         lens = self._job["lens"]
-        ids = np.zeros(K, np.int32)
+        ids = np.full(max(len(lens), K), -1, np.int32)        # a forest job: K anchors per alignment
         flat = np.zeros(int(lens.sum()) * K, np.int32)
         self.L.ka_tree_get_consistency(self.h, _ptr(ids), _ptr(flat))
+        ids = ids[ids >= 0]
         maps, o = [], 0
         for n in lens:
             row = []

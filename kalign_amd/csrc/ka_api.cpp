@@ -1004,20 +1004,53 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
         c->cons_K = 0;
         const int N = c->numseq;
         // the reference silently declines in these cases (anchor_consistency.c:206-217)
-        if (c->n_trees > 1) return fail("consistency tables are per alignment: build them on single-tree jobs");
         if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
-        int K = std::min(n_anchors, N);
-        if (K > KA_NB - 1) return fail("this build carries at most 5 consistency anchors per DP row");
-        select_anchors(c->seq_dist, K, c->cons_anchor_ids);
+        if (n_anchors > KA_NB - 1) return fail("this build carries at most 5 consistency anchors per DP row");
+        // One table per alignment.  A forest job holds several: every tree selects its own anchors among its own
+        // sequences (in ascending index order = that alignment's own order); map k of a sequence is always against
+        // anchor k of ITS tree, so the kernels need no notion of trees.
+        std::vector<std::vector<int>> trees;
+        {
+                std::vector<char> seen(N, 0);
+                for (int t = 0; t < c->n_tasks; t++) {
+                        if (!c->descs[t].is_root) continue;
+                        long long lo, hi;
+                        node_members(c, c->descs[t].c, &lo, &hi);
+                        std::vector<int> m(c->sip_flat.begin() + lo, c->sip_flat.begin() + hi);
+                        std::sort(m.begin(), m.end());
+                        for (int x : m) seen[x] = 1;
+                        trees.push_back(m);
+                }
+                std::sort(trees.begin(), trees.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a[0] < b[0]; });
+        }
+        int K = n_anchors;
+        for (auto& m : trees) if ((int)m.size() >= 3) K = std::min(K, (int)m.size());
+        for (auto& m : trees)
+                if ((int)m.size() >= 3 && (int)m.size() < n_anchors && trees.size() > 1)
+                        return fail("forest job: every alignment with a consistency table needs at least n_anchors sequences");
+        std::vector<int> anchor_of((size_t)N * K, -1);               // anchor k of the tree sequence i belongs to (-1: no table)
+        c->cons_anchor_ids.clear();
+        bool any = false;
+        for (auto& m : trees) {
+                if ((int)m.size() < 3) continue;
+                std::vector<float> d(m.size());
+                for (size_t x = 0; x < m.size(); x++) d[x] = c->seq_dist[m[x]];
+                std::vector<int> ids;
+                select_anchors(d, K, ids);
+                for (int k = 0; k < K; k++) { ids[k] = m[ids[k]]; c->cons_anchor_ids.push_back(ids[k]); }
+                for (int x : m) for (int k = 0; k < K; k++) anchor_of[(size_t)x * K + k] = ids[k];
+                any = true;
+        }
+        if (!any) return KA_OK;
 
-        // N x K pairs (i, anchor_k), i != anchor_k
+        // pairs (i, anchor_k of i's tree), i != anchor
         std::vector<int> ia, ib;
         std::vector<long long> poff;
         long long ptotal = 0;
         for (int i = 0; i < N; i++)
                 for (int k = 0; k < K; k++) {
-                        const int ak = c->cons_anchor_ids[k];
-                        if (i == ak) continue;
+                        const int ak = anchor_of[(size_t)i * K + k];
+                        if (ak < 0 || i == ak) continue;
                         ia.push_back(i); ib.push_back(ak); poff.push_back(ptotal);
                         ptotal += (long long)c->lens[i] + c->lens[ak] + 3;
                 }
@@ -1036,7 +1069,9 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
                 for (int k = 0; k < K; k++) {
                         int* map = c->cons_maps.data() + c->cons_map_off[i] + (long long)k * c->lens[i];
                         const int len_i = c->lens[i];
-                        if (i == c->cons_anchor_ids[k]) { for (int p = 0; p < len_i; p++) map[p] = p; continue; }
+                        const int ak = anchor_of[(size_t)i * K + k];
+                        if (ak < 0) continue;                              // a sequence whose alignment has no table: no positions
+                        if (i == ak) { for (int p = 0; p < len_i; p++) map[p] = p; continue; }
                         const int* path = paths.data() + poff[pk++];
                         int pos_a = 0, pos_b = 0;
                         for (int x = 1; path[x] != 3; x++) {                 // anchor_consistency.c:86-114
@@ -1060,7 +1095,7 @@ extern "C" int ka_tree_get_consistency(ka_ctx* c, int* anchor_ids, int* maps_out
 {
         if (!c || !c->have_job) return -1;
         if (c->cons_K <= 0) return 0;
-        if (anchor_ids) memcpy(anchor_ids, c->cons_anchor_ids.data(), sizeof(int) * c->cons_K);
+        if (anchor_ids) memcpy(anchor_ids, c->cons_anchor_ids.data(), sizeof(int) * c->cons_anchor_ids.size());
         if (maps_out) memcpy(maps_out, c->cons_maps.data(), sizeof(int) * c->cons_maps.size());
         return c->cons_K;
 }

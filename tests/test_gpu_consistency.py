@@ -100,3 +100,25 @@ def test_consistency_declines_like_the_reference(ctx):
     assert ctx.tree_consistency() is None
     with pytest.raises(RuntimeError):
         ctx.tree_build_consistency(6, 2.0)
+
+
+def test_forest_in_default_mode_has_one_table_per_alignment(ctx):
+    """Two independent alignments as one forest job, both in default mode: each selects its own anchors among its
+    own sequences and builds its own position maps; results per tree equal the single-tree goldens."""
+    from kalign_amd import guide
+    g = Golden("cons_prot32x200")
+    codes, tasks, dist, spans = guide.forest([(g.codes, g.tasks, g.seq_distances)] * 2)
+    recs, paths, gaps = ctx.msa_tree(codes, tasks, g.subm, g.scal, dist, n_anchors=int(g.n_anchors), weight=float(g.weight))
+    ids, maps = ctx.tree_consistency()
+    n = len(g.codes)
+    assert np.array_equal(ids, np.concatenate([g.anchor_ids, g.anchor_ids + n]))
+    for (s0, t0, ns, nt) in spans:
+        for t in range(nt):
+            r = recs[t0 + t]
+            assert r.plen == g.rec("plen")[t] and r.score == g.rec("score")[t]
+            assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
+        for got, want in zip(gaps[s0:s0 + ns], g.gaps_list()):
+            assert np.array_equal(got, want)
+        for got_row, want_row in zip(maps[s0:s0 + ns], g.maps_list()):
+            for got, want in zip(got_row, want_row):
+                assert np.array_equal(got, want - 0)          # positions are within the anchor sequence: no offset
