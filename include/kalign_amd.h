@@ -110,6 +110,16 @@ int ka_tree_run(ka_ctx* ctx);
 int ka_tree_sync(ka_ctx* ctx);
 long long ka_tree_paths_size(ka_ctx* ctx);      /* ints needed for paths_out (valid after run+sync) */
 int ka_tree_download(ka_ctx* ctx, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
+
+/* The aligned rows themselves (finalise_alignment + make_linear_sequence, lib/src/msa_op.c:546-598), built on the
+ * device from the residue->column tables of a job uploaded with KA_FLAG_DEVICE_GAPS, after a complete run.
+ *   letters[sum of lens]  the residues as the caller wants them printed (struct msa_seq.seq), laid out like `codes`
+ *   rows_out[numseq * row_stride]  row i holds alnlen(i) bytes -- letters, and gap_char where the reference puts
+ *                         '-' -- followed by a 0 byte; row_stride >= the longest alignment + 1
+ *   alnlen_out[numseq]    (may be NULL) alignment length of the tree sequence i belongs to (struct msa.alnlen)
+ * rows_out == NULL: only alnlen_out is filled (size query). */
+int ka_tree_aligned_rows(ka_ctx* ctx, const uint8_t* letters, uint8_t gap_char, uint8_t* rows_out,
+                         long long row_stride, int* alnlen_out);
 /*
  * Partial runs -- what single-tree multi-GPU sharding is made of (kalign_amd/dist.py:sharded_tree
  * drives them with one process per GPU): a rank runs the tasks of its subtree, the profile of a subtree root moves

@@ -39,7 +39,8 @@ EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_s
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
-           "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch"]
+           "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
+           "ka_tree_aligned_rows"]
 
 
 def lib_path():
@@ -94,6 +95,7 @@ def load_library():
     L.ka_weave_gaps.argtypes = [C.c_int, vp, C.c_int, C.POINTER(TaskRec), vp, vp]
     L.ka_bpm_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
+    L.ka_tree_aligned_rows.argtypes = [vp, vp, C.c_ubyte, vp, C.c_longlong, vp]
     L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
     L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
                                     C.c_float, C.c_float, C.c_float, vp, vp, vp]
@@ -184,6 +186,27 @@ class Context:
                 g.append(gaps[o:o + int(n) + 1].copy())
                 o += int(n) + 1
         return recs, paths, g
+
+    def tree_aligned_rows(self, letters, gap=b"-"):
+        """finalise_alignment on the device: `letters` holds, per sequence, what to print for each residue (bytes,
+        str or uint8 array); returns one bytes object per sequence, as long as the alignment of its tree."""
+        j = self._job
+
+        def as_u8(x):
+            if isinstance(x, np.ndarray):
+                return x.astype(np.uint8)
+            return np.frombuffer(x.encode() if isinstance(x, str) else bytes(x), np.uint8)
+
+        flat = np.ascontiguousarray(np.concatenate([as_u8(x) for x in letters]))
+        if len(flat) != int(j["lens"].sum()) or any(len(x) != n for x, n in zip(letters, j["lens"])):
+            raise KalignAmdError("letters do not match the uploaded sequences")
+        alen = np.zeros(j["n"], np.int32)
+        self._chk(self.L.ka_tree_aligned_rows(self.h, _ptr(flat), gap[0], None, 0, _ptr(alen)))   # size query
+        stride = int(alen.max()) + 1
+        rows = np.zeros((j["n"], stride), np.uint8)
+        self._chk(self.L.ka_tree_aligned_rows(self.h, _ptr(flat), gap[0], _ptr(rows), stride, _ptr(alen)))
+        assert all(rows[i, alen[i]] == 0 for i in range(j["n"]))
+        return [rows[i, :alen[i]].tobytes() for i in range(j["n"])]
 
     def tree_timing(self):
         n = self._job["ntasks"]

@@ -20,6 +20,8 @@
 
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream);
 extern "C" int ka_max_g_host(void);
+extern "C" void ka_launch_rows(const uint8_t* letters, const int* off, const int* lens, const int* colof, const int* alnlen,
+                               int numseq, uint8_t gap, uint8_t* rows, long long stride, hipStream_t stream);
 extern "C" void ka_launch_bpm(const uint8_t* codes, const int* off, const int* lens, int numseq, unsigned long long* peq,
                               const int* ia, const int* ib, int npairs, int* dist, hipStream_t stream);
 extern "C" long long ka_ctl_bytes_host(void);
@@ -120,7 +122,8 @@ struct ka_ctx {
         float cons_weight = 0.0f;
         std::vector<int> cons_anchor_ids, cons_maps;
         std::vector<long long> cons_map_off;
-        DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip;
+        DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip, d_alnlen;
+        DevBuf<uint8_t> d_letters, d_rows;
         DevBuf<long long> d_cons_map_off, d_sip_off;
 };
 
@@ -165,6 +168,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         c->b_peq.release(); c->b_dist.release();
+        c->d_letters.release(); c->d_rows.release(); c->d_alnlen.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -639,6 +643,18 @@ extern "C" int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_
         return KA_OK;
 }
 
+// alignment length of the tree each sequence belongs to (a sequence in no task aligns to itself); needs h_recs
+static void tree_alnlens(ka_ctx* c, std::vector<int>& alen)
+{
+        alen.assign(c->lens.begin(), c->lens.end());
+        for (int t = 0; t < c->n_tasks; t++) {
+                if (!c->descs[t].is_root) continue;
+                long long lo, hi;
+                node_members(c, c->descs[t].c, &lo, &hi);
+                for (long long k = lo; k < hi; k++) alen[c->sip_flat[k]] = c->h_recs[t].plen;
+        }
+}
+
 extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
 {
         if (!c || !c->ran) return fail("nothing to download");
@@ -691,15 +707,8 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
                 // arrays are its first differences, O(sum of lengths) instead of O(N L log N) folding on the host
                 std::vector<int> col(c->colof_n);
                 HIPCHK(hipMemcpy(col.data(), c->d_colof.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToHost));
-                // alignment length of the tree each sequence belongs to (a sequence in no task aligns to itself)
-                std::vector<int> alen(c->numseq);
-                for (int i = 0; i < c->numseq; i++) alen[i] = c->lens[i];
-                for (int t = 0; t < c->n_tasks; t++) {
-                        if (!c->descs[t].is_root) continue;
-                        long long lo, hi;
-                        node_members(c, c->descs[t].c, &lo, &hi);
-                        for (long long k = lo; k < hi; k++) alen[c->sip_flat[k]] = c->h_recs[t].plen;
-                }
+                std::vector<int> alen;
+                tree_alnlens(c, alen);
                 long long g = 0;
                 for (int i = 0; i < c->numseq; i++) {
                         const int* cc = col.data() + c->off[i];
@@ -713,6 +722,39 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
                 return KA_OK;
         }
         if (gaps_out && ka_weave_gaps(c->numseq, c->lens.data(), c->n_tasks, c->h_recs.data(), paths_out, gaps_out)) return KA_FAIL;
+        return KA_OK;
+}
+
+
+// ---- finalise_alignment (msa_op.c:546-598): the aligned rows, built on the device from the residue->column tables ----
+extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t gap_char, uint8_t* rows_out,
+                                    long long row_stride, int* alnlen_out)
+{
+        if (!c || !c->have_job || !c->ran) return fail("no finished run");
+        if (!letters || (!rows_out && !alnlen_out)) return fail("null argument");
+        if (!(c->flags & KA_FLAG_DEVICE_GAPS) || !c->have_colof) return fail("the job was uploaded without KA_FLAG_DEVICE_GAPS");
+        if (c->partial) return fail("aligned rows need a complete run (ka_tree_run), not a partial one");
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->synced && ka_tree_sync(c)) return KA_FAIL;
+        // the records hold the alignment length of every tree
+        c->h_recs.resize(c->n_tasks);
+        HIPCHK(hipMemcpy(c->h_recs.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
+        std::vector<int> alen;
+        tree_alnlens(c, alen);
+        int widest = 0;
+        for (int i = 0; i < c->numseq; i++) widest = std::max(widest, alen[i]);
+        if (!rows_out) { memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq); return KA_OK; }       // size query
+        if (row_stride < (long long)widest + 1) return fail("row_stride is smaller than the longest alignment + terminator");
+        const size_t bytes = (size_t)c->numseq * (size_t)row_stride;
+        if (c->d_letters.alloc(c->h_codes.size()) || c->d_alnlen.alloc(c->numseq) || c->d_rows.alloc(bytes)) return fail("hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(c->d_letters.p, letters, c->h_codes.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_alnlen.p, alen.data(), sizeof(int) * c->numseq, hipMemcpyHostToDevice, c->stream));
+        ka_launch_rows(c->d_letters.p, c->d_seq_off.p, c->d_node_len.p, c->d_colof.p, c->d_alnlen.p, c->numseq, gap_char,
+                       c->d_rows.p, row_stride, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(rows_out, c->d_rows.p, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq);
         return KA_OK;
 }
 
