@@ -203,6 +203,27 @@ int ka_pairwise_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const i
 int ka_bpm_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const int* lens, int numseq,
                  const int* ia, const int* ib, int npairs, int* dist_out);
 
+/*
+ * Guide tree: build_tree_kmeans (lib/src/bisectingKmeans.c:177-271) -- anchors by length
+ * (pick_anchor.c:34-70), N x 32 distances to the anchors, bisecting 2-means on that matrix (split2, :766-971) down
+ * to clusters of fewer than 50 sequences, UPGMA on all-pairs distances inside each cluster (:974-1053), post-order
+ * node labels.  The two distance batches run on the device (ka_bpm_batch); the clustering between them runs on the
+ * host in the reference's fp32 evaluation order, so the task list is the reference's task list.
+ *   codes            the sequences in the alphabet the reference builds its tree in: reduced protein alphabet
+ *                    (ALPHA_redPROTEIN, aln_wrap.c:155-160) or nucleotides; sorted as msa_sort_len_name left them
+ *   n_threads        host threads for the independent halves of the bisection (the result does not depend on it)
+ *   tasks_abc[3*(numseq-1)]  (a, b, c) in TASK_ORDER_TREE order -- what ka_tree_upload / ka_msa_tree take
+ *   seq_distances[numseq]    msa->seq_distances (:244-255); may be NULL
+ */
+int ka_guide_tree(ka_ctx* ctx, int numseq, const uint8_t* codes, const int* off, const int* lens,
+                  int n_threads, int* tasks_abc, float* seq_distances);
+/* The same with the caller's distance source: dist() must fill dist_out[k] with calc_distance(seq ia[k], seq ib[k])
+ * (sequence_distance.c:150-162) for k < npairs and return 0; it is called twice (anchor batch, cluster batch).
+ * Host only: needs no context and no GPU. */
+typedef int (*ka_dist_fn)(void* user, int npairs, const int* ia, const int* ib, int* dist_out);
+int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
+                       int* tasks_abc, float* seq_distances);
+
 /* Kernel time (HIP events on the launch stream) of the last ka_pairwise_batch / ka_bpm_batch, milliseconds. */
 float ka_pairwise_kernel_ms(ka_ctx* ctx);
 

@@ -34,13 +34,16 @@ class TaskRec(C.Structure):
     ]
 
 
+# ka_dist_fn of include/kalign_amd.h
+DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+
 EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
            "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
-           "ka_tree_aligned_rows"]
+           "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from"]
 
 
 def lib_path():
@@ -96,6 +99,8 @@ def load_library():
     L.ka_bpm_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
     L.ka_tree_aligned_rows.argtypes = [vp, vp, C.c_ubyte, vp, C.c_longlong, vp]
+    L.ka_guide_tree.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
+    L.ka_guide_tree_from.argtypes = [C.c_int, vp, DIST_FN, vp, C.c_int, vp, vp]
     L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
     L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
                                     C.c_float, C.c_float, C.c_float, vp, vp, vp]
@@ -336,6 +341,40 @@ def _bpm_batch(self, codes, ia, ib):
 
 
 Context.bpm_batch = _bpm_batch
+
+
+def _guide_tree(self, codes, n_threads=1):
+    """build_tree_kmeans with both distance batches on the device: (tasks[n-1, 3], seq_distances[n]).
+    `codes` in the alphabet the reference builds its tree in (reduced protein alphabet / nucleotides)."""
+    flat, off, lens = _flatten(codes)
+    tasks = np.zeros((len(codes) - 1, 3), np.int32)
+    sd = np.zeros(len(codes), np.float32)
+    self._chk(self.L.ka_guide_tree(self.h, len(codes), _ptr(flat), _ptr(off), _ptr(lens), int(n_threads), _ptr(tasks), _ptr(sd)))
+    return tasks, sd
+
+
+Context.guide_tree = _guide_tree
+
+
+def guide_tree_from(lens, dist, n_threads=1):
+    """build_tree_kmeans with the caller's distance source (ka_guide_tree_from; host only, no GPU needed):
+    dist(ia, ib) -> calc_distance of every pair, as an int array."""
+    L = load_library()
+    lens = np.ascontiguousarray(lens, np.int32)
+
+    def cb(_user, n, ia, ib, out):
+        try:
+            d = dist(np.ctypeslib.as_array(ia, (n,)).copy(), np.ctypeslib.as_array(ib, (n,)).copy())
+            np.ctypeslib.as_array(out, (n,))[:] = d
+            return 0
+        except Exception:                     # reported as "the distance source failed"
+            return 1
+
+    tasks = np.zeros((len(lens) - 1, 3), np.int32)
+    sd = np.zeros(len(lens), np.float32)
+    if L.ka_guide_tree_from(len(lens), _ptr(lens), DIST_FN(cb), None, int(n_threads), _ptr(tasks), _ptr(sd)):
+        raise KalignAmdError(L.ka_last_error().decode())
+    return tasks, sd
 
 
 def weave_gaps(lens, recs, paths):

@@ -30,6 +30,8 @@ extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return KA_FAIL; }
+// ka_guide.cpp reports through the same message (library-internal, not part of the ABI)
+__attribute__((visibility("hidden"))) int ka_fail_message(const char* m) { return fail(m); }
 
 #define HIPCHK(x)                                                                         \
         do {                                                                              \
@@ -132,7 +134,7 @@ static int setup_colof(ka_ctx* c);
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
-extern "C" int ka_abi_version(void) { return 2; }
+extern "C" int ka_abi_version(void) { return 3; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {

@@ -54,6 +54,7 @@ struct refh {
         struct msa* msa;
         struct aln_tasks* tasks;
         struct aln_param* ap;
+        uint8_t* tree_codes;            /* the sequences in the alphabet build_tree_kmeans saw, concatenated */
 };
 
 static uint64_t fnv1a(const void* p, size_t n, uint64_t h)
@@ -71,6 +72,7 @@ void refh_free(void* hv)
         if(h->ap) aln_param_free(h->ap);
         if(h->tasks) free_tasks(h->tasks);
         if(h->msa) kalign_free_msa(h->msa);
+        free(h->tree_codes);
         free(h);
 }
 
@@ -106,6 +108,15 @@ void* refh_prepare(char** seqs, int* lens, int numseq, int type,
 #ifdef HAVE_OPENMP
         omp_set_num_threads(n_threads < 1 ? 1 : n_threads);
 #endif
+        {
+                size_t total = 0, o = 0;
+                for(int i = 0; i < msa->numseq; i++) total += msa->sequences[i]->len;
+                h->tree_codes = malloc(total ? total : 1);
+                for(int i = 0; i < msa->numseq; i++){
+                        memcpy(h->tree_codes + o, msa->sequences[i]->s, msa->sequences[i]->len);
+                        o += msa->sequences[i]->len;
+                }
+        }
         if(build_tree_kmeans(msa, &h->tasks) != OK) goto ERROR;
         if(msa->biotype == ALN_BIOTYPE_PROTEIN){
                 if(convert_msa_to_internal(msa, ALPHA_ambigiousPROTEIN) != OK) goto ERROR;
@@ -133,6 +144,18 @@ void refh_get_seq_info(void* hv, int* lens, int* ranks)
                 lens[i] = msa->sequences[i]->len;
                 ranks[i] = msa->sequences[i]->rank;
         }
+}
+
+/* the codes of all sequences (sorted order, concatenated) as they were when the guide tree was built:
+   reduced protein alphabet / nucleotides (aln_wrap.c:155-160) */
+int refh_get_tree_codes(void* hv, uint8_t* out)
+{
+        struct refh* h = (struct refh*)hv;
+        size_t total = 0;
+        if(!h->tree_codes) return 1;
+        for(int i = 0; i < h->msa->numseq; i++) total += h->msa->sequences[i]->len;
+        memcpy(out, h->tree_codes, total);
+        return 0;
 }
 
 void refh_get_seq_codes(void* hv, int i, uint8_t* out)

@@ -50,6 +50,7 @@ def lib():
         L.refh_get_seq_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.refh_get_seq_codes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.refh_get_seq_distances.argtypes = [C.c_void_p, C.c_void_p]
+        L.refh_get_tree_codes.argtypes = [C.c_void_p, C.c_void_p]
         L.refh_get_seq_distances.restype = C.c_int
         L.refh_get_params.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.refh_param_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -106,6 +107,11 @@ class RefJob:
             buf = np.zeros(int(self.lens[i]), np.uint8)
             L.refh_get_seq_codes(self.h, i, _ptr(buf))
             self.codes.append(buf)
+        flat = np.zeros(max(int(self.lens.sum()), 1), np.uint8)
+        self.tree_codes = None                       # the alphabet build_tree_kmeans saw (reduced protein / nucleotides)
+        if L.refh_get_tree_codes(self.h, _ptr(flat)) == 0:
+            o = np.concatenate([[0], np.cumsum(self.lens)])
+            self.tree_codes = [flat[o[i]:o[i + 1]].copy() for i in range(self.n)]
         self.seq_distances = np.zeros(self.n, np.float32)
         if not L.refh_get_seq_distances(self.h, _ptr(self.seq_distances)):
             self.seq_distances = None

@@ -34,7 +34,7 @@ def tree_case(name, seqs, **kw):
     used = recs[-1].path_off + recs[-1].plen + 2
     d = dict(
         seqs=np.array(seqs), kw=np.array(repr(sorted(kw.items()))),
-        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes),
+        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes), tree_codes=np.concatenate(job.tree_codes),
         seq_distances=job.seq_distances if job.seq_distances is not None else np.zeros(0, np.float32),
         tasks=job.tasks, subm=job.subm,
         scal=np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32),
@@ -63,7 +63,7 @@ def cons_case(name, seqs, n_anchors=5, weight=2.0, **kw):
     used = recs[-1].path_off + recs[-1].plen + 2
     d = dict(
         seqs=np.array(seqs), kw=np.array(repr(sorted(kw.items()))),
-        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes),
+        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes), tree_codes=np.concatenate(job.tree_codes),
         seq_distances=job.seq_distances, tasks=job.tasks, subm=job.subm,
         scal=np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32),
         biotype=np.int32(job.biotype),
@@ -154,14 +154,43 @@ def main():
     param_tables()
 
 
+def guide_case(name, seqs, n_threads=1):
+    """build_tree_kmeans (bisectingKmeans.c:177-271): the sequences in the alphabet the tree builder saw, the task
+    list it made (sorted TASK_ORDER_TREE) and msa->seq_distances."""
+    job = refdrv.RefJob(seqs, n_threads=n_threads)
+    assert job.tree_codes is not None
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), lens=job.lens, tree_codes=np.concatenate(job.tree_codes),
+                        tasks=job.tasks, seq_distances=job.seq_distances, biotype=np.int32(job.biotype))
+    print(name, "n=%d" % job.n, "tasks=%d" % job.ntasks)
+
+
+def guide_cases():
+    rng = np.random.RandomState(5)
+    guide_case("guide_prot300", synth.family(300, 150, seed=21))                  # k-means levels + UPGMA leaves
+    guide_case("guide_dna200", synth.family(200, 120, dna=True, seed=22))
+    guide_case("guide_prot64", synth.family(64, 90, seed=23), n_threads=4)        # one split; thread count must not matter
+    guide_case("guide_prot49", synth.family(49, 80, seed=24))                     # UPGMA only
+    guide_case("guide_prot20", synth.family(20, 60, seed=25))                     # fewer sequences than anchors
+    same = ["".join("ACDEFGHIKLMNPQRSTVWY"[k] for k in rng.randint(0, 20, size=70)) for _ in range(130)]
+    guide_case("guide_samelen130", same)                                          # all lengths tie in the anchor sort
+    fam = synth.family(90, 200, seed=26)
+    guide_case("guide_ragged", [s[:10 + (7 * i) % 190] for i, s in enumerate(fam)])
+    guide_case("guide_prot1100", synth.family(1100, 60, seed=27), n_threads=8)    # deeper k-means recursion
+    guide_case("guide_two", synth.family(2, 50, seed=28))
+
+
 if __name__ == "__main__":
     if not refdrv.available():
         sys.exit("oracle/_ref/libkalign_ref.so missing: run `make -C oracle ref` (needs /root/reference)")
     if len(sys.argv) > 1 and sys.argv[1] == "cons":        # only the consistency cases
         cons_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "guide":
+        guide_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "bpm":
         bpm_case("bpm_mixed", 31)
+        guide_cases()
     else:
         main()
         cons_cases()
         bpm_case("bpm_mixed", 31)
+        guide_cases()

@@ -1,0 +1,62 @@
+"""The guide-tree builder (ka_guide_tree_from = build_tree_kmeans, bisectingKmeans.c:177-271) against the task lists
+the REAL reference produced (tests/golden/guide_*.npz, and the trees inside every tree_/cons_ golden).  CPU only: the
+host-side clustering is product code; the distances come from the oracle's bpm_block restatement here and from the
+device in tests/test_gpu_guide.py."""
+import numpy as np
+import pytest
+
+from util import Golden, cons_cases, guide_cases, tree_cases
+
+
+def oracle_dist(oracle, seqs):
+    return lambda ia, ib: oracle.bpm_batch(seqs, ia, ib)
+
+
+@pytest.mark.parametrize("name", guide_cases())
+@pytest.mark.parametrize("n_threads", [1, 4])
+def test_guide_tree_matches_reference(oracle, name, n_threads):
+    from kalign_amd import api
+    g = Golden(name)
+    tasks, sd = api.guide_tree_from(g.lens, oracle_dist(oracle, g.tree_seqs), n_threads=n_threads)
+    assert np.array_equal(tasks, g.tasks)
+    assert np.array_equal(sd.view(np.uint32), g.seq_distances.view(np.uint32))       # bit for bit
+
+
+@pytest.mark.parametrize("name", tree_cases() + cons_cases())
+def test_trees_of_the_alignment_goldens(oracle, name):
+    """the same for the guide trees the alignment goldens were run on (BAliBASE families, DNA, RNA, ragged lengths)"""
+    from kalign_amd import api
+    g = Golden(name)
+    if len(g.lens) < 2 or g.seq_distances is None:
+        pytest.skip("no tree")
+    tasks, sd = api.guide_tree_from(g.lens, oracle_dist(oracle, g.tree_seqs))
+    assert np.array_equal(tasks, g.tasks)
+    assert np.array_equal(sd.view(np.uint32), g.seq_distances.view(np.uint32))
+
+
+def test_live_against_the_reference_when_it_is_built(oracle):
+    """random families through the real build_tree_kmeans (oracle/_ref) and through ours"""
+    from oracle import refdrv
+    from kalign_amd import api, synth
+    if not refdrv.available():
+        pytest.skip("oracle/_ref not built")
+    for n, length, dna, seed in ((57, 70, False, 101), (140, 50, True, 102), (260, 40, False, 103)):
+        job = refdrv.RefJob(synth.family(n, length, dna=dna, seed=seed))
+        tasks, sd = api.guide_tree_from(job.lens, oracle_dist(oracle, job.tree_codes), n_threads=2)
+        assert np.array_equal(tasks, job.tasks), (n, length, dna)
+        assert np.array_equal(sd, job.seq_distances)
+        job.close()
+
+
+def test_guide_tree_error_behaviour():
+    import kalign_amd
+    from kalign_amd import api
+    with pytest.raises(kalign_amd.KalignAmdError, match="bad arguments"):
+        api.guide_tree_from(np.array([5], np.int32), lambda ia, ib: np.zeros(len(ia), np.int32))
+    with pytest.raises(kalign_amd.KalignAmdError, match="zero-length"):
+        api.guide_tree_from(np.array([5, 0, 3], np.int32), lambda ia, ib: np.zeros(len(ia), np.int32))
+
+    def broken(ia, ib):
+        raise RuntimeError("no distances today")
+    with pytest.raises(kalign_amd.KalignAmdError, match="distance source failed"):
+        api.guide_tree_from(np.array([5, 4, 3], np.int32), broken)

@@ -11,6 +11,10 @@ def tree_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "tree_*.npz")))
 
 
+def guide_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("guide_") and f.endswith(".npz"))
+
+
 def cons_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "cons_*.npz")))
 
@@ -25,7 +29,10 @@ class Golden:
         self.z = z
         self.lens = z["lens"]
         off = np.concatenate([[0], np.cumsum(self.lens)])
-        self.codes = [z["codes"][off[i]:off[i + 1]] for i in range(len(self.lens))]
+        if "codes" in z.files:
+            self.codes = [z["codes"][off[i]:off[i + 1]] for i in range(len(self.lens))]
+        if "tree_codes" in z.files:          # the alphabet the reference built its guide tree in
+            self.tree_seqs = [z["tree_codes"][off[i]:off[i + 1]] for i in range(len(self.lens))]
         for k in z.files:
             if k not in ("lens", "codes"):
                 setattr(self, k, z[k])
