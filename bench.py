@@ -65,7 +65,7 @@ def make_workload(nseq, length, dna, seed):
     codes = guide.encode(seqs, dna=dna)
     tasks = guide.bisecting_tree(nseq, seed=seed)
     dist = np.random.RandomState(seed).uniform(0.3, 0.9, nseq).astype(np.float32)
-    return codes, tasks, dist
+    return codes, tasks, dist, seqs
 
 
 def scoring(dna):
@@ -195,6 +195,71 @@ def default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args, k_anchors=5,
     return info
 
 
+def end_to_end_leg(ctx, seqs, subm, scal, args, k_anchors=5, weight=2.0):
+    """kalign_run's whole alignment phase from letters to aligned rows, host buffers in and out: the guide tree
+    (build_tree_kmeans: two distance batches on the device, 2-means / UPGMA on the host), anchor consistency, the
+    task tree on that guide tree, finalise_alignment on the device -- next to the reference doing the same on the
+    host cores.  The guide tree here is the reference's own k-means tree, not the synthetic one of the headline."""
+    from kalign_amd import api, guide
+    # the order kalign_run gives the sequences before it builds the tree (msa_sort_len_name, msa_sort.c:62-80:
+    # longest first, ties by name = input index here)
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))
+    inp = seqs
+    seqs = [inp[i] for i in order]
+    tcodes = guide.encode_tree(seqs, dna=args.dna)
+    codes = guide.encode(seqs, dna=args.dna)
+    nt = min(os.cpu_count() or 1, 16)
+    got = {}
+
+    def once():
+        t = {}
+        t0 = time.perf_counter()
+        tasks, sd = ctx.guide_tree(tcodes, n_threads=nt)
+        t["guide_tree_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        ctx.tree_upload(codes, tasks, subm, scal, sd, flags=api.FLAG_DEVICE_GAPS)
+        ctx.tree_build_consistency(k_anchors, weight)
+        ctx.tree_run()
+        recs, _, _ = ctx.tree_download()
+        t["align_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        rows = ctx.tree_aligned_rows(seqs)
+        t["rows_ms"] = (time.perf_counter() - t0) * 1e3
+        t["total_ms"] = t["guide_tree_ms"] + t["align_ms"] + t["rows_ms"]
+        t["alnlen"] = len(rows[0])
+        got["rows"] = rows
+        return t
+
+    once()                                                         # warm-up (allocations)
+    info = once()
+    info["anchors"] = k_anchors
+    info["host_threads_for_the_bisection"] = nt
+    if not args.no_cpu:
+        try:
+            from oracle import refdrv
+            t0 = time.perf_counter()
+            job = refdrv.RefJob(inp, type_=0 if args.dna else -1, n_threads=nt)
+            prep = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            job.build_consistency(k_anchors, weight)
+            job.run_tree()
+            aln = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            rows = job.finalise()
+            fin = time.perf_counter() - t0
+            ours = [None] * len(inp)
+            for k, i in enumerate(order):
+                ours[i] = got["rows"][k].decode()
+            info["rows_identical_to_reference"] = bool(ours == rows)
+            info["cpu_reference"] = {"guide_tree_ms": job.tree_seconds * 1e3, "align_ms": aln * 1e3, "rows_ms": fin * 1e3,
+                                     "total_ms": (job.tree_seconds + aln + fin) * 1e3, "alnlen": len(rows[0]), "threads": nt,
+                                     "input_checks_and_encoding_ms": (prep - job.tree_seconds) * 1e3}
+            job.close()
+        except Exception as e:      # pragma: no cover
+            info["cpu_reference"] = str(e)
+    return info
+
+
 def concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank, nsets=8, reps=3):
     """Throughput when independent alignments are available (ensemble members, a batch of families): `nsets`
     copies of the workload as ONE forest job (include/kalign_amd.h: n_tasks < numseq-1) -- the levels of all trees
@@ -247,7 +312,7 @@ def main():
         import torch.distributed as dist
         kd.init("nccl", device=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
 
-    codes, tasks, seq_dist = make_workload(args.nseq, args.len, args.dna, seed=1 + rank)
+    codes, tasks, seq_dist, seqs = make_workload(args.nseq, args.len, args.dna, seed=1 + rank)
     subm, scal = scoring(args.dna)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = kalign_amd.Context(local_rank, stream=stream)
@@ -287,6 +352,9 @@ def main():
     cs_info = None
     if rank == 0 and not args.no_pairs:
         cs_info = concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank)
+    e2e_info = None
+    if rank == 0 and not args.no_default_mode and not args.no_pairs:
+        e2e_info = end_to_end_leg(ctx, seqs, subm, scal, args)
 
     if rank == 0:
         abytes = algorithmic_bytes(recs)
@@ -326,6 +394,8 @@ def main():
             out["default_mode"] = dm_info
         if cs_info:
             out["concurrent_sets"] = cs_info
+        if e2e_info:
+            out["end_to_end"] = e2e_info
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
         print(json.dumps(out))

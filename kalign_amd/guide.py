@@ -43,6 +43,24 @@ def encode(seqs, dna=False):
     return [lut[np.frombuffer(s.encode(), np.uint8)] for s in seqs]
 
 
+def encode_tree(seqs, dna=False):
+    """The alphabet the reference builds its guide tree in (aln_wrap.c:155-160): for proteins the 13 classes of
+    ALPHA_redPROTEIN (alphabet.c:236-290: (L,M) (I,V) (K,R) (E,Q,Z) (A,S,T) (N,D,B) (F,Y) C(,U) G H P W X), for
+    nucleotides A C G T(,U) and one class for every ambiguity code (:203-234).  The edit distances built on these
+    codes depend on the classes only, not on how they are numbered."""
+    classes = ["A", "C", "G", "TU", "NRYSWKMBDHV"] if dna else \
+        ["AST", "CU", "DNB", "EQZ", "FY", "G", "H", "IV", "KR", "LM", "P", "W", "X"]
+    lut = np.full(256, 255, np.uint8)
+    for i, cl in enumerate(classes):
+        for ch in cl:
+            lut[ord(ch)] = i
+            lut[ord(ch.lower())] = i
+    out = [lut[np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), np.uint8)] for s in seqs]
+    if any((c == 255).any() for c in out):
+        raise ValueError("letter outside the alphabet")
+    return out
+
+
 def forest(jobs):
     """Several independent alignment jobs as ONE forest job (kalign_amd.h: n_tasks < numseq-1).
 

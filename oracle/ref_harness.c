@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <float.h>
+#include <time.h>
 
 #ifdef HAVE_OPENMP
 #include <omp.h>
@@ -55,6 +56,7 @@ struct refh {
         struct aln_tasks* tasks;
         struct aln_param* ap;
         uint8_t* tree_codes;            /* the sequences in the alphabet build_tree_kmeans saw, concatenated */
+        double tree_secs;               /* wall time of build_tree_kmeans */
 };
 
 static uint64_t fnv1a(const void* p, size_t n, uint64_t h)
@@ -117,7 +119,13 @@ void* refh_prepare(char** seqs, int* lens, int numseq, int type,
                         o += msa->sequences[i]->len;
                 }
         }
-        if(build_tree_kmeans(msa, &h->tasks) != OK) goto ERROR;
+        {
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                if(build_tree_kmeans(msa, &h->tasks) != OK) goto ERROR;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                h->tree_secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        }
         if(msa->biotype == ALN_BIOTYPE_PROTEIN){
                 if(convert_msa_to_internal(msa, ALPHA_ambigiousPROTEIN) != OK) goto ERROR;
         }
@@ -132,6 +140,7 @@ ERROR:
         return NULL;
 }
 
+double refh_tree_seconds(void* hv){ return ((struct refh*)hv)->tree_secs; }
 int refh_numseq(void* hv){ return ((struct refh*)hv)->msa->numseq; }
 int refh_biotype(void* hv){ return ((struct refh*)hv)->msa->biotype; }
 int refh_ntasks(void* hv){ return ((struct refh*)hv)->tasks->n_tasks; }

@@ -51,6 +51,8 @@ def lib():
         L.refh_get_seq_codes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.refh_get_seq_distances.argtypes = [C.c_void_p, C.c_void_p]
         L.refh_get_tree_codes.argtypes = [C.c_void_p, C.c_void_p]
+        L.refh_tree_seconds.argtypes = [C.c_void_p]
+        L.refh_tree_seconds.restype = C.c_double
         L.refh_get_seq_distances.restype = C.c_int
         L.refh_get_params.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.refh_param_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -112,6 +114,7 @@ class RefJob:
         if L.refh_get_tree_codes(self.h, _ptr(flat)) == 0:
             o = np.concatenate([[0], np.cumsum(self.lens)])
             self.tree_codes = [flat[o[i]:o[i + 1]].copy() for i in range(self.n)]
+        self.tree_seconds = float(L.refh_tree_seconds(self.h))      # wall time of build_tree_kmeans
         self.seq_distances = np.zeros(self.n, np.float32)
         if not L.refh_get_seq_distances(self.h, _ptr(self.seq_distances)):
             self.seq_distances = None

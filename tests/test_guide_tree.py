@@ -60,3 +60,17 @@ def test_guide_tree_error_behaviour():
         raise RuntimeError("no distances today")
     with pytest.raises(kalign_amd.KalignAmdError, match="distance source failed"):
         api.guide_tree_from(np.array([5, 4, 3], np.int32), broken)
+
+
+@pytest.mark.parametrize("name", tree_cases() + cons_cases())
+def test_tree_alphabet_classes(name):
+    """guide.encode_tree puts two letters into one class exactly when the reference's tree alphabet does"""
+    from kalign_amd import guide
+    g = Golden(name)
+    dna = int(g.biotype) != 0 if hasattr(g, "biotype") else False
+    ours = guide.encode_tree(g.sorted_seqs(), dna=dna)
+    a = np.concatenate(ours).astype(np.int64)
+    b = np.concatenate(g.tree_seqs).astype(np.int64)
+    assert len(a) == len(b)
+    pairs = set(zip(a.tolist(), b.tolist()))
+    assert len(pairs) == len(set(p[0] for p in pairs)) == len(set(p[1] for p in pairs))       # a bijection of classes
