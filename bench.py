@@ -57,15 +57,21 @@ def pmc_traffic(args):
         return None
 
 
-def make_workload(nseq, length, dna, seed):
-    from kalign_amd import guide, synth
+def workload_letters(nseq, length, dna, seed):
+    from kalign_amd import synth
     # the reference's own benchmark generator, restated: independent samples of one profile HMM
     # (tests/dssim.c)
-    seqs = synth.dssim(nseq, length, dna=dna, seed=seed)
+    return synth.dssim(nseq, length, dna=dna, seed=seed)
+
+
+def make_workload(nseq, length, dna, seed, seqs=None):
+    from kalign_amd import guide
+    if seqs is None:
+        seqs = workload_letters(nseq, length, dna, seed)
     codes = guide.encode(seqs, dna=dna)
     tasks = guide.bisecting_tree(nseq, seed=seed)
     dist = np.random.RandomState(seed).uniform(0.3, 0.9, nseq).astype(np.float32)
-    return codes, tasks, dist, seqs
+    return codes, tasks, dist
 
 
 def scoring(dna):
@@ -312,7 +318,8 @@ def main():
         import torch.distributed as dist
         kd.init("nccl", device=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
 
-    codes, tasks, seq_dist, seqs = make_workload(args.nseq, args.len, args.dna, seed=1 + rank)
+    seqs = workload_letters(args.nseq, args.len, args.dna, seed=1 + rank)
+    codes, tasks, seq_dist = make_workload(args.nseq, args.len, args.dna, seed=1 + rank, seqs=seqs)
     subm, scal = scoring(args.dna)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = kalign_amd.Context(local_rank, stream=stream)

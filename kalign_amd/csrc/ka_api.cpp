@@ -20,6 +20,8 @@
 
 extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream);
 extern "C" int ka_max_g_host(void);
+extern "C" void ka_launch_posmaps(const int* paths, const long long* poff, const int* pair_of, const int* lens, const long long* map_off,
+                                  int numseq, int K, int* maps, hipStream_t stream);
 extern "C" void ka_launch_rows(const uint8_t* letters, const int* off, const int* lens, const int* colof, const int* alnlen,
                                int numseq, uint8_t gap, uint8_t* rows, long long stride, hipStream_t stream);
 extern "C" void ka_launch_bpm(const uint8_t* codes, const int* off, const int* lens, int numseq, unsigned long long* peq,
@@ -122,15 +124,19 @@ struct ka_ctx {
         size_t colof_n = 0;
         bool have_colof = false;       // residue->column tables + member lists are on the device
         float cons_weight = 0.0f;
-        std::vector<int> cons_anchor_ids, cons_maps;
+        std::vector<int> cons_anchor_ids, cons_maps;  // cons_maps: host copy of d_cons_maps, filled on demand
+        long long cons_maps_total = 0;
         std::vector<long long> cons_map_off;
-        DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip, d_alnlen;
+        DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip, d_alnlen, d_pair_of;
         DevBuf<uint8_t> d_letters, d_rows;
         DevBuf<long long> d_cons_map_off, d_sip_off;
 };
 
 static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out);
 static int setup_colof(ka_ctx* c);
+static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                              const int* ia, const int* ib, int npairs,
+                              const float* subm, float gpo, float gpe, float tgpe, const long long* poff, long long* ptotal_out);
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
@@ -170,7 +176,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         c->b_peq.release(); c->b_dist.release();
-        c->d_letters.release(); c->d_rows.release(); c->d_alnlen.release();
+        c->d_letters.release(); c->d_rows.release(); c->d_alnlen.release(); c->d_pair_of.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -489,6 +495,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.nres = c->nres;
         D.trace = c->h_trace;
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
+        D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
         D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;
         D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
         D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
@@ -1098,37 +1105,34 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
                         ia.push_back(i); ib.push_back(ak); poff.push_back(ptotal);
                         ptotal += (long long)c->lens[i] + c->lens[ak] + 3;
                 }
-        std::vector<int> paths((size_t)std::max<long long>(ptotal, 1));
-        if (!ia.empty() &&
-            ka_pairwise_batch(c, c->h_codes.data(), c->off.data(), c->lens.data(), N, ia.data(), ib.data(), (int)ia.size(),
-                              c->subm, c->scal[0], c->scal[1], c->scal[2], paths.data(), poff.data(), nullptr))
+        if (ia.empty()) return KA_OK;
+        // the N x K alignments on the device; their coded paths become position maps there as well
+        // (anchor_consistency.c:86-114) and never leave HBM unless ka_tree_get_consistency asks for them
+        long long used = 0;
+        if (pairwise_on_device(c, c->h_codes.data(), c->off.data(), c->lens.data(), N, ia.data(), ib.data(), (int)ia.size(),
+                               c->subm, c->scal[0], c->scal[1], c->scal[2], poff.data(), &used))
                 return KA_FAIL;
-
         c->cons_map_off.assign(N, 0);
         long long mt = 0;
         for (int i = 0; i < N; i++) { c->cons_map_off[i] = mt; mt += (long long)K * c->lens[i]; }
-        c->cons_maps.assign((size_t)mt, -1);
-        size_t pk = 0;
-        for (int i = 0; i < N; i++)
-                for (int k = 0; k < K; k++) {
-                        int* map = c->cons_maps.data() + c->cons_map_off[i] + (long long)k * c->lens[i];
-                        const int len_i = c->lens[i];
-                        const int ak = anchor_of[(size_t)i * K + k];
-                        if (ak < 0) continue;                              // a sequence whose alignment has no table: no positions
-                        if (i == ak) { for (int p = 0; p < len_i; p++) map[p] = p; continue; }
-                        const int* path = paths.data() + poff[pk++];
-                        int pos_a = 0, pos_b = 0;
-                        for (int x = 1; path[x] != 3; x++) {                 // anchor_consistency.c:86-114
-                                if (path[x] == 0) { if (pos_a < len_i) map[pos_a] = pos_b; pos_a++; pos_b++; }
-                                else if (path[x] & 1) pos_b++;
-                                else if (path[x] & 2) { if (pos_a < len_i) map[pos_a] = -1; pos_a++; }
+        std::vector<int> pair_of((size_t)N * K, -2);                  // pair index, -1: the anchor itself, -2: no table
+        {
+                int pk = 0;
+                for (int i = 0; i < N; i++)
+                        for (int k = 0; k < K; k++) {
+                                const int ak = anchor_of[(size_t)i * K + k];
+                                if (ak < 0) continue;
+                                pair_of[(size_t)i * K + k] = (i == ak) ? -1 : pk++;
                         }
-                }
-
-        // device copies: maps, member lists, the identity residue->column table
-        if (c->d_cons_maps.alloc(c->cons_maps.size()) || c->d_cons_map_off.alloc(N)) return fail("hipMalloc failed");
-        HIPCHK(hipMemcpy(c->d_cons_maps.p, c->cons_maps.data(), sizeof(int) * c->cons_maps.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_cons_map_off.p, c->cons_map_off.data(), sizeof(long long) * N, hipMemcpyHostToDevice));
+        }
+        if (c->d_cons_maps.alloc((size_t)mt) || c->d_cons_map_off.alloc(N) || c->d_pair_of.alloc(pair_of.size())) return fail("hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(c->d_cons_map_off.p, c->cons_map_off.data(), sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_pair_of.p, pair_of.data(), sizeof(int) * pair_of.size(), hipMemcpyHostToDevice, c->stream));
+        ka_launch_posmaps(c->p_paths.p, c->p_poff.p, c->d_pair_of.p, c->p_len.p, c->d_cons_map_off.p, N, K, c->d_cons_maps.p, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->cons_maps.clear();                                         // host copy on demand
+        c->cons_maps_total = mt;
         if (!c->have_colof && setup_colof(c)) return KA_FAIL;
         c->cons_K = K; c->cons_weight = weight;
         c->ran = false; c->synced = false; c->state_valid = false;
@@ -1140,7 +1144,18 @@ extern "C" int ka_tree_get_consistency(ka_ctx* c, int* anchor_ids, int* maps_out
         if (!c || !c->have_job) return -1;
         if (c->cons_K <= 0) return 0;
         if (anchor_ids) memcpy(anchor_ids, c->cons_anchor_ids.data(), sizeof(int) * c->cons_anchor_ids.size());
-        if (maps_out) memcpy(maps_out, c->cons_maps.data(), sizeof(int) * c->cons_maps.size());
+        if (maps_out) {
+                if (c->cons_maps.empty() && c->cons_maps_total > 0) {
+                        c->cons_maps.resize((size_t)c->cons_maps_total);
+                        if (hipSetDevice(c->device) != hipSuccess ||
+                            hipMemcpy(c->cons_maps.data(), c->d_cons_maps.p, sizeof(int) * c->cons_maps.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+                                c->cons_maps.clear();
+                                fail("ka_tree_get_consistency: copying the position maps back failed");
+                                return -1;
+                        }
+                }
+                memcpy(maps_out, c->cons_maps.data(), sizeof(int) * c->cons_maps.size());
+        }
         return c->cons_K;
 }
 
@@ -1155,13 +1170,11 @@ extern "C" int ka_msa_tree(ka_ctx* c, int numseq, const uint8_t* codes, const in
         return ka_tree_download(c, recs, paths_out, paths_cap, gaps_out);
 }
 
-extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
-                                 const int* ia, const int* ib, int npairs,
-                                 const float* subm, float gpo, float gpe, float tgpe,
-                                 int* paths_out, const long long* poff, float* scores_out)
+// The batch up to and including the kernel: coded paths stay in c->p_paths (pair k at poff[k]), scores in c->p_scores.
+static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                              const int* ia, const int* ib, int npairs,
+                              const float* subm, float gpo, float gpe, float tgpe, const long long* poff, long long* ptotal_out)
 {
-        if (!c) return fail("null ctx");
-        if (npairs <= 0) return KA_OK;
         HIPCHK(hipSetDevice(c->device));
         long long codes_bytes = 0, stride = 0, ptotal = 0;
         for (int i = 0; i < numseq; i++) codes_bytes = std::max<long long>(codes_bytes, (long long)off[i] + lens[i]);
@@ -1208,10 +1221,23 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
                 PCHK(hipMemcpy(&err, d_err.p, sizeof(int), hipMemcpyDeviceToHost));
                 if (err) { cleanup(); return fail("device watchdog: a strip pipeline inside a workgroup stopped making progress"); }
         }
-        PCHK(hipMemcpy(paths_out, d_paths.p, sizeof(int) * (size_t)ptotal, hipMemcpyDeviceToHost));
-        if (scores_out) PCHK(hipMemcpy(scores_out, d_scores.p, sizeof(float) * npairs, hipMemcpyDeviceToHost));
 #undef PCHK
         cleanup();
+        *ptotal_out = ptotal;
+        return KA_OK;
+}
+
+extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
+                                 const int* ia, const int* ib, int npairs,
+                                 const float* subm, float gpo, float gpe, float tgpe,
+                                 int* paths_out, const long long* poff, float* scores_out)
+{
+        if (!c) return fail("null ctx");
+        if (npairs <= 0) return KA_OK;
+        long long ptotal = 0;
+        if (pairwise_on_device(c, codes, off, lens, numseq, ia, ib, npairs, subm, gpo, gpe, tgpe, poff, &ptotal)) return KA_FAIL;
+        HIPCHK(hipMemcpy(paths_out, c->p_paths.p, sizeof(int) * (size_t)ptotal, hipMemcpyDeviceToHost));
+        if (scores_out) HIPCHK(hipMemcpy(scores_out, c->p_scores.p, sizeof(float) * npairs, hipMemcpyDeviceToHost));
         return KA_OK;
 }
 

@@ -70,6 +70,7 @@ struct KaTreeDev {
         int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table
         // ---- anchor consistency (anchor_consistency.c); cons_K == 0: off ----
+        int max_g;                     // workgroups one task may use when clusters merge up the chained launch
         int cons_K;                    // anchors
         int cons_maxlen;               // longest sequence: bounds every anchor position
         float cons_paw;                // weight / (float)K  (per_anchor_weight, anchor_consistency.c:487)

@@ -168,7 +168,15 @@ std::unique_ptr<Sub> bisect(const Builder& B, std::vector<int> samples, int dept
         bool have_best = false;
         for (int i = 0; i < tries; i += 4) {
                 Split cand[4];
-                for (int k = 0; k < 4; k++) split2(B.dm, B.padded, samples, B.num_anchors, (i + k) * step, cand[k]);
+                if (B.n_threads > 1 && num_samples >= 128) {     // the reference: four OpenMP tasks (:325-340)
+                        std::future<void> f[3];
+                        for (int k = 1; k < 4; k++)
+                                f[k - 1] = std::async(std::launch::async, [&, k] { split2(B.dm, B.padded, samples, B.num_anchors, (i + k) * step, cand[k]); });
+                        split2(B.dm, B.padded, samples, B.num_anchors, i * step, cand[0]);
+                        for (int k = 0; k < 3; k++) f[k].get();
+                } else {
+                        for (int k = 0; k < 4; k++) split2(B.dm, B.padded, samples, B.num_anchors, (i + k) * step, cand[k]);
+                }
                 int change = 0;
                 for (int k = 0; k < 4; k++)
                         if (!have_best || best.score > cand[k].score) { best = std::move(cand[k]); have_best = true; change++; }

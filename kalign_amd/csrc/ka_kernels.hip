@@ -1195,7 +1195,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 S.Lb = swapped ? len_a : len_b;
                 // how many of the launched workgroups this task really uses (every member derives the
                 // same number from the operand lengths): one CU saturates at about 8 strips in flight
-                int g_eff = (S.La >= 768) ? 4 : ((S.La >= 320) ? 2 : 1);
+                int g_eff = (S.La >= 1536) ? 8 : ((S.La >= 1152) ? 6 : ((S.La >= 768) ? 4 : ((S.La >= 320) ? 2 : 1)));
                 if (g_eff > g_launch) g_eff = g_launch;
                 S.G = g_eff; S.member = member; S.bar_phase = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
@@ -1324,7 +1324,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
 // as soon as both operands exist instead of at the next launch, clusters grow as the tree narrows, and the
 // whole upper tree is one launch.  All workgroups are resident from the start (<= one per CU), so the waits
 // cannot starve anybody; they are bounded all the same (device watchdog).
-#define KA_MAX_G 4
+#define KA_MAX_G 8
 template <bool LEAN, int NB>
 __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __restrict__ blocks, const int chain)
 {
@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
                         const unsigned int slot = __hip_atomic_fetch_add(&J->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                         if (slot + 1 == need) {
                                 const unsigned int tot = __hip_atomic_load(&J->sum_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const int gp = (int)(tot < KA_MAX_G ? tot : KA_MAX_G);
+                                const int gp = (int)(tot < (unsigned int)D.max_g ? tot : (unsigned int)D.max_g);
                                 J->join_base = S.G; J->join_g = gp;
                                 __hip_atomic_store(&J->go, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                                 __hip_atomic_store(&Jc->role, 1 | (gp << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
