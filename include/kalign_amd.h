@@ -212,17 +212,21 @@ int ka_bpm_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const int* l
  *   codes            the sequences in the alphabet the reference builds its tree in: reduced protein alphabet
  *                    (ALPHA_redPROTEIN, aln_wrap.c:155-160) or nucleotides; sorted as msa_sort_len_name left them
  *   n_threads        host threads for the independent halves of the bisection (the result does not depend on it)
+ *   dm_scale[numseq * min(32, numseq)]  NULL, or build_tree_kmeans_noisy (:76-175, the trees of ensemble members):
+ *                    the multiplier of every anchor distance, row-major [sequence][anchor] -- what the reference
+ *                    draws as max(0.1, tl_random_gaussian(rng, 1.0, sigma)) cast to float, in that order (:103-115).
+ *                    The random numbers stay the caller's: they come from the reference's own generator.
  *   tasks_abc[3*(numseq-1)]  (a, b, c) in TASK_ORDER_TREE order -- what ka_tree_upload / ka_msa_tree take
  *   seq_distances[numseq]    msa->seq_distances (:244-255); may be NULL
  */
 int ka_guide_tree(ka_ctx* ctx, int numseq, const uint8_t* codes, const int* off, const int* lens,
-                  int n_threads, int* tasks_abc, float* seq_distances);
+                  int n_threads, const float* dm_scale, int* tasks_abc, float* seq_distances);
 /* The same with the caller's distance source: dist() must fill dist_out[k] with calc_distance(seq ia[k], seq ib[k])
  * (sequence_distance.c:150-162) for k < npairs and return 0; it is called twice (anchor batch, cluster batch).
  * Host only: needs no context and no GPU. */
 typedef int (*ka_dist_fn)(void* user, int npairs, const int* ia, const int* ib, int* dist_out);
 int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
-                       int* tasks_abc, float* seq_distances);
+                       const float* dm_scale, int* tasks_abc, float* seq_distances);
 
 /* Kernel time (HIP events on the launch stream) of the last ka_pairwise_batch / ka_bpm_batch, milliseconds. */
 float ka_pairwise_kernel_ms(ka_ctx* ctx);

@@ -99,8 +99,8 @@ def load_library():
     L.ka_bpm_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
     L.ka_tree_aligned_rows.argtypes = [vp, vp, C.c_ubyte, vp, C.c_longlong, vp]
-    L.ka_guide_tree.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]
-    L.ka_guide_tree_from.argtypes = [C.c_int, vp, DIST_FN, vp, C.c_int, vp, vp]
+    L.ka_guide_tree.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.ka_guide_tree_from.argtypes = [C.c_int, vp, DIST_FN, vp, C.c_int, vp, vp, vp]
     L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
     L.ka_pairwise_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp,
                                     C.c_float, C.c_float, C.c_float, vp, vp, vp]
@@ -343,20 +343,31 @@ def _bpm_batch(self, codes, ia, ib):
 Context.bpm_batch = _bpm_batch
 
 
-def _guide_tree(self, codes, n_threads=1):
+def _dm_scale(noise, n):
+    if noise is None:
+        return None
+    noise = np.ascontiguousarray(noise, np.float32).reshape(-1)
+    if len(noise) != n * min(32, n):
+        raise KalignAmdError("dm_scale needs numseq * min(32, numseq) multipliers")
+    return noise
+
+
+def _guide_tree(self, codes, n_threads=1, dm_scale=None):
     """build_tree_kmeans with both distance batches on the device: (tasks[n-1, 3], seq_distances[n]).
-    `codes` in the alphabet the reference builds its tree in (reduced protein alphabet / nucleotides)."""
+    `codes` in the alphabet the reference builds its tree in (reduced protein alphabet / nucleotides);
+    dm_scale: the multipliers of build_tree_kmeans_noisy, or None."""
     flat, off, lens = _flatten(codes)
     tasks = np.zeros((len(codes) - 1, 3), np.int32)
     sd = np.zeros(len(codes), np.float32)
-    self._chk(self.L.ka_guide_tree(self.h, len(codes), _ptr(flat), _ptr(off), _ptr(lens), int(n_threads), _ptr(tasks), _ptr(sd)))
+    sc = _dm_scale(dm_scale, len(codes))
+    self._chk(self.L.ka_guide_tree(self.h, len(codes), _ptr(flat), _ptr(off), _ptr(lens), int(n_threads), _ptr(sc), _ptr(tasks), _ptr(sd)))
     return tasks, sd
 
 
 Context.guide_tree = _guide_tree
 
 
-def guide_tree_from(lens, dist, n_threads=1):
+def guide_tree_from(lens, dist, n_threads=1, dm_scale=None):
     """build_tree_kmeans with the caller's distance source (ka_guide_tree_from; host only, no GPU needed):
     dist(ia, ib) -> calc_distance of every pair, as an int array."""
     L = load_library()
@@ -372,7 +383,8 @@ def guide_tree_from(lens, dist, n_threads=1):
 
     tasks = np.zeros((len(lens) - 1, 3), np.int32)
     sd = np.zeros(len(lens), np.float32)
-    if L.ka_guide_tree_from(len(lens), _ptr(lens), DIST_FN(cb), None, int(n_threads), _ptr(tasks), _ptr(sd)):
+    sc = _dm_scale(dm_scale, len(lens))
+    if L.ka_guide_tree_from(len(lens), _ptr(lens), DIST_FN(cb), None, int(n_threads), _ptr(sc), _ptr(tasks), _ptr(sd)):
         raise KalignAmdError(L.ka_last_error().decode())
     return tasks, sd
 

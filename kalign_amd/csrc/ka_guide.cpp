@@ -232,7 +232,7 @@ void collect_leaves(Sub* s, std::vector<Sub*>& out)
 int ka_fail_message(const char* m);      // ka_api.cpp: sets what ka_last_error() returns
 
 extern "C" int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
-                                  int* tasks_abc, float* seq_distances)
+                                  const float* dm_scale, int* tasks_abc, float* seq_distances)
 {
         if (numseq < 2 || !lens || !dist || !tasks_abc) return ka_fail_message("ka_guide_tree_from: bad arguments");
         for (int i = 0; i < numseq; i++)
@@ -250,6 +250,10 @@ extern "C" int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, 
         std::vector<float> dm((size_t)numseq * padded, 0.0f);
         for (int i = 0; i < numseq; i++)
                 for (int j = 0; j < A; j++) dm[(size_t)i * padded + j] = with_length_term(d[(size_t)i * A + j], lens[i], lens[anchors[j]]);
+        // build_tree_kmeans_noisy (:103-115): the caller's multiplicative noise on the anchor distances
+        if (dm_scale)
+                for (int i = 0; i < numseq; i++)
+                        for (int j = 0; j < A; j++) dm[(size_t)i * padded + j] *= dm_scale[(size_t)i * A + j];
 
         // ---- bisecting k-means down to clusters of < 50 sequences ----
         Builder B;
@@ -354,9 +358,9 @@ int device_dist(void* user, int npairs, const int* ia, const int* ib, int* out)
 }  // namespace
 
 extern "C" int ka_guide_tree(ka_ctx* ctx, int numseq, const uint8_t* codes, const int* off, const int* lens,
-                             int n_threads, int* tasks_abc, float* seq_distances)
+                             int n_threads, const float* dm_scale, int* tasks_abc, float* seq_distances)
 {
         if (!ctx || !codes || !off) return ka_fail_message("ka_guide_tree: bad arguments");
         DeviceDist D{ ctx, codes, off, lens, numseq };
-        return ka_guide_tree_from(numseq, lens, device_dist, &D, n_threads, tasks_abc, seq_distances);
+        return ka_guide_tree_from(numseq, lens, device_dist, &D, n_threads, dm_scale, tasks_abc, seq_distances);
 }

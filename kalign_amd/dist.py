@@ -258,3 +258,41 @@ def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
         chunks.append(rp)
         off += len(rp)
     return all_recs, (np.concatenate(chunks) if chunks else np.zeros(0, np.int32))
+
+
+# ------------------------------------------------------------------------------------------------
+# ensemble members, one per GPU (kalign_ensemble's loop, lib/src/ensemble.c:286-339)
+# ------------------------------------------------------------------------------------------------
+def member_on_context(ctx, tree_codes, codes, letters, subm, n_anchors=0, weight=2.0, n_threads=1):
+    """run_member for ensemble_members on a kalign_amd.Context: one kalign_run_seeded call of the reference's
+    ensemble loop -- guide tree (noisy when the member carries dm_scale), consistency, task tree, final rows.
+    A member is a dict: scal (gpo, gpe, tgpe, dist_scale, vsm_amax, use_seq_weights) and optionally dm_scale."""
+    def run(member):
+        tasks, sd = ctx.guide_tree(tree_codes, n_threads=n_threads, dm_scale=member.get("dm_scale"))
+        ctx.msa_tree(codes, tasks, subm, member["scal"], sd, n_anchors=n_anchors, weight=weight)
+        return ctx.tree_aligned_rows(letters)
+    return run
+
+
+def ensemble_members(run_member, members, rank, world, device="cpu"):
+    """Member k runs on rank k % world (replicas with different parameters: no data-path collective); the aligned
+    rows of every member are gathered on every rank for the consensus stage, which stays on the host
+    (POAR tables, lib/src/ensemble.c:341-).  Returns rows[k] = list of bytes, one per sequence."""
+    mine = [k for k in range(len(members)) if k % world == rank]
+    local = {k: run_member(members[k]) for k in mine}
+    if world == 1:
+        return [local[k] for k in range(len(members))]
+    # flatten this rank's members: per member (n rows, row length) + the row bytes
+    head = np.array([[k, len(local[k]), len(local[k][0]) if local[k] else 0] for k in mine], np.int64).reshape(-1, 3)
+    body = np.frombuffer(b"".join(b"".join(local[k]) for k in mine), np.uint8) if mine else np.zeros(0, np.uint8)
+    heads = _gather_bytes(head.view(np.uint8).reshape(-1), world, device)
+    bodies = _gather_bytes(body, world, device)
+    out = [None] * len(members)
+    for r in range(world):
+        h = heads[r].view(np.int64).reshape(-1, 3)
+        o = 0
+        for k, n, width in h:
+            rows = bodies[r][o:o + int(n) * int(width)].reshape(int(n), int(width))
+            out[int(k)] = [row.tobytes() for row in rows]
+            o += int(n) * int(width)
+    return out

@@ -37,6 +37,7 @@
 #include "alphabet.h"
 #include "task.h"
 #include "bisectingKmeans.h"
+#include "tlrng.h"
 #include "aln_param.h"
 #include "aln_struct.h"
 #include "aln_mem.h"
@@ -80,9 +81,43 @@ void refh_free(void* hv)
 
 /* Everything kalign_run_seeded does before the dispatcher (aln_wrap.c:144-207),
    with deterministic sequence names so the len/name sort has no garbage ties. */
+static void* prepare(char** seqs, int* lens, int numseq, int type,
+                     float gpo, float gpe, float tgpe, int n_threads,
+                     float dist_scale, float vsm_amax, float use_seq_weights, uint64_t tree_seed, float tree_noise);
+
 void* refh_prepare(char** seqs, int* lens, int numseq, int type,
                    float gpo, float gpe, float tgpe, int n_threads,
                    float dist_scale, float vsm_amax, float use_seq_weights)
+{
+        return prepare(seqs, lens, numseq, type, gpo, gpe, tgpe, n_threads, dist_scale, vsm_amax, use_seq_weights, 0, 0.0f);
+}
+
+/* the same with the noisy guide tree of ensemble members (kalign_run_seeded with tree_seed / tree_noise,
+   aln_wrap.c:171-176) */
+void* refh_prepare_noisy(char** seqs, int* lens, int numseq, int type,
+                         float gpo, float gpe, float tgpe, int n_threads,
+                         float dist_scale, float vsm_amax, float use_seq_weights, uint64_t tree_seed, float tree_noise)
+{
+        return prepare(seqs, lens, numseq, type, gpo, gpe, tgpe, n_threads, dist_scale, vsm_amax, use_seq_weights, tree_seed, tree_noise);
+}
+
+/* the multipliers build_tree_kmeans_noisy draws (bisectingKmeans.c:103-115), from the reference's own generator */
+int refh_noise_multipliers(uint64_t seed, float sigma, int n, float* out)
+{
+        struct rng_state* rng = init_rng(seed);
+        if(!rng) return 1;
+        for(int i = 0; i < n; i++){
+                double noise = tl_random_gaussian(rng, 1.0, (double)sigma);
+                if(noise < 0.1) noise = 0.1;
+                out[i] = (float)noise;
+        }
+        free_rng(rng);
+        return 0;
+}
+
+static void* prepare(char** seqs, int* lens, int numseq, int type,
+                     float gpo, float gpe, float tgpe, int n_threads,
+                     float dist_scale, float vsm_amax, float use_seq_weights, uint64_t tree_seed, float tree_noise)
 {
         struct refh* h = calloc(1, sizeof(struct refh));
         struct msa* msa = NULL;
@@ -122,7 +157,11 @@ void* refh_prepare(char** seqs, int* lens, int numseq, int type,
         {
                 struct timespec t0, t1;
                 clock_gettime(CLOCK_MONOTONIC, &t0);
-                if(build_tree_kmeans(msa, &h->tasks) != OK) goto ERROR;
+                if(tree_seed != 0 && tree_noise > 0.0f){
+                        if(build_tree_kmeans_noisy(msa, &h->tasks, tree_seed, tree_noise) != OK) goto ERROR;
+                }else{
+                        if(build_tree_kmeans(msa, &h->tasks) != OK) goto ERROR;
+                }
                 clock_gettime(CLOCK_MONOTONIC, &t1);
                 h->tree_secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         }

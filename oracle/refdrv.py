@@ -39,6 +39,11 @@ def lib():
     if _lib is None:
         L = C.CDLL(REF_SO)
         L.refh_prepare.restype = C.c_void_p
+        L.refh_prepare_noisy.restype = C.c_void_p
+        L.refh_prepare_noisy.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_float]
+        L.refh_noise_multipliers.argtypes = [C.c_uint64, C.c_float, C.c_int, C.c_void_p]
         L.refh_prepare.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int,
                                    C.c_float, C.c_float, C.c_float, C.c_int,
                                    C.c_float, C.c_float, C.c_float]
@@ -80,6 +85,14 @@ def lib():
     return _lib
 
 
+def noise_multipliers(seed, sigma, n):
+    """what build_tree_kmeans_noisy multiplies the anchor distances with (the reference's own generator)"""
+    out = np.zeros(n, np.float32)
+    if lib().refh_noise_multipliers(seed, sigma, n, _ptr(out)):
+        raise RuntimeError("rng")
+    return out
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -88,15 +101,19 @@ class RefJob:
     """One alignment job prepared by the real reference up to the dispatcher seam."""
 
     def __init__(self, seqs, type_=-1, gpo=-1.0, gpe=-1.0, tgpe=-1.0, n_threads=1,
-                 dist_scale=0.0, vsm_amax=-1.0, use_seq_weights=-1.0):
+                 dist_scale=0.0, vsm_amax=-1.0, use_seq_weights=-1.0, tree_seed=0, tree_noise=0.0):
         L = lib()
         bs = [s.encode() if isinstance(s, str) else s for s in seqs]
         n = len(bs)
         arr = (C.c_char_p * n)(*bs)
         lens = (C.c_int * n)(*[len(b) for b in bs])
         # the reference treats type 8 (UNDEFINED) / anything unknown as "auto"
-        self.h = L.refh_prepare(arr, lens, n, 8 if type_ < 0 else type_, gpo, gpe, tgpe, n_threads,
-                                dist_scale, vsm_amax, use_seq_weights)
+        if tree_seed and tree_noise > 0.0:          # the guide tree of an ensemble member (build_tree_kmeans_noisy)
+            self.h = L.refh_prepare_noisy(arr, lens, n, 8 if type_ < 0 else type_, gpo, gpe, tgpe, n_threads,
+                                          dist_scale, vsm_amax, use_seq_weights, tree_seed, tree_noise)
+        else:
+            self.h = L.refh_prepare(arr, lens, n, 8 if type_ < 0 else type_, gpo, gpe, tgpe, n_threads,
+                                    dist_scale, vsm_amax, use_seq_weights)
         if not self.h:
             raise RuntimeError("reference refused the input")
         self.n = L.refh_numseq(self.h)

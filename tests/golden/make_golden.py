@@ -154,13 +154,17 @@ def main():
     param_tables()
 
 
-def guide_case(name, seqs, n_threads=1):
-    """build_tree_kmeans (bisectingKmeans.c:177-271): the sequences in the alphabet the tree builder saw, the task
-    list it made (sorted TASK_ORDER_TREE) and msa->seq_distances."""
-    job = refdrv.RefJob(seqs, n_threads=n_threads)
+def guide_case(name, seqs, n_threads=1, tree_seed=0, tree_noise=0.0):
+    """build_tree_kmeans (bisectingKmeans.c:177-271) -- or, with a seed, build_tree_kmeans_noisy (:76-175): the
+    sequences in the alphabet the tree builder saw, the task list it made (sorted TASK_ORDER_TREE), msa->seq_distances
+    and, for the noisy variant, the multipliers the reference's generator drew."""
+    job = refdrv.RefJob(seqs, n_threads=n_threads, tree_seed=tree_seed, tree_noise=tree_noise)
     assert job.tree_codes is not None
+    extra = {}
+    if tree_seed:
+        extra["dm_scale"] = refdrv.noise_multipliers(tree_seed, tree_noise, job.n * min(32, job.n))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), lens=job.lens, tree_codes=np.concatenate(job.tree_codes),
-                        tasks=job.tasks, seq_distances=job.seq_distances, biotype=np.int32(job.biotype))
+                        tasks=job.tasks, seq_distances=job.seq_distances, biotype=np.int32(job.biotype), **extra)
     print(name, "n=%d" % job.n, "tasks=%d" % job.ntasks)
 
 
@@ -177,6 +181,10 @@ def guide_cases():
     guide_case("guide_ragged", [s[:10 + (7 * i) % 190] for i, s in enumerate(fam)])
     guide_case("guide_prot1100", synth.family(1100, 60, seed=27), n_threads=8)    # deeper k-means recursion
     guide_case("guide_two", synth.family(2, 50, seed=28))
+    # the trees of ensemble members (kalign_ensemble -> kalign_run_seeded with tree_seed / tree_noise)
+    guide_case("guide_noisy_prot300", synth.family(300, 150, seed=21), tree_seed=42, tree_noise=0.2)
+    guide_case("guide_noisy_dna200", synth.family(200, 120, dna=True, seed=22), tree_seed=7, tree_noise=0.5)
+    guide_case("guide_noisy_prot40", synth.family(40, 70, seed=29), tree_seed=99, tree_noise=1.5)   # clamps at 0.1
 
 
 if __name__ == "__main__":

@@ -138,3 +138,67 @@ def test_sharded_tree_world2_gloo(tmp_path, case):
         gaps = api.weave_gaps(g.lens, recs, z["paths"])                   # host-only C function, no GPU needed
         for got, want in zip(gaps, g.gaps_list()):
             assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------
+# ensemble members, one per rank (kalign_amd.dist.ensemble_members)
+# ------------------------------------------------------------------------------------------------
+def _members():
+    """three members in the spirit of ensemble.c:55-76: the default one, and two with scaled penalties and a noisy tree"""
+    from util import Golden
+    g = Golden("tree_prot32x200")
+    rng = np.random.RandomState(3)
+    out = [dict(scal=g.scal.copy())]
+    for f in (0.8, 1.3):
+        s = g.scal.copy()
+        s[:3] *= f
+        out.append(dict(scal=s, dm_scale=np.maximum(0.1, rng.normal(1.0, 0.3, len(g.lens) * min(32, len(g.lens)))).astype(np.float32)))
+    return g, out
+
+
+def _oracle_member(g):
+    """run_member built from the oracle and the host-side tree builder (the CPU stand-in of dist.member_on_context)"""
+    from kalign_amd import api
+    from oracle import oracledrv
+
+    def run(member):
+        tasks, sd = api.guide_tree_from(g.lens, lambda ia, ib: oracledrv.bpm_batch(g.tree_seqs, ia, ib), dm_scale=member.get("dm_scale"))
+        _, _, gaps, _ = oracledrv.msa_tree(g.codes, tasks, g.subm, member["scal"], sd)
+        return [r.encode() for r in oracledrv.rows_from_gaps(g.sorted_seqs(), gaps)]
+    return run
+
+
+def _ens_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from kalign_amd import dist as kd
+    kd.init(backend="gloo")
+    g, members = _members()
+    ran = []
+    run = _oracle_member(g)
+
+    def counted(m):
+        ran.append(1)
+        return run(m)
+    rows = kd.ensemble_members(counted, members, rank, world)
+    dist.barrier()
+    np.savez(out % rank, ran=len(ran), **{"m%d" % k: np.array(r) for k, r in enumerate(rows)})
+    dist.destroy_process_group()
+
+
+def test_ensemble_members_world2_gloo(tmp_path):
+    """members are dealt round-robin, every rank ends up with every member's rows, and they equal a single-process run"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ens%d.npz")
+    port = 29500 + ((os.getpid() + 211) % 500)
+    mp.spawn(_ens_worker, args=(2, port, out), nprocs=2, join=True)
+    g, members = _members()
+    from kalign_amd import dist as kd
+    want = kd.ensemble_members(_oracle_member(g), members, 0, 1)
+    assert len(set(len(r) for r in want[0])) == 1 and want[0] != want[1]          # members really differ
+    z0, z1 = np.load(out % 0), np.load(out % 1)
+    assert int(z0["ran"]) == 2 and int(z1["ran"]) == 1
+    for k in range(len(members)):
+        for z in (z0, z1):
+            assert [bytes(x) for x in z["m%d" % k]] == want[k]

@@ -19,7 +19,7 @@ def ctx():
 @pytest.mark.parametrize("name", guide_cases())
 def test_device_guide_tree_matches_reference(ctx, name):
     g = Golden(name)
-    tasks, sd = ctx.guide_tree(g.tree_seqs, n_threads=4)
+    tasks, sd = ctx.guide_tree(g.tree_seqs, n_threads=4, dm_scale=g.dm_scale if hasattr(g, "dm_scale") else None)
     assert np.array_equal(tasks, g.tasks)
     assert np.array_equal(sd.view(np.uint32), g.seq_distances.view(np.uint32))
 
@@ -39,3 +39,39 @@ def test_sequences_to_rows(ctx, name):
     for i, r in enumerate(g.ranks):
         got[int(r)] = rows[i].decode()
     assert got == [str(x) for x in g.rows]
+
+
+def test_ensemble_members_on_a_context(ctx):
+    """kalign_ensemble's member loop (ensemble.c:286-339) through dist.member_on_context: the default member equals
+    the golden; members with scaled penalties and a noisy tree equal the real kalign_run_seeded when oracle/_ref
+    is there to ask."""
+    from kalign_amd import dist as kd
+    from oracle import refdrv
+    g = Golden("tree_prot32x200")
+    n = len(g.lens)
+    members = [dict(scal=g.scal.copy())]
+    specs = [(0.8, 43, 0.2), (1.25, 44, 0.6)]
+    have_ref = refdrv.available()
+    for f, seed, sigma in specs:
+        s = g.scal.copy()
+        s[:3] *= np.float32(f)
+        scale = refdrv.noise_multipliers(seed, sigma, n * min(32, n)) if have_ref else np.ones(n * min(32, n), np.float32)
+        members.append(dict(scal=s, dm_scale=scale))
+    run = kd.member_on_context(ctx, g.tree_seqs, g.codes, g.sorted_seqs(), g.subm)
+    rows = kd.ensemble_members(run, members, 0, 1)
+
+    def input_order(r):
+        out = [None] * n
+        for i, k in enumerate(g.ranks):
+            out[int(k)] = r[i].decode()
+        return out
+    assert input_order(rows[0]) == [str(x) for x in g.rows]
+    if not have_ref:
+        pytest.skip("oracle/_ref not built: members 1.. unchecked")
+    seqs = [str(s) for s in g.seqs]
+    for k, (m, (f, seed, sigma)) in enumerate(zip(members[1:], specs), start=1):
+        job = refdrv.RefJob(seqs, gpo=float(m["scal"][0]), gpe=float(m["scal"][1]), tgpe=float(m["scal"][2]),
+                            tree_seed=seed, tree_noise=sigma)
+        job.run_tree()
+        assert input_order(rows[k]) == job.finalise(), k
+        job.close()

@@ -17,7 +17,9 @@ def oracle_dist(oracle, seqs):
 def test_guide_tree_matches_reference(oracle, name, n_threads):
     from kalign_amd import api
     g = Golden(name)
-    tasks, sd = api.guide_tree_from(g.lens, oracle_dist(oracle, g.tree_seqs), n_threads=n_threads)
+    # guide_noisy_*: build_tree_kmeans_noisy, the multipliers drawn by the reference's generator are part of the golden
+    scale = g.dm_scale if hasattr(g, "dm_scale") else None
+    tasks, sd = api.guide_tree_from(g.lens, oracle_dist(oracle, g.tree_seqs), n_threads=n_threads, dm_scale=scale)
     assert np.array_equal(tasks, g.tasks)
     assert np.array_equal(sd.view(np.uint32), g.seq_distances.view(np.uint32))       # bit for bit
 
@@ -40,10 +42,12 @@ def test_live_against_the_reference_when_it_is_built(oracle):
     from kalign_amd import api, synth
     if not refdrv.available():
         pytest.skip("oracle/_ref not built")
-    for n, length, dna, seed in ((57, 70, False, 101), (140, 50, True, 102), (260, 40, False, 103)):
-        job = refdrv.RefJob(synth.family(n, length, dna=dna, seed=seed))
-        tasks, sd = api.guide_tree_from(job.lens, oracle_dist(oracle, job.tree_codes), n_threads=2)
-        assert np.array_equal(tasks, job.tasks), (n, length, dna)
+    for n, length, dna, seed, noise in ((57, 70, False, 101, 0.0), (140, 50, True, 102, 0.0), (260, 40, False, 103, 0.0),
+                                        (180, 60, False, 104, 0.3), (75, 90, True, 105, 0.8)):
+        job = refdrv.RefJob(synth.family(n, length, dna=dna, seed=seed), tree_seed=seed if noise else 0, tree_noise=noise)
+        scale = refdrv.noise_multipliers(seed, noise, n * min(32, n)) if noise else None
+        tasks, sd = api.guide_tree_from(job.lens, oracle_dist(oracle, job.tree_codes), n_threads=2, dm_scale=scale)
+        assert np.array_equal(tasks, job.tasks), (n, length, dna, noise)
         assert np.array_equal(sd, job.seq_distances)
         job.close()
 
@@ -60,6 +64,8 @@ def test_guide_tree_error_behaviour():
         raise RuntimeError("no distances today")
     with pytest.raises(kalign_amd.KalignAmdError, match="distance source failed"):
         api.guide_tree_from(np.array([5, 4, 3], np.int32), broken)
+    with pytest.raises(kalign_amd.KalignAmdError, match="multipliers"):
+        api.guide_tree_from(np.array([5, 4, 3], np.int32), lambda ia, ib: np.zeros(len(ia), np.int32), dm_scale=np.ones(4))
 
 
 @pytest.mark.parametrize("name", tree_cases() + cons_cases())
