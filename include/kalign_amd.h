@@ -47,6 +47,10 @@ extern "C" {
                                    weave_alignment.c:41-112): ka_tree_download derives gaps_out from it in O(sum of
                                    lengths) instead of folding every task's path on the host; ka_msa_tree sets it
                                    when gaps_out is requested */
+#define KA_FLAG_KEEP_CONSISTENCY 8 /* the realignment pass of kalign_run_realign (aln_wrap.c:424-431,497-502): the same
+                                   sequences with a new task list keep the consistency table ka_tree_build_consistency
+                                   built for the previous job of this context (no table then: none now); fails if the
+                                   sequences differ */
 
 typedef struct ka_ctx ka_ctx;
 
@@ -202,6 +206,21 @@ int ka_pairwise_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const i
  */
 int ka_bpm_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const int* lens, int numseq,
                  const int* ia, const int* ib, int npairs, int* dist_out);
+
+/*
+ * Realignment (kalign_run_realign, lib/src/aln_wrap.c:449-495; the member runs of `--precise`): a new guide tree from
+ * a finished alignment.  compute_aln_pairwise_dist (lib/src/aln_apair_dist.c:9-86: 1 - identity over the columns
+ * where both rows have a residue, all N(N-1)/2 pairs) and build_tree_from_pairwise (bisectingKmeans.c:1150-1200:
+ * mean distance per sequence, then UPGMA on the N x N matrix, :974-1053) both run on the device; labels and tasks as
+ * create_tasks makes them.
+ *   rows             numseq rows of alnlen bytes, row_stride apart, gap_char where the reference has '-'; or NULL:
+ *                    the rows the last ka_tree_aligned_rows built, still in HBM (numseq must match; row_stride,
+ *                    alnlen, gap_char are ignored)
+ *   tasks_abc[3*(numseq-1)], seq_distances[numseq] (may be NULL)  as for ka_guide_tree
+ *   dm_out[numseq*numseq]  (may be NULL) the identity distances, before UPGMA consumed them
+ */
+int ka_aln_guide_tree(ka_ctx* ctx, int numseq, const uint8_t* rows, long long row_stride, int alnlen, uint8_t gap_char,
+                      int* tasks_abc, float* seq_distances, float* dm_out);
 
 /*
  * Guide tree: build_tree_kmeans (lib/src/bisectingKmeans.c:177-271) -- anchors by length

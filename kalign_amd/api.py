@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 FLAG_DEBUG_ROWS = 1
 FLAG_TIMING = 2
 FLAG_DEVICE_GAPS = 4
+FLAG_KEEP_CONSISTENCY = 8
 
 
 class KalignAmdError(RuntimeError):
@@ -43,7 +44,8 @@ EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_s
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
            "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
-           "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from"]
+           "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from",
+           "ka_aln_guide_tree"]
 
 
 def lib_path():
@@ -99,6 +101,7 @@ def load_library():
     L.ka_bpm_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
     L.ka_tree_aligned_rows.argtypes = [vp, vp, C.c_ubyte, vp, C.c_longlong, vp]
+    L.ka_aln_guide_tree.argtypes = [vp, C.c_int, vp, C.c_longlong, C.c_int, C.c_ubyte, vp, vp, vp]
     L.ka_guide_tree.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]
     L.ka_guide_tree_from.argtypes = [C.c_int, vp, DIST_FN, vp, C.c_int, vp, vp, vp]
     L.ka_tree_get_consistency.argtypes = [vp, vp, vp]
@@ -365,6 +368,30 @@ def _guide_tree(self, codes, n_threads=1, dm_scale=None):
 
 
 Context.guide_tree = _guide_tree
+
+
+def _aln_guide_tree(self, rows=None, n=None, gap=b"-", want_dm=False):
+    """The guide tree of a realignment pass (compute_aln_pairwise_dist + build_tree_from_pairwise on the device):
+    (tasks, seq_distances[, dm]).  rows: equal-length byte strings, or None for the rows the last
+    tree_aligned_rows left in HBM (then n = number of sequences of that job)."""
+    if rows is None:
+        n = self._job["n"] if n is None else n
+        flat, stride, alnlen = None, 0, 0
+    else:
+        n = len(rows)
+        alnlen = len(rows[0])
+        if any(len(r) != alnlen for r in rows):
+            raise KalignAmdError("rows of one alignment have one length")
+        flat = np.frombuffer(b"".join(bytes(r) for r in rows), np.uint8)
+        stride = alnlen
+    tasks = np.zeros((n - 1, 3), np.int32)
+    sd = np.zeros(n, np.float32)
+    dm = np.zeros((n, n), np.float32) if want_dm else None
+    self._chk(self.L.ka_aln_guide_tree(self.h, n, _ptr(flat), stride, alnlen, gap[0], _ptr(tasks), _ptr(sd), _ptr(dm)))
+    return (tasks, sd, dm) if want_dm else (tasks, sd)
+
+
+Context.aln_guide_tree = _aln_guide_tree
 
 
 def guide_tree_from(lens, dist, n_threads=1, dm_scale=None):

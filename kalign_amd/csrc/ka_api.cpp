@@ -22,6 +22,11 @@ extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev,
 extern "C" int ka_max_g_host(void);
 extern "C" void ka_launch_posmaps(const int* paths, const long long* poff, const int* pair_of, const int* lens, const long long* map_off,
                                   int numseq, int K, int* maps, hipStream_t stream);
+extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int alnlen, int n, uint8_t gap, float* dm, float* means,
+                                   hipStream_t stream);
+extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* cand, unsigned int* done, int2* merges, int n,
+                                hipStream_t stream);
+int ka_tasks_from_merges(int numseq, const int* merges_ab, int* tasks_abc);      // ka_guide.cpp
 extern "C" void ka_launch_rows(const uint8_t* letters, const int* off, const int* lens, const int* colof, const int* alnlen,
                                int numseq, uint8_t gap, uint8_t* rows, long long stride, hipStream_t stream);
 extern "C" void ka_launch_bpm(const uint8_t* codes, const int* off, const int* lens, int numseq, unsigned long long* peq,
@@ -129,6 +134,8 @@ struct ka_ctx {
         std::vector<long long> cons_map_off;
         DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip, d_alnlen, d_pair_of;
         DevBuf<uint8_t> d_letters, d_rows;
+        long long rows_stride = 0; int rows_n = 0, rows_alnlen = 0; uint8_t rows_gap = 0;   // what d_rows holds (0 rows: nothing)
+        DevBuf<float> d_adm, d_amean; DevBuf<int> d_uactive; DevBuf<unsigned long long> d_ucand; DevBuf<unsigned int> d_udone; DevBuf<int2> d_umerges;
         DevBuf<long long> d_cons_map_off, d_sip_off;
 };
 
@@ -177,6 +184,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         c->b_peq.release(); c->b_dist.release();
         c->d_letters.release(); c->d_rows.release(); c->d_alnlen.release(); c->d_pair_of.release();
+        c->d_adm.release(); c->d_amean.release(); c->d_uactive.release(); c->d_ucand.release(); c->d_udone.release(); c->d_umerges.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -308,9 +316,20 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (numseq < 2 || n_tasks < 1 || n_tasks > numseq - 1) return fail("need numseq >= 2 and 1 <= n_tasks <= numseq-1");
         HIPCHK(hipSetDevice(c->device));
         const int nprof = 2 * numseq - 1;
+        // kalign_run_realign aligns a second time on a new tree with the consistency table of the first pass
+        // (aln_wrap.c:424-431,497-502): same sequences, new task list.  Anything else starts without a table.
+        bool keep_cons = false;
+        if ((flags & KA_FLAG_KEEP_CONSISTENCY) && c->have_job && c->cons_K > 0) {
+                bool same = numseq == c->numseq;
+                for (int i = 0; same && i < numseq; i++)
+                        same = lens[i] == c->lens[i] && off[i] == c->off[i] && memcmp(codes + off[i], c->h_codes.data() + off[i], lens[i]) == 0;
+                if (!same) return fail("KA_FLAG_KEEP_CONSISTENCY: the sequences differ from those the consistency table was built on");
+                keep_cons = true;
+        }
         c->have_job = false; c->ran = false; c->synced = false; c->state_valid = false;
-        c->cons_K = 0;                           // a new job starts without a consistency table
+        if (!keep_cons) c->cons_K = 0;           // a new job starts without a consistency table
         c->have_colof = false;
+        c->rows_n = 0;
         c->numseq = numseq; c->n_tasks = n_tasks; c->flags = flags;
         c->lens.assign(lens, lens + numseq);
         c->off.assign(off, off + numseq);
@@ -439,7 +458,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         HIPCHK(hipMemcpyAsync(c->d_subm.p, subm, sizeof(float) * 23 * 23, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->have_job = true;
-        if ((flags & KA_FLAG_DEVICE_GAPS) && setup_colof(c)) { c->have_job = false; return KA_FAIL; }
+        if (((flags & KA_FLAG_DEVICE_GAPS) || keep_cons) && setup_colof(c)) { c->have_job = false; return KA_FAIL; }
         return KA_OK;
 }
 
@@ -764,7 +783,52 @@ extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t g
         HIPCHK(hipMemcpyAsync(rows_out, c->d_rows.p, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq);
+        // the rows stay in HBM for ka_aln_guide_tree (one alignment only: a forest has no common row length)
+        c->rows_n = (c->n_tasks == c->numseq - 1) ? c->numseq : 0;
+        c->rows_stride = row_stride; c->rows_alnlen = widest; c->rows_gap = gap_char;
         return KA_OK;
+}
+
+// ---- realignment (kalign_run_realign, aln_wrap.c:449-495): compute_aln_pairwise_dist + build_tree_from_pairwise ----
+extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, long long row_stride, int alnlen, uint8_t gap_char,
+                                 int* tasks_abc, float* seq_distances, float* dm_out)
+{
+        if (!c) return fail("null ctx");
+        if (!tasks_abc) return fail("null argument");
+        HIPCHK(hipSetDevice(c->device));
+        const uint8_t* d_rows = nullptr;
+        if (rows) {
+                if (numseq < 2 || alnlen < 1 || row_stride < alnlen) return fail("ka_aln_guide_tree: bad arguments");
+                const size_t bytes = (size_t)numseq * (size_t)row_stride;
+                if (c->d_rows.alloc(bytes)) return fail("hipMalloc failed");
+                HIPCHK(hipMemcpyAsync(c->d_rows.p, rows, bytes, hipMemcpyHostToDevice, c->stream));
+                c->rows_n = 0;                                        // no longer the rows of the last run
+        } else {
+                if (c->rows_n < 2) return fail("ka_aln_guide_tree: no rows on the device (call ka_tree_aligned_rows on a finished single-tree run first)");
+                if (numseq != c->rows_n) return fail("ka_aln_guide_tree: numseq does not match the rows on the device");
+                row_stride = c->rows_stride; alnlen = c->rows_alnlen; gap_char = c->rows_gap;
+        }
+        d_rows = c->d_rows.p;
+        const size_t nn = (size_t)numseq * (size_t)numseq;
+        if (c->d_adm.alloc(nn) || c->d_amean.alloc(numseq) || c->d_uactive.alloc(numseq) || c->d_ucand.alloc(256) ||
+            c->d_udone.alloc(1) || c->d_umerges.alloc(numseq))
+                return fail("hipMalloc failed");
+        ka_launch_aln_dist(d_rows, row_stride, alnlen, numseq, gap_char, c->d_adm.p, c->d_amean.p, c->stream);
+        HIPCHK(hipGetLastError());
+        if (dm_out) HIPCHK(hipMemcpyAsync(dm_out, c->d_adm.p, sizeof(float) * nn, hipMemcpyDeviceToHost, c->stream));
+        if (seq_distances) HIPCHK(hipMemcpyAsync(seq_distances, c->d_amean.p, sizeof(float) * numseq, hipMemcpyDeviceToHost, c->stream));
+        {
+                std::vector<int> ones(numseq, 1);
+                HIPCHK(hipMemcpyAsync(c->d_uactive.p, ones.data(), sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipMemsetAsync(c->d_udone.p, 0, sizeof(unsigned int), c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));              // `ones` leaves scope; dm_out is complete before UPGMA overwrites the matrix
+        }
+        ka_launch_upgma(c->d_adm.p, c->d_uactive.p, c->d_ucand.p, c->d_udone.p, c->d_umerges.p, numseq, c->stream);
+        HIPCHK(hipGetLastError());
+        std::vector<int> merges(2 * (size_t)numseq);
+        HIPCHK(hipMemcpyAsync(merges.data(), c->d_umerges.p, sizeof(int2) * (numseq - 1), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return ka_tasks_from_merges(numseq, merges.data(), tasks_abc);
 }
 
 

@@ -220,6 +220,30 @@ int upgma(Tree& T, std::vector<float>& dm, const std::vector<int>& samples)
         return tree[node_a];
 }
 
+// label_internal + create_tasks + sort_tasks(TASK_ORDER_TREE) (bisectingKmeans.c:1067-1115, task.c:114-136):
+// internal nodes numbered in post-order from numseq, one task per internal node, c ascending.  Returns the task count.
+int emit_tasks(Tree& T, int top, int numseq, int* tasks_abc)
+{
+        int label = numseq, n_tasks = 0;
+        struct Walk { int node; int state; };
+        std::vector<Walk> ws;
+        ws.push_back(Walk{ top, 0 });
+        while (!ws.empty()) {
+                Walk& w = ws.back();
+                Node& nd = T.nodes[w.node];
+                if (nd.left < 0) { ws.pop_back(); continue; }
+                if (w.state == 0) { w.state = 1; ws.push_back(Walk{ nd.left, 0 }); continue; }
+                if (w.state == 1) { w.state = 2; ws.push_back(Walk{ nd.right, 0 }); continue; }
+                nd.id = label++;
+                tasks_abc[3 * n_tasks] = T.nodes[nd.left].id;
+                tasks_abc[3 * n_tasks + 1] = T.nodes[nd.right].id;
+                tasks_abc[3 * n_tasks + 2] = nd.id;
+                n_tasks++;
+                ws.pop_back();
+        }
+        return n_tasks;
+}
+
 void collect_leaves(Sub* s, std::vector<Sub*>& out)
 {
         if (!s->l) { out.push_back(s); return; }
@@ -314,26 +338,7 @@ extern "C" int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, 
                         done.push_back(T.add(l, r, -1));
                         st.pop_back();
                 }
-                // post-order labels and tasks
-                const int top = done.back();
-                int label = numseq, n_tasks = 0;
-                struct Walk { int node; int state; };
-                std::vector<Walk> ws;
-                ws.push_back(Walk{ top, 0 });
-                while (!ws.empty()) {
-                        Walk& w = ws.back();
-                        Node& nd = T.nodes[w.node];
-                        if (nd.left < 0) { ws.pop_back(); continue; }
-                        if (w.state == 0) { w.state = 1; ws.push_back(Walk{ nd.left, 0 }); continue; }
-                        if (w.state == 1) { w.state = 2; ws.push_back(Walk{ nd.right, 0 }); continue; }
-                        nd.id = label++;
-                        tasks_abc[3 * n_tasks] = T.nodes[nd.left].id;
-                        tasks_abc[3 * n_tasks + 1] = T.nodes[nd.right].id;
-                        tasks_abc[3 * n_tasks + 2] = nd.id;
-                        n_tasks++;
-                        ws.pop_back();
-                }
-                if (n_tasks != numseq - 1) return ka_fail_message("ka_guide_tree_from: internal error (task count)");
+                if (emit_tasks(T, done.back(), numseq, tasks_abc) != numseq - 1) return ka_fail_message("ka_guide_tree_from: internal error (task count)");
         }
 
         // ---- msa->seq_distances (bisectingKmeans.c:244-255) ----
@@ -345,6 +350,25 @@ extern "C" int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, 
                         seq_distances[i] = mean_dist / (float)lens[i];
                 }
         return KA_OK;
+}
+
+// upgma()'s bookkeeping (bisectingKmeans.c:996-1047) for a merge sequence found on the device: merge k joins the
+// current subtrees of slots a < b into slot a; the last merge's slot holds the root.  Library-internal.
+__attribute__((visibility("hidden"))) int ka_tasks_from_merges(int numseq, const int* merges_ab, int* tasks_abc)
+{
+        Tree T;
+        std::vector<int> slot(numseq);
+        for (int i = 0; i < numseq; i++) slot[i] = T.add(-1, -1, i);
+        int top = slot[0];
+        for (int k = 0; k < numseq - 1; k++) {
+                const int a = merges_ab[2 * k], b = merges_ab[2 * k + 1];
+                if (a < 0 || b < 0 || a >= numseq || b >= numseq || a == b || slot[a] < 0 || slot[b] < 0)
+                        return ka_fail_message("realignment tree: inconsistent merge sequence");
+                slot[a] = T.add(slot[a], slot[b], -1);
+                slot[b] = -1;
+                top = slot[a];
+        }
+        return emit_tasks(T, top, numseq, tasks_abc) == numseq - 1 ? KA_OK : ka_fail_message("realignment tree: internal error (task count)");
 }
 
 // The distance source of the product: the two batches run on the device (ka_bpm.hip).

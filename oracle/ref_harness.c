@@ -38,6 +38,8 @@
 #include "task.h"
 #include "bisectingKmeans.h"
 #include "tlrng.h"
+#include "aln_apair_dist.h"
+#include "msa_op.h"
 #include "aln_param.h"
 #include "aln_struct.h"
 #include "aln_mem.h"
@@ -402,6 +404,60 @@ int refh_run_tree(void* hv, int* gaps_out, double* secs)
         if(secs) *secs = t1 - t0;
         h->msa->aligned = ALN_STATUS_ALIGNED;
         if(gaps_out) collect_gaps(h->msa, gaps_out);
+        return 0;
+}
+
+/* One iteration of kalign_run_realign's loop up to the new guide tree (aln_wrap.c:449-495), after refh_run_tree:
+   finalise_alignment, compute_aln_pairwise_dist, strip the gaps again, re-encode, set_sip_nsip,
+   build_tree_from_pairwise.  Afterwards refh_get_tasks / refh_get_seq_distances describe the new tree and
+   refh_run_tree aligns on it.  rows_sorted (may be NULL): the finalised rows in sorted order, alnlen+1 bytes each,
+   as compute_aln_pairwise_dist saw them; dm_out (may be NULL): the numseq x numseq identity distances. */
+int refh_realign_tree(void* hv, char** rows_sorted, int* alnlen, float* dm_out, double* secs_dist, double* secs_tree)
+{
+        struct refh* h = (struct refh*)hv;
+        struct msa* msa = h->msa;
+        float** dm = NULL;
+        struct timespec t0, t1, t2;
+        if(finalise_alignment(msa) != OK) return 1;
+        if(alnlen) *alnlen = msa->alnlen;
+        if(rows_sorted){
+                for(int i = 0; i < msa->numseq; i++) memcpy(rows_sorted[i], msa->sequences[i]->seq, msa->alnlen + 1);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        if(compute_aln_pairwise_dist(msa, &dm) != OK) return 1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if(dm_out){
+                for(int i = 0; i < msa->numseq; i++) memcpy(dm_out + (size_t)i * msa->numseq, dm[i], sizeof(float) * msa->numseq);
+        }
+        if(dealign_msa(msa) != OK) return 1;
+        for(int si = 0; si < msa->numseq; si++){
+                struct msa_seq* seq = msa->sequences[si];
+                int w = 0;
+                for(int r = 0; seq->seq[r] != '\0'; r++){
+                        if(seq->seq[r] != '-') seq->seq[w++] = seq->seq[r];
+                }
+                seq->seq[w] = '\0';
+                seq->len = w;
+        }
+        if(msa->biotype == ALN_BIOTYPE_DNA){
+                if(convert_msa_to_internal(msa, ALPHA_defDNA) != OK) return 1;
+        }else{
+                if(convert_msa_to_internal(msa, ALPHA_ambigiousPROTEIN) != OK) return 1;
+        }
+        if(set_sip_nsip(msa) != OK) return 1;
+        free_tasks(h->tasks);
+        h->tasks = NULL;
+        if(alloc_tasks(&h->tasks, msa->numseq) != OK) return 1;
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        if(build_tree_from_pairwise(msa, &h->tasks, dm) != OK) return 1;
+        {
+                struct timespec t3;
+                clock_gettime(CLOCK_MONOTONIC, &t3);
+                if(secs_tree) *secs_tree = (double)(t3.tv_sec - t2.tv_sec) + 1e-9 * (double)(t3.tv_nsec - t2.tv_nsec);
+        }
+        if(secs_dist) *secs_dist = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        free_aln_dm(dm, msa->numseq);
+        if(sort_tasks(h->tasks, TASK_ORDER_TREE) != OK) return 1;
         return 0;
 }
 

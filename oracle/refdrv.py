@@ -57,6 +57,8 @@ def lib():
         L.refh_get_seq_distances.argtypes = [C.c_void_p, C.c_void_p]
         L.refh_get_tree_codes.argtypes = [C.c_void_p, C.c_void_p]
         L.refh_tree_seconds.argtypes = [C.c_void_p]
+        L.refh_realign_tree.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_void_p,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.refh_tree_seconds.restype = C.c_double
         L.refh_get_seq_distances.restype = C.c_int
         L.refh_get_params.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -208,6 +210,26 @@ class RefJob:
         if rc:
             raise RuntimeError("traced replay failed")
         return recs, paths, self.split_gaps(g), dump
+
+    def realign_tree(self, want_dm=True):
+        """One iteration of kalign_run_realign's loop up to the new tree (aln_wrap.c:449-495), after run_tree():
+        returns (finalised rows in sorted order, identity distances N x N, seconds in compute_aln_pairwise_dist,
+        seconds in build_tree_from_pairwise) and refreshes self.tasks / self.seq_distances; run_tree() then
+        aligns on the new tree."""
+        L = lib()
+        cap = int(self.lens.sum()) + 1
+        bufs = [C.create_string_buffer(cap) for _ in range(self.n)]
+        rows = (C.c_char_p * self.n)(*[C.cast(b, C.c_char_p) for b in bufs])
+        alnlen = C.c_int(0)
+        dm = np.zeros((self.n, self.n), np.float32) if want_dm else None
+        sd, st = C.c_double(0), C.c_double(0)
+        if L.refh_realign_tree(self.h, rows, C.byref(alnlen), _ptr(dm), C.byref(sd), C.byref(st)):
+            raise RuntimeError("realign step failed")
+        self.ntasks = L.refh_ntasks(self.h)
+        self.tasks = np.zeros((self.ntasks, 3), np.int32)
+        L.refh_get_tasks(self.h, _ptr(self.tasks))
+        L.refh_get_seq_distances(self.h, _ptr(self.seq_distances))
+        return [b.value.decode() for b in bufs], dm, sd.value, st.value
 
     def finalise(self):
         alnlen = lib().refh_alnlen_from_gaps(self.h)

@@ -168,6 +168,35 @@ def guide_case(name, seqs, n_threads=1, tree_seed=0, tree_noise=0.0):
     print(name, "n=%d" % job.n, "tasks=%d" % job.ntasks)
 
 
+def realign_case(name, seqs, n_anchors=0, weight=2.0, **kw):
+    """One iteration of kalign_run_realign (aln_wrap.c:361-527): first alignment on the BPM/k-means tree, identity
+    distances from that alignment, UPGMA tree from them, second alignment on that tree."""
+    job = refdrv.RefJob(seqs, **kw)
+    if n_anchors:
+        job.build_consistency(n_anchors, weight)
+    tasks1, sd1 = job.tasks.copy(), job.seq_distances.copy()
+    job.run_tree()
+    rows_sorted, dm, _, _ = job.realign_tree()
+    tasks2, sd2 = job.tasks.copy(), job.seq_distances.copy()
+    job.run_tree()
+    final_rows = job.finalise()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                        seqs=np.array(seqs), lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes),
+                        subm=job.subm, biotype=np.int32(job.biotype), n_anchors=np.int32(n_anchors), weight=np.float32(weight),
+                        scal=np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32),
+                        tasks1=tasks1, seq_distances1=sd1, rows_sorted=np.array(rows_sorted), dm=dm,
+                        tasks2=tasks2, seq_distances2=sd2, final_rows=np.array(final_rows))
+    print(name, "n=%d" % job.n, "alnlen %d -> %d" % (len(rows_sorted[0]), len(final_rows[0])))
+
+
+def realign_cases():
+    realign_case("realign_prot40", synth.family(40, 80, seed=3))
+    fam = synth.family(30, 60, seed=4)
+    realign_case("realign_dups", fam + fam[:7] + fam[3:5])                        # identical rows: distance ties in UPGMA
+    realign_case("realign_dna24_cons", synth.family(24, 150, dna=True, seed=5), n_anchors=5)
+    realign_case("realign_prot150", synth.family(150, 70, seed=6))
+
+
 def guide_cases():
     rng = np.random.RandomState(5)
     guide_case("guide_prot300", synth.family(300, 150, seed=21))                  # k-means levels + UPGMA leaves
@@ -194,11 +223,15 @@ if __name__ == "__main__":
         cons_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "guide":
         guide_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "realign":
+        realign_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "bpm":
         bpm_case("bpm_mixed", 31)
         guide_cases()
+        realign_cases()
     else:
         main()
         cons_cases()
         bpm_case("bpm_mixed", 31)
         guide_cases()
+        realign_cases()

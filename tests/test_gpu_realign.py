@@ -1,0 +1,80 @@
+"""GPU parity of the realignment pass (kalign_run_realign, aln_wrap.c:361-527): identity distances from a finished
+alignment (compute_aln_pairwise_dist), the UPGMA tree built on them (build_tree_from_pairwise) -- both on the device --
+and the second alignment on that tree, against goldens the real reference produced (tests/golden/realign_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("realign_") and f.endswith(".npz"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kalign_amd
+    c = kalign_amd.Context(0)
+    yield c
+    c.close()
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    off = np.concatenate([[0], np.cumsum(z["lens"])])
+    codes = [z["codes"][off[i]:off[i + 1]] for i in range(len(z["lens"]))]
+    letters = [str(z["seqs"][r]) for r in z["ranks"]]            # sorted order
+    return z, codes, letters
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_tree_from_given_rows(ctx, name):
+    """host rows in: distances bit for bit, the reference's task list, its seq_distances"""
+    z, _, _ = load(name)
+    rows = [str(r).encode() for r in z["rows_sorted"]]
+    tasks, sd, dm = ctx.aln_guide_tree(rows, want_dm=True)
+    assert np.array_equal(dm.view(np.uint32), z["dm"].view(np.uint32))
+    assert np.array_equal(tasks, z["tasks2"])
+    assert np.array_equal(sd.view(np.uint32), z["seq_distances2"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_align_realign_align(ctx, name):
+    """the whole iteration with everything resident: align, rows, tree from the rows in HBM, align again"""
+    from kalign_amd import api
+    z, codes, letters = load(name)
+    k = int(z["n_anchors"])
+    ctx.msa_tree(codes, z["tasks1"], z["subm"], z["scal"], z["seq_distances1"], n_anchors=k, weight=float(z["weight"]))
+    rows = ctx.tree_aligned_rows(letters)
+    assert [r.decode() for r in rows] == [str(r) for r in z["rows_sorted"]]
+    tasks2, sd2 = ctx.aln_guide_tree()
+    assert np.array_equal(tasks2, z["tasks2"])
+    assert np.array_equal(sd2.view(np.uint32), z["seq_distances2"].view(np.uint32))
+    # second pass: new tree, new distances, the consistency table of the first pass
+    ctx.tree_upload(codes, tasks2, z["subm"], z["scal"], sd2, flags=api.FLAG_DEVICE_GAPS | api.FLAG_KEEP_CONSISTENCY)
+    ctx.tree_run()
+    rows2 = ctx.tree_aligned_rows(letters)
+    got = [None] * len(rows2)
+    for i, r in enumerate(z["ranks"]):
+        got[int(r)] = rows2[i].decode()
+    assert got == [str(r) for r in z["final_rows"]]
+
+
+def test_realign_error_behaviour(ctx):
+    import kalign_amd
+    from kalign_amd import api
+    z, codes, letters = load("realign_prot40")
+    ctx.tree_upload(codes, z["tasks1"], z["subm"], z["scal"], z["seq_distances1"], flags=api.FLAG_DEVICE_GAPS)
+    ctx.tree_run()
+    with pytest.raises(kalign_amd.KalignAmdError, match="no rows on the device"):
+        ctx.aln_guide_tree()
+    with pytest.raises(kalign_amd.KalignAmdError, match="one length"):
+        ctx.aln_guide_tree([b"AC-", b"AC"])
+    # a table must not be kept for other sequences
+    ctx.tree_build_consistency(3, 2.0)
+    other = [c.copy() for c in codes]
+    other[0] = other[0][::-1].copy()
+    with pytest.raises(kalign_amd.KalignAmdError, match="sequences differ"):
+        ctx.tree_upload(other, z["tasks1"], z["subm"], z["scal"], z["seq_distances1"], flags=api.FLAG_KEEP_CONSISTENCY)
