@@ -263,14 +263,25 @@ def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
 # ------------------------------------------------------------------------------------------------
 # ensemble members, one per GPU (kalign_ensemble's loop, lib/src/ensemble.c:286-339)
 # ------------------------------------------------------------------------------------------------
-def member_on_context(ctx, tree_codes, codes, letters, subm, n_anchors=0, weight=2.0, n_threads=1):
-    """run_member for ensemble_members on a kalign_amd.Context: one kalign_run_seeded call of the reference's
-    ensemble loop -- guide tree (noisy when the member carries dm_scale), consistency, task tree, final rows.
-    A member is a dict: scal (gpo, gpe, tgpe, dist_scale, vsm_amax, use_seq_weights) and optionally dm_scale."""
+def member_on_context(ctx, tree_codes, codes, letters, subm, n_anchors=0, weight=2.0, n_threads=1, realign=0):
+    """run_member for ensemble_members on a kalign_amd.Context: one member of the reference's ensemble loop.
+    realign == 0: kalign_run_seeded -- guide tree (noisy when the member carries dm_scale), consistency, task tree,
+    final rows.  realign > 0 (`--precise`): kalign_run_realign -- after the first alignment, `realign` times: identity
+    distances of the rows, UPGMA tree, alignment on that tree with the first pass's consistency table
+    (aln_wrap.c:449-504).  A member is a dict: scal (gpo, gpe, tgpe, dist_scale, vsm_amax, use_seq_weights) and
+    optionally dm_scale."""
+    from . import api
+
     def run(member):
-        tasks, sd = ctx.guide_tree(tree_codes, n_threads=n_threads, dm_scale=member.get("dm_scale"))
+        tasks, sd = ctx.guide_tree(tree_codes, n_threads=n_threads, dm_scale=None if realign else member.get("dm_scale"))
         ctx.msa_tree(codes, tasks, subm, member["scal"], sd, n_anchors=n_anchors, weight=weight)
-        return ctx.tree_aligned_rows(letters)
+        rows = ctx.tree_aligned_rows(letters)
+        for _ in range(realign):
+            tasks, sd = ctx.aln_guide_tree()
+            ctx.tree_upload(codes, tasks, subm, member["scal"], sd, flags=api.FLAG_DEVICE_GAPS | api.FLAG_KEEP_CONSISTENCY)
+            ctx.tree_run()
+            rows = ctx.tree_aligned_rows(letters)
+        return rows
     return run
 
 

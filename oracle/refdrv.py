@@ -96,7 +96,7 @@ def noise_multipliers(seed, sigma, n):
 
 
 def _ptr(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 class RefJob:
