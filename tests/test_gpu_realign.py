@@ -78,3 +78,19 @@ def test_realign_error_behaviour(ctx):
     other[0] = other[0][::-1].copy()
     with pytest.raises(kalign_amd.KalignAmdError, match="sequences differ"):
         ctx.tree_upload(other, z["tasks1"], z["subm"], z["scal"], z["seq_distances1"], flags=api.FLAG_KEEP_CONSISTENCY)
+
+
+@pytest.mark.parametrize("name", ["realign_prot40", "realign_dna24_cons"])
+def test_precise_member_through_dist(ctx, name):
+    """a `--precise` ensemble member (kalign_run_realign, one iteration) through dist.member_on_context, starting
+    from letters: tree alphabet, k-means tree, align, rows, UPGMA tree, align, rows"""
+    from kalign_amd import dist as kd, guide
+    z, codes, letters = load(name)
+    dna = int(z["biotype"]) != 0
+    run = kd.member_on_context(ctx, guide.encode_tree(letters, dna=dna), codes, letters, z["subm"],
+                               n_anchors=int(z["n_anchors"]), weight=float(z["weight"]), realign=1)
+    rows = kd.ensemble_members(run, [dict(scal=z["scal"])], 0, 1)[0]
+    got = [None] * len(rows)
+    for i, r in enumerate(z["ranks"]):
+        got[int(r)] = rows[i].decode()
+    assert got == [str(r) for r in z["final_rows"]]
