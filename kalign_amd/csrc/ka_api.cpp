@@ -297,8 +297,17 @@ static int plan_launches(ka_ctx* c)
                         }
                 }
                 const int m = ((int)order.size() + 7) / 8;
-                c->chain_blocks.assign((size_t)8 * m, make_int2(-1, 0));
-                for (int r = 0; r < (int)order.size(); r++) c->chain_blocks[(size_t)(r % m) * 8 + (r / m)] = make_int2(order[r], 0 | (1 << 8));
+                // A narrow upper tree (the chain-like UPGMA trees of a realignment pass) never merges clusters: its
+                // tasks would all run on the one workgroup they started with.  Start with as many workgroups per
+                // task as a separate launch of this level would get (build_blocks); members of one cluster sit in
+                // one column = one XCD.
+                int G0 = 1;
+                while (G0 * 2 <= c->max_cluster && 8 * m * G0 * 2 <= c->n_cus) G0 *= 2;
+                if (getenv("KA_CHAIN_G1")) G0 = 1;
+                c->chain_blocks.assign((size_t)8 * m * G0, make_int2(-1, 0));
+                for (int r = 0; r < (int)order.size(); r++)
+                        for (int g = 0; g < G0; g++)
+                                c->chain_blocks[((size_t)(r % m) * G0 + g) * 8 + (r / m)] = make_int2(order[r], g | (G0 << 8));
                 c->chain_blocks_off = (int)c->blocks_flat.size();
                 c->blocks_flat.insert(c->blocks_flat.end(), c->chain_blocks.begin(), c->chain_blocks.end());
         }

@@ -1137,8 +1137,8 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ------------------------------------------------------------------------------------------
 // LEAN = true: a level whose tasks are all seq-seq (the guide tree's leaf level): 4 waves, no LDS
 // ring, <=128 VGPRs -> four workgroups per CU instead of one.
-// Returns 0 when this workgroup took part in the task to its end, 1 when it was surplus to the
-// task's cluster or the task failed (arena overflow).
+// Returns 0 when this workgroup took part in the task to its end, 1 when the task failed (arena overflow),
+// 2 when the workgroup was surplus to the task's cluster (the task is too small for all of them).
 template <bool LEAN, int NB>
 __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, const int member, const int g_launch)
 {
@@ -1218,7 +1218,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 }
         }
         __syncthreads();
-        if (S.member >= S.G) return 1;                       // surplus workgroup of an over-provisioned cluster
+        if (S.member >= S.G) return 2;                       // surplus workgroup of an over-provisioned cluster
         ka_cluster_sync(S);
         if (S.ctl->fail) return 1;
         if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0);
@@ -1337,32 +1337,47 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
         const int tid = threadIdx.x;
         while (true) {
                 const int st = ka_task_body<LEAN, NB>(D, task, member, g);
-                if (!chain || st != 0) return;
+                if (!chain || st == 1) return;
+                // A workgroup the task had no use for stays with its cluster: it skips the task, waits for the cluster's
+                // role at the parent and moves up with it -- a bigger task further up may need it (in a chain-like
+                // tree clusters never merge, so a workgroup that left would be gone for good).
+                const bool surplus = st == 2;
                 const int parent = D.tasks[task].parent;
                 if (parent < 0) return;
-                // everything this cluster wrote for the task (profile, node_len, colof) is released ...
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                ka_cluster_sync(S);
                 KaJoin* J = D.join + parent;
                 KaJoin* Jc = D.join + task;
-                if (S.member == 0 && tid == 0) {
-                        const unsigned int need = (unsigned int)D.tasks[parent].chain_need;
-                        __hip_atomic_fetch_add(&J->sum_g, (unsigned int)S.G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned int slot = __hip_atomic_fetch_add(&J->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                        if (slot + 1 == need) {
-                                const unsigned int tot = __hip_atomic_load(&J->sum_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const int gp = (int)(tot < (unsigned int)D.max_g ? tot : (unsigned int)D.max_g);
-                                J->join_base = S.G; J->join_g = gp;
-                                __hip_atomic_store(&J->go, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(&Jc->role, 1 | (gp << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                                __hip_atomic_store(&Jc->role, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!surplus) {
+                        // everything this cluster wrote for the task (profile, node_len, colof) is released ...
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        ka_cluster_sync(S);
+                        if (S.member == 0 && tid == 0) {
+                                const unsigned int need = (unsigned int)D.tasks[parent].chain_need;
+                                // clusters are counted at their launched size g: surplus members are still with them
+                                __hip_atomic_fetch_add(&J->sum_g, (unsigned int)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned int slot = __hip_atomic_fetch_add(&J->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                                if (slot + 1 == need) {
+                                        const unsigned int tot = __hip_atomic_load(&J->sum_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        const int gp = (int)(tot < (unsigned int)D.max_g ? tot : (unsigned int)D.max_g);
+                                        J->join_base = g; J->join_g = gp;
+                                        __hip_atomic_store(&J->go, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                        __hip_atomic_store(&Jc->role, 1 | (gp << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                } else {
+                                        __hip_atomic_store(&Jc->role, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                }
                         }
+                        // ... and the role of this cluster at the parent is published to all of its workgroups
+                        ka_cluster_sync(S);
                 }
-                // ... and the role of this cluster at the parent is published to all of its workgroups
-                ka_cluster_sync(S);
                 if (tid == 0) {
-                        const int role = __hip_atomic_load(&Jc->role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int role = __hip_atomic_load(&Jc->role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (surplus) {
+                                int spins = 0;
+                                while (role == 0) {
+                                        __builtin_amdgcn_s_sleep(32);
+                                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 21, 6, true)) break;
+                                        role = __hip_atomic_load(&Jc->role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                        }
                         int nm, ng;
                         if ((role & 0xff) == 1) {
                                 nm = S.member; ng = role >> 8;
