@@ -818,6 +818,7 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
                 row_stride = c->rows_stride; alnlen = c->rows_alnlen; gap_char = c->rows_gap;
         }
         d_rows = c->d_rows.p;
+        if (numseq > 46340) return fail("ka_aln_guide_tree: more than 46340 sequences (pair indices are 32-bit)");
         const size_t nn = (size_t)numseq * (size_t)numseq;
         if (c->d_adm.alloc(nn) || c->d_amean.alloc(numseq) || c->d_uactive.alloc(numseq) || c->d_ucand.alloc(256) ||
             c->d_udone.alloc(1) || c->d_umerges.alloc(numseq))

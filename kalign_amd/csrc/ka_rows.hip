@@ -145,9 +145,11 @@ __global__ void ka_row_mean_kernel(const float* __restrict__ dm, int n, float* _
 {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i >= n) return;
+        // the matrix is symmetric: walk column i (coalesced across the threads of a wave) instead of row i -- the same
+        // values in the same order
         float sum = 0.0f;
         for (int j = 0; j < n; ++j)
-                if (j != i) sum += dm[(long long)i * n + j];
+                if (j != i) sum += dm[(long long)j * n + i];
         out[i] = (n > 1) ? sum / (float)(n - 1) : 0.0f;
 }
 
