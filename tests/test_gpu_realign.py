@@ -94,3 +94,26 @@ def test_precise_member_through_dist(ctx, name):
     for i, r in enumerate(z["ranks"]):
         got[int(r)] = rows[i].decode()
     assert got == [str(r) for r in z["final_rows"]]
+
+
+def test_tiny_and_degenerate_row_sets(ctx):
+    # two rows: one merge; distance = 1 - 2/3 over the three columns where both have a residue
+    tasks, sd, dm = ctx.aln_guide_tree([b"AC-GT", b"ACTC-"], want_dm=True)
+    assert tasks.tolist() == [[0, 1, 2]]
+    want = np.float32(1.0) - np.float32(2) / np.float32(3)
+    assert dm[0, 1] == want and dm[1, 0] == want and dm[0, 0] == 0 and sd.tolist() == [want, want]
+    # nothing aligned between two rows: distance 1 (aln_apair_dist.c:82-84); identical rows: 0 and the first pair wins
+    rows = [b"AC---", b"---GT", b"AC---", b"AC---"]
+    tasks, sd, dm = ctx.aln_guide_tree(rows, want_dm=True)
+    assert dm[0, 1] == 1.0 and dm[0, 2] == 0.0 and dm[2, 3] == 0.0
+    assert tasks[0].tolist() == [0, 2, 4]                         # the first minimal pair in row-major order
+    # a width that is no multiple of the kernel's 128-column step, a row count that is no multiple of its 16-row tile
+    rng = np.random.RandomState(1)
+    rows = [bytes(rng.choice(list(b"ACDE-"), size=301).astype(np.uint8)) for _ in range(37)]
+    tasks, sd, dm = ctx.aln_guide_tree(rows, want_dm=True)
+    a = np.frombuffer(b"".join(rows), np.uint8).reshape(37, 301)
+    for i, j in ((0, 1), (5, 36), (17, 18), (35, 36)):
+        both = (a[i] != 45) & (a[j] != 45)
+        want = np.float32(1.0) - np.float32(int((both & (a[i] == a[j])).sum())) / np.float32(int(both.sum()))
+        assert dm[i, j] == want and dm[j, i] == want
+    assert sorted(tasks[:, 2].tolist()) == list(range(37, 73))
