@@ -103,6 +103,9 @@ struct ka_ctx {
         DevBuf<ka_task_rec> d_recs;
         long long prof_cap = 0, path_cap = 0, scratch_cap = 0, dbg_cap = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        // two pinned bounce buffers for large downloads into the caller's (pageable) memory
+        char* pin[2] = { nullptr, nullptr };
+        hipEvent_t pin_ev[2] = { nullptr, nullptr };
         int* h_trace = nullptr;       // pinned, device-visible breadcrumbs (KA_TRACE=1)
         bool ran = false, synced = false;
         bool state_valid = false;      // device state reset and consistent with task_done
@@ -187,6 +190,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_adm.release(); c->d_amean.release(); c->d_uactive.release(); c->d_ucand.release(); c->d_udone.release(); c->d_umerges.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
+        for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -481,6 +485,38 @@ static int upload_plan(ka_ctx* c)
         return KA_OK;
 }
 
+// Device -> caller's memory.  A plain hipMemcpy into pageable memory runs at 2-3 GB/s here; large copies go through
+// two pinned bounce buffers instead: the DMA of chunk k+1 overlaps the host-side copy of chunk k.  Ordered after
+// everything queued on the context's stream; complete on return.
+static int copy_to_host(ka_ctx* c, void* dst, const void* src, size_t bytes)
+{
+        const size_t CH = (size_t)1 << 20;
+        bool staged = bytes >= 2 * CH && !getenv("KA_NO_STAGING");
+        for (int k = 0; staged && k < 2; k++) {
+                if (!c->pin[k] && hipHostMalloc((void**)&c->pin[k], CH, hipHostMallocDefault) != hipSuccess) { c->pin[k] = nullptr; staged = false; }
+                if (staged && !c->pin_ev[k] && hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { c->pin_ev[k] = nullptr; staged = false; }
+        }
+        if (!staged) {
+                HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                return KA_OK;
+        }
+        const size_t n = (bytes + CH - 1) / CH;
+        for (size_t k = 0; k <= n; k++) {
+                if (k < n) {
+                        const size_t len = std::min(CH, bytes - k * CH);
+                        HIPCHK(hipMemcpyAsync(c->pin[k & 1], (const char*)src + k * CH, len, hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(hipEventRecord(c->pin_ev[k & 1], c->stream));
+                }
+                if (k > 0) {                                          // chunk k-1 has landed: hand it to the caller while chunk k moves
+                        const size_t j = k - 1, len = std::min(CH, bytes - j * CH);
+                        HIPCHK(hipEventSynchronize(c->pin_ev[j & 1]));
+                        memcpy((char*)dst + j * CH, c->pin[j & 1], len);
+                }
+        }
+        return KA_OK;
+}
+
 // reset the device state so that a run is repeatable
 static int tree_reset(ka_ctx* c)
 {
@@ -702,7 +738,7 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
         c->h_recs.resize(c->n_tasks);
         HIPCHK(hipMemcpy(c->h_recs.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
         std::vector<int> arena((size_t)used);
-        HIPCHK(hipMemcpy(arena.data(), c->d_path_arena.p, sizeof(int) * (size_t)used, hipMemcpyDeviceToHost));
+        if (copy_to_host(c, arena.data(), c->d_path_arena.p, sizeof(int) * (size_t)used)) return KA_FAIL;
         // repack the paths in task order (arena order depends on workgroup scheduling)
         long long o = 0;
         double cells = 0.0;
@@ -743,7 +779,7 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
                 // the kernels kept every residue's column (make_seq / update_gaps in the device's form): the gap
                 // arrays are its first differences, O(sum of lengths) instead of O(N L log N) folding on the host
                 std::vector<int> col(c->colof_n);
-                HIPCHK(hipMemcpy(col.data(), c->d_colof.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToHost));
+                if (copy_to_host(c, col.data(), c->d_colof.p, sizeof(int) * c->colof_n)) return KA_FAIL;
                 std::vector<int> alen;
                 tree_alnlens(c, alen);
                 long long g = 0;
@@ -789,8 +825,7 @@ extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t g
         ka_launch_rows(c->d_letters.p, c->d_seq_off.p, c->d_node_len.p, c->d_colof.p, c->d_alnlen.p, c->numseq, gap_char,
                        c->d_rows.p, row_stride, c->stream);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(rows_out, c->d_rows.p, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (copy_to_host(c, rows_out, c->d_rows.p, bytes)) return KA_FAIL;
         if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq);
         // the rows stay in HBM for ka_aln_guide_tree (one alignment only: a forest has no common row length)
         c->rows_n = (c->n_tasks == c->numseq - 1) ? c->numseq : 0;
@@ -999,7 +1034,7 @@ extern "C" int ka_tree_download_tasks(ka_ctx* c, const int* task_ids, int n, ka_
         std::vector<ka_task_rec> all(c->n_tasks);
         HIPCHK(hipMemcpy(all.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
         std::vector<int> arena((size_t)std::max<long long>(used, 1));
-        HIPCHK(hipMemcpy(arena.data(), c->d_path_arena.p, sizeof(int) * (size_t)used, hipMemcpyDeviceToHost));
+        if (copy_to_host(c, arena.data(), c->d_path_arena.p, sizeof(int) * (size_t)used)) return KA_FAIL;
         long long o = 0;
         for (int i = 0; i < n; i++) {
                 const int t = task_ids[i];
@@ -1310,7 +1345,7 @@ extern "C" int ka_pairwise_batch(ka_ctx* c, const uint8_t* codes, const int* off
         if (npairs <= 0) return KA_OK;
         long long ptotal = 0;
         if (pairwise_on_device(c, codes, off, lens, numseq, ia, ib, npairs, subm, gpo, gpe, tgpe, poff, &ptotal)) return KA_FAIL;
-        HIPCHK(hipMemcpy(paths_out, c->p_paths.p, sizeof(int) * (size_t)ptotal, hipMemcpyDeviceToHost));
+        if (copy_to_host(c, paths_out, c->p_paths.p, sizeof(int) * (size_t)ptotal)) return KA_FAIL;
         if (scores_out) HIPCHK(hipMemcpy(scores_out, c->p_scores.p, sizeof(float) * npairs, hipMemcpyDeviceToHost));
         return KA_OK;
 }
