@@ -24,8 +24,7 @@ extern "C" void ka_launch_posmaps(const int* paths, const long long* poff, const
                                   int numseq, int K, int* maps, hipStream_t stream);
 extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int alnlen, int n, uint8_t gap, float* dm, float* means,
                                    hipStream_t stream);
-extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* cand, unsigned int* done, int2* merges, int n,
-                                hipStream_t stream);
+extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, hipStream_t stream);
 int ka_tasks_from_merges(int numseq, const int* merges_ab, int* tasks_abc);      // ka_guide.cpp
 extern "C" void ka_launch_rows(const uint8_t* letters, const int* off, const int* lens, const int* colof, const int* alnlen,
                                int numseq, uint8_t gap, uint8_t* rows, long long stride, hipStream_t stream);
@@ -855,8 +854,8 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
         d_rows = c->d_rows.p;
         if (numseq > 46340) return fail("ka_aln_guide_tree: more than 46340 sequences (pair indices are 32-bit)");
         const size_t nn = (size_t)numseq * (size_t)numseq;
-        if (c->d_adm.alloc(nn) || c->d_amean.alloc(numseq) || c->d_uactive.alloc(numseq) || c->d_ucand.alloc(256) ||
-            c->d_udone.alloc(1) || c->d_umerges.alloc(numseq))
+        if (c->d_adm.alloc(nn) || c->d_amean.alloc(numseq) || c->d_uactive.alloc(numseq) || c->d_ucand.alloc(2 * (size_t)numseq) ||
+            c->d_umerges.alloc(numseq))
                 return fail("hipMalloc failed");
         ka_launch_aln_dist(d_rows, row_stride, alnlen, numseq, gap_char, c->d_adm.p, c->d_amean.p, c->stream);
         HIPCHK(hipGetLastError());
@@ -865,10 +864,9 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
         {
                 std::vector<int> ones(numseq, 1);
                 HIPCHK(hipMemcpyAsync(c->d_uactive.p, ones.data(), sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
-                HIPCHK(hipMemsetAsync(c->d_udone.p, 0, sizeof(unsigned int), c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));              // `ones` leaves scope; dm_out is complete before UPGMA overwrites the matrix
         }
-        ka_launch_upgma(c->d_adm.p, c->d_uactive.p, c->d_ucand.p, c->d_udone.p, c->d_umerges.p, numseq, c->stream);
+        ka_launch_upgma(c->d_adm.p, c->d_uactive.p, c->d_ucand.p, c->d_umerges.p, numseq, c->stream);
         HIPCHK(hipGetLastError());
         std::vector<int> merges(2 * (size_t)numseq);
         HIPCHK(hipMemcpyAsync(merges.data(), c->d_umerges.p, sizeof(int2) * (numseq - 1), hipMemcpyDeviceToHost, c->stream));

@@ -153,75 +153,104 @@ __global__ void ka_row_mean_kernel(const float* __restrict__ dm, int n, float* _
         out[i] = (n > 1) ? sum / (float)(n - 1) : 0.0f;
 }
 
-// upgma (lib/src/bisectingKmeans.c:974-1053), one launch per merge: every workgroup scans a band of rows for the
-// smallest active dm[i][j], i < j (ties: the first in row-major order, the reference's strict '<' scan); the last
-// workgroup to finish reduces the candidates, records the pair and folds row/column b into a:
-// dm[a][j] = (dm[a][j] + dm[b][j]) * 0.5 + 0.001 for every j != b.
-struct KaUpgma { float* dm; int* active; unsigned long long* cand; unsigned int* done; int2* merges; int n; };
+// upgma (lib/src/bisectingKmeans.c:974-1053), one launch per merge.  The reference scans all active pairs for the
+// smallest dm[i][j], i < j, taking the first in row-major order on ties (strict '<'); here every active row keeps its
+// own minimum as a 64-bit key (value bits << 32 | i * n + j: distances are >= 0, so keys order like (value, i, j)),
+// and a merge costs O(n) instead of O(n^2):
+//   A  every workgroup reduces the n row keys of the previous step to the pair (a, b), a < b;
+//   B  it then updates its own rows: row i folds column b into column a from its own symmetric copies,
+//      dm[i][a] = (dm[i][a] + dm[i][b]) * 0.5 + 0.001 -- the value the reference writes to dm[a][i] and mirrors --,
+//      row a is rebuilt from row b (not written in this step), and a row key is rescanned only when its minimum sat in
+//      column a or b.  Keys are double-buffered: phase A of slow workgroups still reads the old ones.
+struct KaUpgma { float* dm; int* active; unsigned long long* key[2]; int2* merges; int n; };
 
 __device__ __forceinline__ unsigned long long ka_upgma_key(float v, unsigned int idx)
 {
-        // distances are >= 0: their bit patterns order like the values
         return ((unsigned long long)__float_as_uint(v) << 32) | idx;
+}
+
+__device__ __forceinline__ unsigned long long ka_block_min(unsigned long long v, unsigned long long* red)
+{
+        const int tid = threadIdx.x;
+        __syncthreads();
+        red[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+                if (tid < s) red[tid] = red[tid + s] < red[tid] ? red[tid + s] : red[tid];
+                __syncthreads();
+        }
+        return red[0];
+}
+
+// key of row i over the active columns j > i (block-wide); d0, d1: columns merged away in this and the previous step,
+// whose flags are not down yet
+__device__ __forceinline__ unsigned long long ka_upgma_scan_row(const KaUpgma& U, int i, int d0, int d1, unsigned long long* red)
+{
+        const int n = U.n;
+        const float* row = U.dm + (long long)i * n;
+        unsigned long long best = ~0ull;
+        for (int j = i + 1 + threadIdx.x; j < n; j += 256)
+                if (j != d0 && j != d1 && U.active[j]) {
+                        const unsigned long long k = ka_upgma_key(row[j], (unsigned int)(i * n + j));
+                        best = k < best ? k : best;
+                }
+        return ka_block_min(best, red);
+}
+
+__global__ void __launch_bounds__(256) ka_upgma_init_kernel(KaUpgma U)
+{
+        __shared__ unsigned long long red[256];
+        for (int i = blockIdx.x; i < U.n; i += gridDim.x) {
+                const unsigned long long k = ka_upgma_scan_row(U, i, -1, -1, red);
+                if (threadIdx.x == 0) U.key[0][i] = k;
+        }
 }
 
 __global__ void __launch_bounds__(256) ka_upgma_step_kernel(KaUpgma U, int step)
 {
         __shared__ unsigned long long red[256];
-        __shared__ int s_last, s_a, s_b;
         const int n = U.n, tid = threadIdx.x;
+        const unsigned long long* kin = U.key[step & 1];
+        unsigned long long* kout = U.key[(step + 1) & 1];
+        // A: the pair to merge
         unsigned long long best = ~0ull;
-        for (int i = blockIdx.x; i < n - 1; i += gridDim.x) {
-                if (!U.active[i]) continue;
-                const float* row = U.dm + (long long)i * n;
-                for (int j = i + 1 + tid; j < n; j += 256)
-                        if (U.active[j]) {
-                                const unsigned long long k = ka_upgma_key(row[j], (unsigned int)(i * n + j));
-                                best = k < best ? k : best;
-                        }
+        for (int i = tid; i < n; i += 256) { const unsigned long long k = kin[i]; best = k < best ? k : best; }
+        best = ka_block_min(best, red);
+        const unsigned int idx = (unsigned int)(best & 0xffffffffull);
+        const int a = (int)(idx / (unsigned int)n), b = (int)(idx % (unsigned int)n);
+        if (blockIdx.x == 0 && tid == 0) U.merges[step] = make_int2(a, b);
+        // the row merged away one step ago: its flag goes down in this launch (below), so nobody may rely on it yet
+        const int bprev = step ? U.merges[step - 1].y : -1;
+        // B: this workgroup's rows
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+                if (i == b || i == bprev || !U.active[i]) { if (tid == 0) kout[i] = ~0ull; continue; }
+                float* row = U.dm + (long long)i * n;
+                if (i == a) {
+                        const float* rb = U.dm + (long long)b * n;
+                        for (int j = tid; j < n; j += 256)
+                                if (j != b) row[j] = (j == a) ? 0.0f : (row[j] + rb[j]) * 0.5f + 0.001f;
+                        __syncthreads();                               // the scan below reads what other threads wrote
+                        const unsigned long long k = ka_upgma_scan_row(U, a, b, bprev, red);
+                        if (tid == 0) kout[a] = k;
+                        continue;
+                }
+                const unsigned long long k = kin[i];
+                const int jmin = (int)((unsigned int)(k & 0xffffffffull) % (unsigned int)n);
+                float via = 0.0f;
+                if (tid == 0) { via = (row[a] + row[b]) * 0.5f + 0.001f; row[a] = via; }
+                const bool rescan = (k != ~0ull) && (jmin == a || jmin == b) && i < b;
+                if (rescan) {
+                        __syncthreads();                               // row[a] is part of the scan when i < a
+                        const unsigned long long k2 = ka_upgma_scan_row(U, i, b, bprev, red);
+                        if (tid == 0) kout[i] = k2;
+                } else if (tid == 0) {
+                        unsigned long long k2 = k;
+                        if (i < a) { const unsigned long long c = ka_upgma_key(via, (unsigned int)(i * n + a)); k2 = c < k2 ? c : k2; }
+                        kout[i] = k2;
+                }
         }
-        red[tid] = best;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-                if (tid < s) red[tid] = red[tid + s] < red[tid] ? red[tid + s] : red[tid];
-                __syncthreads();
-        }
-        if (tid == 0) {
-                U.cand[blockIdx.x] = red[0];
-                __threadfence();
-                s_last = (atomicAdd(U.done, 1u) == gridDim.x - 1);
-        }
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();
-        best = ~0ull;
-        for (int b = tid; b < (int)gridDim.x; b += 256) {
-                const unsigned long long k = __hip_atomic_load(&U.cand[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                best = k < best ? k : best;
-        }
-        red[tid] = best;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-                if (tid < s) red[tid] = red[tid + s] < red[tid] ? red[tid + s] : red[tid];
-                __syncthreads();
-        }
-        if (tid == 0) {
-                const unsigned int idx = (unsigned int)(red[0] & 0xffffffffull);
-                s_a = (int)(idx / (unsigned int)n); s_b = (int)(idx % (unsigned int)n);
-                U.merges[step] = make_int2(s_a, s_b);
-                U.active[s_b] = 0;
-                *U.done = 0u;
-        }
-        __syncthreads();
-        const int a = s_a, b = s_b;
-        float* ra = U.dm + (long long)a * n;
-        const float* rb = U.dm + (long long)b * n;
-        for (int j = tid; j < n; j += 256)
-                if (j != b) ra[j] = (ra[j] + rb[j]) * 0.5f + 0.001f;
-        __syncthreads();
-        if (tid == 0) ra[a] = 0.0f;
-        __syncthreads();
-        for (int j = tid; j < n; j += 256) U.dm[(long long)j * n + a] = ra[j];
+        // readers of this launch treat bprev as gone whatever its flag says; from the next launch on the flag is down
+        if (blockIdx.x == 0 && tid == 0 && bprev >= 0) U.active[bprev] = 0;
 }
 
 extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int alnlen, int n, uint8_t gap, float* dm, float* means,
@@ -232,12 +261,12 @@ extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int al
         hipLaunchKernelGGL(ka_row_mean_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dm, n, means);
 }
 
-// cand: room for 256 candidates, done: one zeroed counter, active: n ones, merges: n - 1 pairs
-extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* cand, unsigned int* done, int2* merges, int n,
-                                hipStream_t stream)
+// keys: 2 * n words, active: n ones, merges: n - 1 pairs
+extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, hipStream_t stream)
 {
-        KaUpgma U{ dm, active, cand, done, merges, n };
-        const int blocks = n < 512 ? 32 : 256;
+        KaUpgma U{ dm, active, { keys, keys + n }, merges, n };
+        const int blocks = n < 256 ? n : 256;
+        hipLaunchKernelGGL(ka_upgma_init_kernel, dim3(blocks), dim3(256), 0, stream, U);
         for (int step = 0; step < n - 1; ++step)
                 hipLaunchKernelGGL(ka_upgma_step_kernel, dim3(blocks), dim3(256), 0, stream, U, step);
 }
