@@ -137,7 +137,7 @@ struct ka_ctx {
         DevBuf<int> d_cons_maps, d_colof, d_colof_init, d_sip, d_alnlen, d_pair_of;
         DevBuf<uint8_t> d_letters, d_rows;
         long long rows_stride = 0; int rows_n = 0, rows_alnlen = 0; uint8_t rows_gap = 0;   // what d_rows holds (0 rows: nothing)
-        DevBuf<float> d_adm, d_amean; DevBuf<int> d_uactive; DevBuf<unsigned long long> d_ucand; DevBuf<unsigned int> d_udone; DevBuf<int2> d_umerges;
+        DevBuf<float> d_adm, d_amean; DevBuf<int> d_uactive; DevBuf<unsigned long long> d_ucand; DevBuf<int2> d_umerges;
         DevBuf<long long> d_cons_map_off, d_sip_off;
 };
 
@@ -186,7 +186,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->p_err.release(); c->p_subm.release(); c->p_scores.release(); c->p_poff.release(); c->p_scr.release();
         c->b_peq.release(); c->b_dist.release();
         c->d_letters.release(); c->d_rows.release(); c->d_alnlen.release(); c->d_pair_of.release();
-        c->d_adm.release(); c->d_amean.release(); c->d_uactive.release(); c->d_ucand.release(); c->d_udone.release(); c->d_umerges.release();
+        c->d_adm.release(); c->d_amean.release(); c->d_uactive.release(); c->d_ucand.release(); c->d_umerges.release();
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
         for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
@@ -861,11 +861,8 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
         HIPCHK(hipGetLastError());
         if (dm_out) HIPCHK(hipMemcpyAsync(dm_out, c->d_adm.p, sizeof(float) * nn, hipMemcpyDeviceToHost, c->stream));
         if (seq_distances) HIPCHK(hipMemcpyAsync(seq_distances, c->d_amean.p, sizeof(float) * numseq, hipMemcpyDeviceToHost, c->stream));
-        {
-                std::vector<int> ones(numseq, 1);
-                HIPCHK(hipMemcpyAsync(c->d_uactive.p, ones.data(), sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));              // `ones` leaves scope; dm_out is complete before UPGMA overwrites the matrix
-        }
+        std::vector<int> ones(numseq, 1);
+        HIPCHK(hipMemcpyAsync(c->d_uactive.p, ones.data(), sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
         ka_launch_upgma(c->d_adm.p, c->d_uactive.p, c->d_ucand.p, c->d_umerges.p, numseq, c->stream);
         HIPCHK(hipGetLastError());
         std::vector<int> merges(2 * (size_t)numseq);

@@ -206,15 +206,17 @@ __global__ void __launch_bounds__(256) ka_upgma_init_kernel(KaUpgma U)
         }
 }
 
-__global__ void __launch_bounds__(256) ka_upgma_step_kernel(KaUpgma U, int step)
+__device__ __forceinline__ void ka_upgma_step(const KaUpgma& U, const int step, unsigned long long* red)
 {
-        __shared__ unsigned long long red[256];
         const int n = U.n, tid = threadIdx.x;
         const unsigned long long* kin = U.key[step & 1];
         unsigned long long* kout = U.key[(step + 1) & 1];
         // A: the pair to merge
         unsigned long long best = ~0ull;
-        for (int i = tid; i < n; i += 256) { const unsigned long long k = kin[i]; best = k < best ? k : best; }
+        for (int i = tid; i < n; i += 256) {
+                const unsigned long long k = __hip_atomic_load(&kin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                best = k < best ? k : best;
+        }
         best = ka_block_min(best, red);
         const unsigned int idx = (unsigned int)(best & 0xffffffffull);
         const int a = (int)(idx / (unsigned int)n), b = (int)(idx % (unsigned int)n);
@@ -249,8 +251,14 @@ __global__ void __launch_bounds__(256) ka_upgma_step_kernel(KaUpgma U, int step)
                         kout[i] = k2;
                 }
         }
-        // readers of this launch treat bprev as gone whatever its flag says; from the next launch on the flag is down
+        // readers of this step treat bprev as gone whatever its flag says; from the next step on the flag is down
         if (blockIdx.x == 0 && tid == 0 && bprev >= 0) U.active[bprev] = 0;
+}
+
+__global__ void __launch_bounds__(256) ka_upgma_step_kernel(KaUpgma U, int step)
+{
+        __shared__ unsigned long long red[256];
+        ka_upgma_step(U, step, red);
 }
 
 extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int alnlen, int n, uint8_t gap, float* dm, float* means,
@@ -261,7 +269,12 @@ extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int al
         hipLaunchKernelGGL(ka_row_mean_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dm, n, means);
 }
 
-// keys: 2 * n words, active: n ones, merges: n - 1 pairs
+// ---- launching the n - 1 dependent merge steps ----
+// One launch per step, ~11 us each, of which the step's own work is a few.  Measured alternatives on MI355X, both
+// bit-identical and neither faster: the loop replayed as one hipGraph of n kernel nodes (12 us per node: the cost is the
+// dependent dispatch on the GPU, not the host-side launch), and one persistent kernel of 64 workgroups with a barrier
+// in HBM between steps (21 us per step: an agent-scope release/acquire pair across the eight XCDs' L2s costs more than
+// a kernel boundary).  keys: 2 * n words, active: n ones, merges: n - 1 pairs.
 extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, hipStream_t stream)
 {
         KaUpgma U{ dm, active, { keys, keys + n }, merges, n };
