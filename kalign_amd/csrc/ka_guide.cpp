@@ -13,6 +13,7 @@
 #include <future>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "kalign_amd.h"
@@ -170,10 +171,18 @@ std::unique_ptr<Sub> bisect(const Builder& B, std::vector<int> samples, int dept
                 Split cand[4];
                 if (B.n_threads > 1 && num_samples >= 128) {     // the reference: four OpenMP tasks (:325-340)
                         std::future<void> f[3];
-                        for (int k = 1; k < 4; k++)
-                                f[k - 1] = std::async(std::launch::async, [&, k] { split2(B.dm, B.padded, samples, B.num_anchors, (i + k) * step, cand[k]); });
+                        bool started[3] = { false, false, false };
+                        for (int k = 1; k < 4; k++) {
+                                try {
+                                        f[k - 1] = std::async(std::launch::async, [&, k] { split2(B.dm, B.padded, samples, B.num_anchors, (i + k) * step, cand[k]); });
+                                        started[k - 1] = true;
+                                } catch (const std::system_error&) {}     // no thread to be had: this candidate runs here
+                        }
                         split2(B.dm, B.padded, samples, B.num_anchors, i * step, cand[0]);
-                        for (int k = 0; k < 3; k++) f[k].get();
+                        for (int k = 0; k < 3; k++) {
+                                if (started[k]) f[k].get();
+                                else split2(B.dm, B.padded, samples, B.num_anchors, (i + k + 1) * step, cand[k + 1]);
+                        }
                 } else {
                         for (int k = 0; k < 4; k++) split2(B.dm, B.padded, samples, B.num_anchors, (i + k) * step, cand[k]);
                 }
@@ -184,8 +193,15 @@ std::unique_ptr<Sub> bisect(const Builder& B, std::vector<int> samples, int dept
         }
         samples.clear();
         samples.shrink_to_fit();
+        std::future<std::unique_ptr<Sub>> fut;
+        bool forked = false;
         if ((1 << depth) < B.n_threads) {                // the two halves are independent (the reference: OpenMP tasks)
-                auto fut = std::async(std::launch::async, [&] { return bisect(B, std::move(best.sl), depth + 1); });
+                try {
+                        fut = std::async(std::launch::async, [&] { return bisect(B, std::move(best.sl), depth + 1); });
+                        forked = true;
+                } catch (const std::system_error&) {}             // no thread to be had: serial
+        }
+        if (forked) {
                 out->r = bisect(B, std::move(best.sr), depth + 1);
                 out->l = fut.get();
         } else {
@@ -255,8 +271,23 @@ void collect_leaves(Sub* s, std::vector<Sub*>& out)
 
 int ka_fail_message(const char* m);      // ka_api.cpp: sets what ka_last_error() returns
 
+static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
+                           const float* dm_scale, int* tasks_abc, float* seq_distances);
+
 extern "C" int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
                                   const float* dm_scale, int* tasks_abc, float* seq_distances)
+{
+        try {                                            // no exception may cross the C ABI
+                return guide_tree_from(numseq, lens, dist, user, n_threads, dm_scale, tasks_abc, seq_distances);
+        } catch (const std::bad_alloc&) {
+                return ka_fail_message("ka_guide_tree_from: out of memory");
+        } catch (const std::exception& e) {
+                return ka_fail_message((std::string("ka_guide_tree_from: ") + e.what()).c_str());
+        }
+}
+
+static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
+                           const float* dm_scale, int* tasks_abc, float* seq_distances)
 {
         if (numseq < 2 || !lens || !dist || !tasks_abc) return ka_fail_message("ka_guide_tree_from: bad arguments");
         for (int i = 0; i < numseq; i++)
