@@ -266,6 +266,66 @@ def end_to_end_leg(ctx, seqs, subm, scal, args, k_anchors=5, weight=2.0):
     return info
 
 
+def realign_leg(ctx, seqs, subm, scal, args):
+    """One member run of `--precise`: kalign_run_realign with one iteration, fast mode (aln_wrap.c:361-527) -- guide
+    tree, alignment, rows, identity distances + UPGMA tree from those rows (both on the device), alignment on that
+    tree, rows -- next to the reference doing the same on the host cores."""
+    from kalign_amd import api, guide
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))       # msa_sort_len_name
+    inp = seqs
+    seqs = [inp[i] for i in order]
+    tcodes = guide.encode_tree(seqs, dna=args.dna)
+    codes = guide.encode(seqs, dna=args.dna)
+    nt = min(os.cpu_count() or 1, 16)
+    got = {}
+
+    def once():
+        t = {}
+
+        def lap(name, t0=[time.perf_counter()]):
+            now = time.perf_counter()
+            t[name] = (now - t0[0]) * 1e3
+            t0[0] = now
+        lap("_")
+        tasks, sd = ctx.guide_tree(tcodes, n_threads=nt)
+        lap("guide_tree_ms")
+        ctx.msa_tree(codes, tasks, subm, scal, sd)
+        ctx.tree_aligned_rows(seqs)
+        lap("align1_and_rows_ms")
+        tasks2, sd2 = ctx.aln_guide_tree()
+        lap("aln_dist_and_upgma_ms")
+        ctx.tree_upload(codes, tasks2, subm, scal, sd2, flags=api.FLAG_DEVICE_GAPS | api.FLAG_KEEP_CONSISTENCY)
+        ctx.tree_run()
+        got["rows"] = ctx.tree_aligned_rows(seqs)
+        lap("align2_and_rows_ms")
+        del t["_"]
+        t["total_ms"] = sum(t.values())
+        return t
+
+    once()
+    info = once()
+    if not args.no_cpu:
+        try:
+            from oracle import refdrv
+            job = refdrv.RefJob(inp, type_=0 if args.dna else -1, n_threads=nt)
+            t0 = time.perf_counter(); job.run_tree(); a1 = time.perf_counter() - t0
+            _, _, sdist, stree = job.realign_tree(want_dm=False)
+            t0 = time.perf_counter(); job.run_tree(); a2 = time.perf_counter() - t0
+            rows = job.finalise()
+            ours = [None] * len(inp)
+            for k, i in enumerate(order):
+                ours[i] = got["rows"][k].decode()
+            info["rows_identical_to_reference"] = bool(ours == rows)
+            info["cpu_reference"] = {"guide_tree_ms": job.tree_seconds * 1e3, "align1_ms": a1 * 1e3, "aln_dist_ms": sdist * 1e3,
+                                     "upgma_ms": stree * 1e3, "align2_ms": a2 * 1e3, "threads": nt,
+                                     "total_ms": (job.tree_seconds + a1 + sdist + stree + a2) * 1e3,
+                                     "note": "compute_aln_pairwise_dist and upgma are serial in the reference"}
+            job.close()
+        except Exception as e:      # pragma: no cover
+            info["cpu_reference"] = str(e)
+    return info
+
+
 def concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank, nsets=8, reps=3):
     """Throughput when independent alignments are available (ensemble members, a batch of families): `nsets`
     copies of the workload as ONE forest job (include/kalign_amd.h: n_tasks < numseq-1) -- the levels of all trees
@@ -360,8 +420,10 @@ def main():
     if rank == 0 and not args.no_pairs:
         cs_info = concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank)
     e2e_info = None
+    ra_info = None
     if rank == 0 and not args.no_default_mode and not args.no_pairs:
         e2e_info = end_to_end_leg(ctx, seqs, subm, scal, args)
+        ra_info = realign_leg(ctx, seqs, subm, scal, args)
 
     if rank == 0:
         abytes = algorithmic_bytes(recs)
@@ -403,6 +465,8 @@ def main():
             out["concurrent_sets"] = cs_info
         if e2e_info:
             out["end_to_end"] = e2e_info
+        if ra_info:
+            out["realign_member"] = ra_info
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
         print(json.dumps(out))
