@@ -149,7 +149,7 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
-extern "C" int ka_abi_version(void) { return 3; }
+extern "C" int ka_abi_version(void) { return 4; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
