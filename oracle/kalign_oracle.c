@@ -1090,3 +1090,93 @@ int ko_bpm_batch(const uint8_t* codes, const int* off, const int* lens, const in
         }
         return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Realignment pass (kalign_run_realign, lib/src/aln_wrap.c:449-495): the guide tree derived from a
+ * finished alignment.  Restated for the tests of ka_aln_guide_tree; pinned against
+ * tests/golden/realign_*.npz (made by the reference's own loop).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* compute_aln_pairwise_dist (lib/src/aln_apair_dist.c:9-86): dm[i][j] = 1 - matches / aligned over the
+   columns where both rows carry a residue; 1 when there is no such column; 0 on the diagonal. */
+int ko_aln_pairwise_dist(const uint8_t* rows, int n, long long stride, int alnlen, uint8_t gap, float* dm)
+{
+        for (int i = 0; i < n; i++) {
+                dm[(size_t)i * n + i] = 0.0f;
+                for (int j = i + 1; j < n; j++) {
+                        const uint8_t* x = rows + (size_t)i * stride;
+                        const uint8_t* y = rows + (size_t)j * stride;
+                        int both = 0, same = 0;
+                        for (int c = 0; c < alnlen; c++) {
+                                if (x[c] == gap || y[c] == gap) continue;
+                                both++;
+                                same += x[c] == y[c];
+                        }
+                        const float d = both ? 1.0f - (float)same / (float)both : 1.0f;
+                        dm[(size_t)i * n + j] = d;
+                        dm[(size_t)j * n + i] = d;
+                }
+        }
+        return 0;
+}
+
+/* build_tree_from_pairwise (lib/src/bisectingKmeans.c:1150-1200): per-sequence mean distance to the others
+   (summed in index order), then upgma (:974-1053) -- repeatedly the first smallest dm[i][j], i < j, among the
+   slots still alive; slot i takes over, its row and column become (old_i + old_j) / 2 + 0.001 -- then
+   label_internal / create_tasks / sort_tasks: internal nodes numbered in post-order from n, one task per
+   internal node, ordered by c.  dm is consumed.  tasks_abc receives 3 * (n - 1) ints. */
+int ko_tree_from_pairwise(float* dm, int n, int* tasks_abc, float* seq_distances)
+{
+        if (n < 2) return 1;
+        if (seq_distances) {
+                for (int i = 0; i < n; i++) {
+                        float sum = 0.0f;
+                        for (int j = 0; j < n; j++) if (j != i) sum += dm[(size_t)i * n + j];
+                        seq_distances[i] = sum / (float)(n - 1);
+                }
+        }
+        /* tree nodes: 0..n-1 leaves, n.. internal in creation order */
+        int* left = malloc(sizeof(int) * 2 * (size_t)n);
+        int* right = malloc(sizeof(int) * 2 * (size_t)n);
+        int* slot = malloc(sizeof(int) * (size_t)n);      /* node currently held by matrix slot i, -1: merged away */
+        int* label = malloc(sizeof(int) * 2 * (size_t)n);
+        int* stack = malloc(sizeof(int) * 4 * (size_t)n);
+        if (!left || !right || !slot || !label || !stack) { free(left); free(right); free(slot); free(label); free(stack); return 1; }
+        for (int i = 0; i < n; i++) { slot[i] = i; left[i] = right[i] = -1; }
+        int next = n, keep = 0, drop = 0;
+        for (int merge = 0; merge < n - 1; merge++) {
+                float best = FLT_MAX;
+                for (int i = 0; i < n - 1; i++) {
+                        if (slot[i] < 0) continue;
+                        for (int j = i + 1; j < n; j++)
+                                if (slot[j] >= 0 && dm[(size_t)i * n + j] < best) { best = dm[(size_t)i * n + j]; keep = i; drop = j; }
+                }
+                left[next] = slot[keep]; right[next] = slot[drop];
+                slot[keep] = next++; slot[drop] = -1;
+                for (int j = n - 1; j >= 0; j--)
+                        if (j != drop) dm[(size_t)keep * n + j] = (dm[(size_t)keep * n + j] + dm[(size_t)drop * n + j]) * 0.5f + 0.001f;
+                dm[(size_t)keep * n + keep] = 0.0f;
+                for (int j = n - 1; j >= 0; j--) dm[(size_t)j * n + keep] = dm[(size_t)keep * n + j];
+        }
+        /* post-order over the binary tree rooted at slot[keep]: children first, then the node gets its label and task */
+        int sp = 0, lab = n, nt = 0;
+        for (int i = 0; i < n; i++) label[i] = i;
+        stack[sp++] = slot[keep]; stack[sp++] = 0;
+        while (sp) {
+                const int state = stack[--sp], node = stack[--sp];
+                if (left[node] < 0) continue;
+                if (state == 0) {
+                        stack[sp++] = node; stack[sp++] = 1;
+                        stack[sp++] = right[node]; stack[sp++] = 0;      /* popped after the left subtree is done */
+                        stack[sp++] = left[node]; stack[sp++] = 0;
+                } else {
+                        label[node] = lab++;
+                        tasks_abc[3 * nt] = label[left[node]];
+                        tasks_abc[3 * nt + 1] = label[right[node]];
+                        tasks_abc[3 * nt + 2] = label[node];
+                        nt++;
+                }
+        }
+        free(left); free(right); free(slot); free(label); free(stack);
+        return nt == n - 1 ? 0 : 1;
+}

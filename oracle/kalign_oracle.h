@@ -87,6 +87,11 @@ uint64_t ko_fnv1a(const void* p, uint64_t n);
 int ko_bpm_block(const uint8_t* t, const uint8_t* p, int n, int m);
 int ko_bpm_batch(const uint8_t* codes, const int* off, const int* lens, const int* ia, const int* ib, int npairs, int* dist_out);
 
+/* realignment pass (aln_wrap.c:449-495): identity distances of a finished alignment (aln_apair_dist.c:9-86) and the
+   UPGMA task list built on them (bisectingKmeans.c:1150-1200, :974-1053); dm is consumed by the second call */
+int ko_aln_pairwise_dist(const uint8_t* rows, int n, long long stride, int alnlen, uint8_t gap, float* dm);
+int ko_tree_from_pairwise(float* dm, int n, int* tasks_abc, float* seq_distances);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,8 @@ def lib():
         L.ko_update_profile.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp,
                                         C.c_float, C.c_float, C.c_float, C.c_float]
         L.ko_bpm_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+        L.ko_aln_pairwise_dist.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, C.c_ubyte, vp]
+        L.ko_tree_from_pairwise.argtypes = [vp, C.c_int, vp, vp]
         L.ko_fnv1a.argtypes = [vp, C.c_uint64]
         L.ko_fnv1a.restype = C.c_uint64
         _lib = L
@@ -200,3 +202,17 @@ def bpm_batch(codes, ia, ib):
     out = np.zeros(len(ia), np.int32)
     lib().ko_bpm_batch(_ptr(flat), _ptr(off), _ptr(lens), _ptr(ia), _ptr(ib), len(ia), _ptr(out))
     return out
+
+
+def aln_guide_tree(rows, gap=b"-"):
+    """compute_aln_pairwise_dist + build_tree_from_pairwise restated: (tasks, seq_distances, dm) from equal-length rows."""
+    n, alnlen = len(rows), len(rows[0])
+    flat = np.frombuffer(b"".join(r if isinstance(r, bytes) else r.encode() for r in rows), np.uint8).copy()
+    dm = np.zeros((n, n), np.float32)
+    lib().ko_aln_pairwise_dist(_ptr(flat), n, alnlen, alnlen, gap[0], _ptr(dm))
+    work = dm.copy()
+    tasks = np.zeros((n - 1, 3), np.int32)
+    sd = np.zeros(n, np.float32)
+    if lib().ko_tree_from_pairwise(_ptr(work), n, _ptr(tasks), _ptr(sd)):
+        raise RuntimeError("ko_tree_from_pairwise failed")
+    return tasks, sd, dm

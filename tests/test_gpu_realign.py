@@ -117,3 +117,20 @@ def test_tiny_and_degenerate_row_sets(ctx):
         want = np.float32(1.0) - np.float32(int((both & (a[i] == a[j])).sum())) / np.float32(int(both.sum()))
         assert dm[i, j] == want and dm[j, i] == want
     assert sorted(tasks[:, 2].tolist()) == list(range(37, 73))
+
+
+@pytest.mark.parametrize("n,alnlen,seed", [(300, 257, 11), (97, 1000, 12), (513, 130, 13)])
+def test_tree_from_random_rows_matches_the_oracle(ctx, oracle, n, alnlen, seed):
+    """seeded rows with many tied distances (few letters, short rows, duplicated rows): the device's distances and
+    UPGMA task list against the oracle's restatement, bit for bit"""
+    rng = np.random.RandomState(seed)
+    base = rng.choice(list(b"ACD-"), size=(n // 3 + 1, alnlen)).astype(np.uint8)
+    rows = base[rng.randint(0, len(base), size=n)].copy()
+    flip = rng.random_sample(rows.shape) < 0.02
+    rows[flip] = rng.choice(list(b"ACD-"), size=int(flip.sum())).astype(np.uint8)
+    rows = [bytes(r) for r in rows]
+    tasks, sd, dm = ctx.aln_guide_tree(rows, want_dm=True)
+    otasks, osd, odm = oracle.aln_guide_tree(rows)
+    assert np.array_equal(dm.view(np.uint32), odm.view(np.uint32))
+    assert np.array_equal(sd.view(np.uint32), osd.view(np.uint32))
+    assert np.array_equal(tasks, otasks)

@@ -79,3 +79,22 @@ def test_bpm_distances_match_reference(oracle):
     """distance estimation: bpm_block through calc_distance, 1024 pairs, lengths 1..1500"""
     g = Golden("bpm_mixed")
     assert np.array_equal(oracle.bpm_batch(g.codes, g.ia, g.ib), g.dist)
+
+
+def _realign_cases():
+    import os
+    from util import GOLDEN
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("realign_") and f.endswith(".npz"))
+
+
+@pytest.mark.parametrize("name", _realign_cases())
+def test_realign_tree_matches_reference(oracle, name):
+    """the oracle's restatement of compute_aln_pairwise_dist + build_tree_from_pairwise against what the reference's
+    own kalign_run_realign loop produced"""
+    import os
+    from util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    tasks, sd, dm = oracle.aln_guide_tree([str(r) for r in z["rows_sorted"]])
+    assert np.array_equal(dm.view(np.uint32), z["dm"].view(np.uint32))
+    assert np.array_equal(tasks, z["tasks2"])
+    assert np.array_equal(sd.view(np.uint32), z["seq_distances2"].view(np.uint32))
