@@ -44,3 +44,38 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libkalign_oracle" not in src \
                     and "libkalign_ref" not in src, f
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """The boundary is a C ABI: a C99 translation unit that includes the header, takes the address of every entry
+    point and calls the ones that need no GPU must compile without warnings, link against the library and run."""
+    import shutil
+    import subprocess
+    from kalign_amd import api
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    hdr = open(os.path.join(ROOT, "include", "kalign_amd.h")).read()
+    names = sorted(set(re.findall(r"\b(ka_[a-z_]+)\s*\(", hdr)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "kalign_amd.h"\n'
+        "static int dist(void* user, int n, const int* ia, const int* ib, int* out)\n"
+        "{ int k; (void)user; for (k = 0; k < n; k++) out[k] = ia[k] > ib[k] ? ia[k] - ib[k] : ib[k] - ia[k]; return 0; }\n"
+        "int main(void)\n{\n"
+        "        void* fns[] = { " + ", ".join("(void*)" + n for n in names) + " };\n"
+        "        int lens[3] = { 5, 4, 3 }, tasks[6];\n        float sd[3];\n        ka_task_rec rec;\n"
+        "        (void)fns; (void)rec;\n"
+        "        if (ka_abi_version() < 4) return 2;\n"
+        "        if (ka_guide_tree_from(3, lens, dist, NULL, 1, NULL, tasks, sd)) { puts(ka_last_error()); return 3; }\n"
+        "        if (tasks[5] != 4) return 4;                 /* two merges: nodes 3 and 4 */\n"
+        '        if (!ka_guide_tree_from(1, lens, dist, NULL, 1, NULL, tasks, sd)) return 5;   /* one sequence: FAIL + message */\n'
+        '        printf("%s\\n", ka_last_error());\n        return 0;\n}\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(api.lib_path())
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+           "-o", str(exe), "-L", libdir, "-lkalign_amd", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "bad arguments" in r.stdout
