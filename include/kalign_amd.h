@@ -39,6 +39,7 @@ extern "C" {
 #define KA_OK 0
 #define KA_FAIL 1
 #define KA_ERR_PATHS_CAP 2      /* caller's paths_out too small; required size in ka_tree_paths_size() */
+#define KA_ERR_ROWS_STRIDE 3    /* ka_run_encoded: rows_out too narrow; alnlen_out holds the length, the alignment is still on the device */
 
 /* flags for ka_msa_tree / ka_tree_upload */
 #define KA_FLAG_DEBUG_ROWS 1    /* also keep each task's top-level f/b rows (tests: row hashes) */
@@ -221,6 +222,24 @@ int ka_bpm_batch(ka_ctx* ctx, const uint8_t* codes, const int* off, const int* l
  */
 int ka_aln_guide_tree(ka_ctx* ctx, int numseq, const uint8_t* rows, long long row_stride, int alnlen, uint8_t gap_char,
                       int* tasks_abc, float* seq_distances, float* dm_out);
+
+/*
+ * kalign_run_seeded / kalign_run_realign (lib/src/aln_wrap.c:144-251, :361-527) from "sequences encoded" to "rows
+ * finalised" in one call -- ka_guide_tree, ka_tree_upload, ka_tree_build_consistency, ka_tree_run, and per realignment
+ * iteration rows (kept in HBM) -> ka_aln_guide_tree -> upload with KA_FLAG_KEEP_CONSISTENCY -> run; finally the rows.
+ * Sequences in the order msa_sort_len_name left them.
+ *   tree_codes / codes / letters   the sequences three times, all laid out by off[] / lens[]: in the alphabet of the
+ *                    guide tree (reduced protein alphabet / nucleotides), in the alignment alphabet, and as printed
+ *   subm, scal       as for ka_tree_upload; n_anchors 0: the reference's --fast; dm_scale NULL or the noisy tree's
+ *                    multipliers (ka_guide_tree); realign_iterations 0: kalign_run_seeded
+ *   rows_out[numseq * row_stride], alnlen_out[numseq]   as for ka_tree_aligned_rows; rows_out NULL leaves the alignment
+ *                    on the device (alnlen_out says how long); a row_stride that turns out too small returns
+ *                    KA_ERR_ROWS_STRIDE with alnlen_out filled -- ka_tree_aligned_rows then fetches the rows
+ */
+int ka_run_encoded(ka_ctx* ctx, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
+                   const int* off, const int* lens, const float* subm, const float* scal,
+                   int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads,
+                   uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out);
 
 /*
  * Guide tree: build_tree_kmeans (lib/src/bisectingKmeans.c:177-271) -- anchors by length

@@ -45,7 +45,7 @@ EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_s
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
            "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
            "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from",
-           "ka_aln_guide_tree"]
+           "ka_aln_guide_tree", "ka_run_encoded"]
 
 
 def lib_path():
@@ -101,6 +101,8 @@ def load_library():
     L.ka_bpm_batch.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.ka_tree_build_consistency.argtypes = [vp, C.c_int, C.c_float]
     L.ka_tree_aligned_rows.argtypes = [vp, vp, C.c_ubyte, vp, C.c_longlong, vp]
+    L.ka_run_encoded.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, C.c_int,
+                                 C.c_ubyte, vp, C.c_longlong, vp]
     L.ka_aln_guide_tree.argtypes = [vp, C.c_int, vp, C.c_longlong, C.c_int, C.c_ubyte, vp, vp, vp]
     L.ka_guide_tree.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]
     L.ka_guide_tree_from.argtypes = [C.c_int, vp, DIST_FN, vp, C.c_int, vp, vp, vp]
@@ -392,6 +394,30 @@ def _aln_guide_tree(self, rows=None, n=None, gap=b"-", want_dm=False):
 
 
 Context.aln_guide_tree = _aln_guide_tree
+
+
+def _run_encoded(self, tree_codes, codes, letters, subm, scal, n_anchors=0, weight=2.0, realign=0, dm_scale=None,
+                 n_threads=1, gap=b"-"):
+    """ka_run_encoded: guide tree, (consistency,) alignment, `realign` realignment iterations, rows -- one call.
+    Returns the aligned rows (bytes) in the order of the input sequences."""
+    tflat, off, lens = _flatten(tree_codes)
+    cflat, _, _ = _flatten(codes)
+    lflat = np.ascontiguousarray(np.concatenate([np.frombuffer(x.encode() if isinstance(x, str) else bytes(x), np.uint8) for x in letters]))
+    if len(lflat) != len(cflat) or len(tflat) != len(cflat):
+        raise KalignAmdError("the three encodings of the sequences differ in length")
+    n = len(codes)
+    sub = np.ascontiguousarray(subm, np.float32).reshape(-1)
+    sc = np.ascontiguousarray(scal, np.float32)
+    dms = _dm_scale(dm_scale, n)
+    alen = np.zeros(n, np.int32)
+    args = (self.h, n, _ptr(tflat), _ptr(cflat), _ptr(lflat), _ptr(off), _ptr(lens), _ptr(sub), _ptr(sc),
+            int(n_anchors), float(weight), int(realign), _ptr(dms), int(n_threads), gap[0])
+    self._chk(self.L.ka_run_encoded(*args, None, 0, _ptr(alen)))            # the alignment stays in HBM: how long is it?
+    self._job = dict(lens=lens, ntasks=n - 1, n=n)
+    return self.tree_aligned_rows(letters, gap=gap)
+
+
+Context.run_encoded = _run_encoded
 
 
 def guide_tree_from(lens, dist, n_threads=1, dm_scale=None):

@@ -799,11 +799,11 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
 
 
 // ---- finalise_alignment (msa_op.c:546-598): the aligned rows, built on the device from the residue->column tables ----
-extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t gap_char, uint8_t* rows_out,
-                                    long long row_stride, int* alnlen_out)
+// alignment length per sequence of the finished run (checks included)
+static int rows_prepare(ka_ctx* c, const uint8_t* letters, std::vector<int>& alen, int* widest)
 {
         if (!c || !c->have_job || !c->ran) return fail("no finished run");
-        if (!letters || (!rows_out && !alnlen_out)) return fail("null argument");
+        if (!letters) return fail("null argument");
         if (!(c->flags & KA_FLAG_DEVICE_GAPS) || !c->have_colof) return fail("the job was uploaded without KA_FLAG_DEVICE_GAPS");
         if (c->partial) return fail("aligned rows need a complete run (ka_tree_run), not a partial one");
         HIPCHK(hipSetDevice(c->device));
@@ -811,12 +811,15 @@ extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t g
         // the records hold the alignment length of every tree
         c->h_recs.resize(c->n_tasks);
         HIPCHK(hipMemcpy(c->h_recs.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
-        std::vector<int> alen;
         tree_alnlens(c, alen);
-        int widest = 0;
-        for (int i = 0; i < c->numseq; i++) widest = std::max(widest, alen[i]);
-        if (!rows_out) { memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq); return KA_OK; }       // size query
-        if (row_stride < (long long)widest + 1) return fail("row_stride is smaller than the longest alignment + terminator");
+        *widest = 0;
+        for (int i = 0; i < c->numseq; i++) *widest = std::max(*widest, alen[i]);
+        return KA_OK;
+}
+
+// the rows in HBM (c->d_rows, row_stride apart); they stay there for ka_aln_guide_tree
+static int rows_build(ka_ctx* c, const uint8_t* letters, uint8_t gap_char, const std::vector<int>& alen, int widest, long long row_stride)
+{
         const size_t bytes = (size_t)c->numseq * (size_t)row_stride;
         if (c->d_letters.alloc(c->h_codes.size()) || c->d_alnlen.alloc(c->numseq) || c->d_rows.alloc(bytes)) return fail("hipMalloc failed");
         HIPCHK(hipMemcpyAsync(c->d_letters.p, letters, c->h_codes.size(), hipMemcpyHostToDevice, c->stream));
@@ -824,11 +827,25 @@ extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t g
         ka_launch_rows(c->d_letters.p, c->d_seq_off.p, c->d_node_len.p, c->d_colof.p, c->d_alnlen.p, c->numseq, gap_char,
                        c->d_rows.p, row_stride, c->stream);
         HIPCHK(hipGetLastError());
-        if (copy_to_host(c, rows_out, c->d_rows.p, bytes)) return KA_FAIL;
-        if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq);
-        // the rows stay in HBM for ka_aln_guide_tree (one alignment only: a forest has no common row length)
+        HIPCHK(hipStreamSynchronize(c->stream));                      // `alen` and `letters` are the caller's
+        // (one alignment only: a forest has no common row length)
         c->rows_n = (c->n_tasks == c->numseq - 1) ? c->numseq : 0;
         c->rows_stride = row_stride; c->rows_alnlen = widest; c->rows_gap = gap_char;
+        return KA_OK;
+}
+
+extern "C" int ka_tree_aligned_rows(ka_ctx* c, const uint8_t* letters, uint8_t gap_char, uint8_t* rows_out,
+                                    long long row_stride, int* alnlen_out)
+{
+        if (!rows_out && !alnlen_out) return fail("null argument");
+        std::vector<int> alen;
+        int widest = 0;
+        if (rows_prepare(c, letters, alen, &widest)) return KA_FAIL;
+        if (!rows_out) { memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq); return KA_OK; }       // size query
+        if (row_stride < (long long)widest + 1) return fail("row_stride is smaller than the longest alignment + terminator");
+        if (rows_build(c, letters, gap_char, alen, widest, row_stride)) return KA_FAIL;
+        if (copy_to_host(c, rows_out, c->d_rows.p, (size_t)c->numseq * (size_t)row_stride)) return KA_FAIL;
+        if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * c->numseq);
         return KA_OK;
 }
 
@@ -869,6 +886,40 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
         HIPCHK(hipMemcpyAsync(merges.data(), c->d_umerges.p, sizeof(int2) * (numseq - 1), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return ka_tasks_from_merges(numseq, merges.data(), tasks_abc);
+}
+
+// ---- kalign_run_seeded / kalign_run_realign between "sequences encoded" and "rows finalised" (aln_wrap.c:144-251,361-527)
+//      as one call: the composition of the entry points above, with the intermediate rows of realignment passes
+//      never leaving HBM ----
+extern "C" int ka_run_encoded(ka_ctx* c, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
+                              const int* off, const int* lens, const float* subm, const float* scal,
+                              int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads,
+                              uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out)
+{
+        if (!c) return fail("null ctx");
+        if (numseq < 2 || !tree_codes || !codes || !letters || !off || !lens || !subm || !scal || (!rows_out && !alnlen_out))
+                return fail("ka_run_encoded: bad arguments");
+        std::vector<int> tasks(3 * (size_t)(numseq - 1));
+        std::vector<float> sd(numseq);
+        if (ka_guide_tree(c, numseq, tree_codes, off, lens, n_threads, dm_scale, tasks.data(), sd.data())) return KA_FAIL;
+        if (ka_tree_upload(c, numseq, codes, off, lens, sd.data(), numseq - 1, tasks.data(), subm, scal, KA_FLAG_DEVICE_GAPS)) return KA_FAIL;
+        if (n_anchors > 0 && ka_tree_build_consistency(c, n_anchors, weight)) return KA_FAIL;
+        if (ka_tree_run(c) || ka_tree_sync(c)) return KA_FAIL;
+        std::vector<int> alen;
+        int widest = 0;
+        for (int it = 0; it < realign_iterations; it++) {
+                if (rows_prepare(c, letters, alen, &widest) || rows_build(c, letters, gap_char, alen, widest, (long long)widest + 1)) return KA_FAIL;
+                if (ka_aln_guide_tree(c, numseq, nullptr, 0, 0, 0, tasks.data(), sd.data(), nullptr)) return KA_FAIL;
+                if (ka_tree_upload(c, numseq, codes, off, lens, sd.data(), numseq - 1, tasks.data(), subm, scal,
+                                   KA_FLAG_DEVICE_GAPS | KA_FLAG_KEEP_CONSISTENCY)) return KA_FAIL;
+                if (ka_tree_run(c) || ka_tree_sync(c)) return KA_FAIL;
+        }
+        if (rows_prepare(c, letters, alen, &widest)) return KA_FAIL;
+        if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * numseq);
+        if (!rows_out) return KA_OK;                                  // the alignment stays on the device: ka_tree_aligned_rows fetches it
+        if (row_stride < (long long)widest + 1) { g_err = "ka_run_encoded: row_stride is smaller than the alignment + terminator (alnlen_out says how long; ka_tree_aligned_rows fetches the rows)"; return KA_ERR_ROWS_STRIDE; }
+        if (rows_build(c, letters, gap_char, alen, widest, row_stride)) return KA_FAIL;
+        return copy_to_host(c, rows_out, c->d_rows.p, (size_t)numseq * (size_t)row_stride);
 }
 
 
