@@ -1,9 +1,10 @@
-"""Synthetic guide trees for benchmarks and tests.
+"""Synthetic guide trees, alphabets and forests for benchmarks and tests.
 
-The real guide tree comes from Kalign's bisecting k-means (lib/src/bisectingKmeans.c), which is
-outside the hot path.  For synthetic workloads we only need a task list
-with the same contract create_tasks() produces (bisectingKmeans.c:1067-1110): post-order,
-task t merges (a, b) into node c = numseq + t, children before parents, root last.
+The reference's own guide tree (bisecting k-means, lib/src/bisectingKmeans.c) is built by the library
+(ka_guide_tree, kalign_amd/csrc/ka_guide.cpp).  The headline benchmark fixes the tree instead, so that the timed step
+is the dispatcher and nothing else: a task list with the contract create_tasks() produces
+(bisectingKmeans.c:1067-1110): post-order, task t merges (a, b) into node c = numseq + t, children before parents,
+root last.
 """
 import numpy as np
 
