@@ -410,18 +410,20 @@ def main():
 
     # secondary measurement (rank 0 only, outside the timed region): the N x K seq-seq batch of
     # anchor consistency (anchor_consistency.c:246-267) through ka_pairwise_batch
+    # (the secondary legs and the CPU baselines run at N = 1 only: at N > 1 the other ranks would sit in the final barrier)
+    solo = rank == 0 and world == 1
     pair_info = None
-    if rank == 0 and not args.no_pairs:
+    if solo and not args.no_pairs:
         pair_info = pairwise_leg(ctx, codes, subm, scal, args)
     dm_info = None
-    if rank == 0 and not args.no_default_mode and not args.no_pairs:
+    if solo and not args.no_default_mode and not args.no_pairs:
         dm_info = default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args)
     cs_info = None
-    if rank == 0 and not args.no_pairs:
+    if solo and not args.no_pairs:
         cs_info = concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank)
     e2e_info = None
     ra_info = None
-    if rank == 0 and not args.no_default_mode and not args.no_pairs:
+    if solo and not args.no_default_mode and not args.no_pairs:
         e2e_info = end_to_end_leg(ctx, seqs, subm, scal, args)
         ra_info = realign_leg(ctx, seqs, subm, scal, args)
 
@@ -467,7 +469,7 @@ def main():
             out["end_to_end"] = e2e_info
         if ra_info:
             out["realign_member"] = ra_info
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
         print(json.dumps(out))
     ctx.close()
