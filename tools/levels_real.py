@@ -1,0 +1,40 @@
+"""Per-level task timing (KA_FLAG_TIMING) of the task tree on the reference's own k-means guide tree, 1024 x 400 protein;
+argument: number of consistency anchors (default 5, 0 = --fast).  Run on the GPU box from the repo root."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, bench, kalign_amd, torch
+torch.cuda.init()
+from kalign_amd import api, guide, synth
+seqs = synth.dssim(1024, 400, seed=1)
+order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))
+seqs = [seqs[i] for i in order]
+tcodes = guide.encode_tree(seqs); codes = guide.encode(seqs)
+subm, scal = bench.scoring(False)
+ctx = kalign_amd.Context(0)
+tasks, sd = ctx.guide_tree(tcodes, n_threads=16)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+ctx.tree_upload(codes, tasks, subm, scal, sd, flags=api.FLAG_TIMING)
+if K: ctx.tree_build_consistency(K, 2.0)
+for _ in range(3): ctx.tree_run(); ctx.tree_sync()
+recs, paths, _ = ctx.tree_download(want_gaps=False)
+tm = ctx.tree_timing()
+print('ms', ctx.tree_kernel_ms())
+n = len(seqs)
+lvl = {i: 0 for i in range(n)}
+tl = []
+for r in recs:
+    l = 1 + max(lvl[r.a], lvl[r.b]); lvl[r.c] = l; tl.append(l)
+tl = np.array(tl); kind = np.array([r.kind for r in recs])
+GHZ = 2.4
+tot = tm[:, :4].sum(1)
+for l in range(1, tl.max()+1):
+    m = tl == l
+    i = np.argmax(np.where(m, tot, -1))
+    print('L%2d n=%4d kinds=%s  max task %.0f us (prep %.0f hirsch %.0f [pass %.0f meet %.0f] code %.0f merge %.0f) lens %dx%d nsip %d+%d  mean %.0f us' % (
+        l, m.sum(), np.bincount(kind[m], minlength=3), tot[i]/GHZ/1e3, tm[i,0]/GHZ/1e3, tm[i,1]/GHZ/1e3, tm[i,4]/GHZ/1e3, tm[i,5]/GHZ/1e3, tm[i,2]/GHZ/1e3, tm[i,3]/GHZ/1e3,
+        recs[i].len_a, recs[i].len_b, recs[i].nsip_a, recs[i].nsip_b, tot[m].mean()/GHZ/1e3))
+done = {i: 0.0 for i in range(n)}
+for r, t in zip(recs, tot):
+    done[r.c] = max(done[r.a], done[r.b]) + t/GHZ/1e3
+lvmax = sum(max(tot[tl==l]) for l in range(1, tl.max()+1))/GHZ/1e3
+print('sum of per-level max %.0f us; dependency-driven critical path %.0f us' % (lvmax, done[recs[-1].c]))
