@@ -44,3 +44,48 @@ def test_forest_renumbers_nodes_and_runs_like_separate_jobs(oracle):
     assert tasks[len(g1.tasks)][0] >= n1 or tasks[len(g1.tasks)][0] >= n1 + n2
     assert len({int(c) for _, _, c in tasks}) == len(tasks)
     assert dist is not None and len(dist) == n1 + n2
+
+
+def test_member_on_context_call_sequence():
+    """dist.member_on_context drives a context exactly like kalign_run_seeded / kalign_run_realign drive the library:
+    checked with a recording stand-in (no GPU): order of calls, the noisy tree only without realignment, the second
+    pass keeping the consistency table."""
+    import numpy as np
+    from kalign_amd import api, dist as kd
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def guide_tree(self, tree_codes, n_threads=1, dm_scale=None):
+            self.calls.append(("guide_tree", dm_scale is not None))
+            return "tasks0", "sd0"
+
+        def msa_tree(self, codes, tasks, subm, scal, sd, n_anchors=0, weight=2.0):
+            self.calls.append(("msa_tree", tasks, sd, n_anchors))
+
+        def tree_aligned_rows(self, letters):
+            self.calls.append(("rows",))
+            return ["row%d" % len(self.calls)]
+
+        def aln_guide_tree(self):
+            self.calls.append(("aln_guide_tree",))
+            return "tasks%d" % len(self.calls), "sd%d" % len(self.calls)
+
+        def tree_upload(self, codes, tasks, subm, scal, sd, flags=0):
+            self.calls.append(("upload", tasks, sd, flags))
+
+        def tree_run(self):
+            self.calls.append(("run",))
+
+    member = dict(scal=np.zeros(6, np.float32), dm_scale=np.ones(4, np.float32))
+    r = Recorder()
+    rows = kd.member_on_context(r, "tc", "c", "l", "subm", n_anchors=5)(member)
+    assert r.calls == [("guide_tree", True), ("msa_tree", "tasks0", "sd0", 5), ("rows",)] and rows == ["row3"]
+    r = Recorder()
+    rows = kd.member_on_context(r, "tc", "c", "l", "subm", n_anchors=5, realign=2)(member)
+    keep = api.FLAG_DEVICE_GAPS | api.FLAG_KEEP_CONSISTENCY
+    assert r.calls == [("guide_tree", False), ("msa_tree", "tasks0", "sd0", 5), ("rows",),
+                       ("aln_guide_tree",), ("upload", "tasks4", "sd4", keep), ("run",), ("rows",),
+                       ("aln_guide_tree",), ("upload", "tasks8", "sd8", keep), ("run",), ("rows",)]
+    assert rows == ["row11"]
