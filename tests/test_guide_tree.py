@@ -80,3 +80,30 @@ def test_tree_alphabet_classes(name):
     assert len(a) == len(b)
     pairs = set(zip(a.tolist(), b.tolist()))
     assert len(pairs) == len(set(p[0] for p in pairs)) == len(set(p[1] for p in pairs))       # a bijection of classes
+
+
+def test_live_edge_shapes(oracle):
+    """shapes around the builder's thresholds and degenerate inputs, against the real build_tree_kmeans: exactly 50 and
+    51 sequences (UPGMA below 50), 128 (parallel candidate splits), many identical sequences (tied distances, splits
+    decided by the index parity rule), two tight clusters (a 2-means that converges at once), one long outlier"""
+    from oracle import refdrv
+    from kalign_amd import api, synth
+    if not refdrv.available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.RandomState(9)
+    fam = synth.family(60, 80, seed=31)
+    a, b = synth.family(45, 60, seed=32), synth.family(45, 140, seed=33)
+    cases = {
+        "n50": synth.family(50, 60, seed=34), "n51": synth.family(51, 60, seed=35), "n128": synth.family(128, 40, seed=36),
+        "identical": [fam[0]] * 70 + fam[:10],
+        "few_distinct": [fam[i % 3] for i in range(90)],
+        "two_clusters": a + b,
+        "outlier": synth.family(80, 50, seed=37) + ["".join("ACDEFGHIKLMNPQRSTVWY"[k] for k in rng.randint(0, 20, size=900))],
+    }
+    for name, seqs in cases.items():
+        job = refdrv.RefJob(seqs)
+        for nt in (1, 3):
+            tasks, sd = api.guide_tree_from(job.lens, oracle_dist(oracle, job.tree_codes), n_threads=nt)
+            assert np.array_equal(tasks, job.tasks), (name, nt)
+            assert np.array_equal(sd, job.seq_distances), (name, nt)
+        job.close()

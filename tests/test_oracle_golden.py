@@ -98,3 +98,24 @@ def test_realign_tree_matches_reference(oracle, name):
     assert np.array_equal(dm.view(np.uint32), z["dm"].view(np.uint32))
     assert np.array_equal(tasks, z["tasks2"])
     assert np.array_equal(sd.view(np.uint32), z["seq_distances2"].view(np.uint32))
+
+
+def test_realign_tree_live_against_the_reference(oracle):
+    """more shapes than the goldens hold, when oracle/_ref is there to ask: duplicated sequences (tied distances),
+    two sequences, a family whose first alignment has long terminal gaps"""
+    from oracle import refdrv
+    from kalign_amd import synth
+    if not refdrv.available():
+        pytest.skip("oracle/_ref not built")
+    fam = synth.family(25, 70, seed=41)
+    cases = [fam + fam[:9], synth.family(2, 40, seed=42), [s[i % 30:] for i, s in enumerate(synth.family(33, 120, seed=43))],
+             synth.family(64, 50, dna=True, seed=44)]
+    for seqs in cases:
+        job = refdrv.RefJob(seqs)
+        job.run_tree()
+        rows, dm, _, _ = job.realign_tree()
+        tasks, sd, odm = oracle.aln_guide_tree(rows)
+        assert np.array_equal(odm.view(np.uint32), dm.view(np.uint32))
+        assert np.array_equal(tasks, job.tasks)
+        assert np.array_equal(sd.view(np.uint32), job.seq_distances.view(np.uint32))
+        job.close()
