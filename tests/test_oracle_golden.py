@@ -119,3 +119,33 @@ def test_realign_tree_live_against_the_reference(oracle):
         assert np.array_equal(tasks, job.tasks)
         assert np.array_equal(sd.view(np.uint32), job.seq_distances.view(np.uint32))
         job.close()
+
+
+def test_tree_live_against_the_reference(oracle):
+    """the oracle's dispatcher against the real one on seeded inputs the goldens do not hold (both modes, protein and
+    DNA, ragged lengths, distance-scaled penalties), when oracle/_ref is there to ask"""
+    from oracle import refdrv
+    from kalign_amd import synth
+    if not refdrv.available():
+        pytest.skip("oracle/_ref not built")
+    fam = synth.family(28, 110, seed=52)
+    cases = [(synth.family(19, 60, seed=51), dict(), 0), (synth.family(21, 90, dna=True, seed=53), dict(), 4),
+             ([s[:20 + (11 * i) % 90] for i, s in enumerate(fam)], dict(), 5),
+             (synth.family(17, 75, seed=54), dict(dist_scale=0.5, vsm_amax=1.5), 0),
+             (synth.family(3, 30, seed=55), dict(), 0)]
+    for seqs, kw, k in cases:
+        job = refdrv.RefJob(seqs, **kw)
+        scal = np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32)
+        if k:
+            job.build_consistency(k, 2.0)
+        recs, paths, gaps, _ = job.run_tree_traced()
+        if k:
+            orecs, opaths, ogaps, _, _, _ = oracle.msa_tree_cons(job.codes, job.tasks, job.subm, scal, job.seq_distances, k, 2.0)
+        else:
+            orecs, opaths, ogaps, _ = oracle.msa_tree(job.codes, job.tasks, job.subm, scal, job.seq_distances)
+        for r, o in zip(recs, orecs):
+            assert (r.plen, r.meet, r.transition, r.kind, r.swapped, r.score) == (o.plen, o.meet, o.transition, o.kind, o.swapped, o.score)
+            assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], opaths[o.path_off:o.path_off + o.plen + 2])
+        for a, b in zip(gaps, ogaps):
+            assert np.array_equal(a, b)
+        job.close()
