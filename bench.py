@@ -6,11 +6,15 @@ guide tree (seq-seq, seq-profile and profile-profile Gotoh/Hirschberg DP, profil
 coding) through ka_tree_run(), with sequences, task list and scoring tables already resident in
 HBM.  GCUPS = sum over tasks of len_a*len_b ("useful" cell updates) / time.
 
-    python bench.py [--gpus N --steps K --warmup W] [--nseq 1024 --len 400 --dna]
+Headline workload (N = 1): the shape north_star's target is quoted on -- 4096 protein sequences
+x ~400 aa (DSSim family), the reference's `--fast` mode, on the REFERENCE'S OWN guide tree
+(build_tree_kmeans through ka_guide_tree; its time is reported separately).
+Secondary legs with their own roofline objects: C2 (1024 x 400) and C3 (4096 DNA x 2000).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank aligns its own
-independent sequence set of the same shape (the unit the path partitions into without a
-data-path collective) -> weak scaling; the timing is barrier-bracketed and max-reduced.
+    python bench.py [--gpus N --steps K --warmup W] [--nseq 4096 --len 400 --dna]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): see multi_gpu_main() -- ONE guide
+tree (C4's shape) sharded over the ranks by subtree (kalign_amd.dist.sharded_tree) -> strong scaling.
 """
 import argparse
 import json
@@ -43,16 +47,14 @@ def algorithmic_bytes(recs):
     return total
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE collected in separate passes for exactly this workload, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler on itself, so it
-    reports the committed measurement for the default workload and null for any other."""
-    if (args.nseq, args.len, args.dna) != (1024, 400, False):
-        return None
+def pmc_traffic(key):
+    """HBM bytes per STEP (all launches of one ka_tree_run) from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate passes for exactly this workload, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950; profiles/collect.sh).  bench.py cannot run the
+    profiler on itself, so it reports the committed measurement of the named workload and null for any other."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            return float(json.load(fh)["hbm_bytes_per_launch_corrected"])
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            return float(json.load(fh)[key]["hbm_bytes_per_step_corrected"])
     except Exception:
         return None
 
@@ -65,6 +67,7 @@ def workload_letters(nseq, length, dna, seed):
 
 
 def make_workload(nseq, length, dna, seed, seqs=None):
+    """Synthetic balanced guide tree (round 1's headline; kept for the concurrent-sets leg and tests)."""
     from kalign_amd import guide
     if seqs is None:
         seqs = workload_letters(nseq, length, dna, seed)
@@ -72,6 +75,86 @@ def make_workload(nseq, length, dna, seed, seqs=None):
     tasks = guide.bisecting_tree(nseq, seed=seed)
     dist = np.random.RandomState(seed).uniform(0.3, 0.9, nseq).astype(np.float32)
     return codes, tasks, dist
+
+
+def host_threads():
+    return min(os.cpu_count() or 1, 16)
+
+
+def make_job(ctx, nseq, length, dna, seed):
+    """Letters -> what kalign_run hands create_msa_tree: the sequences in msa_sort_len_name order (longest first,
+    msa_sort.c:62-80), encoded, and the reference's own guide tree (build_tree_kmeans, bisectingKmeans.c:177-271,
+    through ka_guide_tree: distances on the device, 2-means / UPGMA on the host).  The tree's time is reported,
+    never part of a timed step ("tree building excluded")."""
+    from kalign_amd import guide
+    inp = workload_letters(nseq, length, dna, seed)
+    order = sorted(range(len(inp)), key=lambda i: (-len(inp[i]), i))
+    seqs = [inp[i] for i in order]
+    tcodes = guide.encode_tree(seqs, dna=dna)
+    codes = guide.encode(seqs, dna=dna)
+    ctx.guide_tree(tcodes, n_threads=host_threads())               # warm-up (allocations)
+    t0 = time.perf_counter()
+    tasks, sd = ctx.guide_tree(tcodes, n_threads=host_threads())
+    gt_ms = (time.perf_counter() - t0) * 1e3
+    return {"input": inp, "order": order, "seqs": seqs, "codes": codes, "tasks": tasks, "seq_distances": sd,
+            "guide_tree_ms": gt_ms, "nseq": nseq, "len": length, "dna": dna}
+
+
+def timed_tree(ctx, job, subm, scal, steps, warmup, barrier=None):
+    """W untimed + K timed passes of ka_tree_run over the job, inputs resident in HBM."""
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    for _ in range(warmup):
+        ctx.tree_run()
+        ctx.tree_sync()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.tree_run()
+    ctx.tree_sync()
+    if barrier:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    recs, _, _ = ctx.tree_download(want_gaps=False)
+    kern_ms, n_launch = ctx.tree_kernel_ms()          # HIP events on the launch stream, last step
+    return {"elapsed": elapsed, "recs": recs, "kern_ms": kern_ms, "n_launch": n_launch,
+            "cells": float(sum(r.len_a * r.len_b for r in recs))}
+
+
+def roofline_of(res, key):
+    abytes = algorithmic_bytes(res["recs"])
+    achieved = abytes / (res["kern_ms"] * 1e-3) / 1e9
+    traffic = pmc_traffic(key)
+    return {"bound": "hbm", "kernel": "ka_task_kernel (all launches of one step)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_unit": "HBM bytes per step (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
+            "algorithmic_bytes_per_step": abytes, "launches_per_step": res["n_launch"],
+            "avg_launch_ms": res["kern_ms"] / max(res["n_launch"], 1), "kernel_ms_per_step": res["kern_ms"]}
+
+
+def workload_name(job, res):
+    kinds = np.bincount([r.kind for r in res["recs"]], minlength=3)
+    return ("%d %s seqs x ~%d (DSSim), --fast mode, the reference's k-means guide tree; whole tree per step: %d seq-seq + %d "
+            "seq-profile + %d profile-profile DP tasks (Hirschberg), profile merge, path coding"
+            % (job["nseq"], "DNA" if job["dna"] else "protein", job["len"], kinds[0], kinds[1], kinds[2]))
+
+
+def pp_share(res):
+    pp = float(sum(r.len_a * r.len_b for r in res["recs"] if r.kind == 2))
+    return pp / max(res["cells"], 1.0)
+
+
+def transfers_leg(ctx, job, subm, scal, reps=3):
+    """SURVEY.md 8(d)'s t_DP bracket: H2D of the sequences and the task list, the task tree, D2H of records and coded
+    paths (ka_msa_tree with host buffers; gap arrays not requested).  Reported beside `value`, never as `value`."""
+    ctx.msa_tree(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        recs, paths, _ = ctx.msa_tree(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    dt = (time.perf_counter() - t0) / reps
+    cells = float(sum(r.len_a * r.len_b for r in recs))
+    return {"ms": dt * 1e3, "gcups": cells / dt / 1e9,
+            "note": "ka_msa_tree, host buffers: upload + host-side task preparation + run + download of records and paths"}
 
 
 def scoring(dna):
@@ -82,42 +165,32 @@ def scoring(dna):
     return z["subm_" + key], z["scal_" + key].copy()
 
 
-def cpu_baseline(codes, tasks, dist, dna, cells):
-    """The reference's own dispatcher (oracle/_ref = the real Kalign sources compiled as they
-    lie) on the host cores, same task list, bounded to ~10-30 s of CPU work."""
+def cpu_baseline(codes, tasks, dist, dna, cells, budget_s=25.0):
+    """The reference's own dispatcher (oracle/_ref = the real Kalign sources compiled as they lie:
+    create_msa_tree, OpenMP) on the host cores, same task list, bounded to ~10-30 s of CPU work.
+    Fails loudly when oracle/_ref is missing (no silent fall-back to another baseline)."""
+    from oracle import refdrv
+    if not refdrv.available():
+        raise RuntimeError("oracle/_ref/libkalign_ref.so is missing: run `make -C oracle ref` in the build container "
+                           "(or pass --no-cpu)")
     ncores = os.cpu_count() or 1
-    try:
-        from oracle import refdrv
-        if not refdrv.available():
-            raise RuntimeError("no oracle/_ref")
-        best = None
-        tried = []
-        budget = time.time() + 25.0
-        for nt in sorted({ncores, min(ncores, 16), 1}, reverse=True):
-            reps = 0
-            while reps < 2 and time.time() < budget:
-                job = refdrv.EncodedJob(codes, tasks, dist, biotype=1 if dna else 0, type_=0 if dna else -1, n_threads=nt)
-                _, secs = job.run_tree()
-                job.close()
-                reps += 1
-                tried.append((nt, secs))
-                if best is None or secs < best[1]:
-                    best = (nt, secs)
-        return {"value": cells / best[1] / 1e9, "unit": "GCUPS", "cores": best[0], "kind": "reference",
-                "sample": "full workload, create_msa_tree of the reference (OpenMP), best of %s (threads, s)" % (
-                    ["%d:%.3f" % t for t in tried])}
-    except Exception as e:  # pragma: no cover - only when the prebuilt reference is missing
-        from oracle import oracledrv
-        n = min(len(codes), 128)
-        from kalign_amd import guide
-        sub_tasks = guide.bisecting_tree(n, seed=1)
-        subm, scal = scoring(dna)
-        t0 = time.time()
-        recs, _, _, _ = oracledrv.msa_tree(codes[:n], sub_tasks, subm, scal, dist[:n])
-        secs = time.time() - t0
-        c = sum(r.len_a * r.len_b for r in recs)
-        return {"value": c / secs / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
-                "sample": "first %d sequences, oracle C restatement, 1 thread (%s)" % (n, e)}
+    best = None
+    tried = []
+    budget = time.time() + budget_s
+    for nt in sorted({ncores, min(ncores, 64), min(ncores, 16), 1}, reverse=True):
+        reps = 0
+        while reps < 2 and time.time() < budget:
+            job = refdrv.EncodedJob(codes, tasks, dist, biotype=1 if dna else 0, type_=0 if dna else -1, n_threads=nt)
+            _, secs = job.run_tree()
+            job.close()
+            reps += 1
+            tried.append((nt, secs))
+            if best is None or secs < best[1]:
+                best = (nt, secs)
+    return {"value": cells / best[1] / 1e9, "unit": "GCUPS", "cores": best[0], "host_logical_cpus": ncores,
+            "kind": "reference",
+            "sample": "full workload (same task list), create_msa_tree of the reference (OpenMP tasks); best of (threads:seconds) %s; "
+                      "`cores` = the thread count of the best run" % (["%d:%.3f" % t for t in tried])}
 
 
 def pairwise_leg(ctx, codes, subm, scal, args, k_anchors=5):
@@ -350,17 +423,31 @@ def concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank, nsets=8,
             "note": "independent copies of the workload scheduled as one forest job in one context"}
 
 
+def secondary_tree_leg(ctx, name, nseq, length, dna, args, steps=3, warmup=1):
+    """A named secondary workload with its own roofline object (C2 / C3 of BASELINE.json)."""
+    job = make_job(ctx, nseq, length, dna, seed=1)
+    subm, scal = scoring(dna)
+    res = timed_tree(ctx, job, subm, scal, steps, warmup)
+    out = {"workload": workload_name(job, res), "value": res["cells"] * steps / res["elapsed"] / 1e9, "unit": "GCUPS",
+           "ms_per_step": res["elapsed"] / steps * 1e3, "steps": steps, "useful_cells_per_step": res["cells"],
+           "profile_profile_share_of_cells": pp_share(res), "guide_tree_ms": job["guide_tree_ms"],
+           "roofline": roofline_of(res, name)}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(job["codes"], job["tasks"], job["seq_distances"], dna, res["cells"], budget_s=12.0)
+    return out, job
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nseq", type=int, default=1024)
+    ap.add_argument("--nseq", type=int, default=4096)
     ap.add_argument("--len", type=int, default=400)
     ap.add_argument("--dna", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-pairs", action="store_true")
-    ap.add_argument("--no-default-mode", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline line only (profiling runs)")
+    ap.add_argument("--no-c3", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -372,110 +459,95 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dist_on = world > 1
-    from kalign_amd import dist as kd
-    if dist_on:
-        import torch.distributed as dist
-        kd.init("nccl", device=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
+    if world > 1:
+        return multi_gpu_main(args, rank, world, local_rank)
 
-    seqs = workload_letters(args.nseq, args.len, args.dna, seed=1 + rank)
-    codes, tasks, seq_dist = make_workload(args.nseq, args.len, args.dna, seed=1 + rank, seqs=seqs)
-    subm, scal = scoring(args.dna)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = kalign_amd.Context(local_rank, stream=stream)
-    ctx.tree_upload(codes, tasks, subm, scal, seq_dist)
+    job = make_job(ctx, args.nseq, args.len, args.dna, seed=1)
+    subm, scal = scoring(args.dna)
 
     def barrier():
         torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
+
+    res = timed_tree(ctx, job, subm, scal, args.steps, args.warmup, barrier)
+    elapsed, cells = res["elapsed"], res["cells"]
+    key = "headline" if (args.nseq, args.len, args.dna) == (4096, 400, False) else "other"
+    out = {
+        "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA",
+        "value": cells * args.steps / elapsed / 1e9,
+        "unit": "GCUPS",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": workload_name(job, res),
+            "nseq": args.nseq, "len": args.len, "type": "dna" if args.dna else "protein", "mode": "--fast (no anchor consistency)",
+            "guide_tree": "reference's bisecting k-means tree (ka_guide_tree), built outside the timed region",
+            "guide_tree_ms": job["guide_tree_ms"],
+            "useful_cells_per_step": cells, "launches_per_step": res["n_launch"],
+            "profile_profile_share_of_cells": pp_share(res),
+            "gcups_profile_profile_lower_bound": pp_share(res) * cells * args.steps / elapsed / 1e9,
+        },
+        "roofline": roofline_of(res, key),
+    }
+    if not args.no_legs:
+        out["t_dp_with_transfers"] = transfers_leg(ctx, job, subm, scal)
+        out["default_mode"] = default_mode_leg(ctx, job["codes"], job["tasks"], subm, scal, job["seq_distances"], args)
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(job["codes"], job["tasks"], job["seq_distances"], args.dna, cells)
+    if not args.no_legs:
+        c2, c2job = secondary_tree_leg(ctx, "c2_1024x400", 1024, 400, False, args, steps=5, warmup=2)
+        out["c2_1024x400_protein"] = c2
+        s2, sc2 = scoring(False)
+        out["seqseq_batch"] = pairwise_leg(ctx, c2job["codes"], s2, sc2, args)
+        out["end_to_end"] = end_to_end_leg(ctx, c2job["input"], s2, sc2, args)
+        out["realign_member"] = realign_leg(ctx, c2job["input"], s2, sc2, args)
+        bc, bt, bd = make_workload(1024, 400, False, seed=1)
+        out["concurrent_sets"] = concurrent_sets_leg(bc, bt, s2, sc2, bd, local_rank)
+        if not args.no_c3:
+            out["c3_4096x2000_dna"], _ = secondary_tree_leg(ctx, "c3_dna_4096x2000", 4096, 2000, True, args, steps=3, warmup=1)
+    print(json.dumps(out))
+    ctx.close()
+
+
+def multi_gpu_main(args, rank, world, local_rank):
+    """N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL)."""
+    import torch
+    import torch.distributed as dist
+    import kalign_amd
+    from kalign_amd import dist as kd
+    kd.init("nccl", device=torch.device("cuda", local_rank))
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = kalign_amd.Context(local_rank, stream=stream)
+    job = make_job(ctx, args.nseq, args.len, args.dna, seed=1 + rank)
+    subm, scal = scoring(args.dna)
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        ctx.tree_run()
-        ctx.tree_sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.tree_run()
-    ctx.tree_sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = kd.reduce_scalar(elapsed, "max", device="cuda")      # MAX over ranks
-
-    recs, paths, _ = ctx.tree_download(want_gaps=False)
-    cells = float(sum(r.len_a * r.len_b for r in recs))
-    kern_ms, n_launch = ctx.tree_kernel_ms()          # HIP events on the launch stream, last step
-    total_cells = kd.reduce_scalar(cells, "sum", device="cuda")    # every rank aligned its own set
-
-    # secondary measurement (rank 0 only, outside the timed region): the N x K seq-seq batch of
-    # anchor consistency (anchor_consistency.c:246-267) through ka_pairwise_batch
-    # (the secondary legs and the CPU baselines run at N = 1 only: at N > 1 the other ranks would sit in the final barrier)
-    solo = rank == 0 and world == 1
-    pair_info = None
-    if solo and not args.no_pairs:
-        pair_info = pairwise_leg(ctx, codes, subm, scal, args)
-    dm_info = None
-    if solo and not args.no_default_mode and not args.no_pairs:
-        dm_info = default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args)
-    cs_info = None
-    if solo and not args.no_pairs:
-        cs_info = concurrent_sets_leg(codes, tasks, subm, scal, seq_dist, local_rank)
-    e2e_info = None
-    ra_info = None
-    if solo and not args.no_default_mode and not args.no_pairs:
-        e2e_info = end_to_end_leg(ctx, seqs, subm, scal, args)
-        ra_info = realign_leg(ctx, seqs, subm, scal, args)
-
+    res = timed_tree(ctx, job, subm, scal, args.steps, args.warmup, barrier)
+    elapsed = kd.reduce_scalar(res["elapsed"], "max", device="cuda")
+    total_cells = kd.reduce_scalar(res["cells"], "sum", device="cuda")
     if rank == 0:
-        abytes = algorithmic_bytes(recs)
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        kinds = np.bincount([r.kind for r in recs], minlength=3)
-        out = {
-            "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA",
-            "value": total_cells * args.steps / elapsed / 1e9,
-            "unit": "GCUPS",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "%d %s seqs x ~%d, whole guide tree per step: %d seq-seq + %d seq-profile + %d profile-profile DP tasks (Hirschberg), profile merge, path coding; one independent set per GPU"
-                            % (args.nseq, "DNA" if args.dna else "protein", args.len, kinds[0], kinds[1], kinds[2]),
-                "nseq": args.nseq, "len": args.len, "type": "dna" if args.dna else "protein",
-                "useful_cells_per_step": cells, "tree_levels": n_launch,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": "ka_task_kernel",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args),
-                "algorithmic_bytes_per_step": abytes, "launches_per_step": n_launch,
-                "avg_launch_ms": kern_ms / max(n_launch, 1),
-                "kernel_ms_per_step": kern_ms,
-            },
-        }
-        if pair_info:
-            out["seqseq_batch"] = pair_info
-        if dm_info:
-            out["default_mode"] = dm_info
-        if cs_info:
-            out["concurrent_sets"] = cs_info
-        if e2e_info:
-            out["end_to_end"] = e2e_info
-        if ra_info:
-            out["realign_member"] = ra_info
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(codes, tasks, seq_dist, args.dna, cells)
-        print(json.dumps(out))
+        print(json.dumps({
+            "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA", "value": total_cells * args.steps / elapsed / 1e9,
+            "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload_name(job, res) + "; one independent set per GPU", "nseq": args.nseq, "len": args.len},
+            "roofline": roofline_of(res, "other")}))
     ctx.close()
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

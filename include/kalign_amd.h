@@ -83,6 +83,9 @@ int  ka_ctx_set_stream(ka_ctx* ctx, void* hip_stream);
    them resident; a shared context runs every task on one workgroup, one launch per guide-tree level -- slower for
    a single tree, safe under any co-scheduling.  Takes effect at the next ka_tree_upload. */
 int  ka_ctx_set_shared(ka_ctx* ctx, int shared);
+/* How often a run of this context fell back to that plan on its own because a wait between workgroups never
+   completed (another process was using the GPU): the run is repeated and correct, but slower -- visible here. */
+int  ka_ctx_fallback_runs(ka_ctx* ctx);
 const char* ka_last_error(void);
 /* ABI revision of this header (bumped when entry points are added) */
 int  ka_abi_version(void);
@@ -160,6 +163,12 @@ int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats)
    recursion level of the root task, followed by 512 values that only profiling builds (-DKA_PROF) fill:
    out must hold 8*n_tasks + 48 + 512 values. */
 int ka_tree_get_timing(ka_ctx* ctx, long long* out);
+/* Tests only -- fault injection for the recovery paths of ka_tree_sync (takes effect at the next ka_tree_upload):
+   KA_DEBUG_SMALL_ARENAS starts with device arenas that are certainly too small (overflow -> grow -> re-run),
+   KA_DEBUG_STARVE_ROOT_JOIN makes the root's join wait for a workgroup that never comes (watchdog -> re-plan). */
+#define KA_DEBUG_SMALL_ARENAS 1
+#define KA_DEBUG_STARVE_ROOT_JOIN 2
+int ka_debug_set_hooks(ka_ctx* ctx, int hooks);
 /* Debug: 64 breadcrumb words written by workgroup 0 (context created with KA_TRACE=1 in the
    environment); readable while a kernel is still running. */
 int ka_debug_trace(ka_ctx* ctx, int* out64);
@@ -176,7 +185,8 @@ int ka_tree_kernel_ms(ka_ctx* ctx, float* ms, int* n_launches);
  * the position maps in HBM; from then on every DP of ka_tree_run adds the consistency bonus that do_align
  * builds with anchor_consistency_get_bonus_profile (aln_run.c:262-295).  Like the reference it declines
  * silently (returns OK, no table) when n_anchors <= 0, numseq < 3 or there are no seq_distances.
- * n_anchors <= 5 (the reference's default is 5, src/parameters.c:72-73; weight 2.0).
+ * n_anchors <= 5 (the reference's default is 5, src/parameters.c:72-73; weight 2.0); fewer than 65536 sequences per
+ * alignment (the member votes count in 16 bits; rejected up front).
  * In a forest job every alignment gets its own table (its own anchors among its own sequences).
  * ka_tree_upload drops the table again.
  */

@@ -38,7 +38,7 @@ class TaskRec(C.Structure):
 # ka_dist_fn of include/kalign_amd.h
 DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
-EXPORTS = ["ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
+EXPORTS = ["ka_debug_set_hooks", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
@@ -71,6 +71,8 @@ def load_library():
     L.ka_ctx_set_stream.argtypes = [vp, vp]
     L.ka_ctx_set_shared.argtypes = [vp, C.c_int]
     L.ka_last_error.restype = C.c_char_p
+    L.ka_debug_set_hooks.argtypes = [vp, C.c_int]
+    L.ka_ctx_fallback_runs.argtypes = [vp]
     L.ka_abi_version.restype = C.c_int
     L.ka_msa_tree.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                               C.POINTER(TaskRec), vp, C.c_longlong, vp]
@@ -151,6 +153,13 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def debug_set_hooks(self, hooks):
+        """tests only: ka_debug_set_hooks (KA_DEBUG_SMALL_ARENAS = 1, KA_DEBUG_STARVE_ROOT_JOIN = 2)"""
+        self._chk(self.L.ka_debug_set_hooks(self.h, int(hooks)))
+
+    def fallback_runs(self):
+        return int(self.L.ka_ctx_fallback_runs(self.h))
 
     def _chk(self, rc):
         if rc:

@@ -79,6 +79,9 @@ struct ka_ctx {
         int max_cluster = 4;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
         int n_cus = 256;                             // compute units of the device (hipDeviceProp)
         bool shared_gpu = false;                     // ka_ctx_set_shared: no multi-workgroup tasks, no chained launch
+        bool shared_by_fallback = false;             // shared_gpu was forced by a join watchdog (ka_tree_sync), not by the caller
+        int fallback_runs = 0;                       // how often that happened (ka_ctx_fallback_runs)
+        int test_hooks = 0;                          // ka_debug_set_hooks (tests only)
         std::vector<long long> leaf_prof_off;
         long long leaf_prof_total = 0;
         long long sum_len = 0;
@@ -149,7 +152,7 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
-extern "C" int ka_abi_version(void) { return 4; }
+extern "C" int ka_abi_version(void) { return 5; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
@@ -163,15 +166,31 @@ extern "C" int ka_ctx_create(int device, ka_ctx** out)
                 hipDeviceProp_t prop;
                 if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
         }
-        HIPCHK(hipEventCreate(&c->ev0));
-        HIPCHK(hipEventCreate(&c->ev1));
-        if (getenv("KA_TRACE")) {
-                HIPCHK(hipHostMalloc((void**)&c->h_trace, 64 * sizeof(int), hipHostMallocMapped));
-                memset(c->h_trace, 0xff, 64 * sizeof(int));
+        hipError_t e = hipEventCreate(&c->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+        if (e == hipSuccess && getenv("KA_TRACE")) {
+                e = hipHostMalloc((void**)&c->h_trace, 64 * sizeof(int), hipHostMallocMapped);
+                if (e == hipSuccess) memset(c->h_trace, 0xff, 64 * sizeof(int));
+        }
+        if (e != hipSuccess) {
+                ka_ctx_destroy(c);
+                return fail(std::string("ka_ctx_create: ") + hipGetErrorString(e));
         }
         *out = c;
         return KA_OK;
 }
+
+// Tests only: fault injection that used to hide behind environment variables.
+extern "C" int ka_debug_set_hooks(ka_ctx* c, int hooks)
+{
+        if (!c) return fail("null ctx");
+        c->test_hooks = hooks;
+        return KA_OK;
+}
+
+// How often a run of this context had to fall back to the no-cluster / no-chain plan because workgroups that wait for
+// each other were not all resident (somebody else was using the GPU).
+extern "C" int ka_ctx_fallback_runs(ka_ctx* c) { return c ? c->fallback_runs : -1; }
 
 extern "C" void ka_ctx_destroy(ka_ctx* c)
 {
@@ -190,6 +209,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_cons_maps.release(); c->d_colof.release(); c->d_colof_init.release(); c->d_sip.release();
         c->d_cons_map_off.release(); c->d_sip_off.release();
         for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
+        if (c->h_trace) (void)hipHostFree(c->h_trace);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -202,7 +222,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
 extern "C" int ka_ctx_set_shared(ka_ctx* c, int shared)
 {
         if (!c) return fail("null ctx");
-        c->shared_gpu = shared != 0;
+        c->shared_gpu = shared != 0; c->shared_by_fallback = false;
         return KA_OK;
 }
 
@@ -265,7 +285,7 @@ static int plan_launches(ka_ctx* c)
                         }
                         // tests: make the last join wait for a workgroup that never comes (a residency failure as seen
                         // from the device) -- the bounded wait must report it and ka_tree_sync must re-plan and re-run
-                        if (getenv("KA_TEST_STARVE")) c->descs[n_tasks - 1].chain_need += 1;
+                        if (c->test_hooks & KA_DEBUG_STARVE_ROOT_JOIN) c->descs[n_tasks - 1].chain_need += 1;
                 }
         }
 
@@ -339,6 +359,9 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 keep_cons = true;
         }
         c->have_job = false; c->ran = false; c->synced = false; c->state_valid = false;
+        // a join watchdog of an earlier job forced the no-cluster plan: a new job gets the fast plan again (the
+        // fallback is counted, ka_ctx_fallback_runs); a caller's own ka_ctx_set_shared stays
+        if (c->shared_by_fallback) { c->shared_gpu = false; c->shared_by_fallback = false; }
         if (!keep_cons) c->cons_K = 0;           // a new job starts without a consistency table
         c->have_colof = false;
         c->rows_n = 0;
@@ -379,6 +402,11 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
                 const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
                 if (a < 0 || b < 0 || cc < numseq || a >= nprof || b >= nprof || cc >= nprof || !made[a] || !made[b] || made[cc])
                         return fail("task list is not in TASK_ORDER_TREE order (children before parents)");
+                // a node is the operand of at most one task, and never both operands of it (its member list is
+                // handed to the parent below)
+                if (a == b || made[a] == 2 || made[b] == 2)
+                        return fail("task list is not in TASK_ORDER_TREE order (a node is consumed twice)");
+                made[a] = 2; made[b] = 2;
                 KaTaskDesc& d = c->descs[t];
                 float gap_scale = 1.0f, soff = 0.0f;
                 int cnt = 0;
@@ -446,7 +474,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
         if (c->chain_level >= 0) scr *= (long long)std::min(max_level - c->chain_level, 8);   // the chained launch never resets the scratch counter; grows on demand
         c->scratch_cap = std::max(c->scratch_cap, scr);
-        if (getenv("KA_SMALL_ARENAS")) {
+        if (c->test_hooks & KA_DEBUG_SMALL_ARENAS) {
                 // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run
                 // path of ka_tree_sync is exercised (also across the join points of the chained launch)
                 c->prof_cap = top + 64LL * KA_REC; c->path_cap = 64; c->scratch_cap = 1 << 16;
@@ -641,12 +669,12 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         // workgroups that wait for each other were not all resident: somebody else is using the GPU.
                         // Fall back to the plan that needs no co-residency (ka_ctx_set_shared) and run again.
                         if (c->shared_gpu || c->partial) return fail("device watchdog: a wait between workgroups never completed");
-                        c->shared_gpu = true;
+                        c->shared_gpu = true; c->shared_by_fallback = true; c->fallback_runs++;
                         if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
                         if (tree_launch(c)) return KA_FAIL;
                         continue;
                 }
-                if (err == 7) return fail("consistency: a profile is too long for the LDS vote table");
+                if (err == 7) return fail("consistency: a node has 65536 or more member sequences (vote counters are 16 bits wide)");
                 if (c->partial) return fail("a device arena overflowed during a partial run (ka_tree_run_tasks does not re-run)");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)
                 if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
@@ -1229,6 +1257,10 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
                 }
                 std::sort(trees.begin(), trees.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a[0] < b[0]; });
         }
+        // the vote of a profile packs its `total` and `agree` counts into 16 bits each (ka_cons_votes)
+        for (auto& m : trees)
+                if (m.size() >= 65536)
+                        return fail("consistency: an alignment of 65536 or more sequences is beyond the vote counters of this build (use n_anchors = 0)");
         int K = n_anchors;
         for (auto& m : trees) if ((int)m.size() >= 3) K = std::min(K, (int)m.size());
         for (auto& m : trees)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <future>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <system_error>
 #include <vector>
@@ -195,7 +196,10 @@ std::unique_ptr<Sub> bisect(const Builder& B, std::vector<int> samples, int dept
         samples.shrink_to_fit();
         std::future<std::unique_ptr<Sub>> fut;
         bool forked = false;
-        if ((1 << depth) < B.n_threads) {                // the two halves are independent (the reference: OpenMP tasks)
+        // (a degenerate input can peel one sequence off per split: bound the recursion -- the C ABI wrapper turns
+        // this into KA_FAIL -- instead of overflowing the stack)
+        if (depth > 4096) throw std::runtime_error("bisecting k-means degenerated (recursion deeper than 4096)");
+        if (depth < 30 && (1 << depth) < B.n_threads) {                // the two halves are independent (the reference: OpenMP tasks)
                 try {
                         fut = std::async(std::launch::async, [&] { return bisect(B, std::move(best.sl), depth + 1); });
                         forked = true;
@@ -260,16 +264,27 @@ int emit_tasks(Tree& T, int top, int numseq, int* tasks_abc)
         return n_tasks;
 }
 
-void collect_leaves(Sub* s, std::vector<Sub*>& out)
+void collect_leaves(Sub* root, std::vector<Sub*>& out)
 {
-        if (!s->l) { out.push_back(s); return; }
-        collect_leaves(s->l.get(), out);
-        collect_leaves(s->r.get(), out);
+        std::vector<Sub*> st(1, root);                   // iterative pre-order, left before right
+        while (!st.empty()) {
+                Sub* s = st.back(); st.pop_back();
+                if (!s->l) { out.push_back(s); continue; }
+                st.push_back(s->r.get());
+                st.push_back(s->l.get());
+        }
 }
 
 }  // namespace
 
 int ka_fail_message(const char* m);      // ka_api.cpp: sets what ka_last_error() returns
+
+// the library's own distance source (ka_bpm_batch) has already said why: keep its text
+static int dist_failed()
+{
+        const std::string inner = ka_last_error();
+        return ka_fail_message(("ka_guide_tree_from: the distance source failed" + (inner.empty() ? std::string() : ": " + inner)).c_str());
+}
 
 static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
                            const float* dm_scale, int* tasks_abc, float* seq_distances);
@@ -301,7 +316,7 @@ static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* u
         std::vector<int> ia((size_t)numseq * A), ib((size_t)numseq * A), d((size_t)numseq * A);
         for (int i = 0; i < numseq; i++)
                 for (int j = 0; j < A; j++) { ia[(size_t)i * A + j] = i; ib[(size_t)i * A + j] = anchors[j]; }
-        if (dist(user, numseq * A, ia.data(), ib.data(), d.data())) return ka_fail_message("ka_guide_tree_from: the distance source failed");
+        if (dist(user, numseq * A, ia.data(), ib.data(), d.data())) return dist_failed();
         std::vector<float> dm((size_t)numseq * padded, 0.0f);
         for (int i = 0; i < numseq; i++)
                 for (int j = 0; j < A; j++) dm[(size_t)i * padded + j] = with_length_term(d[(size_t)i * A + j], lens[i], lens[anchors[j]]);
@@ -333,7 +348,7 @@ static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* u
                 for (size_t i = 0; i < s.size(); i++)
                         for (size_t j = i + 1; j < s.size(); j++, p++) { ia[p] = s[j]; ib[p] = s[i]; }
         }
-        if (!ia.empty() && dist(user, (int)ia.size(), ia.data(), ib.data(), d.data())) return ka_fail_message("ka_guide_tree_from: the distance source failed");
+        if (!ia.empty() && dist(user, (int)ia.size(), ia.data(), ib.data(), d.data())) return dist_failed();
 
         // ---- UPGMA inside the clusters, then labels and tasks in post-order (label_internal, create_tasks,
         //      sort_tasks(TASK_ORDER_TREE): c ascending == post-order) ----

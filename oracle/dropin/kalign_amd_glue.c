@@ -1,0 +1,405 @@
+/*
+ * kalign_amd_glue.c -- the reference-side binding of libkalign_amd.so: the replacement bodies a Kalign
+ * maintainer adds for the four call sites of INTEGRATION.md.  This is the text INTEGRATION.md quotes.
+ *
+ * TEST INFRASTRUCTURE: it is compiled only by `make -C oracle dropin` (build container, where the
+ * reference sources lie under /root/reference) into oracle/_ref/libkalign_dropin.so -- the reference's own
+ * lib/src compiled where it lies, with the four functions below taken from here instead (the reference's
+ * definitions are renamed at compile time, -Dcreate_msa_tree=kalign_ref_create_msa_tree etc.), linked against
+ * libkalign_amd.so and exporting lib/include/kalign/kalign.h unchanged.  The product (kalign_amd/) links
+ * nothing from the reference and nothing from here.
+ *
+ *   create_msa_tree            lib/src/aln_run.c:43-78        -> ka_tree_upload / ka_tree_build_consistency / ka_tree_run
+ *   anchor_consistency_build   lib/src/anchor_consistency.c:200-275 -> ka_tree_build_consistency (+ a host copy of the table)
+ *   build_tree_kmeans          lib/src/bisectingKmeans.c:177-271    -> ka_guide_tree
+ *   finalise_alignment         lib/src/msa_op.c:546-576       -> ka_tree_aligned_rows
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef HAVE_OPENMP
+#include <omp.h>
+#endif
+
+#include "tldevel.h"
+#include "msa_struct.h"
+#include "task.h"
+#include "aln_param.h"
+#include "anchor_consistency.h"
+
+#include "kalign_amd.h"
+
+/* the reference's own definitions, renamed by the drop-in build (oracle/Makefile) */
+extern int kalign_ref_finalise_alignment(struct msa* msa);
+
+static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
+static const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
+static int glue_job_numseq = 0;
+
+static int glue_context(void)
+{
+        if(!glue_ctx && ka_ctx_create(0, &glue_ctx)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        return OK;
+ERROR:
+        return FAIL;
+}
+
+/* sequences of the msa as one code array (msa->sequences[i]->s in whatever alphabet they are in right now) */
+static int glue_flatten(struct msa* msa, uint8_t** codes_out, int** off_out, int** lens_out, long long* total_out)
+{
+        uint8_t* codes = NULL;
+        int* off = NULL;
+        int* lens = NULL;
+        long long total = 0;
+        int n = msa->numseq;
+        int i;
+        MMALLOC(off, sizeof(int) * n);
+        MMALLOC(lens, sizeof(int) * n);
+        for(i = 0; i < n; i++){
+                off[i] = (int)total;
+                lens[i] = msa->sequences[i]->len;
+                total += lens[i];
+        }
+        MMALLOC(codes, total + 1);
+        for(i = 0; i < n; i++){
+                memcpy(codes + off[i], msa->sequences[i]->s, lens[i]);
+        }
+        *codes_out = codes; *off_out = off; *lens_out = lens; *total_out = total;
+        return OK;
+ERROR:
+        if(off) MFREE(off);
+        if(lens) MFREE(lens);
+        if(codes) MFREE(codes);
+        return FAIL;
+}
+
+/* a valid task list over n leaves (pairs level by level): the consistency stage needs the sequences on the device,
+   not the guide tree */
+static void glue_pairing_tasks(int n, int* abc)
+{
+        int* cur = (int*)malloc(sizeof(int) * n);
+        int m = n, next = n, t = 0, i;
+        for(i = 0; i < n; i++) cur[i] = i;
+        while(m > 1){
+                int k = 0;
+                for(i = 0; i + 1 < m; i += 2){
+                        abc[3 * t] = cur[i]; abc[3 * t + 1] = cur[i + 1]; abc[3 * t + 2] = next;
+                        cur[k++] = next++;
+                        t++;
+                }
+                if(m & 1) cur[k++] = cur[m - 1];
+                m = k;
+        }
+        free(cur);
+}
+
+static void glue_params(struct aln_param* ap, float* subm, float* scal)
+{
+        int i, j;
+        for(i = 0; i < 23; i++){
+                for(j = 0; j < 23; j++){
+                        subm[i * 23 + j] = ap->subm[i][j];
+                }
+        }
+        scal[0] = ap->gpo; scal[1] = ap->gpe; scal[2] = ap->tgpe;
+        scal[3] = ap->dist_scale; scal[4] = ap->vsm_amax; scal[5] = ap->use_seq_weights;
+}
+
+static const struct consistency_table* glue_ct_resident = NULL;   /* the table the device holds right now */
+
+/*
+ * anchor_consistency_build (anchor_consistency.c:200-275).  The reference aligns every sequence to K anchors here,
+ * one pair after the other on the host.  Replacement: the same N x K alignments as one batch on the device
+ * (ka_tree_build_consistency: anchors, seq-seq alignments with the unscaled parameters, position maps).  The maps
+ * stay in HBM for the dispatcher -- which then builds every task's bonus on the device instead of the reference's
+ * dense La x Lb matrix (aln_run.c:262-295) -- and a complete host copy goes into the reference's own table layout
+ * (anchor_consistency.h:17-24), so that host code that reads it (refinement, aln_refine.c) keeps working.
+ * Same decline rules as the reference (:209-218).
+ */
+int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchors, float weight, struct consistency_table** ct_out)
+{
+        struct consistency_table* ct = NULL;
+        uint8_t* codes = NULL;
+        int* off = NULL;
+        int* lens = NULL;
+        int* abc = NULL;
+        int* maps = NULL;
+        float subm[23 * 23];
+        float scal[6];
+        long long total = 0;
+        long long o = 0;
+        int n = msa->numseq;
+        int K = n_anchors;
+        int i, k;
+        *ct_out = NULL;
+        if(K <= 0 || n < 3 || msa->seq_distances == NULL){
+                return OK;
+        }
+        if(K > n){
+                K = n;
+        }
+        RUN(glue_context());
+        RUN(glue_flatten(msa, &codes, &off, &lens, &total));
+        MMALLOC(abc, sizeof(int) * 3 * (n - 1));
+        glue_pairing_tasks(n, abc);
+        glue_params(ap, subm, scal);
+        glue_job_msa = NULL;
+        glue_ct_resident = NULL;
+        if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0) ||
+           ka_tree_build_consistency(glue_ctx, K, weight)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        MMALLOC(ct, sizeof(struct consistency_table));
+        ct->pos_maps = NULL;
+        ct->map_lengths = NULL;
+        ct->anchor_ids = NULL;
+        ct->n_anchors = K;
+        ct->numseq = n;
+        ct->weight = weight;
+        MMALLOC(ct->anchor_ids, sizeof(int) * K);
+        MMALLOC(ct->pos_maps, sizeof(int*) * n * K);
+        MMALLOC(ct->map_lengths, sizeof(int) * n * K);
+        for(i = 0; i < n * K; i++){
+                ct->pos_maps[i] = NULL;
+                ct->map_lengths[i] = 0;
+        }
+        MMALLOC(maps, sizeof(int) * (total * K + 1));
+        if(ka_tree_get_consistency(glue_ctx, ct->anchor_ids, maps) != K){
+                ERROR_MSG("kalign_amd: the device declined to build the consistency table");
+        }
+        for(i = 0; i < n; i++){
+                for(k = 0; k < K; k++){
+                        /* (the map of an anchor against itself is the identity, as in the reference, :251-258) */
+                        ct->map_lengths[i * K + k] = lens[i];
+                        MMALLOC(ct->pos_maps[i * K + k], sizeof(int) * lens[i]);
+                        memcpy(ct->pos_maps[i * K + k], maps + o, sizeof(int) * lens[i]);
+                        o += lens[i];
+                }
+        }
+        if(!msa->quiet){
+                LOG_MSG("Anchor consistency: K=%d, weight=%.1f", K, weight);
+        }
+        glue_ct_resident = ct;
+        *ct_out = ct;
+        MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc); MFREE(maps);
+        return OK;
+ERROR:
+        if(codes) MFREE(codes);
+        if(off) MFREE(off);
+        if(lens) MFREE(lens);
+        if(abc) MFREE(abc);
+        if(maps) MFREE(maps);
+        if(ct){
+                anchor_consistency_free(ct);
+        }
+        return FAIL;
+}
+
+/*
+ * create_msa_tree (aln_run.c:43-78, do_align :213-441 per task).  Reads numseq, sequences[i]->s/len,
+ * seq_distances, the task list; leaves sequences[i]->gaps[], nsip[], sip[][], plen[], task confidence -- exactly
+ * the state the reference's dispatcher leaves.  Merged profiles stay in HBM.
+ */
+int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
+{
+        struct consistency_table* ct = (struct consistency_table*)msa->consistency_table;
+        int n = msa->numseq;
+        int nt = t->n_tasks;
+        int* off = NULL;
+        int* lens = NULL;
+        int* abc = NULL;
+        int* gaps = NULL;
+        int* paths = NULL;
+        uint8_t* codes = NULL;
+        ka_task_rec* recs = NULL;
+        float subm[23 * 23];
+        float scal[6];
+        long long total = 0;
+        long long cap;
+        int flags = KA_FLAG_DEVICE_GAPS;
+        int i, j, g;
+
+        RUN(sort_tasks(t, TASK_ORDER_TREE));             /* as the reference does, aln_run.c:48 */
+        RUN(glue_context());
+        glue_job_msa = NULL;
+
+        RUN(glue_flatten(msa, &codes, &off, &lens, &total));
+        MMALLOC(abc, sizeof(int) * 3 * nt);
+        for(i = 0; i < nt; i++){
+                abc[3 * i] = t->list[i]->a;
+                abc[3 * i + 1] = t->list[i]->b;
+                abc[3 * i + 2] = t->list[i]->c;
+        }
+        glue_params(ap, subm, scal);
+
+        /* the table anchor_consistency_build left in HBM for these sequences is kept across the upload (also by the
+           realignment passes of kalign_run_realign, aln_wrap.c:449-504: same sequences, new tree); if another job has
+           used the device since, it is built again (same anchors, same maps) */
+        if(ct && ct == glue_ct_resident){
+                flags |= KA_FLAG_KEEP_CONSISTENCY;
+        }
+        if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, nt, abc, subm, scal, flags)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        if(ct && ct != glue_ct_resident){
+                if(ka_tree_build_consistency(glue_ctx, ct->n_anchors, ct->weight)){
+                        ERROR_MSG("kalign_amd: %s", ka_last_error());
+                }
+        }
+        glue_ct_resident = ct;                           /* NULL: this upload dropped whatever table there was */
+        if(ka_tree_run(glue_ctx) || ka_tree_sync(glue_ctx)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        cap = ka_tree_paths_size(glue_ctx);
+        MMALLOC(recs, sizeof(ka_task_rec) * nt);
+        MMALLOC(gaps, sizeof(int) * (total + n));
+        MMALLOC(paths, sizeof(int) * (cap + 1));
+        if(ka_tree_download(glue_ctx, recs, paths, cap, gaps)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+
+        /* leave exactly the state do_align leaves (aln_run.c:391-436) */
+        for(i = 0, g = 0; i < n; i++){
+                memcpy(msa->sequences[i]->gaps, gaps + g, sizeof(int) * (lens[i] + 1));
+                g += lens[i] + 1;
+        }
+        for(i = 0; i < nt; i++){
+                int a = recs[i].a;
+                int b = recs[i].b;
+                int c = recs[i].c;
+                int k = 0;
+                t->list[i]->confidence = recs[i].confidence;
+                msa->plen[c] = recs[i].plen;
+                msa->nsip[c] = msa->nsip[a] + msa->nsip[b];
+                MREALLOC(msa->sip[c], sizeof(int) * msa->nsip[c]);
+                for(j = msa->nsip[a]; j--;){
+                        msa->sip[c][k++] = msa->sip[a][j];
+                }
+                for(j = msa->nsip[b]; j--;){
+                        msa->sip[c][k++] = msa->sip[b][j];
+                }
+        }
+        glue_job_msa = msa;
+        glue_job_numseq = n;
+        MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc); MFREE(recs); MFREE(gaps); MFREE(paths);
+        return OK;
+ERROR:
+        if(off) MFREE(off);
+        if(lens) MFREE(lens);
+        if(codes) MFREE(codes);
+        if(abc) MFREE(abc);
+        if(recs) MFREE(recs);
+        if(gaps) MFREE(gaps);
+        if(paths) MFREE(paths);
+        return FAIL;
+}
+
+/*
+ * build_tree_kmeans (bisectingKmeans.c:177-271): the two distance batches on the device, the 2-means bisection and
+ * UPGMA between them on the host in the reference's fp32 order -- the same task list and seq_distances, bit for bit.
+ * msa->sequences[i]->s holds the tree alphabet at this point (aln_wrap.c:155-160).
+ */
+int build_tree_kmeans(struct msa* msa, struct aln_tasks** tasks)
+{
+        struct aln_tasks* t = *tasks;
+        int n = msa->numseq;
+        int* off = NULL;
+        int* lens = NULL;
+        int* abc = NULL;
+        uint8_t* codes = NULL;
+        long long total = 0;
+        int n_threads = 1;
+        int i;
+        ASSERT(n >= 2, "build_tree_kmeans needs at least two sequences");
+        RUN(glue_context());
+        if(!t){
+                RUN(alloc_tasks(&t, n));
+        }
+#ifdef HAVE_OPENMP
+        n_threads = omp_get_max_threads();
+#endif
+        RUN(glue_flatten(msa, &codes, &off, &lens, &total));
+        MMALLOC(abc, sizeof(int) * 3 * (n - 1));
+        if(msa->seq_distances == NULL){
+                MMALLOC(msa->seq_distances, sizeof(float) * n);
+        }
+        if(ka_guide_tree(glue_ctx, n, codes, off, lens, n_threads, NULL, abc, msa->seq_distances)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        for(i = 0; i < n - 1; i++){
+                t->list[i]->a = abc[3 * i];
+                t->list[i]->b = abc[3 * i + 1];
+                t->list[i]->c = abc[3 * i + 2];
+        }
+        t->n_tasks = n - 1;                              /* already in TASK_ORDER_TREE order */
+        *tasks = t;
+        MFREE(off); MFREE(lens); MFREE(abc); MFREE(codes);
+        return OK;
+ERROR:
+        if(off) MFREE(off);
+        if(lens) MFREE(lens);
+        if(abc) MFREE(abc);
+        if(codes) MFREE(codes);
+        return FAIL;
+}
+
+/*
+ * finalise_alignment (msa_op.c:546-576).  The device holds the column of every residue of the alignment the
+ * dispatcher above just made: the rows come back ready-made.  Any other msa (an alignment read from a file, one
+ * whose gaps[] were edited on the host: refinement, consensus) goes through the reference's own function.
+ */
+int finalise_alignment(struct msa* msa)
+{
+        int n = msa->numseq;
+        int* alnlen = NULL;
+        uint8_t* letters = NULL;
+        uint8_t* rows = NULL;
+        long long total = 0;
+        long long o = 0;
+        int width = 0;
+        int i;
+        if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx){
+                return kalign_ref_finalise_alignment(msa);
+        }
+        glue_job_msa = NULL;                             /* the rows below replace seq->seq: one shot */
+        ASSERT(msa->aligned == ALN_STATUS_ALIGNED, "Sequences are not aligned");
+        for(i = 0; i < n; i++){
+                total += msa->sequences[i]->len;
+        }
+        MMALLOC(letters, total + 1);
+        MMALLOC(alnlen, sizeof(int) * n);
+        for(i = 0; i < n; i++){
+                memcpy(letters + o, msa->sequences[i]->seq, msa->sequences[i]->len);
+                o += msa->sequences[i]->len;
+        }
+        if(ka_tree_aligned_rows(glue_ctx, letters, '-', NULL, 0, alnlen)){      /* size query */
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        for(i = 0; i < n; i++){
+                if(alnlen[i] > width){
+                        width = alnlen[i];
+                }
+        }
+        MMALLOC(rows, (size_t)n * (width + 1));
+        if(ka_tree_aligned_rows(glue_ctx, letters, '-', rows, width + 1, alnlen)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        for(i = 0; i < n; i++){
+                char* s = NULL;
+                MMALLOC(s, alnlen[i] + 1);
+                memcpy(s, rows + (size_t)i * (width + 1), alnlen[i] + 1);       /* terminator included */
+                MFREE(msa->sequences[i]->seq);
+                msa->sequences[i]->seq = s;
+        }
+        msa->alnlen = alnlen[0];
+        msa->aligned = ALN_STATUS_FINAL;
+        MFREE(letters); MFREE(alnlen); MFREE(rows);
+        return OK;
+ERROR:
+        if(letters) MFREE(letters);
+        if(alnlen) MFREE(alnlen);
+        if(rows) MFREE(rows);
+        return FAIL;
+}

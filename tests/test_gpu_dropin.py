@@ -1,0 +1,117 @@
+"""The drop-in boundary, for real: Kalign's own library and CLI with the MI355X dispatcher underneath.
+
+oracle/_ref/dropin/libkalign.so.3 is the reference's lib/src compiled where it lies with four seams replaced by
+oracle/dropin/kalign_amd_glue.c (= the text of INTEGRATION.md) and linked against kalign_amd/libkalign_amd.so;
+oracle/_ref/dropin/kalign is the reference's CLI (src/run_kalign.c) on that library.  Built by `make -C oracle dropin`
+in the build container (__graft_entry__.build), shipped prebuilt to the GPU box.  Every result must be byte-identical
+to the unmodified reference (oracle/_ref/libkalign_ref.so, oracle/_ref/kalign_ref) on the same input."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+KALIGN_TYPE_DNA_INTERNAL = 1          # lib/include/kalign/kalign.h:18-27
+KALIGN_TYPE_PROTEIN = 3
+KALIGN_TYPE_UNDEFINED = 8
+
+
+def _need(name):
+    p = os.path.join(REFDIR, name)
+    assert os.path.exists(p), "%s missing: run `make -C oracle dropin cli` in the build container" % p
+    return p
+
+
+def _cli(binary, infile, outfile, *flags):
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    r = subprocess.run([_need(binary), "-i", infile, "-o", outfile, "-n", "8"] + list(flags), env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    with open(outfile, "rb") as fh:
+        return fh.read()
+
+
+def _write_fasta(path, seqs):
+    with open(path, "w") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(">seq%d\n%s\n" % (i, s))
+
+
+CLI_CASES = [
+    ("BB11001.tfa", []), ("BB11001.tfa", ["--fast"]),
+    ("BB30014.tfa", []), ("BB30014.tfa", ["--fast"]),
+    ("BB12006.tfa", []), ("BB12006.tfa", ["--realign", "1"]),
+    ("BB30014.tfa", ["--precise"]),
+]
+
+
+@pytest.mark.parametrize("name,flags", CLI_CASES, ids=["%s%s" % (n.split(".")[0], "".join(f).replace("--", "_")) for n, f in CLI_CASES])
+def test_cli_output_is_byte_identical(tmp_path, name, flags):
+    """`kalign -i in -o out [flags]`: the aligned FASTA written by the drop-in equals the reference's."""
+    inp = os.path.join(DATA, name)
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags)
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), *flags)
+    assert len(want) > 100 and got == want
+
+
+@pytest.mark.parametrize("dna,n,length,flags", [(False, 32, 200, []), (False, 32, 200, ["--fast"]),
+                                                (True, 16, 300, ["--type", "dna"]), (False, 200, 150, [])])
+def test_cli_on_dssim_sets(tmp_path, dna, n, length, flags):
+    from kalign_amd import synth
+    inp = str(tmp_path / "in.fa")
+    _write_fasta(inp, synth.dssim(n, length, dna=dna, seed=1))
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags)
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), *flags)
+    assert got == want
+
+
+def _lib_kalign(libname, seqs, type_, n_threads=4):
+    """kalign() of lib/include/kalign/kalign.h:36-40 through ctypes"""
+    L = C.CDLL(_need(libname))
+    L.kalign.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                         C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_int)]
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*[s.encode() for s in seqs])
+    lens = (C.c_int * n)(*[len(s) for s in seqs])
+    out = C.POINTER(C.c_char_p)()
+    alen = C.c_int(0)
+    rc = L.kalign(arr, lens, n, n_threads, type_, -1.0, -1.0, -1.0, C.byref(out), C.byref(alen))
+    assert rc == 0
+    return [out[i].decode() for i in range(n)], alen.value
+
+
+def _distinct_lengths(seqs):
+    """kalign_arr_to_msa leaves the sequence names uninitialised (msa_op.c:482) and msa_sort_len_name breaks length
+    ties by name (msa_sort.c:62-80): with equal lengths the REFERENCE's own result changes from call to call.  Sets
+    whose lengths are all different have one defined answer."""
+    seen, out = set(), []
+    for s in seqs:
+        if len(s) not in seen:
+            seen.add(len(s))
+            out.append(s)
+    return out
+
+
+def test_library_kalign_entry_point():
+    """the 4-sequence DNA case of the reference's tests/kalign_lib_test.c:33-46 and DSSim protein sets through
+    kalign(): same rows from the drop-in and from the reference; residues preserved"""
+    from kalign_amd import synth
+    dna = ["ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTTGCATGCATGCATGCATGCATGCATGCA"] * 3 + \
+          ["ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT"]
+    prot_a = _distinct_lengths(synth.dssim(64, 200, seed=1))
+    prot_b = _distinct_lengths(synth.dssim(96, 120, seed=3))
+    assert len(prot_a) >= 16 and len(prot_b) >= 12
+    for seqs, type_ in ((dna, KALIGN_TYPE_DNA_INTERNAL), (prot_a, KALIGN_TYPE_PROTEIN), (prot_b, KALIGN_TYPE_UNDEFINED),
+                        (prot_a, KALIGN_TYPE_PROTEIN)):
+        got, glen = _lib_kalign("dropin/libkalign.so.3", seqs, type_)
+        want, wlen = _lib_kalign("libkalign_ref.so", seqs, type_)
+        assert glen == wlen and got == want
+        assert [r.replace("-", "") for r in got] == list(seqs)
+        assert all(len(r) == glen for r in got)

@@ -120,21 +120,25 @@ def test_error_behaviour():
         ctx.msa_tree([a, (a + 30).astype(np.uint8)], np.array([[0, 1, 2]], np.int32), subm, scal)
     with pytest.raises(kalign_amd.KalignAmdError):          # more tasks than a tree over 3 sequences can have
         ctx.msa_tree([a, a, a], np.array([[0, 1, 3], [3, 2, 4], [4, 0, 5]], np.int32), subm, scal)
+    with pytest.raises(kalign_amd.KalignAmdError):          # a node consumed by two tasks
+        ctx.msa_tree([a, a, a, a], np.array([[0, 1, 4], [0, 2, 5]], np.int32), subm, scal)
+    with pytest.raises(kalign_amd.KalignAmdError):          # a node aligned to itself
+        ctx.msa_tree([a, a, a], np.array([[0, 0, 3]], np.int32), subm, scal)
     # fewer tasks than numseq-1 is a forest (here: one pair plus a sequence that stays alone)
     recs, paths, gaps = ctx.msa_tree([a, a, a], np.array([[0, 1, 3]], np.int32), subm, scal)
     assert recs[0].plen == 5 and all(int(g.sum()) == 0 for g in gaps)
     ctx.close()
 
 
-def test_arena_overflow_grows_and_reruns(monkeypatch):
+def test_arena_overflow_grows_and_reruns():
     """Device arenas (profiles, paths, scratch) are bump-allocated by the kernels; when one overflows the run is
     repeated with a bigger arena (ka_tree_sync).  Start with arenas that are far too small: the result must be
     the reference's, and a failed task must not leave the clusters waiting at its parent's join point hanging."""
     import kalign_amd
     from util import Golden
-    monkeypatch.setenv("KA_SMALL_ARENAS", "1")
     g = Golden("tree_prot64_gon")
     ctx = kalign_amd.Context(0)
+    ctx.debug_set_hooks(1)                                   # KA_DEBUG_SMALL_ARENAS
     recs, paths, gaps = ctx.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
     ctx.close()
     for t, r in enumerate(recs):
@@ -144,15 +148,19 @@ def test_arena_overflow_grows_and_reruns(monkeypatch):
         assert np.array_equal(got, want)
 
 
-def test_starved_join_is_reported_and_the_run_replanned(monkeypatch):
+def test_starved_join_is_reported_and_the_run_replanned():
     """A join of the chained launch whose sibling never arrives (what a non-resident workgroup looks like from the
     device): the wait is bounded (~2 s), the run is re-planned without joins / clusters and repeated."""
     import kalign_amd
     from util import Golden
-    monkeypatch.setenv("KA_TEST_STARVE", "1")
     g = Golden("tree_prot64_gon")
     ctx = kalign_amd.Context(0)
+    ctx.debug_set_hooks(2)                                   # KA_DEBUG_STARVE_ROOT_JOIN
     recs, paths, gaps = ctx.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    assert ctx.fallback_runs() == 1                          # visible to the caller, not a silent cliff
+    ctx.debug_set_hooks(0)
+    ctx.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    assert ctx.fallback_runs() == 1                          # the next job is back on the fast plan
     ctx.close()
     for t, r in enumerate(recs):
         assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t

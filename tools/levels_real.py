@@ -1,18 +1,23 @@
-"""Per-level task timing (KA_FLAG_TIMING) of the task tree on the reference's own k-means guide tree, 1024 x 400 protein;
-argument: number of consistency anchors (default 5, 0 = --fast).  Run on the GPU box from the repo root."""
+"""Per-level task timing (KA_FLAG_TIMING) of the task tree on the reference's own k-means guide tree;
+arguments: [anchors (default 5, 0 = --fast)] [nseq 1024] [len 400] [dna 0] [bal = balanced synthetic tree].  Run on the GPU box from the repo root."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench, kalign_amd, torch
 torch.cuda.init()
 from kalign_amd import api, guide, synth
-seqs = synth.dssim(1024, 400, seed=1)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+NSEQ = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+LEN = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+DNA = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False
+seqs = synth.dssim(NSEQ, LEN, dna=DNA, seed=1)
 order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))
 seqs = [seqs[i] for i in order]
-tcodes = guide.encode_tree(seqs); codes = guide.encode(seqs)
-subm, scal = bench.scoring(False)
+tcodes = guide.encode_tree(seqs, dna=DNA); codes = guide.encode(seqs, dna=DNA)
+subm, scal = bench.scoring(DNA)
 ctx = kalign_amd.Context(0)
 tasks, sd = ctx.guide_tree(tcodes, n_threads=16)
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if len(sys.argv) > 5 and sys.argv[5] == 'bal':          # balanced synthetic tree instead (profile-profile at every level)
+    tasks = guide.bisecting_tree(NSEQ, seed=1, jitter=0.0)
 ctx.tree_upload(codes, tasks, subm, scal, sd, flags=api.FLAG_TIMING)
 if K: ctx.tree_build_consistency(K, 2.0)
 for _ in range(3): ctx.tree_run(); ctx.tree_sync()
@@ -38,3 +43,19 @@ for r, t in zip(recs, tot):
     done[r.c] = max(done[r.a], done[r.b]) + t/GHZ/1e3
 lvmax = sum(max(tot[tl==l]) for l in range(1, tl.max()+1))/GHZ/1e3
 print('sum of per-level max %.0f us; dependency-driven critical path %.0f us' % (lvmax, done[recs[-1].c]))
+
+# the tasks on the dependency-driven critical path, root first
+start = {}
+for r, t in zip(recs, tot):
+    start[r.c] = max(done[r.a], done[r.b])
+by_c = {r.c: (r, t, tmr) for r, t, tmr in zip(recs, tot, tm)}
+node = recs[-1].c
+print('critical path (root first): node lens nsip kind  start_us  total_us  prep hirsch[pass meet levels] code merge')
+while node in by_c:
+    r, t, x = by_c[node]
+    print('  %6d %5dx%-5d %4d+%-4d k%d  %8.0f %7.0f   %5.0f %6.0f [%6.0f %5.0f %2d] %4.0f %5.0f' % (
+        node, r.len_a, r.len_b, r.nsip_a, r.nsip_b, r.kind, start[node], t/GHZ/1e3, x[0]/GHZ/1e3, x[1]/GHZ/1e3, x[4]/GHZ/1e3, x[5]/GHZ/1e3, x[6], x[2]/GHZ/1e3, x[3]/GHZ/1e3))
+    node = r.a if done[r.a] >= done[r.b] else r.b
+print('root task, per Hirschberg level: sub-problems, pass us, meetup us')
+for l, (nsub, cp, cm) in enumerate(ctx.root_levels):
+    if nsub: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
