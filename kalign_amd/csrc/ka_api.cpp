@@ -18,7 +18,20 @@
 
 #include "ka_device.h"
 
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int lean, int chain, hipStream_t stream);
+// the task kernels live in four translation units (ka_kernels.hip, -DKA_UNIT=0..3)
+extern "C" void ka_unit0_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream);   // 8 waves
+extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream);   // 8 waves + consistency
+extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // half (4 waves, 2 per CU)
+extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // lean (seq-seq levels)
+// kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
+static void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
+{
+        const int cons = D->cons_K > 0;
+        if (kind == 1) ka_unit3_launch(D, blocks_dev, nblocks, cons, stream);
+        else if (kind == 2) ka_unit2_launch(D, blocks_dev, nblocks, cons, stream);
+        else if (cons) ka_unit1_launch(D, blocks_dev, nblocks, chain, stream);
+        else ka_unit0_launch(D, blocks_dev, nblocks, chain, stream);
+}
 extern "C" int ka_max_g_host(void);
 extern "C" void ka_launch_posmaps(const int* paths, const long long* poff, const int* pair_of, const int* lens, const long long* map_off,
                                   int numseq, int K, int* maps, hipStream_t stream);
@@ -76,7 +89,7 @@ struct ka_ctx {
         std::vector<int2> blocks_flat;               // per level: (task, member | cluster size << 8) per workgroup
         std::vector<int> blocks_off;
         std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
-        int max_cluster = 4;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
+        int max_cluster = 8;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
         int n_cus = 256;                             // compute units of the device (hipDeviceProp)
         bool shared_gpu = false;                     // ka_ctx_set_shared: no multi-workgroup tasks, no chained launch
         bool shared_by_fallback = false;             // shared_gpu was forced by a join watchdog (ka_tree_sync), not by the caller
@@ -377,7 +390,8 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         for (int i = 0; i < numseq; i++)
                 for (int j = 0; j < lens[i]; j++) max_code = std::max<int>(max_code, codes[off[i] + j]);
         if (max_code > 22) return fail("sequence code out of range (alphabet is 0..22)");
-        c->nres = (max_code < 5) ? 5 : 23;      // nucleotide alphabets use codes 0..4 (alphabet.c:206-245)
+        // nucleotide alphabets use codes 0..4 (alphabet.c:206-245); proteins without B / Z / X only codes 0..19
+        c->nres = (max_code < 5) ? 5 : (max_code < 20 ? 20 : 23);
         for (int i = 0; i < numseq; i++) {
                 if (lens[i] < 1) return fail("zero-length sequence (the reference removes them before the dispatcher, msa_check.c:66)");
                 c->sum_len += lens[i];
@@ -473,6 +487,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         // the sum of their members' lengths
         scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
         if (c->chain_level >= 0) scr *= (long long)std::min(max_level - c->chain_level, 8);   // the chained launch never resets the scratch counter; grows on demand
+        if (c->max_cluster > 1 && !c->shared_gpu) scr *= 2;          // clusters: every member's private queues and row buffers
         c->scratch_cap = std::max(c->scratch_cap, scr);
         if (c->test_hooks & KA_DEBUG_SMALL_ARENAS) {
                 // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run
@@ -585,6 +600,8 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.numseq = c->numseq; D.flags = c->flags; D.error = c->d_error.p;
         D.nres = c->nres;
         D.trace = c->h_trace;
+        D.prof_task = -1;
+        if (const char* e = getenv("KA_PROF_TASK")) D.prof_task = atoi(e);      // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
         D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;

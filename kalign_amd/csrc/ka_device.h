@@ -67,6 +67,7 @@ struct KaTreeDev {
         int flags;
         int nres;                      // alphabet size: 23 protein, 5 nucleotide (alphabet.c)
         long long* timing;             // [n_tasks][8] phase cycle counts (KA_FLAG_TIMING) or null
+        int prof_task;                 // KA_FLAG_TIMING: the task whose per-level times are kept (-1: the root; KA_PROF_TASK in the environment)
         int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table
         // ---- anchor consistency (anchor_consistency.c); cons_K == 0: off ----

@@ -111,9 +111,18 @@ struct TaskShared {
         float* conf_c;
         int* invj;                     // anchor position -> DP column
         char* vote;                    // HBM vote tables for profiles too long for LDS (16 B per column)
-        KaCtl* ctl;                    // -> ctl_lds (one workgroup) or the task's block in HBM (cluster)
+        KaCtl* ctl;                    // the task's control block: -> ctl_lds (one workgroup) or the task's block in HBM (cluster)
+        KaCtl* lctl;                   // level counters + margin sums of the recursion: == ctl until a cluster SPLITS, then -> ctl_lds
         KaCtl ctl_lds;
         int G, member;                 // cluster size / this workgroup's index in it
+        // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
+        // over the workgroups, agent-scope hand-over, two cluster barriers per level).  As soon as a level has at least
+        // G sub-problems (or single-strip passes) the cluster SPLITS: every workgroup takes its share of the
+        // sub-problems -- independent subtrees of the recursion -- into private queues / row buffers and finishes them
+        // on its own (Gw = 1: workgroup barriers and workgroup-scope hand-over only); one cluster barrier at the end.
+        int Gw, member_w;              // cluster size / member index the recursion currently works with
+        int split;
+        struct Priv { KaSub* q[2]; int2* items[2]; int* prog[2]; int2* pack[2][2]; KaState* f; KaState* b; } priv;
         unsigned int bar_phase;        // cluster barriers passed so far
         int2* items[2];                // work items of the current / next recursion level: (sub-problem, dir<<16 | strip)
         int* prog[2];                  // per-item progress words (columns of the strip's last row published)
@@ -209,11 +218,11 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         o.items = S.items[parity]; o.prog = S.prog[parity];
         o.pack16 = S.pack[parity][0]; o.pack4 = S.pack[parity][1];
         (void)next;
-        o.nitems = &S.ctl->lvl[parity].nitems;
-        o.n16 = &S.ctl->lvl[parity].npack[0];
-        o.n4 = &S.ctl->lvl[parity].npack[1];
-        o.nsub = &S.ctl->lvl[parity].nsub;
-        o.rowalloc = &S.ctl->lvl[parity].rowalloc;
+        o.nitems = &S.lctl->lvl[parity].nitems;
+        o.n16 = &S.lctl->lvl[parity].npack[0];
+        o.n4 = &S.lctl->lvl[parity].npack[1];
+        o.nsub = &S.lctl->lvl[parity].nsub;
+        o.rowalloc = &S.lctl->lvl[parity].rowalloc;
         return o;
 }
 
@@ -373,7 +382,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 if (tot[2]) base[2] = atomicAdd(lout.nitems, tot[2]);
                 if (tot[3]) base[3] = atomicAdd(lout.n16, tot[3]);
                 if (tot[4]) base[4] = atomicAdd(lout.n4, tot[4]);
-                if (mcnt_w) { atomicAdd(&S.ctl->msum, msum_w); atomicAdd(&S.ctl->mcount, mcnt_w); }
+                if (mcnt_w) { atomicAdd(&S.lctl->msum, msum_w); atomicAdd(&S.lctl->mcount, mcnt_w); }
         }
 #pragma unroll
         for (int x = 0; x < 5; ++x) base[x] = __shfl(base[x], 0, 64) + off[x];
@@ -411,7 +420,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
 __device__ void ka_cluster_sync(TaskShared& S)
 {
         __syncthreads();
-        if (S.G == 1) return;
+        if (S.G == 1 || S.split) return;
         if (threadIdx.x == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -440,6 +449,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         const int g = max(S.La, S.Lb) + 2;
         const bool lead = (S.member == 0);
         if (lead) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
+        if (tid == 0) { S.lctl = S.ctl; S.Gw = S.G; S.member_w = S.member; S.split = 0; }
         if (lead && tid == 0) {
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
@@ -452,6 +462,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 }
                 S.ctl->lvl[0].nsub = (S.La > 0 && S.Lb > 0) ? 1 : 0;
                 S.ctl->lvl[0].rowalloc = S.Lb + 1;
+                S.lctl = S.ctl;
                 if (S.ctl->lvl[0].nsub) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La, S.Lb);
                 S.ctl->msum = 0.0; S.ctl->mcount = 0;
                 S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f;
@@ -459,16 +470,56 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         }
         ka_cluster_sync(S);
         int level = 0;
+        bool did_split = false;                                       // (a register copy of S.split: uniform over the workgroup)
         while (true) {
-                KaCtl::Lvl* const cur = &S.ctl->lvl[level & 1];
+                // ---- split the cluster (see TaskShared::Gw): from here on every workgroup recurses on its own ----
+                if (S.G > 1 && !did_split && level >= 1) {
+                        const int nshared = S.ctl->lvl[level & 1].nsub;
+                        // every member sees the same numbers here (the barrier that ended the previous level published them)
+                        if (nshared >= S.G || (S.La >> (level + 1)) <= KA_STRIP_ROWS / 2) {
+                                did_split = true;
+                                __syncthreads();
+                                if (tid == 0) {
+                                        const KaSub* shared_q = S.q[level & 1];
+                                        S.q[0] = S.priv.q[0]; S.q[1] = S.priv.q[1];
+                                        S.items[0] = S.priv.items[0]; S.items[1] = S.priv.items[1];
+                                        S.prog[0] = S.priv.prog[0]; S.prog[1] = S.priv.prog[1];
+                                        S.pack[0][0] = S.priv.pack[0][0]; S.pack[0][1] = S.priv.pack[0][1];
+                                        S.pack[1][0] = S.priv.pack[1][0]; S.pack[1][1] = S.priv.pack[1][1];
+                                        S.fbuf = S.priv.f; S.bbuf = S.priv.b;
+                                        S.lctl = &S.ctl_lds;
+                                        for (int par = 0; par < 2; ++par) {
+                                                KaCtl::Lvl& L = S.ctl_lds.lvl[par];
+                                                L.nsub = 0; L.rowalloc = 0; L.nitems = 0; L.next_item = 0; L.next_job = 0; L.npack[0] = 0; L.npack[1] = 0;
+                                        }
+                                        S.ctl_lds.msum = 0.0; S.ctl_lds.mcount = 0;
+                                        KaCtl::Lvl& L = S.ctl_lds.lvl[level & 1];
+                                        const KaLevelOut lo = ka_level_out(S, level & 1, false);
+                                        // this member's share: every G-th sub-problem of the level (they are independent
+                                        // subtrees of the recursion; their order in the queue is arbitrary)
+                                        for (int k = S.member; k < nshared; k += S.G) {
+                                                KaSub sb = shared_q[k];
+                                                sb.roff = L.rowalloc;
+                                                L.rowalloc += sb.endb - sb.startb + 1;
+                                                S.q[level & 1][L.nsub] = sb;
+                                                ka_emit_items(lo, L.nsub, sb.starta, sb.enda, sb.endb - sb.startb);
+                                                L.nsub += 1;
+                                        }
+                                        S.Gw = 1; S.member_w = 0; S.split = 1;
+                                }
+                                __syncthreads();
+                        }
+                }
+                const bool lead_w = (S.member_w == 0);
+                KaCtl::Lvl* const cur = &S.lctl->lvl[level & 1];
                 const int ncur = cur->nsub;
                 if (ncur == 0) break;
                 KaSub* qc = S.q[level & 1];
                 KaSub* qn = S.q[(level + 1) & 1];
-                if (lead && tid == 0 && level > 0) {
+                if (lead_w && tid == 0 && level > 0) {
                         // the other parity was consumed by level-1 and is idle until this level's meetups
                         // (which start after the barrier below): reset it now
-                        KaCtl::Lvl* const nxt = &S.ctl->lvl[(level + 1) & 1];
+                        KaCtl::Lvl* const nxt = &S.lctl->lvl[(level + 1) & 1];
                         nxt->nsub = 0; nxt->rowalloc = 0; nxt->nitems = 0; nxt->next_item = 0; nxt->next_job = 0; nxt->npack[0] = 0; nxt->npack[1] = 0;
                 }
                 const long long tp0 = __builtin_amdgcn_s_memtime();
@@ -491,17 +542,24 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         // dynamically.  (Item i only ever waits for items < i, and every wave takes its items in
                         // increasing order, so the dealing cannot deadlock the strip pipelines.)
                         const int ntotal = nitems + njobs16 + njobs4;
-                        const int nslots = __builtin_amdgcn_readfirstlane(KA_NW * S.G);
+                        const int Gw = __builtin_amdgcn_readfirstlane(S.Gw), member_w = __builtin_amdgcn_readfirstlane(S.member_w);
+                        const int nslots = __builtin_amdgcn_readfirstlane(KA_NW * Gw);
                         // a level that keeps only waves 0 .. NW/2-1 (or NW/4-1) of every workgroup busy: its packed jobs may
                         // stage their columns in the idle waves' LDS regions too (ka_packed)
                         int nreg = 1;
                         if (ntotal <= nslots) {
-                                const int per_wg = (ntotal + S.G - 1) / S.G;
+                                const int per_wg = (ntotal + Gw - 1) / Gw;
                                 if (per_wg <= KA_NW / 4) nreg = 4; else if (per_wg <= KA_NW / 2) nreg = 2;
                         }
                         nreg = __builtin_amdgcn_readfirstlane(nreg);
                         const int reg_stride = (KA_NW / nreg) * KA_WAVE_LDS;
-                        int it = __builtin_amdgcn_readfirstlane(wave * S.G + S.member);   // this wave's statically dealt item
+                        // static dealing in contiguous blocks: workgroup m of the cluster takes items m*per .. m*per+per-1, one per
+                        // wave -- the strips of one pass are consecutive items, so a strip and the strip it hands its last row to
+                        // mostly sit in the same workgroup (workgroup-scope hand-over; the agent-scope one costs an L2
+                        // write-back per 64 columns, and that gets slower the more the other CUs of the XCD have written)
+                        const int nstatic = min(ntotal, nslots);
+                        const int per = max((nstatic + Gw - 1) / Gw, 1);
+                        int it = __builtin_amdgcn_readfirstlane((wave < per && member_w * per + wave < nstatic) ? member_w * per + wave : ntotal);
                         bool dealt = true;
                         while (true) {
                                 // One lane takes the next item, then it is broadcast.  The puller lane is
@@ -544,9 +602,14 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 const float ja = ka_uniform_f(dir == KA_FWD ? sp->fin.a : sp->bin.a);
                                 const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
                                 const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
+                                const int mid_ = ((ea - sa) / 2) + sa;
+                                const int ns = ka_strips_of(dir == KA_FWD ? mid_ - sa : ea - mid_);
+                                const bool st_me = it < nstatic;
+                                const bool prod_local = k > 0 && st_me && (it - 1) / per == member_w;
+                                const bool cons_local = k + 1 < ns && st_me && it + 1 < nstatic && (it + 1) / per == member_w;
                                 ka_strip<KIND, NRES, NB>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                      (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
-                                                     lds_waves + wave * KA_WAVE_LDS, tss, pslot);
+                                                     lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
                         }
                 }
 #ifdef KA_PROF
@@ -569,13 +632,13 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const KaLevelOut lout = ka_level_out(S, (level + 1) & 1, true);
                         const int est_cols = S.Lb >> level;          // typical columns per sub-problem at this depth
                         if (est_cols > 48) {
-                                for (int k = S.member * KA_NW + wave; k < ncur; k += KA_NW * S.G)
+                                for (int k = S.member_w * KA_NW + wave; k < ncur; k += KA_NW * S.Gw)
                                         ka_meetup<KIND, 64>(S, qc, k, ncur, qn, lout, lane, level == 0);
                         } else if (est_cols > 6) {
-                                for (int k = (S.member * KA_NW + wave) * 4; k < ncur; k += KA_NW * S.G * 4)
+                                for (int k = (S.member_w * KA_NW + wave) * 4; k < ncur; k += KA_NW * S.Gw * 4)
                                         ka_meetup<KIND, 16>(S, qc, k, ncur, qn, lout, lane, level == 0);
                         } else {
-                                for (int k = (S.member * KA_NW + wave) * 16; k < ncur; k += KA_NW * S.G * 16)
+                                for (int k = (S.member_w * KA_NW + wave) * 16; k < ncur; k += KA_NW * S.Gw * 16)
                                         ka_meetup<KIND, 4>(S, qc, k, ncur, qn, lout, lane, level == 0);
                         }
                 }
@@ -586,6 +649,16 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         if (level < 16) { S.lvl_n[level] = ncur; S.lvl_pass[level] = (int)(tp1 - tp0); S.lvl_meet[level] = (int)(tp2 - tp1); }
                 }
                 ++level;
+        }
+        if (S.split) {
+                // the members of a split cluster meet again: margins into the task's block, then ONE cluster barrier
+                // (agent-scope release / acquire: the raw path rows every member wrote become visible to the first one)
+                __syncthreads();
+                if (tid == 0) {
+                        if (S.ctl_lds.mcount) { atomicAdd(&S.ctl->msum, S.ctl_lds.msum); atomicAdd(&S.ctl->mcount, S.ctl_lds.mcount); }
+                        S.split = 0; S.lctl = S.ctl;
+                }
+                ka_cluster_sync(S);
         }
 }
 
@@ -1060,8 +1133,8 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 }
 
 // dynamic-LDS layout of a workgroup
-#define KA_LDS_DBG 768
-#define KA_LDS_TSS 784
+#define KA_LDS_DBG 1008
+#define KA_LDS_TSS 1024
 #define KA_LDS_WAVES 4096                                           // per-wave regions: 2048-B aligned (ring addressing ORs the column offset in)
 static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table overlaps the wave regions");
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
@@ -1082,6 +1155,16 @@ __device__ void ka_build_tss(float* tss, const float* subm, float soff)
 }
 
 __device__ __forceinline__ long long ka_align_up(long long x, long long a) { return (x + a - 1) / a * a; }
+
+// bytes of one member's private recursion state (queues, work lists, row buffers) in a cluster that splits
+__device__ __host__ inline long long ka_private_bytes(long long la, long long lb)
+{
+        const long long n = la + lb + 8;
+        const long long nq = (la < lb ? la : lb) + 4;
+        const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
+        return 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16) + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
+             + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16);
+}
 
 // carve the per-task scratch region (cons_maxlen > 0: the job has a consistency table)
 __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen)
@@ -1105,6 +1188,23 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         S.prog[1] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
         for (int par = 0; par < 2; ++par)
                 for (int cls = 0; cls < 2; ++cls) { S.pack[par][cls] = (int2*)(base + o); o += ka_align_up(2 * nq * 8, 16); }
+        // a cluster that splits (TaskShared::Gw): every member's private queues, work lists and row buffers
+        if (S.G > 1) {
+                const long long pb = ka_private_bytes(la, lb);
+                char* pr = base + o + (long long)S.member * pb;
+                long long x = 0;
+                S.priv.q[0] = (KaSub*)(pr + x); x += ka_align_up(nq * (long long)sizeof(KaSub), 16);
+                S.priv.q[1] = (KaSub*)(pr + x); x += ka_align_up(nq * (long long)sizeof(KaSub), 16);
+                S.priv.items[0] = (int2*)(pr + x); x += ka_align_up(ni * 8, 16);
+                S.priv.items[1] = (int2*)(pr + x); x += ka_align_up(ni * 8, 16);
+                S.priv.prog[0] = (int*)(pr + x); x += ka_align_up(ni * 4, 16);
+                S.priv.prog[1] = (int*)(pr + x); x += ka_align_up(ni * 4, 16);
+                for (int par = 0; par < 2; ++par)
+                        for (int cls = 0; cls < 2; ++cls) { S.priv.pack[par][cls] = (int2*)(pr + x); x += ka_align_up(2 * nq * 8, 16); }
+                S.priv.f = (KaState*)(pr + x); x += ka_align_up(n * 12, 16);
+                S.priv.b = (KaState*)(pr + x); x += ka_align_up(n * 12, 16);
+                o += (long long)S.G * pb;
+        }
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
         if (cons_maxlen > 0) {
                 S.ent = (int2*)(base + o);    o += ka_align_up(n * 8 * KA_NB, 16);
@@ -1119,7 +1219,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         return o;
 }
 
-__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen)
+__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1)
 {
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 4;
@@ -1128,6 +1228,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
+        if (g > 1) b += g * ka_private_bytes(la, lb);
         if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 12 + 15) / 16 * 16;
         return b;
 }
@@ -1198,11 +1299,13 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 int g_eff = (S.La >= 1536) ? 8 : ((S.La >= 1152) ? 6 : ((S.La >= 768) ? 4 : ((S.La >= 320) ? 2 : 1)));
                 if (g_eff > g_launch) g_eff = g_launch;
                 S.G = g_eff; S.member = member; S.bar_phase = 0;
+                S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
+                S.lctl = S.ctl;
                 if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; }
                 s_dbg = nullptr;
                 if (member == 0) {
-                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0);
+                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff);
                         const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                         if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
                         // an earlier task of this run already failed (arena overflow): its outputs -- possibly this
@@ -1246,6 +1349,9 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
         else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
         else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB>(S, s_dbg, lds_waves, tss, D.trace);
+        // no B / Z / X in the job (the usual case): every profile's counts [20..22] are zero and the reference skips
+        // zero counts (aln_profileprofile.c:70-77) -- 20 terms per cell instead of 23
+        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB>(S, s_dbg, lds_waves, tss, D.trace);
         else ka_hirschberg<KA_PP, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         tk2 = __builtin_amdgcn_s_memtime();
@@ -1302,7 +1408,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         long long* tm = D.timing + 8ll * task;
                         tm[0] = tk1 - tk0; tm[1] = tk2 - tk1; tm[2] = tk3 - tk2; tm[3] = __builtin_amdgcn_s_memtime() - tk3;
                         tm[4] = S.t_pass; tm[5] = S.t_meet; tm[6] = S.n_levels; tm[7] = (long long)S.La * S.Lb;
-                        if (T.is_root) {
+                        if (D.prof_task >= 0 ? task == D.prof_task : T.is_root) {
                                 long long* lv = D.timing + 8ll * (D.numseq - 1);
                                 for (int l = 0; l < 16; ++l) {
                                         lv[3 * l] = l < S.n_levels ? S.lvl_n[l] : 0;
@@ -1401,17 +1507,55 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
         }
 }
 
+// The kernels are compiled as four translation units from this one file (-DKA_UNIT=0..3, csrc/Makefile): every
+// instantiation of ka_task_body takes about a minute of compile time, the units build in parallel.
+//   unit 0: ka_task_kernel            unit 1: ka_task_kernel_cons
+//   unit 2: the two half kernels      unit 3: the two lean kernels + ka_pair_kernel
+#ifndef KA_UNIT
+#error "compile with -DKA_UNIT=0..3 (see csrc/Makefile)"
+#endif
+
+// more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+template <typename K>
+static hipError_t ka_optin(K kernel, int bytes, bool* done)
+{
+        if (*done) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) *done = true;
+        return e;
+}
+
+#if KA_UNIT == 0
 __global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
         ka_task_entry<false, 0>(D, blocks, chain);
 }
-
-// (the second launch-bound is waves per SIMD: 4 -> <=128 VGPRs -> two 8-wave workgroups per CU)
-__global__ __launch_bounds__(KA_LEAN_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+extern "C" void ka_unit0_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream)
 {
-        ka_task_entry<true, 0>(D, blocks, 0);
+        static bool done = false;
+        if (ka_optin(ka_task_kernel, KA_LDS_TOTAL, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
 }
+extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen) { return ka_scratch_bytes(la, lb, cons_maxlen); }
+extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }
+extern "C" int ka_max_g_host(void) { return KA_MAX_G; }
+#endif
 
+#if KA_UNIT == 1
+// the same with the anchor-consistency bonus (default mode of the reference's CLI)
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<false, KA_NB>(D, blocks, chain);
+}
+extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream)
+{
+        static bool done = false;
+        if (ka_optin(ka_task_kernel_cons, KA_LDS_TOTAL, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
+}
+#endif
+
+#if KA_UNIT == 2
 // Throughput variant for levels with more tasks than CUs (big trees, forests): 4 waves, 4 rings -> TWO workgroups per
 // CU.  The four strip waves of one task keep a CU's SIMDs busy only part of the time (pipeline fill and drain, deep
 // recursion levels, meetups); a second resident task fills the holes.  Latency per task is no better -- levels
@@ -1420,22 +1564,44 @@ __global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half(const Ka
 {
         ka_task_entry<false, 0>(D, blocks, 0);
 }
-
 __global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
         ka_task_entry<false, KA_NB>(D, blocks, 0);
 }
-
-// the same two with the anchor-consistency bonus (default mode of the reference's CLI)
-__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
 {
-        ka_task_entry<false, KA_NB>(D, blocks, chain);
+        static bool done0 = false, done1 = false;
+        if (cons) {
+                if (ka_optin(ka_task_kernel_half_cons, KA_LDS_HALF, &done1) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
+        } else {
+                if (ka_optin(ka_task_kernel_half, KA_LDS_HALF, &done0) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
+        }
 }
+#endif
 
+#if KA_UNIT == 3
+// (the second launch-bound is waves per SIMD: 4 -> <=128 VGPRs -> two 8-wave workgroups per CU)
+__global__ __launch_bounds__(KA_LEAN_BLOCK, 4) void ka_task_kernel_lean(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<true, 0>(D, blocks, 0);
+}
 // the bonus entries cost ~40 VGPRs: 4 waves, 3 waves per SIMD (<=168 VGPRs) -> three workgroups per CU
 __global__ __launch_bounds__(KA_PAIR_BLOCK, 3) void ka_task_kernel_lean_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
 {
         ka_task_entry<true, KA_NB>(D, blocks, 0);
+}
+extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
+{
+        static bool done0 = false, done1 = false;
+        if (cons) {
+                if (ka_optin(ka_task_kernel_lean_cons, KA_LDS_PAIR, &done1) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+        } else {
+                if (ka_optin(ka_task_kernel_lean, KA_LDS_LEAN, &done0) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev, 0);
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1454,6 +1620,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0;
+                S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;
                 S.kind = KA_SS; S.swapped = swapped;
@@ -1480,53 +1647,10 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
         for (int i = tid; i < S.ctl->alnlen + 2; i += KA_NT) dst[i] = S.coded[i];
 }
 
-// ------------------------------------------------------------------------------------------
-// launchers (called from ka_api.cpp)
-// ------------------------------------------------------------------------------------------
-// more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-static hipError_t ka_lds_optin()
-{
-        static bool done = false;
-        if (done) return hipSuccess;
-        hipError_t e = hipFuncSetAttribute((const void*)ka_task_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_task_kernel_lean, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_LEAN);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_task_kernel_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_TOTAL);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_task_kernel_half, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_HALF);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_task_kernel_half_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_HALF);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)ka_task_kernel_lean_cons, hipFuncAttributeMaxDynamicSharedMemorySize, KA_LDS_PAIR);
-        if (e != hipSuccess) return e;
-        done = true;
-        return hipSuccess;
-}
-
-// kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
-extern "C" void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
-{
-        if (ka_lds_optin() != hipSuccess) return;
-        if (D->cons_K > 0) {
-                if (kind == 1) hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
-                else if (kind == 2) hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
-                else hipLaunchKernelGGL(ka_task_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
-        } else {
-                if (kind == 1) hipLaunchKernelGGL(ka_task_kernel_lean, dim3(nblocks), dim3(KA_LEAN_BLOCK), KA_LDS_LEAN, stream, *D, blocks_dev, 0);
-                else if (kind == 2) hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
-                else hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
-        }
-}
-
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 {
-        if (ka_lds_optin() != hipSuccess) return;
+        static bool done = false;
+        if (ka_optin(ka_pair_kernel, KA_LDS_PAIR, &done) != hipSuccess) return;
         hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *P);
 }
-
-extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen) { return ka_scratch_bytes(la, lb, cons_maxlen); }
-extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }
-extern "C" int ka_max_g_host(void) { return KA_MAX_G; }
+#endif

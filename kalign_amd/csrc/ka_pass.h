@@ -87,6 +87,12 @@ __device__ __forceinline__ float wave_rol1(float x)
         return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x134, 0xf, 0xf, true));
 }
 
+// Chunks (16 B = 4 fields) of a column record's fields [32..59] that an alphabet of NRES residues reads: the scores
+// [32 .. 32+NRES) and the gap fields [55..57] (chunks 5 and 6).  Nucleotides (NRES = 5): chunks 0, 1, 5, 6 -- the other
+// three would be dead global->LDS copies and LDS reads on every column of every step.
+template <int NRES>
+__device__ __forceinline__ constexpr bool ka_chunk_used(int ch) { return ch * 4 < NRES || ch >= 5; }
+
 __device__ __forceinline__ int ka_strips_of(int nrows) { return nrows <= 0 ? 1 : (nrows + KA_STRIP_ROWS - 1) / KA_STRIP_ROWS; }
 
 // NB > 0: anchor-consistency build -- every DP row carries NB (column, value) bonus entries with distinct
@@ -117,7 +123,8 @@ template <int KIND, int NRES, int NB>
 __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
                                          const float inj_a, const float inj_ga, const float inj_gb,
                                          const int dir, const int k, KaState* rows, int* prog,
-                                         const int lane, char* wlds, const float* tss, long long* pslot = nullptr)
+                                         const int lane, char* wlds, const float* tss, const bool acq_agent, const bool rel_agent,
+                                         long long* pslot = nullptr)
 {
         const int ncols = endb - startb;
         const int mid = ((enda - starta) / 2) + starta;
@@ -166,7 +173,15 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const int lastl = nl - 1;                                     // lane holding the strip's last row
         const bool last_is_b = (nr & 1) == 0;
         const bool first = (k == 0);
-        const bool clustered = __builtin_amdgcn_readfirstlane(S.G) > 1;
+        // Hand-over batches: a strip starts 63 columns (the lane skew) plus one batch behind the strip above it.  Inside a
+        // workgroup the batch is 16 columns (start delay 79 instead of 127 columns); across workgroups it stays at 64 --
+        // every batch costs an agent-scope release there.
+        // (declared below: first = strip 0 of its pass has no strip above; the last strip's row is read after the level's barrier)
+        const int CBM = (acq_agent || k == 0) ? 63 : 15;              // consumer side: batch mask of the strip above
+        const int PBM = (rel_agent || k + 1 >= ka_strips_of(nrows)) ? 63 : 15;   // producer side
+        // acq_agent: the strip above (k-1) runs in ANOTHER workgroup of the cluster; rel_agent: the strip below (k+1) does
+        // (or may: work items beyond the statically dealt ones are pulled by whoever is free).  Neighbours inside this
+        // workgroup hand over at workgroup scope: no L2 write-back, no L1 invalidate.
         const bool actB = 2 * lane + 1 < nr;
         const int uA = u0 + min(2 * lane, nr - 1);
         const int uB = u0 + min(2 * lane + 1, nr - 1);
@@ -243,7 +258,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         char* dst = wlds + (nb & (KA_RING_SLOTS - 1)) * (KA_RING_BATCH * 16);
 #pragma unroll
                         for (int ch = 0; ch < KA_REC_CHUNKS; ++ch)
-                                __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 2048), 16, 0, 0);
+                                if (ka_chunk_used<NRES>(ch))
+                                        __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 2048), 16, 0, 0);
                 }
         };
         // The ring reads are issued as inline asm so that the compiler does not track them: its
@@ -254,6 +270,16 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         auto ring_read = [&](float4v* dstq, int vcol, float2v& dep) {
                 // (the wave's LDS region is 2048-B aligned: OR instead of ADD)
                 const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
+                if (NRES <= 8) {
+                        asm volatile("ds_read_b128 %0, %5\n\t"
+                                     "ds_read_b128 %1, %5 offset:2048\n\t"
+                                     "ds_read_b128 %2, %5 offset:10240\n\t"
+                                     "ds_read_b128 %3, %5 offset:12288"
+                                     : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[5]), "=&v"(dstq[6]), "+v"(dep)
+                                     : "v"(a)
+                                     : "memory");
+                        return;
+                }
                 asm volatile("ds_read_b128 %0, %8\n\t"
                              "ds_read_b128 %1, %8 offset:2048\n\t"
                              "ds_read_b128 %2, %8 offset:4096\n\t"
@@ -267,6 +293,10 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                              : "memory");
         };
         auto ring_wait = [&](float4v* qq) {
+                if (NRES <= 8) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");
+                        return;
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6])
                              :
@@ -343,14 +373,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         }
                         bta = inia; btga = iniga; btgb = inigb;
                 } else {
-                        if (EV && (t & 63) == 0) {
+                        if (EV && (t & CBM) == 0) {
                                 if (t <= ncols) {
-                                        // the previous strip must have published columns t .. t+63
-                                        const int need = min(t + 64, ncols + 1);
+                                        // the previous strip must have published columns t .. t+CBM
+                                        const int need = min(t + CBM + 1, ncols + 1);
                                         if (lane == 0) {
                                                 // bounded spin: a stuck pipeline must surface as an error, never as a hung GPU
                                                 int spins = 0;
-                                                if (clustered) {
+                                                if (acq_agent) {
                                                         while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                                                                 __builtin_amdgcn_s_sleep(4);
                                                                 if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
@@ -363,7 +393,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                                 }
                                         }
                                         // the producer may be a wave of another workgroup (another CU) of the cluster
-                                        if (clustered) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                        if (acq_agent) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                                         else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                                         const ka_gfloat* r = grows + 3 * IDX(min(t + lane, ncols));
                                         bta = r[0]; btga = r[1]; btgb = r[2];
@@ -468,17 +498,17 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 const float lgb = lane_bcast(last_is_b ? cBgb : cAgb, lastl);
                                 if (lane == (vL & 63)) { oba = la; obga = lga; obgb = lgb; }
                         }
-                        if (EV && ((vL & 63) == 63 || vL == ncols)) {
+                        if (EV && ((vL & PBM) == PBM || vL == ncols)) {
                                 // FULL: lane i holds column vL - 63 + i; partial: lane i holds column (vL & ~63) + i
-                                const int c0 = vL & ~63;
-                                const int col = FULL ? (vL - 63 + lane) : (c0 + lane);
+                                const int c0 = vL & ~PBM;
+                                const int col = FULL ? (vL - 63 + lane) : ((vL & ~63) + lane);
                                 if (col >= c0 && col <= vL) {
                                         ka_gfloat* w = grows + 3 * IDX(col);
                                         w[0] = oba; w[1] = obga; w[2] = obgb;
                                 }
                                 // publish: the next strip (another wave of this workgroup, or of another
                                 // workgroup of the cluster) may read them
-                                if (clustered) {
+                                if (rel_agent) {
                                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                                         if (lane == 0) __hip_atomic_store(prog + k, vL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -494,7 +524,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 if (KIND == KA_PP) {
                         ring_wait(q[1]);
 #pragma unroll
-                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) q[0][ch] = q[1][ch];
+                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) q[0][ch] = q[1][ch];
                 }
         };
         // run steps [t, tend): pairs with alternating q halves; an odd leftover step is followed
@@ -516,8 +546,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         auto run_steady = [&](int& t, const int tend, auto full_tag, auto first_tag) {
                 while (t < tend) {
                         const int e1 = t | 31;
-                        const int e2 = (t + 63) & ~63;
-                        const int e3 = t + ((lastl - 1 - t) & 63);
+                        const int e2 = (t + CBM) & ~CBM;
+                        const int e3 = t + ((lastl - 1 - t) & PBM);
                         const int ev = min(e1, min(e2, e3));
                         const int fend = min(ev, tend);
                         for (; t + 1 < fend; t += 2) {
@@ -678,7 +708,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                                 const int idx = lds_base + vv;
                                 char* dst = wlds + (idx >> 7) * reg_stride + (idx & 127) * 16;
 #pragma unroll
-                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) *(float4v*)(dst + ch * 2048) = g[ch];
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) *(float4v*)(dst + ch * 2048) = g[ch];
                         }
                         // written and read by different lanes of this wave only
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -696,11 +726,11 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                                 const int idx = lds_base + vv;
                                 const char* src = wlds + (idx >> 7) * reg_stride + (idx & 127) * 16;
 #pragma unroll
-                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = *(const float4v*)(src + ch * 2048);
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) dstq[ch] = *(const float4v*)(src + ch * 2048);
                         } else {
                                 ka_gfloat4c* g = (ka_gfloat4c*)(S.p2 + ((long long)REC(vv) << 6) + 32);
 #pragma unroll
-                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) dstq[ch] = g[ch];
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) dstq[ch] = g[ch];
                         }
                 } else {
                         dstres = ((ka_gbytec*)S.s2)[min(max(REC(max(vv, 1)) - 1, 0), S.Lb - 1)];

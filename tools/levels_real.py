@@ -56,6 +56,6 @@ while node in by_c:
     print('  %6d %5dx%-5d %4d+%-4d k%d  %8.0f %7.0f   %5.0f %6.0f [%6.0f %5.0f %2d] %4.0f %5.0f' % (
         node, r.len_a, r.len_b, r.nsip_a, r.nsip_b, r.kind, start[node], t/GHZ/1e3, x[0]/GHZ/1e3, x[1]/GHZ/1e3, x[4]/GHZ/1e3, x[5]/GHZ/1e3, x[6], x[2]/GHZ/1e3, x[3]/GHZ/1e3))
     node = r.a if done[r.a] >= done[r.b] else r.b
-print('root task, per Hirschberg level: sub-problems, pass us, meetup us')
+print('%s task, per Hirschberg level: sub-problems, pass us, meetup us' % (os.environ.get('KA_PROF_TASK', 'root')))
 for l, (nsub, cp, cm) in enumerate(ctx.root_levels):
     if nsub: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
