@@ -144,17 +144,36 @@ def pp_share(res):
     return pp / max(res["cells"], 1.0)
 
 
-def transfers_leg(ctx, job, subm, scal, reps=3):
-    """SURVEY.md 8(d)'s t_DP bracket: H2D of the sequences and the task list, the task tree, D2H of records and coded
-    paths (ka_msa_tree with host buffers; gap arrays not requested).  Reported beside `value`, never as `value`."""
-    ctx.msa_tree(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+def transfers_leg(ctx, job, subm, scal, reps=5):
+    """SURVEY.md 8(d)'s t_DP bracket: H2D of the sequences and the task list, host-side task preparation, the task
+    tree, D2H of records and coded paths -- ONE ka_msa_tree call of the C ABI with host buffers (the binding's own
+    Python-side flattening / unpacking is outside the bracket, it is not what a C caller pays).  Reported beside
+    `value`, never as `value`."""
+    import ctypes as C
+    from kalign_amd import api
+    flat, off, lens = api._flatten(job["codes"])
+    tasks = np.ascontiguousarray(job["tasks"], np.int32)
+    sd = np.ascontiguousarray(job["seq_distances"], np.float32)
+    sub = np.ascontiguousarray(subm, np.float32).reshape(-1)
+    sc = np.ascontiguousarray(scal, np.float32)
+    nt = len(tasks)
+    recs = (api.TaskRec * nt)()
+    cap = int(lens.sum()) * 40 + 4 * nt + 1024
+    paths = np.zeros(cap, np.int32)
+    p = api._ptr
+
+    def once():
+        rc = ctx.L.ka_msa_tree(ctx.h, len(lens), p(flat), p(off), p(lens), p(sd), nt, p(tasks), p(sub), p(sc), 0, recs, p(paths), cap, None)
+        if rc:
+            raise RuntimeError(ctx.L.ka_last_error().decode())
+    once()
     t0 = time.perf_counter()
     for _ in range(reps):
-        recs, paths, _ = ctx.msa_tree(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+        once()
     dt = (time.perf_counter() - t0) / reps
     cells = float(sum(r.len_a * r.len_b for r in recs))
     return {"ms": dt * 1e3, "gcups": cells / dt / 1e9,
-            "note": "ka_msa_tree, host buffers: upload + host-side task preparation + run + download of records and paths"}
+            "note": "one ka_msa_tree call, host buffers: upload + host-side task preparation + run + download of records and coded paths"}
 
 
 def scoring(dna):
@@ -256,7 +275,7 @@ def default_mode_leg(ctx, codes, tasks, subm, scal, seq_dist, args, k_anchors=5,
             "useful_cells": pair_cells + tree_cells,
             "gcups_tree": tree_cells / tree_s / 1e9,
             "gcups_total": (pair_cells + tree_cells) / (build_s + tree_s) / 1e9}
-    if not args.no_cpu:
+    if not args.no_cpu and len(codes) <= 1024:        # (the reference builds its position maps serially: 100 s at 4096 x 400)
         try:
             from oracle import refdrv
             nt = min(os.cpu_count() or 1, 16)
@@ -437,6 +456,32 @@ def secondary_tree_leg(ctx, name, nseq, length, dna, args, steps=3, warmup=1):
     return out, job
 
 
+def c4_single_gpu_leg(ctx, steps=3):
+    """The workload `bench.py --gpus N` (N > 1) shards, on ONE GPU: 16384 protein x ~500, default mode -- one step =
+    anchor_consistency_build + the task tree, as in multi_gpu_main.  The N = 1 point of the strong-scaling curve."""
+    job = make_job(ctx, 16384, 500, False, seed=1)
+    subm, scal = scoring(False)
+    lens = np.array([len(c) for c in job["codes"]], np.int64)
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+
+    def step():
+        ctx.tree_build_consistency(5, 2.0)
+        ctx.tree_run()
+        ctx.tree_sync()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    recs, _, _ = ctx.tree_download(want_gaps=False)
+    cells = float(sum(r.len_a * r.len_b for r in recs))
+    ids, _ = ctx.tree_consistency()
+    pair_cells = float(sum(int(lens[i]) * int(lens[a]) for i in range(len(lens)) for a in ids if a != i))
+    return {"workload": "16384 protein seqs x ~500 (DSSim), default mode (5 anchors), the reference's guide tree, one GPU",
+            "value": (cells + pair_cells) / dt / 1e9, "unit": "GCUPS", "ms_per_step": dt * 1e3, "steps": steps,
+            "useful_cells_tree": cells, "useful_cells_consistency_batch": pair_cells, "guide_tree_ms": job["guide_tree_ms"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -448,6 +493,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline line only (profiling runs)")
     ap.add_argument("--no-c3", action="store_true")
+    ap.add_argument("--no-c4", action="store_true")
+    ap.add_argument("--scale-workload", action="store_true", help="N > 1: shard --nseq x --len instead of C4 (tests)")
+    ap.add_argument("--scale-fast", action="store_true", help="N > 1: --fast mode instead of the default mode")
     args = ap.parse_args()
 
     import torch
@@ -458,6 +506,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if world > 1 and os.environ.get("KA_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = 0                                             # tests: every rank on the one GPU of the box (gloo)
     torch.cuda.set_device(local_rank)
     if world > 1:
         return multi_gpu_main(args, rank, world, local_rank)
@@ -513,38 +563,99 @@ def main():
         out["concurrent_sets"] = concurrent_sets_leg(bc, bt, s2, sc2, bd, local_rank)
         if not args.no_c3:
             out["c3_4096x2000_dna"], _ = secondary_tree_leg(ctx, "c3_dna_4096x2000", 4096, 2000, True, args, steps=3, warmup=1)
+        if not args.no_c4:
+            out["c4_single_gpu"] = c4_single_gpu_leg(ctx)
     print(json.dumps(out))
     ctx.close()
 
 
 def multi_gpu_main(args, rank, world, local_rank):
-    """N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL)."""
+    """N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL).  STRONG scaling of ONE alignment -- C4 of
+    BASELINE.json: 16384 protein sequences x ~500, the reference's default mode (5 consistency anchors), the
+    reference's guide tree:
+      * anchor_consistency_build: the N x K seq-seq batch sharded over the ranks, every rank's share of the position
+        maps broadcast in place HBM to HBM (dist.sharded_consistency);
+      * the task tree cut into one subtree per rank (dist.sharded_tree); above the cut the profile of a subtree root
+        moves device to device (RCCL send / recv) to the rank that runs the parent;
+      * records and coded paths gathered on every rank.
+    One step = all of that (SURVEY.md 8d's t_DP for default mode); `value` = the alignment's useful cells / time --
+    the same cell count at every N.  The N = 1 number of this workload is the `c4_single_gpu` leg of the N = 1 line."""
     import torch
     import torch.distributed as dist
     import kalign_amd
+    from kalign_amd import api
     from kalign_amd import dist as kd
-    kd.init("nccl", device=torch.device("cuda", local_rank))
+    backend = os.environ.get("KA_BENCH_BACKEND", "nccl")          # tests on one GPU: gloo, every rank on cuda:0
+    same_gpu = backend != "nccl"
+    if same_gpu:
+        torch.cuda.set_device(0)
+        kd.init(backend)
+    else:
+        kd.init("nccl", device=torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = kalign_amd.Context(local_rank, stream=stream)
-    job = make_job(ctx, args.nseq, args.len, args.dna, seed=1 + rank)
-    subm, scal = scoring(args.dna)
+    ctx = kalign_amd.Context(0 if same_gpu else local_rank, stream=stream, shared=same_gpu)
+    nseq, length = (args.nseq, args.len) if args.scale_workload else (16384, 500)
+    job = make_job(ctx, nseq, length, False, seed=1)               # every rank: the same sequences, the same guide tree
+    subm, scal = scoring(False)
+    lens = np.array([len(c) for c in job["codes"]], np.int64)
+    anchors = 0 if args.scale_fast else 5
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+
+    def step():
+        ctx.tree_reset()
+        if anchors:
+            kd.sharded_consistency(ctx, anchors, 2.0, rank, world)
+        return kd.sharded_tree(ctx, job["tasks"], lens, rank, world, api.TaskRec, device="cuda")
 
     def barrier():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    res = timed_tree(ctx, job, subm, scal, args.steps, args.warmup, barrier)
-    elapsed = kd.reduce_scalar(res["elapsed"], "max", device="cuda")
-    total_cells = kd.reduce_scalar(res["cells"], "sum", device="cuda")
+    for _ in range(max(args.warmup, 1)):
+        recs, paths = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs, paths = step()
+    barrier()
+    elapsed = kd.reduce_scalar(time.perf_counter() - t0, "max", device="cuda")
+    cells = float(sum(r.len_a * r.len_b for r in recs))
+    pair_cells = 0.0
+    if anchors:
+        ids = ctx.tree_consistency()[0] if ctx.tree_consistency() else []
+        pair_cells = float(sum(int(lens[i]) * int(lens[a]) for i in range(len(lens)) for a in ids if a != i))
+    # every rank holds every record and path: a checksum over all of them must agree across the ranks
+    chk = int(np.asarray(paths, np.int64).sum() % (1 << 31)) ^ int(sum(r.plen for r in recs))
+    chk_max = kd.reduce_scalar(float(chk), "max", device="cuda")
+    same_as_one_gpu = None
     if rank == 0:
+        # the same job as ONE whole-tree run on this rank's GPU (outside the timed region): results must not depend on N
+        if anchors:
+            ctx.tree_build_consistency(anchors, 2.0)
+        ctx.tree_run()
+        r1, p1, _ = ctx.tree_download(want_gaps=False)
+        same_as_one_gpu = bool(len(r1) == len(recs) and all(
+            a.plen == b.plen and np.array_equal(p1[a.path_off:a.path_off + a.plen + 2], paths[b.path_off:b.path_off + b.plen + 2])
+            for a, b in zip(r1, recs)))
+    if rank == 0:
+        kinds = np.bincount([r.kind for r in recs], minlength=3)
         print(json.dumps({
-            "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA", "value": total_cells * args.steps / elapsed / 1e9,
-            "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA", "value": (cells + pair_cells) * args.steps / elapsed / 1e9,
+            "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_name(job, res) + "; one independent set per GPU", "nseq": args.nseq, "len": args.len},
-            "roofline": roofline_of(res, "other")}))
+            "config": {"workload": "%d protein seqs x ~%d (DSSim), ONE alignment sharded over %d GPUs: %s, the reference's k-means guide "
+                                   "tree cut into one subtree per GPU (%d seq-seq + %d seq-profile + %d profile-profile DP tasks), profiles "
+                                   "handed over HBM to HBM above the cut, records and paths gathered" % (
+                                       nseq, length, world, ("default mode, the N x %d consistency batch sharded + position maps broadcast" % anchors)
+                                       if anchors else "--fast mode", kinds[0], kinds[1], kinds[2]),
+                       "nseq": nseq, "len": length, "mode": "default (5 anchors)" if anchors else "--fast",
+                       "useful_cells_tree": cells, "useful_cells_consistency_batch": pair_cells,
+                       "guide_tree_ms_every_rank": job["guide_tree_ms"],
+                       "identical_results_on_all_ranks": bool(chk_max == float(chk)),
+                       "identical_to_a_single_gpu_run": same_as_one_gpu},
+        }))
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()

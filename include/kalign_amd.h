@@ -145,6 +145,12 @@ int ka_tree_aligned_rows(ka_ctx* ctx, const uint8_t* letters, uint8_t gap_char, 
  *     recs[t] needs a, b, c, path_off.
  */
 int ka_tree_run_tasks(ka_ctx* ctx, const int* task_ids, int n);
+/* The same hand-over without the host: ka_tree_profile_dev says where the (plen+2)*64 floats of a node's profile lie in
+ * this context's HBM, ka_tree_reserve_profile_dev reserves room for an incoming profile of `plen` columns on the
+ * receiving context and makes the node available to ka_tree_run_tasks; the caller moves the bytes device to device
+ * (RCCL send / recv over xGMI -- kalign_amd/dist.py -- or hipMemcpyPeer) before it runs the parent. */
+int ka_tree_profile_dev(ka_ctx* ctx, int node, void** dev_ptr, int* plen_out);
+int ka_tree_reserve_profile_dev(ka_ctx* ctx, int node, int plen, void** dev_ptr);
 int ka_tree_reset(ka_ctx* ctx);
 int ka_tree_node_len(ka_ctx* ctx, int node);
 int ka_tree_set_profile(ka_ctx* ctx, int node, const float* prof, int plen);
@@ -191,6 +197,14 @@ int ka_tree_kernel_ms(ka_ctx* ctx, float* ms, int* n_launches);
  * ka_tree_upload drops the table again.
  */
 int ka_tree_build_consistency(ka_ctx* ctx, int n_anchors, float weight);
+/* The N x K batch sharded over `nparts` GPUs: every rank uploads the same job and calls this with its
+ * own `part`; it selects the same anchors, aligns only its contiguous share of the sequences (balanced by length) and
+ * fills their position maps.  The table is complete once every rank's share has been copied into every other rank's
+ * table: ka_tree_consistency_maps_dev gives the table in HBM (total_ints int32), ka_tree_consistency_part_range the
+ * int range [lo, hi) part `part` fills -- kalign_amd/dist.py broadcasts each range in place with RCCL. */
+int ka_tree_build_consistency_part(ka_ctx* ctx, int n_anchors, float weight, int part, int nparts);
+int ka_tree_consistency_part_range(ka_ctx* ctx, int part, int nparts, long long* lo, long long* hi);
+int ka_tree_consistency_maps_dev(ka_ctx* ctx, void** maps_dev, long long* total_ints);
 /* Returns K (0: no table).  anchor_ids[K] (a forest job: K per alignment that has a table, in order of the
    alignments' first sequences); maps_out: all position maps concatenated in (i*K + k) order,
    each lens[i] ints (pos_maps, anchor_consistency.h:17-24).  Either pointer may be NULL. */

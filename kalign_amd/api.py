@@ -38,7 +38,8 @@ class TaskRec(C.Structure):
 # ka_dist_fn of include/kalign_amd.h
 DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
-EXPORTS = ["ka_debug_set_hooks", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
+EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_consistency_part",
+           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
@@ -72,6 +73,11 @@ def load_library():
     L.ka_ctx_set_shared.argtypes = [vp, C.c_int]
     L.ka_last_error.restype = C.c_char_p
     L.ka_debug_set_hooks.argtypes = [vp, C.c_int]
+    L.ka_tree_profile_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]
+    L.ka_tree_reserve_profile_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ka_tree_build_consistency_part.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.c_int]
+    L.ka_tree_consistency_part_range.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.ka_tree_consistency_maps_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_longlong)]
     L.ka_ctx_fallback_runs.argtypes = [vp]
     L.ka_abi_version.restype = C.c_int
     L.ka_msa_tree.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
@@ -285,6 +291,62 @@ class Context:
         if ncols:
             cols = np.ascontiguousarray(state[len(state) - ncols:]).view(np.int32)
             self._chk(self.L.ka_tree_set_node_cols(self.h, int(node), _ptr(cols)))
+
+    # ---- device-to-device hand-over (sharded trees; kalign_amd/dist.py wraps the pointers as torch tensors) ----
+    def tree_profile_dev(self, node):
+        """(device pointer, plen) of a node's merged profile: (plen+2)*64 float32 in this context's HBM"""
+        ptr, plen = C.c_void_p(), C.c_int(0)
+        self._chk(self.L.ka_tree_profile_dev(self.h, int(node), C.byref(ptr), C.byref(plen)))
+        return ptr.value, plen.value
+
+    def tree_reserve_profile_dev(self, node, plen):
+        """room for an incoming profile of `plen` columns; returns the device pointer to fill before the parent runs"""
+        ptr = C.c_void_p()
+        self._chk(self.L.ka_tree_reserve_profile_dev(self.h, int(node), int(plen), C.byref(ptr)))
+        return ptr.value
+
+    def tree_node_cols(self, node):
+        """residue -> column table of a node's members (None without a consistency table)"""
+        if self.L.ka_tree_get_consistency(self.h, None, None) <= 0:
+            return None
+        n = int(self.L.ka_tree_node_cols_size(self.h, int(node)))
+        cols = np.zeros(n, np.int32)
+        self._chk(self.L.ka_tree_get_node_cols(self.h, int(node), _ptr(cols)))
+        return cols
+
+    def tree_set_node_cols(self, node, cols):
+        cols = np.ascontiguousarray(cols, np.int32)
+        self._chk(self.L.ka_tree_set_node_cols(self.h, int(node), _ptr(cols)))
+
+    def tree_build_consistency_part(self, n_anchors, weight, part, nparts):
+        """this rank's share of the N x K batch of a sharded consistency build (ka_tree_build_consistency_part)"""
+        self._chk(self.L.ka_tree_build_consistency_part(self.h, int(n_anchors), float(weight), int(part), int(nparts)))
+
+    def tree_consistency_part_range(self, part, nparts):
+        lo, hi = C.c_longlong(0), C.c_longlong(0)
+        self._chk(self.L.ka_tree_consistency_part_range(self.h, int(part), int(nparts), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def tree_consistency_maps_dev(self):
+        """(device pointer, number of int32) of the position-map table in HBM"""
+        ptr, n = C.c_void_p(), C.c_longlong(0)
+        self._chk(self.L.ka_tree_consistency_maps_dev(self.h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    # (the executor interface of kalign_amd.dist.sharded_consistency)
+    def cons_build_part(self, n_anchors, weight, part, nparts):
+        self.tree_build_consistency_part(n_anchors, weight, part, nparts)
+
+    def cons_part_range(self, part, nparts):
+        return self.tree_consistency_part_range(part, nparts)
+
+    def cons_table(self):
+        import torch
+        from . import dist as kd
+        if self.L.ka_tree_get_consistency(self.h, None, None) <= 0:
+            return None
+        ptr, n = self.tree_consistency_maps_dev()
+        return kd.dev_tensor(ptr, n, torch.int32)
 
     def tree_download_tasks(self, task_ids):
         """(recs, paths) of the listed tasks; recs[i].path_off indexes `paths`."""

@@ -165,7 +165,7 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
-extern "C" int ka_abi_version(void) { return 5; }
+extern "C" int ka_abi_version(void) { return 6; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
@@ -1060,6 +1060,46 @@ extern "C" int ka_tree_set_profile(ka_ctx* c, int node, const float* prof, int p
         return KA_OK;
 }
 
+// Device-to-device hand-over of a subtree root's profile between the GPUs of a sharded tree: the source exposes
+// where the profile lies in its arena, the destination reserves arena space for it; the caller moves the bytes HBM to
+// HBM (RCCL send / recv over xGMI, hipMemcpyPeer) -- no host bounce.
+extern "C" int ka_tree_profile_dev(ka_ctx* c, int node, void** dev_ptr, int* plen_out)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (node < 0 || node >= 2 * c->numseq - 1 || !dev_ptr || !plen_out) return fail("bad node");
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int len = 0;
+        long long po = -1;
+        HIPCHK(hipMemcpy(&len, c->d_node_len.p + node, sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&po, c->d_node_prof.p + node, sizeof(long long), hipMemcpyDeviceToHost));
+        if (po < 0) return fail("node has no profile (root, or not computed)");
+        *dev_ptr = c->d_prof_arena.p + po;
+        *plen_out = len;
+        return KA_OK;
+}
+
+extern "C" int ka_tree_reserve_profile_dev(ka_ctx* c, int node, int plen, void** dev_ptr)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (node < c->numseq || node >= 2 * c->numseq - 1 || plen < 1 || !dev_ptr) return fail("bad node / profile");
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->state_valid && tree_reset(c)) return KA_FAIL;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        unsigned long long top = 0;
+        HIPCHK(hipMemcpy(&top, c->d_counters.p, sizeof(top), hipMemcpyDeviceToHost));
+        const unsigned long long need = (unsigned long long)(plen + 2) * KA_REC;
+        if ((long long)(top + need) > c->prof_cap) return fail("profile arena too small for the incoming profile");
+        const long long po = (long long)top;
+        top += need;
+        HIPCHK(hipMemcpy(c->d_counters.p, &top, sizeof(top), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_node_len.p + node, &plen, sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_node_prof.p + node, &po, sizeof(long long), hipMemcpyHostToDevice));
+        c->injected.push_back(node);
+        *dev_ptr = c->d_prof_arena.p + po;
+        return KA_OK;
+}
+
 // Consistency state of a node for partial runs: the residue -> column table of its member sequences, concatenated
 // in the node's member order (sum of their lengths ints).  Moves with the profile when a node changes GPUs.
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi)
@@ -1248,12 +1288,57 @@ static void select_anchors(const std::vector<float>& dist, int K, std::vector<in
         }
 }
 
+// Sequences [lo, hi) of part `part` of `nparts`: contiguous ranges with balanced total length (every sequence is
+// aligned to the same K anchors, so a sequence's share of the N x K batch is proportional to its length).
+static void cons_part_seqs(const ka_ctx* c, int part, int nparts, int* lo, int* hi)
+{
+        const int N = c->numseq;
+        auto cut = [&](int r) -> int {
+                if (r <= 0) return 0;
+                if (r >= nparts) return N;
+                const long long target = c->sum_len * (long long)r / nparts;
+                long long acc = 0;
+                int i = 0;
+                while (i < N && acc < target) acc += c->lens[i++];
+                return i;
+        };
+        *lo = cut(part); *hi = cut(part + 1);
+}
+
 extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
 {
+        return ka_tree_build_consistency_part(c, n_anchors, weight, 0, 1);
+}
+
+extern "C" int ka_tree_consistency_part_range(ka_ctx* c, int part, int nparts, long long* lo, long long* hi)
+{
+        if (!c || !c->have_job || c->cons_K <= 0) return fail("no consistency table on this context");
+        if (nparts < 1 || part < 0 || part >= nparts || !lo || !hi) return fail("bad part");
+        int s0, s1;
+        cons_part_seqs(c, part, nparts, &s0, &s1);
+        *lo = s0 < c->numseq ? c->cons_map_off[s0] : c->cons_maps_total;
+        *hi = s1 < c->numseq ? c->cons_map_off[s1] : c->cons_maps_total;
+        return KA_OK;
+}
+
+extern "C" int ka_tree_consistency_maps_dev(ka_ctx* c, void** maps_dev, long long* total_ints)
+{
+        if (!c || !c->have_job || c->cons_K <= 0) return fail("no consistency table on this context");
+        if (maps_dev) *maps_dev = c->d_cons_maps.p;
+        if (total_ints) *total_ints = c->cons_maps_total;
+        c->cons_maps.clear();                                         // the caller may write the table: drop the host copy
+        return KA_OK;
+}
+
+extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float weight, int part, int nparts)
+{
         if (!c || !c->have_job) return fail("no uploaded job");
+        if (nparts < 1 || part < 0 || part >= nparts) return fail("bad part");
         HIPCHK(hipSetDevice(c->device));
         c->cons_K = 0;
         const int N = c->numseq;
+        int part_lo = 0, part_hi = N;
+        cons_part_seqs(c, part, nparts, &part_lo, &part_hi);
         // the reference silently declines in these cases (anchor_consistency.c:206-217)
         if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
         if (n_anchors > KA_NB - 1) return fail("this build carries at most 5 consistency anchors per DP row");
@@ -1302,37 +1387,42 @@ extern "C" int ka_tree_build_consistency(ka_ctx* c, int n_anchors, float weight)
         std::vector<int> ia, ib;
         std::vector<long long> poff;
         long long ptotal = 0;
-        for (int i = 0; i < N; i++)
+        for (int i = part_lo; i < part_hi; i++)                       // (this part's sequences; all of them when nparts == 1)
                 for (int k = 0; k < K; k++) {
                         const int ak = anchor_of[(size_t)i * K + k];
                         if (ak < 0 || i == ak) continue;
                         ia.push_back(i); ib.push_back(ak); poff.push_back(ptotal);
                         ptotal += (long long)c->lens[i] + c->lens[ak] + 3;
                 }
-        if (ia.empty()) return KA_OK;
+        if (ia.empty() && nparts == 1) return KA_OK;
+        if (ia.empty() && part_hi > part_lo) return fail("a part of the consistency batch holds only anchors: use fewer parts");
         // the N x K alignments on the device; their coded paths become position maps there as well
         // (anchor_consistency.c:86-114) and never leave HBM unless ka_tree_get_consistency asks for them
         long long used = 0;
-        if (pairwise_on_device(c, c->h_codes.data(), c->off.data(), c->lens.data(), N, ia.data(), ib.data(), (int)ia.size(),
+        if (!ia.empty() &&
+            pairwise_on_device(c, c->h_codes.data(), c->off.data(), c->lens.data(), N, ia.data(), ib.data(), (int)ia.size(),
                                c->subm, c->scal[0], c->scal[1], c->scal[2], poff.data(), &used))
                 return KA_FAIL;
         c->cons_map_off.assign(N, 0);
         long long mt = 0;
         for (int i = 0; i < N; i++) { c->cons_map_off[i] = mt; mt += (long long)K * c->lens[i]; }
-        std::vector<int> pair_of((size_t)N * K, -2);                  // pair index, -1: the anchor itself, -2: no table
+        // pair index, -1: the anchor itself, -2: no table, -3: another part's sequence (its maps arrive from the rank
+        // that aligned it: ka_tree_consistency_maps_dev / _part_range)
+        std::vector<int> pair_of((size_t)N * K, -2);
         {
                 int pk = 0;
                 for (int i = 0; i < N; i++)
                         for (int k = 0; k < K; k++) {
                                 const int ak = anchor_of[(size_t)i * K + k];
                                 if (ak < 0) continue;
-                                pair_of[(size_t)i * K + k] = (i == ak) ? -1 : pk++;
+                                if (i < part_lo || i >= part_hi) pair_of[(size_t)i * K + k] = -3;
+                                else pair_of[(size_t)i * K + k] = (i == ak) ? -1 : pk++;
                         }
         }
         if (c->d_cons_maps.alloc((size_t)mt) || c->d_cons_map_off.alloc(N) || c->d_pair_of.alloc(pair_of.size())) return fail("hipMalloc failed");
         HIPCHK(hipMemcpyAsync(c->d_cons_map_off.p, c->cons_map_off.data(), sizeof(long long) * N, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_pair_of.p, pair_of.data(), sizeof(int) * pair_of.size(), hipMemcpyHostToDevice, c->stream));
-        ka_launch_posmaps(c->p_paths.p, c->p_poff.p, c->d_pair_of.p, c->p_len.p, c->d_cons_map_off.p, N, K, c->d_cons_maps.p, c->stream);
+        if (!ia.empty()) ka_launch_posmaps(c->p_paths.p, c->p_poff.p, c->d_pair_of.p, c->p_len.p, c->d_cons_map_off.p, N, K, c->d_cons_maps.p, c->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         c->cons_maps.clear();                                         // host copy on demand

@@ -41,7 +41,8 @@ extern "C" void ka_launch_rows(const uint8_t* letters, const int* off, const int
 // Position maps of anchor consistency (reference lib/src/anchor_consistency.c:86-114): the coded path of the
 // alignment (sequence i, anchor k) becomes map[p] = anchor position aligned to residue p of i, or -1.
 // One wave per (i, k): 64 path elements per step, the running positions are ballot prefix counts.
-// pair_of[i*K+k]: index of the pair in the batch, -1: i is the anchor itself (identity), -2: no table (all -1).
+// pair_of[i*K+k]: index of the pair in the batch, -1: i is the anchor itself (identity), -2: no table (all -1),
+// -3: not this rank's part of a sharded table (left alone).
 __global__ void __launch_bounds__(256) ka_posmap_kernel(const int* __restrict__ paths, const long long* __restrict__ poff,
                                                         const int* __restrict__ pair_of, const int* __restrict__ lens,
                                                         const long long* __restrict__ map_off, int n_entries, int K,
@@ -54,6 +55,7 @@ __global__ void __launch_bounds__(256) ka_posmap_kernel(const int* __restrict__ 
         const int len = lens[i];
         int* map = maps + map_off[i] + (long long)k * len;
         const int pk = pair_of[e];
+        if (pk == -3) return;                                        // another rank's share of a sharded table
         if (pk < 0) {
                 for (int p = lane; p < len; p += 64) map[p] = (pk == -1) ? p : -1;
                 return;

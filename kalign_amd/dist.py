@@ -195,6 +195,39 @@ def _gather_bytes(arr, world, device):
     return [o.cpu().numpy()[:int(k.item())] for o, k in zip(out, ns)]
 
 
+class _DevArray:
+    """a raw device pointer as a CUDA-array-interface object (torch.as_tensor aliases it, no copy)"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def dev_tensor(ptr, n, dtype):
+    """torch tensor over `n` elements of library-owned HBM at `ptr` (float32 / int32)"""
+    import torch
+    typestr = {torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device="cuda")
+
+
+def sharded_consistency(ex, n_anchors, weight, rank, world):
+    """anchor_consistency_build over `world` GPUs: every rank aligns its share of the N x K seq-seq
+    batch (contiguous, length-balanced ranges of sequences) and fills their position maps in its copy of the table;
+    then every rank's range is broadcast IN PLACE into the other ranks' tables (HBM to HBM over RCCL / xGMI; the
+    table never visits the host).  ex: kalign_amd.Context after tree_upload, or anything with cons_build_part(part,
+    nparts), cons_table() -> 1-D int32 torch tensor aliasing the table, cons_part_range(part, nparts)."""
+    import torch.distributed as dist
+    ex.cons_build_part(n_anchors, weight, rank, world)
+    if world == 1:
+        return
+    table = ex.cons_table()
+    if table is None:                                             # the job declined (no distances / fewer than 3 sequences)
+        return
+    for r in range(world):
+        lo, hi = ex.cons_part_range(r, world)
+        if hi > lo:
+            dist.broadcast(table[lo:hi], src=r)
+
+
 def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
     """One guide tree over `world` ranks (one process per GPU).
 
@@ -224,7 +257,31 @@ def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
             src = holder.get(child)
             if child < numseq or src is None or src == dst or world == 1:
                 continue
-            if rank == src:
+            d2d = hasattr(ex, "tree_profile_dev") and str(device).startswith("cuda")
+            if d2d:
+                # HBM to HBM: the profile is sent from where it lies in the source's arena into room reserved in the
+                # destination's arena (RCCL send / recv over xGMI); only the residue -> column table of a default-mode
+                # job (ints, scattered over the member sequences on the device) is packed through the host
+                if rank == src:
+                    ptr, plen = ex.tree_profile_dev(child)
+                    cols = ex.tree_node_cols(child)
+                    ncols = 0 if cols is None else len(cols)
+                    dist.send(torch.tensor([plen, ncols], dtype=torch.int64, device=device), dst)
+                    dist.send(dev_tensor(ptr, (plen + 2) * 64, torch.float32), dst)
+                    if ncols:
+                        dist.send(torch.as_tensor(cols, dtype=torch.int32, device=device), dst)
+                elif rank == dst:
+                    meta = torch.zeros(2, dtype=torch.int64, device=device)
+                    dist.recv(meta, src)
+                    plen, ncols = int(meta[0].item()), int(meta[1].item())
+                    ptr = ex.tree_reserve_profile_dev(child, plen)
+                    dist.recv(dev_tensor(ptr, (plen + 2) * 64, torch.float32), src)
+                    if ncols:
+                        cbuf = torch.zeros(ncols, dtype=torch.int32, device=device)
+                        dist.recv(cbuf, src)
+                        ex.tree_set_node_cols(child, cbuf.cpu().numpy())
+                    torch.cuda.synchronize()
+            elif rank == src:
                 prof = ex.tree_get_node(child)
                 dist.send(torch.tensor([len(prof)], dtype=torch.int64, device=device), dst)
                 dist.send(torch.as_tensor(prof, dtype=torch.float32, device=device), dst)

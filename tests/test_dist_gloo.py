@@ -140,6 +140,119 @@ def test_sharded_tree_world2_gloo(tmp_path, case):
             assert np.array_equal(got, want)
 
 
+@pytest.mark.timeout(240)
+def test_sharded_tree_world4_gloo(tmp_path):
+    """Four ranks: three levels of the tree above the cut, profiles cross ranks twice on the way to the root; every
+    rank ends up with the whole result, identical to the single-process golden."""
+    import torch.multiprocessing as mp
+    from util import Golden
+    case = "tree_prot64_gon"
+    out = str(tmp_path / "q%d.npz")
+    port = 29500 + ((os.getpid() + 131) % 500)
+    mp.spawn(_tree_worker, args=(4, port, out, case), nprocs=4, join=True)
+    g = Golden(case)
+    zs = [np.load(out % r) for r in range(4)]
+    assert all(int(z["ran_here"]) > 0 for z in zs) and sum(int(z["ran_here"]) for z in zs) == len(g.tasks)
+    for z in zs:
+        assert np.array_equal(z["plen"], g.rec("plen")) and np.array_equal(z["score"], g.rec("score"))
+        for t in range(len(g.tasks)):
+            o, n = int(z["path_off"][t]), int(z["plen"][t])
+            assert np.array_equal(z["paths"][o:o + n + 2], g.path(t)), t
+
+
+# ------------------------------------------------------------------------------------------------
+# the N x K consistency batch over several ranks (kalign_amd.dist.sharded_consistency) -- default mode
+# ------------------------------------------------------------------------------------------------
+class _ConsExecutor:
+    """CPU stand-in of kalign_amd.Context's consistency interface: its share of the position maps comes from the
+    oracle's seq-seq alignments (tests only); the table is a torch tensor like the device table of the real thing."""
+
+    def __init__(self, g):
+        import torch
+        self.g = g
+        self.lens = np.asarray(g.lens, np.int64)
+        self.K = int(g.n_anchors)
+        self.off = np.concatenate([[0], np.cumsum(self.lens * self.K)])
+        self.table = torch.full((int(self.off[-1]),), -7, dtype=torch.int32)
+
+    def _seq_range(self, part, nparts):
+        # (the library's rule: contiguous ranges with balanced total length, ka_api.cpp:cons_part_seqs)
+        total, n = int(self.lens.sum()), len(self.lens)
+
+        def cut(r):
+            if r <= 0:
+                return 0
+            if r >= nparts:
+                return n
+            target, acc, i = total * r // nparts, 0, 0
+            while i < n and acc < target:
+                acc += int(self.lens[i]); i += 1
+            return i
+        return cut(part), cut(part + 1)
+
+    def cons_part_range(self, part, nparts):
+        lo, hi = self._seq_range(part, nparts)
+        return int(self.off[lo]), int(self.off[hi])
+
+    def cons_table(self):
+        return self.table
+
+    def cons_build_part(self, n_anchors, weight, part, nparts):
+        import torch
+        from oracle import oracledrv
+        g = self.g
+        ids = [int(x) for x in g.anchor_ids]
+        lo, hi = self._seq_range(part, nparts)
+        for i in range(lo, hi):
+            for k, a in enumerate(ids):
+                if a == i:
+                    m = np.arange(self.lens[i], dtype=np.int32)
+                else:
+                    paths, _ = oracledrv.pairwise_batch(g.codes, np.array([i], np.int32), np.array([a], np.int32), g.subm,
+                                                        float(g.scal[0]), float(g.scal[1]), float(g.scal[2]))
+                    p, m, pa, pb = paths[0], np.full(self.lens[i], -1, np.int32), 0, 0
+                    for c in p[1:]:                                    # path -> position map, anchor_consistency.c:93-114
+                        if c == 3:
+                            break
+                        if c == 0:
+                            m[pa] = pb; pa += 1; pb += 1
+                        elif c & 1:
+                            pb += 1
+                        else:
+                            pa += 1
+                o = int(self.off[i]) + k * int(self.lens[i])
+                self.table[o:o + int(self.lens[i])] = torch.as_tensor(m)
+
+
+def _cons_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from kalign_amd import dist as kd
+    from util import Golden
+    kd.init(backend="gloo")
+    ex = _ConsExecutor(Golden("cons_prot32x200"))
+    kd.sharded_consistency(ex, ex.K, 2.0, rank, world)
+    dist.barrier()
+    np.savez(out % rank, table=ex.table.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_sharded_consistency_world4_gloo(tmp_path):
+    """default mode: four ranks align a quarter of the N x K batch each; after the in-place broadcasts every rank holds
+    the complete position-map table, equal to the reference's (golden cons_prot32x200)"""
+    import torch.multiprocessing as mp
+    from util import Golden
+    out = str(tmp_path / "c%d.npz")
+    port = 29500 + ((os.getpid() + 303) % 500)
+    mp.spawn(_cons_worker, args=(4, port, out), nprocs=4, join=True)
+    g = Golden("cons_prot32x200")
+    want = np.concatenate([np.asarray(m, np.int32) for row in g.maps_list() for m in row])
+    for r in range(4):
+        assert np.array_equal(np.load(out % r)["table"], want), r
+
+
 # ------------------------------------------------------------------------------------------------
 # ensemble members, one per rank (kalign_amd.dist.ensemble_members)
 # ------------------------------------------------------------------------------------------------
