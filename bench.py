@@ -62,7 +62,9 @@ def pmc_traffic(key):
 def workload_letters(nseq, length, dna, seed):
     from kalign_amd import synth
     # the reference's own benchmark generator, restated: independent samples of one profile HMM
-    # (tests/dssim.c)
+    # (tests/dssim.c); the big sets through the vectorised sampler of the same model
+    if nseq > 4096:
+        return synth.dssim_fast(nseq, length, dna=dna, seed=seed)
     return synth.dssim(nseq, length, dna=dna, seed=seed)
 
 

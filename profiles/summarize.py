@@ -1,13 +1,15 @@
 """Fold the rocprofv3 outputs of profiles/collect.sh into small tracked summaries.
 
-usage: python profiles/summarize.py <tag> <dir with kt/ pmc_fetch/ pmc_write/ pmc_sq/ bench.json>
-writes profiles/<tag>_kernel_stats.csv, <tag>_last_step_launches.csv, <tag>_pmc_sq.csv,
-<tag>_bench.json and profiles/r01_pmc_traffic.json (the file bench.py reads for roofline.traffic).
+usage: python profiles/summarize.py <tag> <workload> <dir with kt/ pmc_fetch/ pmc_write/ [pmc_sq/] bench.json>
+writes profiles/<tag>_<workload>_kernel_stats.csv, _last_step_launches.csv, [_pmc_sq.csv], _bench.json and updates
+profiles/<tag>_pmc_traffic.json (the file bench.py reads for roofline.traffic; one entry per workload).
 """
 import csv, glob, json, os, sys
 
-tag, d = sys.argv[1], sys.argv[2]
+tag, wl, d = sys.argv[1], sys.argv[2], sys.argv[3]
 here = os.path.dirname(os.path.abspath(__file__))
+KEY = {"headline": "headline", "c2": "c2_1024x400", "c3": "c3_dna_4096x2000"}.get(wl, wl)
+pre = "%s_%s" % (tag, wl)
 
 
 def find(sub, suffix):
@@ -20,28 +22,38 @@ def rows(path):
         return list(csv.DictReader(f))
 
 
-LAUNCHES_FOR_TRACE = 13
+bench = None
 _b = os.path.join(d, "bench.json")
 if os.path.exists(_b):
     for _l in open(_b).read().splitlines():
         if _l.startswith("{"):
-            LAUNCHES_FOR_TRACE = int(json.loads(_l)["roofline"]["launches_per_step"])
+            bench = json.loads(_l)
+LAUNCHES = int(bench["roofline"]["launches_per_step"]) if bench else 1
 # ---- kernel trace: stats + the launches of the last timed step ----
 st = find("kt", "kernel_stats.csv")
 if st:
-    with open(st) as f, open(os.path.join(here, tag + "_kernel_stats.csv"), "w") as g:
+    with open(st) as f, open(os.path.join(here, pre + "_kernel_stats.csv"), "w") as g:
         g.write(f.read())
 tr = find("kt", "kernel_trace.csv")
 if tr:
     r = [x for x in rows(tr) if x["Kernel_Name"].startswith("ka_task_kernel")]
     r.sort(key=lambda x: int(x["Start_Timestamp"]))
-    last = r[-LAUNCHES_FOR_TRACE:]
-    with open(os.path.join(here, tag + "_last_step_launches.csv"), "w") as g:
+    last = r[-LAUNCHES:]
+    tot = 0.0
+    with open(os.path.join(here, pre + "_last_step_launches.csv"), "w") as g:
         g.write("kernel,grid,workgroup,lds_bytes,vgprs,sgprs,duration_us\n")
         for x in last:
+            us = (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3
+            tot += us
             g.write("%s,%s,%s,%s,%s,%s,%.1f\n" % (x["Kernel_Name"].split("(")[0], x["Grid_Size_X"], x["Workgroup_Size_X"], x.get("LDS_Block_Size", ""),
-                                            x.get("VGPR_Count", ""), x.get("SGPR_Count", ""),
-                                            (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3))
+                                            x.get("VGPR_Count", ""), x.get("SGPR_Count", ""), us))
+    # mean over every traced step (13 = 3 warm-up + 10 timed)
+    nsteps = len(r) // LAUNCHES if LAUNCHES else 0
+    if nsteps:
+        allus = sum((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in r)
+        print("kernel-trace: %d task-kernel launches = %d steps x %d; mean kernel time per step %.3f ms (last step %.3f ms); bench kernel_ms_per_step %.3f" % (
+            len(r), nsteps, LAUNCHES, allus / nsteps / 1e3, tot / 1e3, bench["roofline"]["kernel_ms_per_step"] if bench else -1))
+
 
 # ---- PMC: HBM traffic per step ----
 def pmc_sum(sub, counter):
@@ -54,24 +66,22 @@ def pmc_sum(sub, counter):
             tot += float(x["Counter_Value"]); n += 1
     return tot, n
 
+
 fetch, nf = pmc_sum("pmc_fetch", "FETCH_SIZE")
 write, nw = pmc_sum("pmc_write", "WRITE_SIZE")
-LAUNCHES = 13
-b0 = os.path.join(d, "bench.json")
-if os.path.exists(b0):
-    for l in open(b0).read().splitlines():
-        if l.startswith("{"):
-            LAUNCHES = int(json.loads(l)["roofline"]["launches_per_step"])
 if fetch is not None and write is not None and nf and nw:
     steps_f, steps_w = nf / LAUNCHES, nw / LAUNCHES
     fkb, wkb = fetch / steps_f, write / steps_w
     corrected = (2.0 * fkb + wkb) * 1024.0
-    out = {"workload": "bench.py default (1024 protein x ~400, dssim seed 1)", "tag": tag, "launches_per_step": LAUNCHES,
-           "FETCH_SIZE_KB_per_step": fkb, "WRITE_SIZE_KB_per_step": wkb,
-           "hbm_bytes_per_step_corrected": corrected, "hbm_bytes_per_launch_corrected": corrected / LAUNCHES,
-           "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncalibrated"}
-    json.dump(out, open(os.path.join(here, "r01_pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(out))
+    path = os.path.join(here, tag + "_pmc_traffic.json")
+    allw = json.load(open(path)) if os.path.exists(path) else {}
+    allw[KEY] = {"workload": bench["config"]["workload"] if bench else wl, "tag": pre, "launches_per_step": LAUNCHES,
+                 "FETCH_SIZE_KB_per_step": fkb, "WRITE_SIZE_KB_per_step": wkb, "hbm_bytes_per_step_corrected": corrected,
+                 "algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_step"] if bench else None,
+                 "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), summed over the task-kernel launches of a step; FETCH_SIZE doubled per "
+                         "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); WRITE_SIZE uncalibrated"}
+    json.dump(allw, open(path, "w"), indent=1)
+    print(json.dumps(allw[KEY]))
 
 # ---- PMC: SQ issue counters, summed over the task kernels ----
 p = find("pmc_sq", "counter_collection.csv")
@@ -81,14 +91,11 @@ if p:
         if x["Kernel_Name"].startswith("ka_task_kernel"):
             k = (x["Kernel_Name"].split("(")[0], x["Counter_Name"])
             acc[k] = acc.get(k, 0.0) + float(x["Counter_Value"])
-    with open(os.path.join(here, tag + "_pmc_sq.csv"), "w") as g:
+    with open(os.path.join(here, pre + "_pmc_sq.csv"), "w") as g:
         g.write("kernel,counter,sum_over_launches\n")
         for (k, c), v in sorted(acc.items()):
             g.write("%s,%s,%.0f\n" % (k, c, v))
 
-b = os.path.join(d, "bench.json")
-if os.path.exists(b):
-    line = [l for l in open(b).read().splitlines() if l.startswith("{")]
-    if line:
-        open(os.path.join(here, tag + "_bench.json"), "w").write(line[-1] + "\n")
-        print(line[-1][:300])
+if bench:
+    open(os.path.join(here, pre + "_bench.json"), "w").write(json.dumps(bench) + "\n")
+    print(json.dumps(bench)[:300])
