@@ -596,6 +596,9 @@ def multi_gpu_main(args, rank, world, local_rank):
         kd.init("nccl", device=torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
     ctx = kalign_amd.Context(0 if same_gpu else local_rank, stream=stream, shared=same_gpu)
+    # RCCL: collectives and hand-overs on HBM buffers.  gloo (tests): host tensors -- gloo fills a device tensor from the CPU
+    # side, past the GPU's caches
+    coll_dev = "cpu" if same_gpu else "cuda"
     nseq, length = (args.nseq, args.len) if args.scale_workload else (16384, 500)
     job = make_job(ctx, nseq, length, False, seed=1)               # every rank: the same sequences, the same guide tree
     subm, scal = scoring(False)
@@ -607,7 +610,7 @@ def multi_gpu_main(args, rank, world, local_rank):
         ctx.tree_reset()
         if anchors:
             kd.sharded_consistency(ctx, anchors, 2.0, rank, world)
-        return kd.sharded_tree(ctx, job["tasks"], lens, rank, world, api.TaskRec, device="cuda")
+        return kd.sharded_tree(ctx, job["tasks"], lens, rank, world, api.TaskRec, device=coll_dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -621,7 +624,7 @@ def multi_gpu_main(args, rank, world, local_rank):
     for _ in range(args.steps):
         recs, paths = step()
     barrier()
-    elapsed = kd.reduce_scalar(time.perf_counter() - t0, "max", device="cuda")
+    elapsed = kd.reduce_scalar(time.perf_counter() - t0, "max", device=coll_dev)
     cells = float(sum(r.len_a * r.len_b for r in recs))
     pair_cells = 0.0
     if anchors:
@@ -629,7 +632,7 @@ def multi_gpu_main(args, rank, world, local_rank):
         pair_cells = float(sum(int(lens[i]) * int(lens[a]) for i in range(len(lens)) for a in ids if a != i))
     # every rank holds every record and path: a checksum over all of them must agree across the ranks
     chk = int(np.asarray(paths, np.int64).sum() % (1 << 31)) ^ int(sum(r.plen for r in recs))
-    chk_max = kd.reduce_scalar(float(chk), "max", device="cuda")
+    chk_max = kd.reduce_scalar(float(chk), "max", device=coll_dev)
     same_as_one_gpu = None
     if rank == 0:
         # the same job as ONE whole-tree run on this rank's GPU (outside the timed region): results must not depend on N
@@ -637,9 +640,13 @@ def multi_gpu_main(args, rank, world, local_rank):
             ctx.tree_build_consistency(anchors, 2.0)
         ctx.tree_run()
         r1, p1, _ = ctx.tree_download(want_gaps=False)
-        same_as_one_gpu = bool(len(r1) == len(recs) and all(
-            a.plen == b.plen and np.array_equal(p1[a.path_off:a.path_off + a.plen + 2], paths[b.path_off:b.path_off + b.plen + 2])
-            for a, b in zip(r1, recs)))
+        diff = [t for t, (a, b) in enumerate(zip(r1, recs))
+                if a.plen != b.plen or not np.array_equal(p1[a.path_off:a.path_off + a.plen + 2], paths[b.path_off:b.path_off + b.plen + 2])]
+        same_as_one_gpu = bool(len(r1) == len(recs) and not diff)
+        if diff:
+            run_rank, top = kd.plan_subtrees(job["tasks"], lens, world)
+            sys.stderr.write("sharded run differs from the single-GPU run at tasks %s (of %d); ranks %s; above the cut: %s\n" % (
+                diff[:12], len(recs), [int(run_rank[t]) for t in diff[:12]], [t in set(top) for t in diff[:12]]))
     if rank == 0:
         kinds = np.bincount([r.kind for r in recs], minlength=3)
         print(json.dumps({

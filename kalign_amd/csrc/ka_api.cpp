@@ -21,14 +21,14 @@
 // the task kernels live in four translation units (ka_kernels.hip, -DKA_UNIT=0..3)
 extern "C" void ka_unit0_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream);   // 8 waves
 extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream);   // 8 waves + consistency
-extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // half (4 waves, 2 per CU)
+extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, int nqueue, hipStream_t stream);   // half (4 waves, 2 per CU)
 extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // lean (seq-seq levels)
 // kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
 static void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
 {
         const int cons = D->cons_K > 0;
         if (kind == 1) ka_unit3_launch(D, blocks_dev, nblocks, cons, stream);
-        else if (kind == 2) ka_unit2_launch(D, blocks_dev, nblocks, cons, stream);
+        else if (kind == 2) ka_unit2_launch(D, blocks_dev, nblocks, cons, 0, stream);
         else if (cons) ka_unit1_launch(D, blocks_dev, nblocks, chain, stream);
         else ka_unit0_launch(D, blocks_dev, nblocks, chain, stream);
 }
@@ -111,6 +111,8 @@ struct ka_ctx {
         DevBuf<KaJoin> d_join;
         int n_trees = 1;               // guide trees in the job (a forest when > 1)
         int chain_level = -1;          // first level of the chained launch (-1: every level is its own launch)
+        int queue_first = -1;          // queued launch: levels queue_first .. chain_level-1 run as ONE launch of the half kernel (-1: none)
+        int queue_off = 0, queue_n = 0; // its task list in blocks_flat
         std::vector<int2> chain_blocks;
         int chain_blocks_off = 0;
         DevBuf<int2> d_blocks;
@@ -137,7 +139,7 @@ struct ka_ctx {
         DevBuf<long long> p_poff; DevBuf<char> p_scr;
         DevBuf<unsigned long long> b_peq; DevBuf<int> b_dist;   // ka_bpm_batch
         std::vector<ka_task_rec> h_recs;
-        unsigned long long h_counters[4] = {0, 0, 0, 0};
+        unsigned long long h_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // ---- anchor consistency (ka_tree_build_consistency) ----
         std::vector<uint8_t> h_codes;                // host copy of the uploaded sequences
         std::vector<float> seq_dist;                 // msa->seq_distances (empty: none)
@@ -300,6 +302,31 @@ static int plan_launches(ka_ctx* c)
                         // from the device) -- the bounded wait must report it and ka_tree_sync must re-plan and re-run
                         if (c->test_hooks & KA_DEBUG_STARVE_ROOT_JOIN) c->descs[n_tasks - 1].chain_need += 1;
                 }
+                // ---- the queued launch: every level between the seq-seq leaves and the chained launch (each holds more
+                // tasks than the GPU has workgroup slots) as ONE launch of the half kernel; see ka_task_queue_entry.
+                // KA_NO_QUEUE=1 keeps one launch per level.
+                for (int t = 0; t < n_tasks; t++) { c->descs[t].qa = -1; c->descs[t].qb = -1; }
+                c->queue_first = -1;
+                if (c->chain_level >= 1 && !getenv("KA_NO_QUEUE") && !getenv("KA_NO_HALF")) {
+                        int L0 = 0;
+                        while (L0 < c->chain_level) {                       // skip the leading seq-seq levels (lean kernel)
+                                bool all_ss = true;
+                                for (int t : c->levels[L0]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
+                                if (!all_ss) break;
+                                L0++;
+                        }
+                        bool ok = c->chain_level - L0 >= 2;                 // one level alone gains nothing
+                        for (int L = L0; ok && L < c->chain_level; L++) if ((int)c->levels[L].size() <= c->n_cus) ok = false;
+                        if (ok) {
+                                c->queue_first = L0;
+                                for (int t = 0; t < n_tasks; t++) {
+                                        if (c->task_level[t] < L0 || c->task_level[t] >= c->chain_level) continue;
+                                        const int a = abc[3 * t], b = abc[3 * t + 1];
+                                        if (a >= numseq && c->task_level[task_of[a]] >= L0) c->descs[t].qa = task_of[a];
+                                        if (b >= numseq && c->task_level[task_of[b]] >= L0) c->descs[t].qb = task_of[b];
+                                }
+                        }
+                }
         }
 
         // ---- workgroup tables, one per dependency level (build_blocks) ----
@@ -315,6 +342,11 @@ static int plan_launches(ka_ctx* c)
                 c->blocks_off.push_back((int)c->blocks_flat.size());
         }
 
+        c->queue_off = (int)c->blocks_flat.size(); c->queue_n = 0;
+        if (c->queue_first >= 0) {
+                for (int L = c->queue_first; L < c->chain_level; L++)
+                        for (int t : c->levels[L]) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
+        }
         if (c->chain_level >= 0) {
                 // Every task of the chain's first level starts on a single workgroup; clusters form on the way up.
                 // Entries are laid out in depth-first order of the upper tree, one contiguous run per XCD
@@ -485,9 +517,12 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         long long scr = 0;
         // per level every sequence is a member of at most one task; profile lengths never exceed
         // the sum of their members' lengths
-        scr = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
-        if (c->chain_level >= 0) scr *= (long long)std::min(max_level - c->chain_level, 8);   // the chained launch never resets the scratch counter; grows on demand
+        const long long scr_level = ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len) / 2 + (long long)numseq * (2048 + 12LL * c->max_len) + 65536;
+        scr = scr_level;
+        // the chained launch and the queued launch never reset the scratch counter: several levels' worth; grows on demand
+        if (c->chain_level >= 0) scr = scr_level * (long long)std::min(max_level - c->chain_level, 8);
         if (c->max_cluster > 1 && !c->shared_gpu) scr *= 2;          // clusters: every member's private queues and row buffers
+        if (c->queue_first >= 0) scr = std::max(scr, scr_level * (long long)(c->chain_level - c->queue_first));
         c->scratch_cap = std::max(c->scratch_cap, scr);
         if (c->test_hooks & KA_DEBUG_SMALL_ARENAS) {
                 // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run
@@ -500,7 +535,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
             c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
             c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
-            c->d_counters.alloc(4) || c->d_timing.alloc(8 * (size_t)n_tasks + 48 + 512) ||
+            c->d_counters.alloc(8) || c->d_timing.alloc(8 * (size_t)n_tasks + 48 + 512) ||
             c->d_ctl.alloc((size_t)ka_ctl_bytes_host() * n_tasks) || c->d_join.alloc(n_tasks) || c->d_blocks.alloc(c->blocks_flat.size()) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||
             c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
             c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
@@ -566,7 +601,7 @@ static int tree_reset(ka_ctx* c)
         std::vector<int> node_len(nprof, 0);
         std::vector<long long> node_prof(nprof, -1);
         for (int i = 0; i < numseq; i++) { node_len[i] = c->lens[i]; node_prof[i] = c->leaf_prof_off[i]; }
-        unsigned long long counters[4] = { (unsigned long long)c->leaf_prof_total, 0, 0, 0 };
+        unsigned long long counters[8] = { (unsigned long long)c->leaf_prof_total, 0, 0, 0, 0, 0, 0, 0 };
         int zero = 0;
         HIPCHK(hipMemcpyAsync(c->d_node_len.p, node_len.data(), sizeof(int) * nprof, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_node_prof.p, node_prof.data(), sizeof(long long) * nprof, hipMemcpyHostToDevice, c->stream));
@@ -643,6 +678,14 @@ static int tree_launch(ka_ctx* c)
                 const int n = (int)c->levels[L].size();
                 if (!n) continue;
                 if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                if ((int)L == c->queue_first) {
+                        // levels queue_first .. chain_level-1: one launch, two workgroups per CU pulling from the ordered list
+                        const int nwg = std::min(c->queue_n, 2 * c->n_cus);
+                        ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
+                        c->n_launches++;
+                        L = (size_t)c->chain_level - 1;
+                        continue;
+                }
                 if ((int)L == c->chain_level) {
                         // this level and everything above it: one launch, tasks chained through their join points
                         ka_launch_task_level(&D, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, c->stream);

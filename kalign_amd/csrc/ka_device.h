@@ -22,6 +22,7 @@ struct KaTaskDesc {
         float gap_scale;
         int parent;                    // task that consumes node c (-1: root)
         int chain_need;                // chained launch: how many children of this task run inside the same launch (0: entry task)
+        int qa, qb;                    // queued launch: the tasks of the same launch that produce operands a / b (-1: ready before it starts)
 };
 
 // Join point of a task in a chained launch (see ka_task_entry): the clusters that computed its children meet here.
@@ -51,7 +52,7 @@ struct KaTreeDev {
         int* node_len;                 // [2N-1] sequence length / profile length (msa->plen)
         long long* node_prof;          // [2N-1] offset (floats) of the node's profile in prof_arena
         float* prof_arena;
-        unsigned long long* counters;  // [0] prof_top, [1] scratch_top, [2] path_top, [3] dbg_top (floats)
+        unsigned long long* counters;  // [0] prof_top, [1] scratch_top, [2] path_top, [3] dbg_top (floats), [4] head of the queued launch
         long long prof_cap, scratch_cap, path_cap, dbg_cap;
         char* scratch;
         int* path_arena;

@@ -1507,6 +1507,49 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
         }
 }
 
+// Queued launch (the guide-tree levels between the seq-seq leaves and the chained launch, which hold more tasks than
+// the GPU has workgroup slots): ONE launch over all of those levels.  Every workgroup pulls the next task of a list
+// ordered by level; a task whose operands come from the same launch waits for their producers' done flags
+// (KaJoin::go).  A producer was pulled before its consumer, so it is already running on a resident workgroup: the
+// wait cannot deadlock, whatever the residency (no co-scheduling assumption, unlike the chained launch).  No launch
+// boundary between levels: the tail of one level overlaps the head of the next.
+template <bool LEAN, int NB>
+__device__ __forceinline__ void ka_task_queue_entry(const KaTreeDev& D, const int2* __restrict__ order, const int n)
+{
+        extern __shared__ __attribute__((aligned(16))) char ka_smem[];
+        TaskShared& S = *(TaskShared*)ka_smem;
+        const int tid = threadIdx.x;
+        while (true) {
+                __syncthreads();
+                if (tid == 0) S.next_member = (int)atomicAdd(&D.counters[4], 1ull);
+                __syncthreads();
+                const int qi = S.next_member;
+                if (qi >= n) return;
+                const int task = order[qi].x;
+                if (tid == 0) {
+                        const int dep[2] = { D.tasks[task].qa, D.tasks[task].qb };
+                        bool waited = false;
+                        for (int k = 0; k < 2; ++k) {
+                                if (dep[k] < 0) continue;
+                                int spins = 0;
+                                while (__hip_atomic_load(&D.join[dep[k]].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                        __builtin_amdgcn_s_sleep(16);
+                                        if (ka_spin_expired(D.error, ++spins, 1 << 22, 6, true)) break;
+                                }
+                                waited = true;
+                        }
+                        if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                ka_task_body<LEAN, NB>(D, task, 0, 1);
+                // everything this workgroup wrote for the task (profile, node_len / node_prof, colof) is released, then the
+                // done flag goes up -- also after a failed task: its consumers must not hang, the host repeats the run anyway
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(&D.join[task].go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+
 // The kernels are compiled as four translation units from this one file (-DKA_UNIT=0..3, csrc/Makefile): every
 // instantiation of ka_task_body takes about a minute of compile time, the units build in parallel.
 //   unit 0: ka_task_kernel            unit 1: ka_task_kernel_cons
@@ -1560,23 +1603,27 @@ extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 // CU.  The four strip waves of one task keep a CU's SIMDs busy only part of the time (pipeline fill and drain, deep
 // recursion levels, meetups); a second resident task fills the holes.  Latency per task is no better -- levels
 // with at most one task per CU use the 8-wave kernel.
-__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+// nqueue > 0: a queued launch over the first nqueue entries of `blocks` (ka_task_queue_entry); else one workgroup per entry
+__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half(const KaTreeDev D, const int2* __restrict__ blocks, const int nqueue)
 {
-        ka_task_entry<false, 0>(D, blocks, 0);
+        if (nqueue > 0) ka_task_queue_entry<false, 0>(D, blocks, nqueue);
+        else ka_task_entry<false, 0>(D, blocks, 0);
 }
-__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int nqueue)
 {
-        ka_task_entry<false, KA_NB>(D, blocks, 0);
+        if (nqueue > 0) ka_task_queue_entry<false, KA_NB>(D, blocks, nqueue);
+        else ka_task_entry<false, KA_NB>(D, blocks, 0);
 }
-extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
+// nqueue > 0: `nblocks` workgroups share the `nqueue` tasks listed in blocks_dev
+extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, int nqueue, hipStream_t stream)
 {
         static bool done0 = false, done1 = false;
         if (cons) {
                 if (ka_optin(ka_task_kernel_half_cons, KA_LDS_HALF, &done1) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
+                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
         } else {
                 if (ka_optin(ka_task_kernel_half, KA_LDS_HALF, &done0) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, 0);
+                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
         }
 }
 #endif

@@ -222,10 +222,23 @@ def sharded_consistency(ex, n_anchors, weight, rank, world):
     table = ex.cons_table()
     if table is None:                                             # the job declined (no distances / fewer than 3 sequences)
         return
+    import torch
+    # RCCL moves the ranges HBM to HBM in place.  Any other backend (gloo: the one-GPU tests) goes through host tensors:
+    # gloo would write into the device table from the CPU side, past the GPU's caches.
+    direct = (not table.is_cuda) or dist.get_backend() == "nccl"
     for r in range(world):
         lo, hi = ex.cons_part_range(r, world)
-        if hi > lo:
+        if hi <= lo:
+            continue
+        if direct:
             dist.broadcast(table[lo:hi], src=r)
+        else:
+            tmp = table[lo:hi].cpu() if r == dist.get_rank() else torch.empty(hi - lo, dtype=table.dtype)
+            dist.broadcast(tmp, src=r)
+            if r != dist.get_rank():
+                table[lo:hi].copy_(tmp)
+    if table.is_cuda:
+        torch.cuda.synchronize()                                  # the table is complete before any kernel reads it
 
 
 def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
@@ -257,7 +270,8 @@ def sharded_tree(ex, tasks, lens, rank, world, rec_type, device="cpu"):
             src = holder.get(child)
             if child < numseq or src is None or src == dst or world == 1:
                 continue
-            d2d = hasattr(ex, "tree_profile_dev") and str(device).startswith("cuda")
+            # (device pointers only over RCCL: gloo would fill the arena from the CPU side, past the GPU's caches)
+            d2d = hasattr(ex, "tree_profile_dev") and str(device).startswith("cuda") and dist.get_backend() == "nccl"
             if d2d:
                 # HBM to HBM: the profile is sent from where it lies in the source's arena into room reserved in the
                 # destination's arena (RCCL send / recv over xGMI); only the residue -> column table of a default-mode

@@ -68,6 +68,71 @@ def test_subtrees_on_separate_contexts_match_golden(case, world):
         c.close()
 
 
+@pytest.mark.parametrize("case,world", [("tree_prot64_gon", 4), ("cons_BB30014", 3), ("tree_dna16x300", 2)])
+def test_device_to_device_hand_over(case, world):
+    """The device-pointer ABI of the RCCL path (ka_tree_profile_dev / ka_tree_reserve_profile_dev, wrapped as torch
+    tensors by kalign_amd.dist.dev_tensor): subtree roots move HBM to HBM between contexts -- here with a device-side
+    copy between two contexts on one GPU, over xGMI with RCCL send / recv when every context has its own GPU -- and,
+    in default mode, the consistency table is assembled from the ranks' parts (ka_tree_build_consistency_part) by
+    device-side copies of the part ranges.  Results equal the whole-tree goldens."""
+    import torch
+    import kalign_amd
+    from kalign_amd import dist as kd
+    torch.cuda.init()
+    g = Golden(case)
+    cons = case.startswith("cons_")
+    ctxs = [kalign_amd.Context(0) for _ in range(world)]
+    for r, c in enumerate(ctxs):
+        c.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+        if cons:
+            c.tree_build_consistency_part(int(g.n_anchors), float(g.weight), r, world)
+    if cons:
+        tables = [c.cons_table() for c in ctxs]
+        for r in range(world):                                  # what dist.sharded_consistency's broadcasts do
+            lo, hi = ctxs[r].cons_part_range(r, world)
+            for q in range(world):
+                assert ctxs[q].cons_part_range(r, world) == (lo, hi)
+                if q != r and hi > lo:
+                    tables[q][lo:hi].copy_(tables[r][lo:hi])
+        torch.cuda.synchronize()
+        want = np.concatenate([np.asarray(m, np.int32) for row in g.maps_list() for m in row])
+        for t in tables:
+            assert np.array_equal(t.cpu().numpy(), want)
+    run_rank, top = kd.plan_subtrees(g.tasks, g.lens, world)
+    top_set = set(top)
+    n = len(g.lens)
+    for r, c in enumerate(ctxs):
+        mine = [t for t in range(len(g.tasks)) if run_rank[t] == r and t not in top_set]
+        if mine:
+            c.tree_run_tasks(mine)
+    holder = {int(g.tasks[t][2]): int(run_rank[t]) for t in range(len(g.tasks)) if t not in top_set}
+    moved = 0
+    for t in top:
+        a, b, cnode = (int(v) for v in g.tasks[t])
+        dst = int(run_rank[t])
+        for child in (a, b):
+            if child >= n and holder[child] != dst:
+                src = ctxs[holder[child]]
+                ptr, plen = src.tree_profile_dev(child)
+                dptr = ctxs[dst].tree_reserve_profile_dev(child, plen)
+                kd.dev_tensor(dptr, (plen + 2) * 64, torch.float32).copy_(kd.dev_tensor(ptr, (plen + 2) * 64, torch.float32))
+                torch.cuda.synchronize()
+                cols = src.tree_node_cols(child)
+                if cols is not None:
+                    ctxs[dst].tree_set_node_cols(child, cols)
+                moved += 1
+        ctxs[dst].tree_run_tasks([t])
+        holder[cnode] = dst
+    assert moved >= world - 1
+    for r, c in enumerate(ctxs):
+        ran = [t for t in range(len(g.tasks)) if run_rank[t] == r]
+        recs, paths = c.tree_download_tasks(ran)
+        for t, rec in zip(ran, recs):
+            assert rec.plen == g.rec("plen")[t] and rec.score == g.rec("score")[t]
+            assert np.array_equal(paths[rec.path_off:rec.path_off + rec.plen + 2], g.path(t)), t
+        c.close()
+
+
 def test_shared_contexts_run_concurrently_and_match_golden():
     """ka_ctx_set_shared: several alignments in flight on one GPU (separate streams).  Shared contexts use neither
     multi-workgroup tasks nor the chained launch, so no workgroup ever waits for one that is not resident."""
