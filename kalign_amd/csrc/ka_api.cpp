@@ -279,6 +279,19 @@ static int plan_launches(ka_ctx* c)
                         if (b >= numseq) c->descs[task_of[b]].parent = t;
                 }
                 for (int t = 0; t < n_tasks; t++) c->descs[t].is_root = (c->descs[t].parent < 0);
+                {
+                        // join watchdog of the chained launch: ~2 s per 4e9 estimated DP cells below the task (a healthy
+                        // sibling subtree of a huge job may legitimately take longer than the base bound)
+                        std::vector<double> len(2 * numseq - 1, 0.0), cells(2 * numseq - 1, 0.0);
+                        for (int i = 0; i < numseq; i++) len[i] = c->lens[i];
+                        for (int t = 0; t < n_tasks; t++) {
+                                const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                                len[cc] = 1.1 * std::max(len[a], len[b]);
+                                cells[cc] = cells[a] + cells[b] + len[a] * len[b];
+                                c->descs[t].wait_mult = 1 + (int)std::min(63.0, cells[cc] / 4e9);
+                                c->descs[t].pad = 0;
+                        }
+                }
                 c->n_trees = numseq - n_tasks;
                 c->chain_level = -1;
                 if (!getenv("KA_NO_CHAIN") && !c->shared_gpu) {

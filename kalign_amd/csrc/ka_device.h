@@ -23,6 +23,8 @@ struct KaTaskDesc {
         int parent;                    // task that consumes node c (-1: root)
         int chain_need;                // chained launch: how many children of this task run inside the same launch (0: entry task)
         int qa, qb;                    // queued launch: the tasks of the same launch that produce operands a / b (-1: ready before it starts)
+        int wait_mult;                 // chained launch: multiplier of the join watchdog (~2 s each), from the estimated DP cells below this task
+        int pad;
 };
 
 // Join point of a task in a chained launch (see ka_task_entry): the clusters that computed its children meet here.

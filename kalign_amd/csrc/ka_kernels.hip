@@ -1480,7 +1480,7 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
                                 int spins = 0;
                                 while (role == 0) {
                                         __builtin_amdgcn_s_sleep(32);
-                                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 21, 6, true)) break;
+                                        if (ka_spin_expired(S.watchdog, ++spins, (1 << 21) * max(1, min(D.tasks[parent].wait_mult, 64)), 6, true)) break;
                                         role = __hip_atomic_load(&Jc->role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 }
                         }
@@ -1491,7 +1491,9 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
                                 int spins = 0;
                                 while (__hip_atomic_load(&J->go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                                         __builtin_amdgcn_s_sleep(32);
-                                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 21, 6, true)) break;   // ~2 s: then the host re-plans without joins
+                                        // ~2 s per unit of wait_mult (the host scales it with the DP cells of the subtrees that
+                                        // meet here: a healthy sibling of a huge job may take longer): then the host re-plans without joins
+                                        if (ka_spin_expired(S.watchdog, ++spins, (1 << 21) * max(1, min(D.tasks[parent].wait_mult, 64)), 6, true)) break;
                                 }
                                 nm = __hip_atomic_load(&J->join_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + S.member;
                                 ng = __hip_atomic_load(&J->join_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1519,29 +1521,39 @@ __device__ __forceinline__ void ka_task_queue_entry(const KaTreeDev& D, const in
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
         TaskShared& S = *(TaskShared*)ka_smem;
         const int tid = threadIdx.x;
+        // n == 0: not a queue -- one workgroup per entry of `order` (a per-level launch); one body, one call site
         while (true) {
-                __syncthreads();
-                if (tid == 0) S.next_member = (int)atomicAdd(&D.counters[4], 1ull);
-                __syncthreads();
-                const int qi = S.next_member;
-                if (qi >= n) return;
-                const int task = order[qi].x;
-                if (tid == 0) {
-                        const int dep[2] = { D.tasks[task].qa, D.tasks[task].qb };
-                        bool waited = false;
-                        for (int k = 0; k < 2; ++k) {
-                                if (dep[k] < 0) continue;
-                                int spins = 0;
-                                while (__hip_atomic_load(&D.join[dep[k]].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                                        __builtin_amdgcn_s_sleep(16);
-                                        if (ka_spin_expired(D.error, ++spins, 1 << 22, 6, true)) break;
+                int task, member = 0, g = 1;
+                if (n > 0) {
+                        __syncthreads();
+                        if (tid == 0) S.next_member = (int)atomicAdd(&D.counters[4], 1ull);
+                        __syncthreads();
+                        const int qi = S.next_member;
+                        if (qi >= n) return;
+                        task = order[qi].x;
+                        if (tid == 0) {
+                                const int dep[2] = { D.tasks[task].qa, D.tasks[task].qb };
+                                bool waited = false;
+                                for (int k = 0; k < 2; ++k) {
+                                        if (dep[k] < 0) continue;
+                                        int spins = 0;
+                                        while (__hip_atomic_load(&D.join[dep[k]].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                                __builtin_amdgcn_s_sleep(16);
+                                                if (ka_spin_expired(D.error, ++spins, 1 << 22, 6, true)) break;
+                                        }
+                                        waited = true;
                                 }
-                                waited = true;
+                                if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         }
-                        if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        __syncthreads();
+                } else {
+                        const int2 blk = order[blockIdx.x];
+                        task = blk.x;
+                        if (task < 0) return;
+                        member = blk.y & 0xff; g = blk.y >> 8;
                 }
-                __syncthreads();
-                ka_task_body<LEAN, NB>(D, task, 0, 1);
+                ka_task_body<LEAN, NB>(D, task, member, g);
+                if (n == 0) return;
                 // everything this workgroup wrote for the task (profile, node_len / node_prof, colof) is released, then the
                 // done flag goes up -- also after a failed task: its consumers must not hang, the host repeats the run anyway
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1606,13 +1618,11 @@ extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 // nqueue > 0: a queued launch over the first nqueue entries of `blocks` (ka_task_queue_entry); else one workgroup per entry
 __global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half(const KaTreeDev D, const int2* __restrict__ blocks, const int nqueue)
 {
-        if (nqueue > 0) ka_task_queue_entry<false, 0>(D, blocks, nqueue);
-        else ka_task_entry<false, 0>(D, blocks, 0);
+        ka_task_queue_entry<false, 0>(D, blocks, nqueue);
 }
 __global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int nqueue)
 {
-        if (nqueue > 0) ka_task_queue_entry<false, KA_NB>(D, blocks, nqueue);
-        else ka_task_entry<false, KA_NB>(D, blocks, 0);
+        ka_task_queue_entry<false, KA_NB>(D, blocks, nqueue);
 }
 // nqueue > 0: `nblocks` workgroups share the `nqueue` tasks listed in blocks_dev
 extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, int nqueue, hipStream_t stream)

@@ -191,6 +191,27 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const int prevA = (dir == KA_FWD) ? recA - 1 : recA + 1;
         const int prevB = (dir == KA_FWD) ? recB - 1 : recB + 1;
 
+        const unsigned wlds_u = (unsigned)(unsigned long long)wlds;
+        auto ring_issue = [&](int nb) {
+                // start the global->LDS copy of column batch nb (32 columns x 7 chunks)
+                if (lane < KA_RING_BATCH && nb * KA_RING_BATCH <= ncols) {
+                        const int vv = min(nb * KA_RING_BATCH + lane, ncols);
+                        const float* g = S.p2 + ((long long)REC(vv) << 6) + 32;
+                        // ring layout: chunk-major, 128 columns per chunk row (2048 B): column v of chunk ch at
+                        // ch * 2048 + (v & 127) * 16 -- the read address is one AND + one shift-OR
+                        char* dst = wlds + (nb & (KA_RING_SLOTS - 1)) * (KA_RING_BATCH * 16);
+#pragma unroll
+                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch)
+                                if (ka_chunk_used<NRES>(ch))
+                                        __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 2048), 16, 0, 0);
+                }
+        };
+        // prime the column ring BEFORE the row operand is fetched: the two latencies (L2 / HBM) overlap
+        if (KIND == KA_PP) {
+                __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);              // earlier strip's ring traffic is done
+                ring_issue(0);
+                ring_issue(1);
+        }
         // ---- stationary row operand ----
         float oA, eA, tA, oB, eB, tB, orpA, orpB;
         float2v p1v[NRES];
@@ -206,18 +227,27 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 orpA = S.p1[((long long)prevA << 6) + 55] * m1;
                 orpB = S.p1[((long long)prevB << 6) + 55] * m1;
                 if (KIND == KA_PP) {
+                        // the NRES counts of a row are the head of its 256-B record: 16-B loads (a dword load per count made
+                        // 2 x NRES load instructions of 64 scattered lines each at the start of every strip)
+                        constexpr int NV = (NRES + 3) / 4;
+                        float4v va[NV], vb[NV];
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
 #pragma unroll
                         for (int c = 0; c < NRES; ++c) {
-                                p1v[c].x = pA[c];
-                                p1v[c].y = actB ? pB[c] : 0.0f;
+                                p1v[c].x = va[c >> 2][c & 3];
+                                p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
                         }
                 } else {
                         // seq-profile: score = P1[row][32 + residue], residue varies per step ->
                         // keep this lane's two score rows in its private LDS lines
                         float* tA_ = sp_tbl + (2 * lane) * KA_SP_STRIDE;
                         float* tB_ = tA_ + KA_SP_STRIDE;
+                        float4v sa[6], sb[6];
 #pragma unroll
-                        for (int c = 0; c < 23; ++c) { tA_[c] = pA[32 + c]; tB_[c] = pB[32 + c]; }
+                        for (int i = 0; i < 6; ++i) { sa[i] = ((const float4v*)(pA + 32))[i]; sb[i] = ((const float4v*)(pB + 32))[i]; }
+#pragma unroll
+                        for (int c = 0; c < 23; ++c) { tA_[c] = sa[c >> 2][c & 3]; tB_[c] = sb[c >> 2][c & 3]; }
                 }
         }
 
@@ -247,21 +277,6 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         float scA = 0.0f, scB = 0.0f;                                 // sequence columns: this step's two scores, looked up one step ahead
         float4v q[2][KA_REC_CHUNKS];                                  // column record: current / next step (ping-pong)
 
-        const unsigned wlds_u = (unsigned)(unsigned long long)wlds;
-        auto ring_issue = [&](int nb) {
-                // start the global->LDS copy of column batch nb (32 columns x 7 chunks)
-                if (lane < KA_RING_BATCH && nb * KA_RING_BATCH <= ncols) {
-                        const int vv = min(nb * KA_RING_BATCH + lane, ncols);
-                        const float* g = S.p2 + ((long long)REC(vv) << 6) + 32;
-                        // ring layout: chunk-major, 128 columns per chunk row (2048 B): column v of chunk ch at
-                        // ch * 2048 + (v & 127) * 16 -- the read address is one AND + one shift-OR
-                        char* dst = wlds + (nb & (KA_RING_SLOTS - 1)) * (KA_RING_BATCH * 16);
-#pragma unroll
-                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch)
-                                if (ka_chunk_used<NRES>(ch))
-                                        __builtin_amdgcn_global_load_lds((ka_glb_ptr)(g + 4 * ch), (ka_lds_ptr)(dst + ch * 2048), 16, 0, 0);
-                }
-        };
         // The ring reads are issued as inline asm so that the compiler does not track them: its
         // own s_waitcnt for this step's half of q (loaded one step ago) would otherwise also wait
         // for the loads just issued for the next step (lgkmcnt is a plain in-order counter), exposing
@@ -304,10 +319,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         };
 
         if (KIND == KA_PP) {
-                __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);              // earlier strip's ring traffic is done
-                ring_issue(0);
-                ring_issue(1);
-                __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
+                __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);              // the two ring batches issued at the top have landed
                 { float2v nodep = {0.0f, 0.0f}; ring_read(q[0], min(max(-lane, 0), ncols), nodep); }
         } else {
                 // Sequence columns run one step ahead: at step t the residue and the two score look-ups of
@@ -653,10 +665,14 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 orpA = S.p1[((long long)min(prevA, S.La + 1) << 6) + 55] * m1;
                 orpB = S.p1[((long long)min(prevB, S.La + 1) << 6) + 55] * m1;
                 if (KIND == KA_PP) {
+                        constexpr int NV = (NRES + 3) / 4;                // 16-B loads, as in ka_strip
+                        float4v va[NV], vb[NV];
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
 #pragma unroll
                         for (int c = 0; c < NRES; ++c) {
-                                p1v[c].x = pA[c];
-                                p1v[c].y = actB ? pB[c] : 0.0f;
+                                p1v[c].x = va[c >> 2][c & 3];
+                                p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
                         }
                 } else {
                         // seq-profile: score = P1[row][32 + residue] with a different residue every step ->
