@@ -52,6 +52,9 @@ typedef struct {
         int* path;
         float msum;
         int mcount;
+        /* refinement trials (aln_struct.h:32-35; round-robin mode of aln_seqseq.c:385-414) */
+        float flip_threshold;
+        int flip_trial, flip_stride, flip_counter;
 } dp_t;
 
 /* ---- gap / score terms --------------------------------- */
@@ -195,15 +198,15 @@ static void ko_pass(dp_t* d, int dir, int r0, int r1, int startb, int endb)
  * aln_profileprofile.c:301-483).  Candidate order per column: codes 1,2,3,5,6,7;
  * at the last column only 3 and 6.  First strictly-greater wins.
  */
-typedef struct { float max, max2; int c, t; } best_t;
+typedef struct { float max, max2; int c, t, c2, t2; } best_t;
 
 static inline void consider(best_t* b, float s, int i, int code)
 {
         if(s > b->max){
-                b->max2 = b->max;
+                b->max2 = b->max; b->c2 = b->c; b->t2 = b->t;
                 b->max = s; b->t = code; b->c = i;
         }else if(s > b->max2){
-                b->max2 = s;
+                b->max2 = s; b->c2 = i; b->t2 = code;
         }
 }
 
@@ -211,7 +214,7 @@ static void ko_meetup(dp_t* d, int startb, int endb, int mid, int* meet, int* tr
 {
         const st* f = d->f;
         const st* b = d->b;
-        best_t B = { -F, -F, -1, -1 };
+        best_t B = { -F, -F, -1, -1, -1, -1 };
         const float middle = (float)(endb - startb) / 2.0F + (float)startb;
         const int rrec = mid + 1;                 /* R  = P1[mid+1], R- = P1[mid] */
         const float g3 = row_open(d, rrec);
@@ -239,6 +242,17 @@ static void ko_meetup(dp_t* d, int startb, int endb, int mid, int* meet, int* tr
         if(B.max2 > -F){                          /* aln_seqseq.c:376-383 */
                 d->msum += B.max - B.max2;
                 d->mcount++;
+        }
+        /* perturbation of refinement trials, round-robin mode (aln_seqseq.c:385-414): an uncertain meetup -- margin
+           below the threshold -- takes the second-best choice when its running number falls on this trial's slot */
+        if(d->flip_threshold > 0.0F && B.c2 >= 0 && B.max2 > -F){
+                const float margin = B.max - B.max2;
+                if(margin < d->flip_threshold){
+                        if(d->flip_trial > 0 && d->flip_counter % d->flip_stride == d->flip_trial - 1){
+                                B.c = B.c2; B.t = B.t2;
+                        }
+                        d->flip_counter++;
+                }
         }
         *meet = B.c; *tr = B.t; *score = B.max;
 }
@@ -409,6 +423,119 @@ int ko_code_path(const int* raw, int len_a, int len_b, int* coded)
                 while(coded[i] != 0){ coded[i] |= 32; i--; }
         }
         return 0;
+}
+
+/*
+ * convert_raw_path (aln_refine.c:591-672): the path coding of the refinement pass.  Unlike add_gap_info_to_path_n it
+ * fills the gap-in-a run before a match from the last MATCHED column, and its flag loop does execute: 4 = first op of
+ * a gap run, 8 = continuation, 16 (or +8 when it already carries 8) = last op before a match, 32 = terminal runs.
+ */
+int ko_convert_raw_path(const int* raw, int len_a, int len_b, int* o)
+{
+        int j = 1, b_last = 0, i;
+        for(i = 0; i < len_a + len_b + 2; i++) o[i] = 0;
+        for(i = 1; i <= len_a; i++){
+                if(raw[i] == -1){
+                        o[j++] = 2;
+                }else{
+                        for(int a = b_last + 1; a < raw[i]; a++) o[j++] = 1;
+                        o[j++] = 0;
+                        b_last = raw[i];
+                }
+        }
+        for(int a = b_last + 1; a <= len_b; a++) o[j++] = 1;
+        o[0] = j - 1;
+        o[j] = 3;
+        i = 2;
+        while(o[i] != 3){
+                if((o[i - 1] & 3) && !(o[i] & 3)){
+                        if(o[i - 1] & 8) o[i - 1] += 8; else o[i - 1] |= 16;
+                }else if(!(o[i - 1] & 3) && (o[i] & 3)){
+                        o[i] |= 4;
+                }else if((o[i - 1] & 1) && (o[i] & 1)){
+                        o[i] |= 8;
+                }else if((o[i - 1] & 2) && (o[i] & 2)){
+                        o[i] |= 8;
+                }
+                i++;
+        }
+        i = 1;
+        while(o[i] != 0){ o[i] |= 32; i++; }
+        i = o[0];
+        while(o[i] != 0){ o[i] |= 32; i--; }
+        return 0;
+}
+
+/*
+ * compute_sp_score (sp_score.c:75-201): profile-based sum-of-pairs score of the cross-group pairs along a coded
+ * path -- integer residue / gap counts per column of both groups (build_profile, :22-58, from the members' residues
+ * and their gaps[] BEFORE this merge), then one sequential fp32 walk: substitution terms in (i, j) order, gap terms.
+ */
+static void sp_build_profile(const uint8_t* codes, const int* off, const int* lens, int** gaps,
+                             const int* sip, int nsip, int prof_len, int* freq, int* n_gap)
+{
+        for(int m = 0; m < nsip; m++){
+                const int si = sip[m];
+                int pos = 0;
+                for(int j = 0; j < lens[si]; j++){
+                        for(int k = 0; k < gaps[si][j]; k++){ n_gap[pos]++; pos++; }
+                        const int r = codes[off[si] + j];
+                        if(r < 23) freq[pos * 23 + r]++; else n_gap[pos]++;
+                        pos++;
+                }
+                for(int k = 0; k < gaps[si][lens[si]]; k++){ n_gap[pos]++; pos++; }
+                (void)prof_len;
+        }
+}
+
+static float ko_sp_score(const uint8_t* codes, const int* off, const int* lens, int** gaps, const int* path,
+                         const int* sip_a, int nsip_a, const int* sip_b, int nsip_b,
+                         const float* subm, float gpo, float gpe, float tgpe)
+{
+        int pla = lens[sip_a[0]], plb = lens[sip_b[0]];
+        for(int i = 0; i <= lens[sip_a[0]]; i++) pla += gaps[sip_a[0]][i];
+        for(int i = 0; i <= lens[sip_b[0]]; i++) plb += gaps[sip_b[0]][i];
+        int* fa = calloc((size_t)pla * 23 + 1, sizeof(int));
+        int* ga = calloc((size_t)pla + 1, sizeof(int));
+        int* fb = calloc((size_t)plb * 23 + 1, sizeof(int));
+        int* gb = calloc((size_t)plb + 1, sizeof(int));
+        float total = 0.0F;
+        int pos_a = 0, pos_b = 0, in_a = 0, in_b = 0;
+        sp_build_profile(codes, off, lens, gaps, sip_a, nsip_a, pla, fa, ga);
+        sp_build_profile(codes, off, lens, gaps, sip_b, nsip_b, plb, fb, gb);
+        for(int c = 1; c <= path[0]; c++){
+                const int step = path[c] & 3;
+                const float pen = (path[c] & 32) ? tgpe : gpe;
+                if(step == 0){
+                        const int* xa = fa + pos_a * 23;
+                        const int* xb = fb + pos_b * 23;
+                        for(int i = 0; i < 23; i++){
+                                if(xa[i] == 0) continue;
+                                for(int j = 0; j < 23; j++){
+                                        if(xb[j] == 0) continue;
+                                        total += (float)(xa[i] * xb[j]) * subm[i * 23 + j];
+                                }
+                        }
+                        {
+                                const int n_res_a = nsip_a - ga[pos_a], n_gap_b = gb[pos_b];
+                                const int n_gap_a = ga[pos_a], n_res_b = nsip_b - gb[pos_b];
+                                total -= (float)(n_res_a * n_gap_b + n_gap_a * n_res_b) * pen;
+                        }
+                        in_a = 0; in_b = 0; pos_a++; pos_b++;
+                }else if(step == 1){
+                        const int n_pairs = nsip_a * (nsip_b - gb[pos_b]);
+                        if(!in_a) total -= (float)n_pairs * gpo;
+                        total -= (float)n_pairs * pen;
+                        in_a = 1; in_b = 0; pos_b++;
+                }else if(step == 2){
+                        const int n_pairs = (nsip_a - ga[pos_a]) * nsip_b;
+                        if(!in_b) total -= (float)n_pairs * gpo;
+                        total -= (float)n_pairs * pen;
+                        in_a = 0; in_b = 1; pos_a++;
+                }
+        }
+        free(fa); free(ga); free(fb); free(gb);
+        return total;
 }
 
 /*
@@ -749,14 +876,18 @@ static float* ko_bonus_profile(const ko_cons* ct, const int* lens, int** gaps,
  * anchor-consistency bonus when n_anchors > 0 (aln_wrap.c:207-214, aln_run.c:262-295).
  * Tasks must be in TASK_ORDER_TREE order (children before parents; the last task is the root).
  */
-int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int* lens,
+/* refine_mode 0: create_msa_tree.  1 / 2: refine_alignment (aln_refine.c:36-88; KALIGN_REFINE_ALL / _CONFIDENT) --
+   the same walk over the edges with convert_raw_path coding, and refine_edge's five trials (:93-346) on the edges to
+   refine; conf_in = the first pass's task confidences (mode 2: edges at or below their median are refined). */
+static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const int* lens,
                      const float* seq_distances,
                      int n_tasks, const int* abc,
                      const float* subm, const float* scal,
                      int n_anchors, float cons_weight,
                      ko_task_rec* recs, int* paths_out, long long paths_cap,
                      int* gaps_out, int dump_task, float* prof_dump,
-                     int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out)
+                     int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out,
+                     int refine_mode, const float* conf_in)
 {
         const int nprof = 2 * numseq - 1;
         const float gpo0 = scal[0], gpe0 = scal[1], tgpe0 = scal[2];
@@ -768,7 +899,21 @@ int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int
         int** gaps = calloc((size_t)numseq, sizeof(int*));
         long long poff = 0;
         int rc = 0;
+        float conf_threshold = 0.0f;
         ko_cons* ct = ko_cons_build(numseq, codes, off, lens, seq_distances, subm, gpo0, gpe0, tgpe0, n_anchors, cons_weight);
+
+        if(refine_mode == 2){                                      /* compute_confidence_threshold, aln_refine.c:674-712 */
+                float* cf = malloc(sizeof(float) * (size_t)n_tasks);
+                for(int i = 0; i < n_tasks; i++) cf[i] = conf_in[i];
+                for(int i = 1; i < n_tasks; i++){
+                        float tmp = cf[i];
+                        int j = i - 1;
+                        while(j >= 0 && cf[j] > tmp){ cf[j + 1] = cf[j]; j--; }
+                        cf[j + 1] = tmp;
+                }
+                conf_threshold = (n_tasks % 2 == 0) ? (cf[n_tasks / 2 - 1] + cf[n_tasks / 2]) / 2.0F : cf[n_tasks / 2];
+                free(cf);
+        }
 
         if(ct && anchor_ids_out) for(int k = 0; k < ct->K; k++) anchor_ids_out[k] = ct->anchor_ids[k];
         if(ct && maps_out){
@@ -866,12 +1011,52 @@ int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int
                 raw2 = malloc(sizeof(int) * (size_t)(len_a + len_b + 2));
                 coded = malloc(sizeof(int) * (size_t)(len_a + len_b + 3));
                 d.path = raw;
-                ko_align(&d, &probe);
-                if(swapped){
-                        ko_mirror_path(raw, len_a, len_b, raw2);
-                        ko_code_path(raw2, len_a, len_b, coded);
+                float task_conf = 0.0f;
+                if(!refine_mode){
+                        ko_align(&d, &probe);
+                        if(swapped){
+                                ko_mirror_path(raw, len_a, len_b, raw2);
+                                ko_code_path(raw2, len_a, len_b, coded);
+                        }else{
+                                ko_code_path(raw, len_a, len_b, coded);
+                        }
+                        task_conf = d.mcount > 0 ? d.msum / (float)d.mcount : 0.0f;
                 }else{
-                        ko_code_path(raw, len_a, len_b, coded);
+                        /* refine_edge (multi-trial) or replay_edge (one trial); trial 0 is the deterministic baseline,
+                           trials 1..4 flip uncertain meetups round-robin with the baseline's mean margin as threshold */
+                        const int refine_it = refine_mode == 1 || (refine_mode == 2 && conf_in[tid] <= conf_threshold);
+                        const int n_trials = refine_it ? 5 : 1;
+                        int* cand = malloc(sizeof(int) * (size_t)(len_a + len_b + 3));
+                        float best_sp = -F, avg_margin = 0.0F, best_msum = 0.0F;
+                        int best_mcount = 0;
+                        for(int k = 0; k < n_trials; k++){
+                                probe_t skip;
+                                memset(&skip, 0, sizeof(skip));
+                                skip.have_top = 1;
+                                d.flip_threshold = (k == 0) ? 0.0F : avg_margin;
+                                d.flip_trial = k; d.flip_stride = n_trials - 1; d.flip_counter = 0;
+                                ko_align(&d, k == 0 ? &probe : &skip);
+                                if(swapped){
+                                        ko_mirror_path(raw, len_a, len_b, raw2);
+                                        ko_convert_raw_path(raw2, len_a, len_b, cand);
+                                }else{
+                                        ko_convert_raw_path(raw, len_a, len_b, cand);
+                                }
+                                if(refine_it){
+                                        const float sp = ko_sp_score(codes, off, lens, gaps, cand, sip[a], nsip[a], sip[b], nsip[b], subm, gpo, gpe, tgpe);
+                                        if(sp > best_sp){
+                                                best_sp = sp; best_msum = d.msum; best_mcount = d.mcount;
+                                                memcpy(coded, cand, sizeof(int) * (size_t)(cand[0] + 2));
+                                        }
+                                }else{
+                                        best_msum = d.msum; best_mcount = d.mcount;
+                                        memcpy(coded, cand, sizeof(int) * (size_t)(cand[0] + 2));
+                                }
+                                if(k == 0 && d.mcount > 0) avg_margin = d.msum / (float)d.mcount;
+                        }
+                        d.flip_threshold = 0.0F;
+                        task_conf = best_mcount > 0 ? best_msum / (float)best_mcount : 0.0f;
+                        free(cand);
                 }
 
                 r->a = a; r->b = b; r->c = c;
@@ -882,7 +1067,7 @@ int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int
                 r->score = probe.have_top ? probe.top_score : 0.0f;
                 r->fhash = probe.fhash; r->bhash = probe.bhash;
                 r->gap_scale = gap_scale; r->subm_off = soff;
-                r->confidence = d.mcount > 0 ? d.msum / (float)d.mcount : 0.0f;
+                r->confidence = task_conf;
                 r->prof_hash = 0;
                 if(poff + coded[0] + 2 > paths_cap){
                         rc = 2;
@@ -921,6 +1106,35 @@ int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int
         for(int i = 0; i < numseq; i++) free(gaps[i]);
         free(prof); free(sip); free(nsip); free(plen); free(gaps);
         return rc;
+}
+
+int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                     const float* seq_distances,
+                     int n_tasks, const int* abc,
+                     const float* subm, const float* scal,
+                     int n_anchors, float cons_weight,
+                     ko_task_rec* recs, int* paths_out, long long paths_cap,
+                     int* gaps_out, int dump_task, float* prof_dump,
+                     int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out)
+{
+        return ko_tree_impl(numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, n_anchors, cons_weight,
+                            recs, paths_out, paths_cap, gaps_out, dump_task, prof_dump, anchor_ids_out, maps_out, bonus_hash_out, 0, NULL);
+}
+
+/* refine_alignment (aln_refine.c:36-88) as its own pass: mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT with
+   conf_in[n_tasks] = the task confidences of the alignment being refined.  recs[t].confidence / plen / paths are those of
+   the refined edges (paths in convert_raw_path coding), gaps_out the refined alignment. */
+int ko_msa_tree_refine(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                       const float* seq_distances,
+                       int n_tasks, const int* abc,
+                       const float* subm, const float* scal,
+                       int n_anchors, float cons_weight, int mode, const float* conf_in,
+                       ko_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
+{
+        if(mode != 1 && mode != 2) return 1;
+        if(mode == 2 && !conf_in) return 1;
+        return ko_tree_impl(numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, n_anchors, cons_weight,
+                            recs, paths_out, paths_cap, gaps_out, -1, NULL, NULL, NULL, NULL, mode, conf_in);
 }
 
 int ko_msa_tree(int numseq, const uint8_t* codes, const int* off, const int* lens,

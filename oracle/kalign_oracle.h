@@ -55,6 +55,18 @@ int ko_msa_tree_cons(int numseq, const uint8_t* codes, const int* off, const int
                      int* gaps_out, int dump_task, float* prof_dump,
                      int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out);
 
+/* refinement: refine_alignment (aln_refine.c:36-346) -- the second pass over every edge with
+   convert_raw_path coding (:591-672), refine_edge's five trials (baseline + four round-robin flips of uncertain meetups,
+   aln_seqseq.c:385-414) scored with compute_sp_score (sp_score.c:75-201), best trial kept.  mode 1 = KALIGN_REFINE_ALL,
+   2 = KALIGN_REFINE_CONFIDENT (conf_in = the task confidences of the alignment being refined). */
+int ko_msa_tree_refine(int numseq, const uint8_t* codes, const int* off, const int* lens,
+                       const float* seq_distances,
+                       int n_tasks, const int* tasks_abc,
+                       const float* subm, const float* scal,
+                       int n_anchors, float cons_weight, int mode, const float* conf_in,
+                       ko_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
+int ko_convert_raw_path(const int* raw_path, int len_a, int len_b, int* coded);
+
 int ko_pairwise_batch(const uint8_t* codes, const int* off, const int* lens,
                       const int* ia, const int* ib, int npairs,
                       const float* subm, float gpo, float gpe, float tgpe,

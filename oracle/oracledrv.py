@@ -58,6 +58,9 @@ def lib():
                                   C.POINTER(TaskRec), vp, C.c_longlong, vp, C.c_int, vp]
         L.ko_msa_tree_cons.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float,
                                        C.POINTER(TaskRec), vp, C.c_longlong, vp, C.c_int, vp, vp, vp, vp]
+        L.ko_msa_tree_refine.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp,
+                                         C.POINTER(TaskRec), vp, C.c_longlong, vp]
+        L.ko_convert_raw_path.argtypes = [vp, C.c_int, C.c_int, vp]
         L.ko_pairwise_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_float, C.c_float, C.c_float,
                                         vp, vp, vp]
         L.ko_dp_single.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp,
@@ -148,6 +151,31 @@ def msa_tree_cons(codes, tasks, subm, scal, seq_distances, n_anchors=5, weight=2
             o += int(lens[i])
         maps.append(row)
     return recs, paths, g, ids[:K], maps, bh
+
+
+def msa_tree_refine(codes, tasks, subm, scal, seq_distances, mode=1, conf_in=None, n_anchors=0, weight=2.0):
+    """refine_alignment as the oracle restates it (ko_msa_tree_refine): the second pass over every edge.
+    Returns (recs, paths, gaps per seq)."""
+    flat, off, lens = flatten(codes)
+    tasks = np.ascontiguousarray(tasks, np.int32)
+    nt = len(tasks)
+    recs = (TaskRec * nt)()
+    cap = (int(lens.max()) * 2 + 4) * nt + int(lens.sum()) * 2 * 40
+    paths = np.zeros(cap, np.int32)
+    gaps = np.zeros(int(lens.sum()) + len(codes), np.int32)
+    sd = None if seq_distances is None else np.ascontiguousarray(seq_distances, np.float32)
+    cf = None if conf_in is None else np.ascontiguousarray(conf_in, np.float32)
+    rc = lib().ko_msa_tree_refine(len(codes), _ptr(flat), _ptr(off), _ptr(lens), _ptr(sd), nt, _ptr(tasks),
+                                  _ptr(np.ascontiguousarray(subm, np.float32).reshape(-1)),
+                                  _ptr(np.ascontiguousarray(scal, np.float32)), int(n_anchors), float(weight), int(mode), _ptr(cf),
+                                  recs, _ptr(paths), cap, _ptr(gaps))
+    if rc:
+        raise RuntimeError("ko_msa_tree_refine rc=%d" % rc)
+    g, o = [], 0
+    for n in lens:
+        g.append(gaps[o:o + int(n) + 1].copy())
+        o += int(n) + 1
+    return recs, paths, g
 
 
 def pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe):

@@ -49,6 +49,7 @@
 #include "aln_seqprofile.h"
 #include "aln_profileprofile.h"
 #include "aln_run.h"
+#include "aln_refine.h"
 #include "weave_alignment.h"
 #include "anchor_consistency.h"
 #include "bpm.h"
@@ -403,6 +404,24 @@ int refh_run_tree(void* hv, int* gaps_out, double* secs)
 #endif
         if(secs) *secs = t1 - t0;
         h->msa->aligned = ALN_STATUS_ALIGNED;
+        if(gaps_out) collect_gaps(h->msa, gaps_out);
+        return 0;
+}
+
+/* refine_alignment (aln_refine.c:36-88) after refh_run_tree: the second, multi-trial pass over every edge
+   (mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT).  conf_before / conf_after (n_tasks floats, may be NULL):
+   task.confidence before and after; plen_out (num_profiles ints, may be NULL): msa->plen afterwards. */
+int refh_refine(void* hv, int mode, int* gaps_out, float* conf_before, float* conf_after, int* plen_out)
+{
+        struct refh* h = (struct refh*)hv;
+        if(sort_tasks(h->tasks, TASK_ORDER_TREE) != OK) return 1;
+        if(conf_before) for(int i = 0; i < h->tasks->n_tasks; i++) conf_before[i] = h->tasks->list[i]->confidence;
+#ifdef HAVE_OPENMP
+        omp_set_num_threads(h->ap->nthreads < 1 ? 1 : h->ap->nthreads);
+#endif
+        if(refine_alignment(h->msa, h->ap, h->tasks, mode) != OK) return 1;
+        if(conf_after) for(int i = 0; i < h->tasks->n_tasks; i++) conf_after[i] = h->tasks->list[i]->confidence;
+        if(plen_out) for(int i = 0; i < h->msa->num_profiles; i++) plen_out[i] = h->msa->plen[i];
         if(gaps_out) collect_gaps(h->msa, gaps_out);
         return 0;
 }

@@ -77,6 +77,7 @@ def lib():
                                            C.c_float, C.c_float, C.c_float, C.c_int,
                                            C.c_float, C.c_float, C.c_float]
         L.refh_build_consistency.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.refh_refine.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.refh_get_consistency.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.refh_set_bonus_hash_out.argtypes = [C.c_void_p]
         L.refh_set_bonus_hash_out.restype = None
@@ -193,6 +194,17 @@ class RefJob:
                 o += int(self.lens[i])
             maps.append(row)
         return ids, maps
+
+    def refine(self, mode=1):
+        """refine_alignment (aln_refine.c:36-88) after run_tree(): mode 1 = KALIGN_REFINE_ALL, 2 = _CONFIDENT.
+        Returns (gaps per sorted sequence, task.confidence before, after, plen of every node)."""
+        g = self._gaps_buf()
+        cb = np.zeros(self.ntasks, np.float32)
+        ca = np.zeros(self.ntasks, np.float32)
+        plen = np.zeros(2 * self.n - 1, np.int32)
+        if lib().refh_refine(self.h, int(mode), _ptr(g), _ptr(cb), _ptr(ca), _ptr(plen)):
+            raise RuntimeError("refine_alignment failed")
+        return self.split_gaps(g), cb, ca, plen
 
     def run_tree_traced(self, dump_task=-1, bonus_hash=None):
         """bonus_hash: optional uint64[ntasks] array receiving the FNV hash of each task's bonus matrix."""

@@ -168,6 +168,52 @@ def guide_case(name, seqs, n_threads=1, tree_seed=0, tree_noise=0.0):
     print(name, "n=%d" % job.n, "tasks=%d" % job.ntasks)
 
 
+def refine_case(name, seqs, mode, n_anchors=0, weight=2.0, **kw):
+    """refine_alignment (aln_refine.c:36-346) after the first alignment: mode 1 = KALIGN_REFINE_ALL, 2 = _CONFIDENT.
+    Everything but `paths` / `path_off` comes from the real reference; the per-task coded paths (the reference frees them)
+    are the oracle's, stored only after its gap arrays, confidences and lengths have been found identical to the
+    reference's."""
+    job = refdrv.RefJob(seqs, **kw)
+    if n_anchors:
+        job.build_consistency(n_anchors, weight)
+    gaps1, _ = job.run_tree()
+    gaps, cb, ca, plen = job.refine(mode)
+    rows = job.finalise()
+    scal = np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32)
+    recs, paths, og = oracledrv.msa_tree_refine(job.codes, job.tasks, job.subm, scal, job.seq_distances, mode=mode, conf_in=cb,
+                                               n_anchors=n_anchors, weight=weight)
+    assert all(np.array_equal(a, b) for a, b in zip(gaps, og)), name
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), ca), name
+    assert all(recs[t].plen == plen[job.tasks[t][2]] for t in range(len(recs))), name
+    used = recs[-1].path_off + recs[-1].plen + 2
+    d = dict(
+        seqs=np.array(seqs), kw=np.array(repr(sorted(kw.items()))), mode=np.int32(mode),
+        lens=job.lens, ranks=job.ranks, codes=np.concatenate(job.codes), tree_codes=np.concatenate(job.tree_codes),
+        seq_distances=job.seq_distances if job.seq_distances is not None else np.zeros(0, np.float32),
+        tasks=job.tasks, subm=job.subm, scal=scal, biotype=np.int32(job.biotype),
+        n_anchors=np.int32(n_anchors), weight=np.float32(weight),
+        gaps_first=np.concatenate(gaps1), conf_before=cb, conf_after=ca, plen_after=plen,
+        gaps=np.concatenate(gaps), rows=np.array(rows),
+        paths=paths[:used], path_off=np.array([r.path_off for r in recs], np.int32),
+        n_differ=np.int32(sum(not np.array_equal(a, b) for a, b in zip(gaps1, gaps))),
+    )
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "n=%d" % job.n, "alnlen=%d" % len(rows[0]), "sequences whose gaps changed:", int(d["n_differ"]))
+
+
+def refine_cases():
+    data = os.path.join(HERE, "data")
+    refine_case("refine_prot32x200_all", synth.dssim(32, 200, seed=1), 1)
+    refine_case("refine_prot32x200_conf", synth.dssim(32, 200, seed=1), 2)
+    refine_case("refine_dna16x300_all", synth.dssim(16, 300, dna=True, seed=1), 1, type_=0)
+    refine_case("refine_cons_prot48_all", synth.dssim(48, 150, seed=5), 1, n_anchors=5)
+    refine_case("refine_cons_prot24_conf", synth.dssim(24, 120, seed=7), 2, n_anchors=3)
+    refine_case("refine_BB11001_all", synth.read_fasta(os.path.join(data, "BB11001.tfa"))[1], 1, n_anchors=5)
+    refine_case("refine_BB30014_conf", synth.read_fasta(os.path.join(data, "BB30014.tfa"))[1], 2)
+    refine_case("refine_prot24_scaled_all", synth.dssim(24, 150, seed=11), 1, dist_scale=0.5, use_seq_weights=1.0)
+    refine_case("refine_ragged_all", [s[:40 + 13 * i] for i, s in enumerate(synth.dssim(20, 400, seed=13))], 1)
+
+
 def realign_case(name, seqs, n_anchors=0, weight=2.0, **kw):
     """One iteration of kalign_run_realign (aln_wrap.c:361-527): first alignment on the BPM/k-means tree, identity
     distances from that alignment, UPGMA tree from them, second alignment on that tree."""
@@ -225,13 +271,17 @@ if __name__ == "__main__":
         guide_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "realign":
         realign_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "refine":
+        refine_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "bpm":
         bpm_case("bpm_mixed", 31)
         guide_cases()
         realign_cases()
+        refine_cases()
     else:
         main()
         cons_cases()
         bpm_case("bpm_mixed", 31)
         guide_cases()
         realign_cases()
+        refine_cases()

@@ -3,7 +3,7 @@ the REAL reference (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from util import Golden, compare_recs, cons_cases, pair_cases, tree_cases
+from util import Golden, compare_recs, cons_cases, pair_cases, refine_cases, tree_cases
 
 EXACT = ["a", "b", "c", "len_a", "len_b", "nsip_a", "nsip_b", "plen", "kind", "swapped",
          "meet", "transition", "gap_scale", "subm_off", "score", "prof_hash", "fhash", "bhash"]
@@ -149,3 +149,23 @@ def test_tree_live_against_the_reference(oracle):
         for a, b in zip(gaps, ogaps):
             assert np.array_equal(a, b)
         job.close()
+
+
+@pytest.mark.parametrize("name", refine_cases())
+def test_refinement_matches_reference(oracle, name):
+    """refine_alignment: second pass with convert_raw_path coding, five trials per refined edge
+    (round-robin flips of uncertain meetups in DFS order), SP scoring, best trial kept -- gap arrays, task confidences,
+    lengths and rows of the real reference (KALIGN_REFINE_ALL and _CONFIDENT, with and without consistency)"""
+    g = Golden(name)
+    recs, paths, gaps = oracle.msa_tree_refine(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, mode=int(g.mode),
+                                               conf_in=g.conf_before, n_anchors=int(g.n_anchors), weight=float(g.weight))
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+    assert all(recs[t].plen == g.plen_after[g.tasks[t][2]] for t in range(len(recs)))
+    assert int(g.n_differ) > 0                                   # the refinement really changed the alignment
+    rows_sorted = oracle.rows_from_gaps(g.sorted_seqs(), gaps)
+    rows = [None] * len(rows_sorted)
+    for i, r in enumerate(g.ranks):
+        rows[int(r)] = rows_sorted[i]
+    assert rows == [str(x) for x in g.rows]

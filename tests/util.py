@@ -19,6 +19,10 @@ def cons_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "cons_*.npz")))
 
 
+def refine_cases():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "refine_*.npz")))
+
+
 def pair_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "pairs_*.npz")))
 
