@@ -40,7 +40,7 @@ DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTE
 
 EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_consistency_part",
            "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
-           "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_sync", "ka_tree_paths_size",
+           "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_refine", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
@@ -84,6 +84,7 @@ def load_library():
                               C.POINTER(TaskRec), vp, C.c_longlong, vp]
     L.ka_tree_upload.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int]
     L.ka_tree_run.argtypes = [vp]
+    L.ka_tree_refine.argtypes = [vp, C.c_int, vp]
     L.ka_tree_sync.argtypes = [vp]
     L.ka_tree_paths_size.argtypes = [vp]
     L.ka_tree_paths_size.restype = C.c_longlong
@@ -184,6 +185,14 @@ class Context:
 
     def tree_run(self):
         self._chk(self.L.ka_tree_run(self.h))
+
+    def tree_refine(self, mode, conf_in=None):
+        """refine_alignment (aln_refine.c:34-85) over the uploaded tree: mode 1 = all edges, 2 = edges whose
+        first-pass confidence (conf_in) is at or below the median."""
+        cf = None if conf_in is None else np.ascontiguousarray(conf_in, np.float32)
+        if cf is not None and len(cf) != self._job["ntasks"]:
+            raise KalignAmdError("tree_refine: one confidence per task")
+        self._chk(self.L.ka_tree_refine(self.h, int(mode), None if cf is None else _ptr(cf)))
 
     def tree_sync(self):
         self._chk(self.L.ka_tree_sync(self.h))

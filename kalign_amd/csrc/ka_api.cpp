@@ -23,6 +23,7 @@ extern "C" void ka_unit0_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream);   // 8 waves + consistency
 extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, int nqueue, hipStream_t stream);   // half (4 waves, 2 per CU)
 extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // lean (seq-seq levels)
+extern "C" void ka_unit4_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // refinement pass (one workgroup per task)
 // kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
 static void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
 {
@@ -90,6 +91,8 @@ struct ka_ctx {
         std::vector<int> blocks_off;
         std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
         int max_cluster = 8;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
+        int refine_mode = 0;                         // the run in flight is a refinement pass (ka_tree_refine): 1 all, 2 confident
+        DevBuf<int2> d_refine_blocks;                   // its workgroup table: one workgroup per task, level after level
         int n_cus = 256;                             // compute units of the device (hipDeviceProp)
         bool shared_gpu = false;                     // ka_ctx_set_shared: no multi-workgroup tasks, no chained launch
         bool shared_by_fallback = false;             // shared_gpu was forced by a join watchdog (ka_tree_sync), not by the caller
@@ -167,7 +170,7 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
-extern "C" int ka_abi_version(void) { return 6; }
+extern "C" int ka_abi_version(void) { return 7; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
@@ -289,7 +292,7 @@ static int plan_launches(ka_ctx* c)
                                 len[cc] = 1.1 * std::max(len[a], len[b]);
                                 cells[cc] = cells[a] + cells[b] + len[a] * len[b];
                                 c->descs[t].wait_mult = 1 + (int)std::min(63.0, cells[cc] / 4e9);
-                                c->descs[t].pad = 0;
+                                c->descs[t].refine = 0;
                         }
                 }
                 c->n_trees = numseq - n_tasks;
@@ -648,6 +651,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.numseq = c->numseq; D.flags = c->flags; D.error = c->d_error.p;
         D.nres = c->nres;
         D.trace = c->h_trace;
+        D.refine_mode = 0;
         D.prof_task = -1;
         if (const char* e = getenv("KA_PROF_TASK")) D.prof_task = atoi(e);      // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
@@ -683,7 +687,8 @@ static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector
 static int tree_launch(ka_ctx* c)
 {
         if (tree_reset(c)) return KA_FAIL;
-        const KaTreeDev D = tree_dev(c);
+        KaTreeDev D = tree_dev(c);
+        D.refine_mode = c->refine_mode;
         c->partial = false;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
@@ -691,6 +696,14 @@ static int tree_launch(ka_ctx* c)
                 const int n = (int)c->levels[L].size();
                 if (!n) continue;
                 if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                if (c->refine_mode) {
+                        // refinement pass: the trials of one edge are serial by construction (refine_edge), one workgroup each
+                        size_t o = 0;
+                        for (size_t l = 0; l < L; l++) o += c->levels[l].size();
+                        ka_unit4_launch(&D, c->d_refine_blocks.p + o, n, D.cons_K > 0, c->stream);
+                        c->n_launches++;
+                        continue;
+                }
                 if ((int)L == c->queue_first) {
                         // levels queue_first .. chain_level-1: one launch, two workgroups per CU pulling from the ordered list
                         const int nwg = std::min(c->queue_n, 2 * c->n_cus);
@@ -719,9 +732,68 @@ extern "C" int ka_tree_run(ka_ctx* c)
         if (!c || !c->have_job) return fail("no uploaded job");
         HIPCHK(hipSetDevice(c->device));
         c->ran = false; c->synced = false;
+        if (c->refine_mode) {                            // the plan on the device carries the refine marks of the last ka_tree_refine
+                c->refine_mode = 0;
+                for (auto& d : c->descs) d.refine = 0;
+                if (upload_plan(c)) return KA_FAIL;
+        }
         if (tree_launch(c)) return KA_FAIL;
         c->ran = true;
         return KA_OK;
+}
+
+// refine_alignment (aln_refine.c:199-325): a second pass over every edge of the tree with the flip trials of
+// refine_edge; mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT (edges whose first-pass confidence is at or
+// below the median), 3 = the first pass again with the depth-first engine (task confidences are then the reference's
+// exact float sums).  conf_in: the first-pass confidence of every task (the reference reads task->confidence); only
+// read for mode 2, NULL = computed here by a mode-3 pass.  The job keeps its tree, parameters and consistency table.
+static int refine_launch(ka_ctx* c, int mode)
+{
+        c->refine_mode = mode;
+        if (upload_plan(c)) return KA_FAIL;
+        c->ran = false; c->synced = false;
+        if (tree_launch(c)) return KA_FAIL;
+        c->ran = true;
+        return KA_OK;
+}
+
+extern "C" int ka_tree_refine(ka_ctx* c, int mode, const float* conf_in)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (mode < 1 || mode > 3) return fail("ka_tree_refine: mode must be 1 (all), 2 (confident) or 3 (first pass, exact confidences)");
+        if (c->n_tasks < 1) return fail("ka_tree_refine: no tasks");
+        HIPCHK(hipSetDevice(c->device));
+        if (c->ran && !c->synced && ka_tree_sync(c)) return KA_FAIL;
+        if (!c->have_colof) {                            // the sum-of-pairs score reads every member's column
+                if (setup_colof(c)) return KA_FAIL;
+        }
+        c->flags |= KA_FLAG_DEVICE_GAPS;
+        std::vector<int2> tbl;
+        for (auto& L : c->levels) for (int t : L) tbl.push_back(make_int2(t, 1 << 8));
+        if (c->d_refine_blocks.alloc(tbl.size())) return fail("hipMalloc failed");
+        HIPCHK(hipMemcpy(c->d_refine_blocks.p, tbl.data(), sizeof(int2) * tbl.size(), hipMemcpyHostToDevice));
+        std::vector<float> conf;
+        if (mode == 2 && !conf_in) {
+                // task->confidence of the first pass is a float sum in depth-first order (aln_controller.c:194-436): the
+                // level-synchronous first pass adds the same margins in another order, so its value can differ in the last
+                // bits -- and the median rule below compares them.  Run the first pass again depth first and read its sums.
+                for (auto& d : c->descs) d.refine = 0;
+                if (refine_launch(c, 3) || ka_tree_sync(c)) return KA_FAIL;
+                std::vector<ka_task_rec> r(c->n_tasks);
+                HIPCHK(hipMemcpy(r.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
+                conf.resize(c->n_tasks);
+                for (int t = 0; t < c->n_tasks; t++) conf[t] = r[t].confidence;
+                conf_in = conf.data();
+        }
+        float thr = 0.0f;
+        if (mode == 2) {                                 // compute_confidence_threshold (aln_refine.c:674-712): the median
+                std::vector<float> v(conf_in, conf_in + c->n_tasks);
+                std::sort(v.begin(), v.end());
+                const int n = c->n_tasks;
+                thr = (n % 2 == 0) ? (v[n / 2 - 1] + v[n / 2]) / 2.0F : v[n / 2];
+        }
+        for (int t = 0; t < c->n_tasks; t++) c->descs[t].refine = mode == 1 ? 1 : (mode == 2 && conf_in[t] <= thr ? 1 : 0);
+        return refine_launch(c, mode);
 }
 
 extern "C" int ka_tree_sync(ka_ctx* c)

@@ -24,7 +24,7 @@ struct KaTaskDesc {
         int chain_need;                // chained launch: how many children of this task run inside the same launch (0: entry task)
         int qa, qb;                    // queued launch: the tasks of the same launch that produce operands a / b (-1: ready before it starts)
         int wait_mult;                 // chained launch: multiplier of the join watchdog (~2 s each), from the estimated DP cells below this task
-        int pad;
+        int refine;                    // refinement pass, KALIGN_REFINE_CONFIDENT: this edge is refined (confidence at or below the median)
 };
 
 // Join point of a task in a chained launch (see ka_task_entry): the clusters that computed its children meet here.
@@ -70,6 +70,7 @@ struct KaTreeDev {
         int flags;
         int nres;                      // alphabet size: 23 protein, 5 nucleotide (alphabet.c)
         long long* timing;             // [n_tasks][8] phase cycle counts (KA_FLAG_TIMING) or null
+        int refine_mode;               // refinement pass (ka_tree_refine): 0 none, 1 KALIGN_REFINE_ALL, 2 KALIGN_REFINE_CONFIDENT
         int prof_task;                 // KA_FLAG_TIMING: the task whose per-level times are kept (-1: the root; KA_PROF_TASK in the environment)
         int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table

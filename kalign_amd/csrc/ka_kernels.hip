@@ -120,6 +120,13 @@ struct TaskShared {
         // G sub-problems (or single-strip passes) the cluster SPLITS: every workgroup takes its share of the
         // sub-problems -- independent subtrees of the recursion -- into private queues / row buffers and finishes them
         // on its own (Gw = 1: workgroup barriers and workgroup-scope hand-over only); one cluster barrier at the end.
+        // refinement trial state (ka_meetup<.., FLIP>; aln_struct.h:32-35): threshold, trial / stride / running counter of the
+        // round-robin flips, fp32 margin sum and count in DFS order
+        struct Refine { float thr; int trial, stride, counter; float msum; int mcount; } rf;
+        int dfs_top, dfs_valid;        // ka_hirschberg_dfs: sub-problems on the stack / a sub-problem was popped
+        int* best_coded; int* best_srcA; int* best_srcB;   // refinement: the best trial's coded path and column sources
+        int* sp_freq;                  // refinement: residue counts [23] + residues per column [1] of both operands (compute_sp_score)
+        float sp_value;
         int Gw, member_w;              // cluster size / member index the recursion currently works with
         int split;
         struct Priv { KaSub* q[2]; int2* items[2]; int* prog[2]; int2* pack[2][2]; KaState* f; KaState* b; } priv;
@@ -162,21 +169,28 @@ __device__ __forceinline__ void col_terms(const TaskShared& S, int rec, float& c
 // Meetup of one sub-problem by one wave (aln_seqseq.c:241-420 and the two profile variants),
 // then aln_continue: path writes and the two child sub-problems (aln_controller.c:194-436).
 // ------------------------------------------------------------------------------------------
-struct Best { float mx; float mx2; int key; };
+struct Best { float mx; float mx2; int key; int key2; };          // key2 (who the runner-up is) only matters to refinement trials
 
 __device__ __forceinline__ void best_consider(Best& b, float s, int key)
 {
-        if (s > b.mx) { b.mx2 = b.mx; b.mx = s; b.key = key; }
-        else if (s > b.mx2) { b.mx2 = s; }
+        if (s > b.mx) { b.mx2 = b.mx; b.key2 = b.key; b.mx = s; b.key = key; }
+        else if (s > b.mx2) { b.mx2 = s; b.key2 = key; }
 }
 
-__device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int okey)
+// (value, key) pairs in the order the reference's sequential scan ranks them: higher value first, among equal values the
+// earlier candidate (a later candidate only displaces on a strictly greater value, aln_seqseq.c:284-291)
+__device__ __forceinline__ bool best_before(float v1, int k1, float v2, int k2) { return v1 > v2 || (v1 == v2 && k1 < k2); }
+
+__device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int okey, int okey2 = 0x7fffffff)
 {
-        if (omx > x.mx || (omx == x.mx && okey < x.key)) {
-                const float second = (omx > x.mx) ? fmaxf(x.mx, omx2) : x.mx;
-                x.mx2 = second; x.mx = omx; x.key = okey;
+        if (best_before(omx, okey, x.mx, x.key)) {
+                // the other side's best wins: the runner-up is the better of our best and its runner-up
+                const bool mine = best_before(x.mx, x.key, omx2, okey2);
+                x.mx2 = mine ? x.mx : omx2; x.key2 = mine ? x.key : okey2;
+                x.mx = omx; x.key = okey;
         } else {
-                x.mx2 = (x.mx > omx) ? fmaxf(omx, x.mx2) : omx;        // equal maxima: the duplicate is the runner-up
+                const bool theirs = best_before(omx, okey, x.mx2, x.key2);
+                x.mx2 = theirs ? omx : x.mx2; x.key2 = theirs ? okey : x.key2;
         }
 }
 
@@ -228,7 +242,9 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
 
 // GL lanes per sub-problem (64 / GL sub-problems per wave): deep recursion levels have hundreds of
 // sub-problems with a handful of columns each.
-template <int KIND, int GL>
+// FLIP: a refinement trial (one sub-problem per call, in DFS order): the margins are summed in fp32 in that order and an
+// uncertain meetup may take its runner-up (aln_seqseq.c:376-414, round-robin mode); state in S.rf.
+template <int KIND, int GL, bool FLIP = false>
 __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const int k0, const int ncur, KaSub* qnext,
                                           const KaLevelOut& lout, const int wlane, const bool top_level)
 {
@@ -254,7 +270,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 g6n = (startb == 0) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
                 g6f = (endb == S.Lb) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
         }
-        Best B = { -KA_F, -KA_F, 0x7fffffff };
+        Best B = { -KA_F, -KA_F, 0x7fffffff, 0x7fffffff };
         for (int i = startb + lane; valid && i <= endb; i += GL) {
                 const KaState fi = f[i - startb], bi = b[i - startb];
                 float sub = fabsf(middle - (float)i);
@@ -281,7 +297,8 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 const float omx = __shfl_xor(B.mx, off, 64);
                 const float omx2 = __shfl_xor(B.mx2, off, 64);
                 const int okey = __shfl_xor(B.key, off, 64);
-                best_merge(B, omx, omx2, okey);
+                const int okey2 = FLIP ? __shfl_xor(B.key2, off, 64) : 0x7fffffff;
+                best_merge(B, omx, omx2, okey, okey2);
         }
         // ---- aln_continue for the group's sub-problem (its lane 0 = "leader"), wave-cooperatively: the level's
         // counters live in HBM when a cluster shares the task, and per-sub-problem atomics on five addresses
@@ -295,6 +312,22 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 tr = ord + 1 + (ord >= 3 ? 1 : 0);
         }
         if (leader && is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
+        if (FLIP && leader) {
+                // the reference's meetups run one after the other in DFS order: fp32 margin sum in that order, and the
+                // running number of uncertain meetups decides which of them a trial flips (round-robin)
+                if (B.mx2 > -KA_F) { S.rf.msum += B.mx - B.mx2; S.rf.mcount += 1; }
+                if (S.rf.thr > 0.0f && B.key2 != 0x7fffffff && B.mx2 > -KA_F) {
+                        const float margin = B.mx - B.mx2;
+                        if (margin < S.rf.thr) {
+                                if (S.rf.trial > 0 && S.rf.counter % S.rf.stride == S.rf.trial - 1) {
+                                        const int ord2 = B.key2 & 7;
+                                        meet = startb + (B.key2 >> 3);
+                                        tr = ord2 + 1 + (ord2 >= 3 ? 1 : 0);
+                                }
+                                S.rf.counter += 1;
+                        }
+                }
+        }
 
         const KaState Z = { 0.0f, -KA_F, -KA_F };
         const KaState GA = { -KA_F, 0.0f, -KA_F };
@@ -440,6 +473,101 @@ __device__ void ka_cluster_sync(TaskShared& S)
 // debug breadcrumbs into a host-pinned buffer (KA_TRACE=1): survives a hung kernel
 #define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
 
+// The passes of one recursion level: its work items (strips, packed jobs) dealt to / pulled by the waves of the team.
+template <int KIND, int NRES, int NB>
+__device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cur, const int level, const KaSub* qc, char* lds_waves,
+                                             const float* tss, long long* pslot)
+{
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        {
+                        const int2* items = S.items[level & 1];
+                        int* prog = S.prog[level & 1];
+                        const int nitems = cur->nitems;
+                        const int n16 = cur->npack[0], n4 = cur->npack[1];
+                        const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
+                        const int2* pack16 = S.pack[level & 1][0];
+                        const int2* pack4 = S.pack[level & 1][1];
+                        // A wave64 VALU instruction occupies its SIMD for 4 cycles and both strips and packed jobs are
+                        // almost pure VALU: two of them on one SIMD run at half speed each.  The first 8*G work items
+                        // are therefore dealt out statically, spread first over the workgroups of the cluster and
+                        // over waves 0..3 of each (one per SIMD), then over waves 4..7; whatever is left is pulled
+                        // dynamically.  (Item i only ever waits for items < i, and every wave takes its items in
+                        // increasing order, so the dealing cannot deadlock the strip pipelines.)
+                        const int ntotal = nitems + njobs16 + njobs4;
+                        const int Gw = __builtin_amdgcn_readfirstlane(S.Gw), member_w = __builtin_amdgcn_readfirstlane(S.member_w);
+                        const int nslots = __builtin_amdgcn_readfirstlane(KA_NW * Gw);
+                        // a level that keeps only waves 0 .. NW/2-1 (or NW/4-1) of every workgroup busy: its packed jobs may
+                        // stage their columns in the idle waves' LDS regions too (ka_packed)
+                        int nreg = 1;
+                        if (ntotal <= nslots) {
+                                const int per_wg = (ntotal + Gw - 1) / Gw;
+                                if (per_wg <= KA_NW / 4) nreg = 4; else if (per_wg <= KA_NW / 2) nreg = 2;
+                        }
+                        nreg = __builtin_amdgcn_readfirstlane(nreg);
+                        const int reg_stride = (KA_NW / nreg) * KA_WAVE_LDS;
+                        // static dealing in contiguous blocks: workgroup m of the cluster takes items m*per .. m*per+per-1, one per
+                        // wave -- the strips of one pass are consecutive items, so a strip and the strip it hands its last row to
+                        // mostly sit in the same workgroup (workgroup-scope hand-over; the agent-scope one costs an L2
+                        // write-back per 64 columns, and that gets slower the more the other CUs of the XCD have written)
+                        const int nstatic = min(ntotal, nslots);
+                        const int per = max((nstatic + Gw - 1) / Gw, 1);
+                        int it = __builtin_amdgcn_readfirstlane((wave < per && member_w * per + wave < nstatic) ? member_w * per + wave : ntotal);
+                        bool dealt = true;
+                        while (true) {
+                                // One lane takes the next item, then it is broadcast.  The puller lane is
+                                // compared through an opaque copy: with a plain `lane == 0` the optimiser
+                                // threads this test with the `lane == 0` regions inside ka_strip, splits the
+                                // loop per lane set and runs readfirstlane without lane 0 (observed: lanes
+                                // 1..63 spinning on item 0 forever).
+                                if (!dealt) {
+                                        if (ntotal <= nslots) break;
+                                        int puller = lane;
+                                        asm volatile("" : "+v"(puller));
+                                        int x = 0;
+                                        if (puller == 0) x = atomicAdd(&cur->next_item, 1);
+                                        it = nslots + __builtin_amdgcn_readfirstlane(x);
+                                }
+                                dealt = false;
+                                if (it >= ntotal) break;
+        #ifdef KA_PROF
+                                if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
+        #endif
+                                if (it >= nitems + njobs16) {
+                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
+                                        continue;
+                                }
+                                if (it >= nitems) {
+                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
+                                        continue;
+                                }
+                                // everything about the item is wave-uniform: keep it in SGPRs
+                                const int2 item = items[it];
+                                const int subi = __builtin_amdgcn_readfirstlane(item.x);
+                                const int dk = __builtin_amdgcn_readfirstlane(item.y);
+                                const KaSub* sp = qc + subi;
+                                const int dir = dk >> 16, k = dk & 0xffff;
+                                const int sa = __builtin_amdgcn_readfirstlane(sp->starta);
+                                const int ea = __builtin_amdgcn_readfirstlane(sp->enda);
+                                const int sbb = __builtin_amdgcn_readfirstlane(sp->startb);
+                                const int eb = __builtin_amdgcn_readfirstlane(sp->endb);
+                                const int roff = __builtin_amdgcn_readfirstlane(sp->roff);
+                                const float ja = ka_uniform_f(dir == KA_FWD ? sp->fin.a : sp->bin.a);
+                                const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
+                                const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
+                                const int mid_ = ((ea - sa) / 2) + sa;
+                                const int ns = ka_strips_of(dir == KA_FWD ? mid_ - sa : ea - mid_);
+                                const bool st_me = it < nstatic;
+                                const bool prod_local = k > 0 && st_me && (it - 1) / per == member_w;
+                                const bool cons_local = k + 1 < ns && st_me && it + 1 < nstatic && (it + 1) / per == member_w;
+                                ka_strip<KIND, NRES, NB>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                                     (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
+                                                     lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
+                        }
+        }
+}
+
 template <int KIND, int NRES, int NB>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
@@ -527,91 +655,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
 #ifdef KA_PROF
                 if (S.prof && lead && level < 8) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; } }
 #endif
-                {
-                        const int2* items = S.items[level & 1];
-                        int* prog = S.prog[level & 1];
-                        const int nitems = cur->nitems;
-                        const int n16 = cur->npack[0], n4 = cur->npack[1];
-                        const int njobs16 = (n16 + 3) / 4, njobs4 = (n4 + 15) / 16;
-                        const int2* pack16 = S.pack[level & 1][0];
-                        const int2* pack4 = S.pack[level & 1][1];
-                        // A wave64 VALU instruction occupies its SIMD for 4 cycles and both strips and packed jobs are
-                        // almost pure VALU: two of them on one SIMD run at half speed each.  The first 8*G work items
-                        // are therefore dealt out statically, spread first over the workgroups of the cluster and
-                        // over waves 0..3 of each (one per SIMD), then over waves 4..7; whatever is left is pulled
-                        // dynamically.  (Item i only ever waits for items < i, and every wave takes its items in
-                        // increasing order, so the dealing cannot deadlock the strip pipelines.)
-                        const int ntotal = nitems + njobs16 + njobs4;
-                        const int Gw = __builtin_amdgcn_readfirstlane(S.Gw), member_w = __builtin_amdgcn_readfirstlane(S.member_w);
-                        const int nslots = __builtin_amdgcn_readfirstlane(KA_NW * Gw);
-                        // a level that keeps only waves 0 .. NW/2-1 (or NW/4-1) of every workgroup busy: its packed jobs may
-                        // stage their columns in the idle waves' LDS regions too (ka_packed)
-                        int nreg = 1;
-                        if (ntotal <= nslots) {
-                                const int per_wg = (ntotal + Gw - 1) / Gw;
-                                if (per_wg <= KA_NW / 4) nreg = 4; else if (per_wg <= KA_NW / 2) nreg = 2;
-                        }
-                        nreg = __builtin_amdgcn_readfirstlane(nreg);
-                        const int reg_stride = (KA_NW / nreg) * KA_WAVE_LDS;
-                        // static dealing in contiguous blocks: workgroup m of the cluster takes items m*per .. m*per+per-1, one per
-                        // wave -- the strips of one pass are consecutive items, so a strip and the strip it hands its last row to
-                        // mostly sit in the same workgroup (workgroup-scope hand-over; the agent-scope one costs an L2
-                        // write-back per 64 columns, and that gets slower the more the other CUs of the XCD have written)
-                        const int nstatic = min(ntotal, nslots);
-                        const int per = max((nstatic + Gw - 1) / Gw, 1);
-                        int it = __builtin_amdgcn_readfirstlane((wave < per && member_w * per + wave < nstatic) ? member_w * per + wave : ntotal);
-                        bool dealt = true;
-                        while (true) {
-                                // One lane takes the next item, then it is broadcast.  The puller lane is
-                                // compared through an opaque copy: with a plain `lane == 0` the optimiser
-                                // threads this test with the `lane == 0` regions inside ka_strip, splits the
-                                // loop per lane set and runs readfirstlane without lane 0 (observed: lanes
-                                // 1..63 spinning on item 0 forever).
-                                if (!dealt) {
-                                        if (ntotal <= nslots) break;
-                                        int puller = lane;
-                                        asm volatile("" : "+v"(puller));
-                                        int x = 0;
-                                        if (puller == 0) x = atomicAdd(&cur->next_item, 1);
-                                        it = nslots + __builtin_amdgcn_readfirstlane(x);
-                                }
-                                dealt = false;
-                                if (it >= ntotal) break;
-#ifdef KA_PROF
-                                if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
-#endif
-                                if (it >= nitems + njobs16) {
-                                        ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
-                                        continue;
-                                }
-                                if (it >= nitems) {
-                                        ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
-                                        continue;
-                                }
-                                // everything about the item is wave-uniform: keep it in SGPRs
-                                const int2 item = items[it];
-                                const int subi = __builtin_amdgcn_readfirstlane(item.x);
-                                const int dk = __builtin_amdgcn_readfirstlane(item.y);
-                                const KaSub* sp = qc + subi;
-                                const int dir = dk >> 16, k = dk & 0xffff;
-                                const int sa = __builtin_amdgcn_readfirstlane(sp->starta);
-                                const int ea = __builtin_amdgcn_readfirstlane(sp->enda);
-                                const int sbb = __builtin_amdgcn_readfirstlane(sp->startb);
-                                const int eb = __builtin_amdgcn_readfirstlane(sp->endb);
-                                const int roff = __builtin_amdgcn_readfirstlane(sp->roff);
-                                const float ja = ka_uniform_f(dir == KA_FWD ? sp->fin.a : sp->bin.a);
-                                const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
-                                const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
-                                const int mid_ = ((ea - sa) / 2) + sa;
-                                const int ns = ka_strips_of(dir == KA_FWD ? mid_ - sa : ea - mid_);
-                                const bool st_me = it < nstatic;
-                                const bool prod_local = k > 0 && st_me && (it - 1) / per == member_w;
-                                const bool cons_local = k + 1 < ns && st_me && it + 1 < nstatic && (it + 1) / per == member_w;
-                                ka_strip<KIND, NRES, NB>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
-                                                     (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
-                                                     lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
-                        }
-                }
+                ka_run_items<KIND, NRES, NB>(S, cur, level, qc, lds_waves, tss, pslot);
 #ifdef KA_PROF
                 if (pslot && lane == 0) pslot[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -659,6 +703,74 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         S.split = 0; S.lctl = S.ctl;
                 }
                 ka_cluster_sync(S);
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// Depth-first Hirschberg recursion for refinement trials (aln_refine.c:93-346).  A trial flips the n-th uncertain
+// meetup in DFS order, and a flip changes the sub-problems below it: the number of uncertain meetups in the whole left
+// subtree decides what happens in the right one, so the sub-problems of a trial are inherently sequential (as in the
+// reference, aln_controller.c: child 1 completely before child 2).  One sub-problem per iteration: its two passes run
+// as the usual work items (strips pipelined over the waves, packed jobs), then its meetup (wave 0, with the flip rule
+// and the fp32 margin sum of S.rf), then its children go on the stack, right one first.  The stack is S.q[0]; the
+// sub-problem in flight is S.q[1][0], its children arrive in S.q[1][8..9]; row buffers are reused from offset 0.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int NRES, int NB>
+__device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves, const float* tss, const bool first_trial)
+{
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const int g = max(S.La, S.Lb) + 2;
+        for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;               // init_alnmem / the re-initialisation of refine_edge (:206-215)
+        if (tid == 0) {
+                KaSub root;
+                const KaState Z = { 0.0f, -KA_F, -KA_F };
+                root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
+                root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
+                S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
+                S.dfs_top = 0;
+                if (S.La > 0 && S.Lb > 0) { S.q[0][0] = root; S.dfs_top = 1; }
+                S.rf.msum = 0.0f; S.rf.mcount = 0; S.rf.counter = 0;
+                S.ctl->msum = 0.0; S.ctl->mcount = 0;
+                if (first_trial) { S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f; }
+        }
+        __syncthreads();
+        bool at_root = true;
+        while (true) {
+                if (tid == 0) {
+                        S.dfs_valid = 0;
+                        if (S.dfs_top > 0) {
+                                KaSub cur = S.q[0][--S.dfs_top];
+                                cur.roff = 0;
+                                S.q[1][0] = cur;
+                                for (int par = 0; par < 2; ++par) {
+                                        KaCtl::Lvl& L = S.ctl->lvl[par];
+                                        L.nsub = 0; L.rowalloc = 0; L.nitems = 0; L.next_item = 0; L.next_job = 0; L.npack[0] = 0; L.npack[1] = 0;
+                                }
+                                S.ctl->lvl[0].nsub = 1;
+                                S.ctl->lvl[0].rowalloc = cur.endb - cur.startb + 1;
+                                ka_emit_items(ka_level_out(S, 0, false), 0, cur.starta, cur.enda, cur.endb - cur.startb);
+                                S.dfs_valid = 1;
+                        }
+                }
+                __syncthreads();
+                if (!S.dfs_valid) break;
+                const KaSub* qc = S.q[1];
+                ka_run_items<KIND, NRES, NB>(S, &S.ctl->lvl[0], 0, qc, lds_waves, tss, nullptr);
+                __syncthreads();
+                if (wave == 0) {
+                        const KaLevelOut lout = ka_level_out(S, 1, true);
+                        ka_meetup<KIND, 64, true>(S, qc, 0, 1, S.q[1] + 8, lout, lane, first_trial && at_root);
+                }
+                at_root = false;
+                __syncthreads();
+                if (tid == 0) {
+                        // children: the left one is processed first, so it goes on the stack last
+                        const int nchild = S.ctl->lvl[1].nsub;
+                        for (int k = nchild - 1; k >= 0; --k) S.q[0][S.dfs_top++] = S.q[1][8 + k];
+                }
+                __syncthreads();
         }
 }
 
@@ -743,6 +855,195 @@ __device__ void ka_code_path(TaskShared& S, int* lds)
         // match column; the 4/8/16 flag loop never executes in the reference
         const int z1 = *zmin, z2 = *zmax;
         for (int c = 1 + tid; c <= alnlen; c += KA_NT) if (c < z1 || c > z2) o[c] |= 32;
+        __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Path coding of the refinement pass: convert_raw_path (aln_refine.c:591-672) by the whole workgroup.  Differences to
+// add_gap_info_to_path_n (ka_code_path): the gap-in-a run in front of a match is counted from the last MATCHED column
+// (a prefix maximum over the rows), and the open / extend / close flags are real: 4 = first op of a gap run that
+// follows a match, 8 = continuation of a run of the same kind, 16 = last op before a match (an op carrying 8 gets +8,
+// which is 16 as well), 32 = runs before the first / after the last match.  Every flag depends on the op kinds of the
+// two neighbours only.  `lds` = 3*blockDim.x+4 ints of scratch.
+// ------------------------------------------------------------------------------------------
+__device__ void ka_code_path_refine(TaskShared& S, int* lds)
+{
+        const int tid = threadIdx.x;
+        const int len_a = S.len_a, len_b = S.len_b;
+        const int* raw = S.raw;
+        if (S.swapped) {
+                int* r2 = S.raw2;
+                for (int i = tid; i < len_a + 2; i += KA_NT) r2[i] = -1;
+                __syncthreads();
+                for (int i = 1 + tid; i <= len_b; i += KA_NT) { const int c = S.raw[i]; if (c != -1) r2[c] = i; }
+                __syncthreads();
+                raw = r2;
+        }
+        int* o = S.coded;
+        int* tot_ops = lds;
+        int* tot_b = lds + KA_NT;
+        int* tot_m = lds + 2 * KA_NT;
+        int* zmin = lds + 3 * KA_NT;
+        int* zmax = zmin + 1;
+        const int per = (len_a + KA_NT - 1) / KA_NT;
+        const int lo = 1 + tid * per, hi = min(len_a + 1, lo + per);
+        // last matched column before this thread's rows: exclusive prefix maximum over the threads
+        int mymax = 0;
+        for (int i = lo; i < hi; ++i) mymax = max(mymax, raw[i]);
+        const int lane_ = tid & 63, wave_ = tid >> 6;
+        int sc_m = mymax;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sc_m, d, 64); if (lane_ >= d) sc_m = max(sc_m, y); }
+        if (lane_ == 63) tot_m[wave_] = sc_m;
+        if (tid == 0) { *zmin = 0x7fffffff; *zmax = 0; }
+        __syncthreads();
+        int blast = __shfl_up(sc_m, 1, 64);
+        if (lane_ == 0) blast = 0;
+        for (int k = 0; k < wave_; ++k) blast = max(blast, tot_m[k]);
+        blast = max(blast, 0);
+        // ops and b positions of this thread's rows
+        int nops = 0, nb = 0;
+        {
+                int bl = blast;
+                for (int i = lo; i < hi; ++i) {
+                        const int cur = raw[i];
+                        if (cur == -1) { nops += 1; }
+                        else { const int gpre = max(cur - bl - 1, 0); nops += gpre + 1; nb += gpre + 1; bl = cur; }
+                }
+        }
+        int sc_ops = nops, sc_b = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+                const int y1 = __shfl_up(sc_ops, d, 64), y2 = __shfl_up(sc_b, d, 64);
+                if (lane_ >= d) { sc_ops += y1; sc_b += y2; }
+        }
+        if (lane_ == 63) { tot_ops[wave_] = sc_ops; tot_b[wave_] = sc_b; }
+        __syncthreads();
+        int off = sc_ops - nops, offb = sc_b - nb, all_ops = 0, total_b = 0, all_max = 0;
+        for (int k = 0; k < KA_NW; ++k) {
+                const int a = tot_ops[k], b2 = tot_b[k];
+                if (k < wave_) { off += a; offb += b2; }
+                all_ops += a; total_b += b2; all_max = max(all_max, tot_m[k]);
+        }
+        all_max = max(all_max, 0);
+        const int tail = len_b - all_max;                                 // trailing gap-in-a run (:630-634)
+        const int alnlen = all_ops + tail;
+        int my_zmin = 0x7fffffff, my_zmax = 0;
+        {
+                int j = 1 + off, rb = 1 + offb, bl = blast;
+                for (int i = lo; i < hi; ++i) {
+                        const int cur = raw[i];
+                        if (cur == -1) { o[j] = 2; S.srcA[j] = i; S.srcB[j] = -1; ++j; }
+                        else {
+                                const int gpre = max(cur - bl - 1, 0);
+                                for (int k = 0; k < gpre; ++k) { o[j] = 1; S.srcA[j] = -1; S.srcB[j] = rb++; ++j; }
+                                o[j] = 0; S.srcA[j] = i; S.srcB[j] = rb++;
+                                my_zmin = min(my_zmin, j); my_zmax = max(my_zmax, j);
+                                ++j; bl = cur;
+                        }
+                }
+        }
+        if (my_zmax > 0) { atomicMin(zmin, my_zmin); atomicMax(zmax, my_zmax); }
+        for (int k = tid; k < tail; k += KA_NT) { o[1 + all_ops + k] = 1; S.srcA[1 + all_ops + k] = -1; S.srcB[1 + all_ops + k] = 1 + total_b + k; }
+        if (tid == 0) { o[0] = alnlen; o[alnlen + 1] = 3; S.ctl->alnlen = alnlen; }
+        __syncthreads();
+        const int z1 = *zmin, z2 = *zmax;
+        // flags: the op kinds are final; every position reads its neighbours' kinds (low two bits) and writes itself
+        for (int c = 1 + tid; c <= alnlen; c += KA_NT) {
+                const int t = o[c] & 3;
+                int v = t;
+                if (t != 0) {
+                        if (c >= 2) {
+                                const int tp = o[c - 1] & 3;
+                                if (tp == 0) v |= 4; else if (tp == t) v |= 8;
+                        }
+                        if (c <= alnlen - 1 && (o[c + 1] & 3) == 0) { if (v & 8) v += 8; else v |= 16; }
+                }
+                if (c < z1 || c > z2) v |= 32;
+                S.raw2[c] = v;                                            // (raw2 is free once the path is mirrored / coded)
+        }
+        __syncthreads();
+        for (int c = 1 + tid; c <= alnlen; c += KA_NT) o[c] = S.raw2[c];
+        __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// compute_sp_score (sp_score.c:22-201): residue counts per column of both groups from the members' residue -> column
+// tables (build_profile expands every member through its gaps[]; D.colof is the same information), then ONE sequential
+// fp32 walk along the coded path -- substitution terms in (i, j) order, then the gap term, exactly as the reference
+// accumulates them (the total decides which trial wins; it is not reassociated).
+// S.sp_freq: [col][24] for operand a (23 counts + residues in the column), then the same for b.
+// ------------------------------------------------------------------------------------------
+__device__ void ka_sp_build(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+{
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const long long total = 24ll * (S.len_a + S.len_b);
+        for (long long x = tid; x < total; x += KA_NT) S.sp_freq[x] = 0;
+        __syncthreads();
+        const int na = T.nsip_a, nb = T.nsip_b;
+        const int* ma = D.sip + D.sip_off[T.a];
+        const int* mb = D.sip + D.sip_off[T.b];
+        for (int m = wave; m < na + nb; m += KA_NW) {
+                const bool in_a = m < na;
+                const int si = in_a ? ma[m] : mb[m - na];
+                int* fr = S.sp_freq + (in_a ? 0 : 24 * S.len_a);
+                const int* col = D.colof + D.seq_off[si];
+                const uint8_t* res = D.codes + D.seq_off[si];
+                const int len = D.node_len[si];
+                for (int p = lane; p < len; p += 64) {
+                        const int c = col[p], r = res[p];
+                        if (r < 23) { atomicAdd(&fr[24 * c + r], 1); atomicAdd(&fr[24 * c + 23], 1); }
+                }
+        }
+        __syncthreads();
+}
+
+__device__ void ka_sp_score(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+{
+        if (threadIdx.x == 0) {
+                const int* path = S.coded;
+                const int* fa0 = S.sp_freq;
+                const int* fb0 = S.sp_freq + 24 * S.len_a;
+                const int nsa = T.nsip_a, nsb = T.nsip_b;
+                const float gpo = T.gpo, gpe = T.gpe, tgpe = T.tgpe;
+                const float* subm = D.subm;
+                float total = 0.0f;
+                int pos_a = 0, pos_b = 0;
+                bool in_a = false, in_b = false;
+                const int plen = path[0];
+                for (int c = 1; c <= plen; ++c) {
+                        const int step = path[c] & 3;
+                        const float pen = (path[c] & 32) ? tgpe : gpe;
+                        if (step == 0) {
+                                const int* fa = fa0 + 24 * pos_a;
+                                const int* fb = fb0 + 24 * pos_b;
+                                for (int i = 0; i < 23; ++i) {
+                                        const int ai = fa[i];
+                                        if (ai == 0) continue;
+                                        for (int j = 0; j < 23; ++j) {
+                                                const int bj = fb[j];
+                                                if (bj == 0) continue;
+                                                total += (float)(ai * bj) * subm[i * 23 + j];
+                                        }
+                                }
+                                const int n_res_a = fa[23], n_res_b = fb[23];
+                                const int n_gap_a = nsa - n_res_a, n_gap_b = nsb - n_res_b;
+                                total -= (float)(n_res_a * n_gap_b + n_gap_a * n_res_b) * pen;
+                                in_a = false; in_b = false; pos_a++; pos_b++;
+                        } else if (step == 1) {
+                                const int n_pairs = nsa * fb0[24 * pos_b + 23];
+                                if (!in_a) total -= (float)n_pairs * gpo;
+                                total -= (float)n_pairs * pen;
+                                in_a = true; in_b = false; pos_b++;
+                        } else {
+                                const int n_pairs = fa0[24 * pos_a + 23] * nsb;
+                                if (!in_b) total -= (float)n_pairs * gpo;
+                                total -= (float)n_pairs * pen;
+                                in_a = false; in_b = true; pos_a++;
+                        }
+                }
+                S.sp_value = total;
+        }
         __syncthreads();
 }
 
@@ -1160,14 +1461,14 @@ __device__ __forceinline__ long long ka_align_up(long long x, long long a) { ret
 __device__ __host__ inline long long ka_private_bytes(long long la, long long lb)
 {
         const long long n = la + lb + 8;
-        const long long nq = (la < lb ? la : lb) + 4;
+        const long long nq = (la < lb ? la : lb) + 20;
         const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
         return 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16) + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16);
 }
 
 // carve the per-task scratch region (cons_maxlen > 0: the job has a consistency table)
-__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen)
+__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen, bool refine = false)
 {
         const long long n = (long long)la + lb + 8;
         long long o = 0;
@@ -1178,7 +1479,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         S.srcB = (int*)(base + o);  o += ka_align_up(n * 4, 16);
         S.fbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
         S.bbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
-        const long long nq = (long long)(la < lb ? la : lb) + 4;
+        const long long nq = (long long)(la < lb ? la : lb) + 20;
         S.q[0] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
         S.q[1] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
         const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
@@ -1205,6 +1506,13 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
                 S.priv.b = (KaState*)(pr + x); x += ka_align_up(n * 12, 16);
                 o += (long long)S.G * pb;
         }
+        S.best_coded = nullptr; S.best_srcA = nullptr; S.best_srcB = nullptr; S.sp_freq = nullptr;
+        if (refine) {
+                S.best_coded = (int*)(base + o); o += ka_align_up(n * 4, 16);
+                S.best_srcA = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+                S.best_srcB = (int*)(base + o);  o += ka_align_up(n * 4, 16);
+                S.sp_freq = (int*)(base + o);    o += ka_align_up(n * 24 * 4, 16);
+        }
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
         if (cons_maxlen > 0) {
                 S.ent = (int2*)(base + o);    o += ka_align_up(n * 8 * KA_NB, 16);
@@ -1219,16 +1527,17 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         return o;
 }
 
-__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1)
+__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1, bool refine = false)
 {
         const long long n = la + lb + 8;
-        const long long nq = (la < lb ? la : lb) + 4;
+        const long long nq = (la < lb ? la : lb) + 20;
         const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
         long long b = 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
         if (g > 1) b += g * ka_private_bytes(la, lb);
+        if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16;
         if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 12 + 15) / 16 * 16;
         return b;
 }
@@ -1421,6 +1730,162 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Refinement pass (refine_alignment, aln_refine.c:36-346): one workgroup per edge.  Operand preparation as in
+// ka_task_body; then refine_edge's trials -- trial 0 without flips, trials 1..4 with the baseline's mean margin as the
+// flip threshold (replay_edge: trial 0 only) -- each one a depth-first recursion (ka_hirschberg_dfs), coded with
+// convert_raw_path and, on a refined edge, scored with compute_sp_score; the first best trial's path makes the merged
+// profile (update_n honours its open / extend / close flags) and moves the members' columns.
+// ------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const int task)
+{
+        extern __shared__ __attribute__((aligned(16))) char ka_smem[];
+        TaskShared& S = *(TaskShared*)ka_smem;
+        float* tss = (float*)(ka_smem + KA_LDS_TSS);
+        char* lds_waves = ka_smem + KA_LDS_WAVES;
+        const KaTaskDesc T = D.tasks[task];
+        const int tid = threadIdx.x;
+        if (tid == 0) {
+                const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
+                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = 0; S.prof = nullptr;
+                S.len_a = len_a; S.len_b = len_b;
+                S.profa = D.prof_arena + D.node_prof[T.a];
+                S.profb = D.prof_arena + D.node_prof[T.b];
+                S.subm = D.subm;
+                S.gpo = T.gpo; S.gpe = T.gpe; S.tgpe = T.tgpe; S.soff = T.soff;
+                S.s1 = nullptr; S.s2 = nullptr; S.p1 = nullptr; S.p2 = nullptr;
+                S.sp_open = 0.0f; S.sp_ext = 0.0f; S.sp_text = 0.0f;
+                int swapped = 0, kind;
+                if (T.nsip_a == 1 && T.nsip_b == 1) {                // operand selection and swap rules, aln_refine.c:476-560
+                        kind = KA_SS;
+                        if (len_a < len_b) { S.s1 = D.codes + D.seq_off[T.a]; S.s2 = D.codes + D.seq_off[T.b]; }
+                        else { swapped = 1; S.s1 = D.codes + D.seq_off[T.b]; S.s2 = D.codes + D.seq_off[T.a]; }
+                } else if (T.nsip_a == 1) {
+                        kind = KA_SP; swapped = 1;
+                        S.s2 = D.codes + D.seq_off[T.a]; S.p1 = S.profb;
+                        S.sp_open = T.gpo * (float)T.nsip_b; S.sp_ext = T.gpe * (float)T.nsip_b; S.sp_text = T.tgpe * (float)T.nsip_b;
+                } else if (T.nsip_b == 1) {
+                        kind = KA_SP;
+                        S.s2 = D.codes + D.seq_off[T.b]; S.p1 = S.profa;
+                        S.sp_open = T.gpo * (float)T.nsip_a; S.sp_ext = T.gpe * (float)T.nsip_a; S.sp_text = T.tgpe * (float)T.nsip_a;
+                } else {
+                        kind = KA_PP;
+                        if (len_a < len_b) { S.p1 = S.profa; S.p2 = S.profb; }
+                        else { swapped = 1; S.p1 = S.profb; S.p2 = S.profa; }
+                }
+                S.kind = kind; S.swapped = swapped;
+                S.p1_mult = swapped ? (float)T.nsip_a : (float)T.nsip_b;
+                S.p2_mult = swapped ? (float)T.nsip_b : (float)T.nsip_a;
+                S.La = swapped ? len_b : len_a;
+                S.Lb = swapped ? len_a : len_b;
+                S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0;
+                S.ctl = &S.ctl_lds; S.lctl = S.ctl;
+                S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
+                const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true);
+                const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
+                if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
+                if (__hip_atomic_load(D.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.ctl->fail = 1;
+                S.ctl->scratch_off = (long long)so;
+                if (!S.ctl->fail) ka_carve(S, D.scratch + so, len_a, len_b, NB ? D.cons_maxlen : 0, true);
+        }
+        __syncthreads();
+        if (S.ctl->fail) return;
+
+        // P1
+        ka_build_tss(tss, D.subm, T.soff);
+        __syncthreads();
+        if (T.nsip_a == 1) ka_make_leaf_profile(S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, tss);
+        if (T.nsip_b == 1) ka_make_leaf_profile(S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, tss);
+        if (NB) {
+                __syncthreads();
+                ka_cons_votes<false>(S, D, T, lds_waves, (long long)KA_NW * KA_WAVE_LDS);
+                __syncthreads();
+                ka_cons_entries(S, D);
+        }
+        const bool refine_it = D.refine_mode == 1 || (D.refine_mode == 2 && T.refine != 0);
+        const int n_trials = refine_it ? 5 : 1;
+        if (refine_it) ka_sp_build(S, D, T);
+        __syncthreads();
+
+        // P2: the trials
+        float best_sp = -KA_F, avg_margin = 0.0f, best_msum = 0.0f;
+        int best_mcount = 0;
+        for (int k = 0; k < n_trials; ++k) {
+                if (tid == 0) { S.rf.thr = (k == 0) ? 0.0f : avg_margin; S.rf.trial = k; S.rf.stride = max(n_trials - 1, 1); }
+                __syncthreads();
+                if (S.kind == KA_SS) ka_hirschberg_dfs<KA_SS, 23, NB>(S, lds_waves, tss, k == 0);
+                else if (S.kind == KA_SP) ka_hirschberg_dfs<KA_SP, 23, NB>(S, lds_waves, tss, k == 0);
+                else if (D.nres <= 5) ka_hirschberg_dfs<KA_PP, 5, NB>(S, lds_waves, tss, k == 0);
+                else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
+                __syncthreads();
+                if (D.refine_mode == 3) ka_code_path(S, (int*)lds_waves);     // the first pass again, depth first (exact confidences)
+                else ka_code_path_refine(S, (int*)lds_waves);
+                const float tr_msum = S.rf.msum;
+                const int tr_mcount = S.rf.mcount;
+                bool take = true;
+                if (refine_it) {
+                        ka_sp_score(S, D, T);
+                        take = S.sp_value > best_sp;
+                        if (take) best_sp = S.sp_value;
+                }
+                if (take) {
+                        best_msum = tr_msum; best_mcount = tr_mcount;
+                        const int n = S.coded[0] + 2;
+                        for (int i = tid; i < n; i += KA_NT) { S.best_coded[i] = S.coded[i]; S.best_srcA[i] = S.srcA[i]; S.best_srcB[i] = S.srcB[i]; }
+                }
+                if (k == 0 && tr_mcount > 0) avg_margin = tr_msum / (float)tr_mcount;
+                __syncthreads();
+        }
+        {
+                const int n = S.best_coded[0] + 2;
+                for (int i = tid; i < n; i += KA_NT) { S.coded[i] = S.best_coded[i]; S.srcA[i] = S.best_srcA[i]; S.srcB[i] = S.best_srcB[i]; }
+                if (tid == 0) S.ctl->alnlen = S.best_coded[0];
+        }
+        __syncthreads();
+
+        // P3: output slots and the task record
+        if (tid == 0) {
+                const int alnlen = S.ctl->alnlen;
+                const unsigned long long pn = (unsigned long long)alnlen + 2;
+                const unsigned long long po = atomicAdd(&D.counters[2], pn);
+                if ((long long)(po + pn) > D.path_cap) { S.ctl->fail = 1; atomicExch(D.error, 3); }
+                S.ctl->path_off = (long long)po;
+                S.ctl->newp_off = -1;
+                D.node_len[T.c] = alnlen;
+                if (!T.is_root) {
+                        const unsigned long long fn = pn * 64ull;
+                        const unsigned long long fo = atomicAdd(&D.counters[0], fn);
+                        if ((long long)(fo + fn) > D.prof_cap) { S.ctl->fail = 1; atomicExch(D.error, 1); }
+                        else { S.ctl->newp_off = (long long)fo; D.node_prof[T.c] = (long long)fo; }
+                }
+                ka_task_rec r;
+                r.a = T.a; r.b = T.b; r.c = T.c;
+                r.len_a = S.len_a; r.len_b = S.len_b; r.nsip_a = T.nsip_a; r.nsip_b = T.nsip_b;
+                r.plen = alnlen; r.kind = S.kind; r.swapped = S.swapped;
+                r.meet = S.ctl->top_meet; r.transition = S.ctl->top_tr;
+                r.path_off = (int)po;
+                r.gap_scale = T.gap_scale; r.subm_off = T.soff;
+                r.score = S.ctl->top_score;
+                r.confidence = (best_mcount > 0) ? best_msum / (float)best_mcount : 0.0f;
+                r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
+                D.recs[task] = r;
+        }
+        __syncthreads();
+        if (S.ctl->fail) return;
+
+        // P4
+        if (tid == 0) {
+                S.path_dst = D.path_arena + S.ctl->path_off;
+                S.newp = (S.ctl->newp_off >= 0) ? (D.prof_arena + S.ctl->newp_off) : nullptr;
+        }
+        __syncthreads();
+        const int alnlen = S.ctl->alnlen;
+        for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
+        if (S.newp) ka_update_profile(S, D, T, alnlen);
+        ka_update_colof(S, D, T, alnlen);
+}
+
 // Entry of the task kernels.  blocks[b] = (task, member | launched cluster size << 8); task < 0: padding.
 //
 // chain != 0: the launch covers the first guide-tree level with at most one task per CU AND everything above
@@ -1567,7 +2032,7 @@ __device__ __forceinline__ void ka_task_queue_entry(const KaTreeDev& D, const in
 //   unit 0: ka_task_kernel            unit 1: ka_task_kernel_cons
 //   unit 2: the two half kernels      unit 3: the two lean kernels + ka_pair_kernel
 #ifndef KA_UNIT
-#error "compile with -DKA_UNIT=0..3 (see csrc/Makefile)"
+#error "compile with -DKA_UNIT=0..4 (see csrc/Makefile)"
 #endif
 
 // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
@@ -1594,6 +2059,31 @@ extern "C" void ka_unit0_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen) { return ka_scratch_bytes(la, lb, cons_maxlen); }
 extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }
 extern "C" int ka_max_g_host(void) { return KA_MAX_G; }
+#endif
+
+#if KA_UNIT == 4
+// refinement pass (unit 4): one workgroup per edge, per-level launches
+__global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
+{
+        const int task = blocks[blockIdx.x].x;
+        if (task >= 0) ka_task_body_refine<0>(D, task);
+}
+__global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
+{
+        const int task = blocks[blockIdx.x].x;
+        if (task >= 0) ka_task_body_refine<KA_NB>(D, task);
+}
+extern "C" void ka_unit4_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
+{
+        static bool done0 = false, done1 = false;
+        if (cons) {
+                if (ka_optin(ka_refine_kernel_cons, KA_LDS_TOTAL, &done1) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_refine_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
+        } else {
+                if (ka_optin(ka_refine_kernel, KA_LDS_TOTAL, &done0) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_refine_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
+        }
+}
 #endif
 
 #if KA_UNIT == 1

@@ -1,0 +1,128 @@
+"""Refinement on the device: ka_tree_refine against the real reference's refine_alignment
+(aln_refine.c:34-325) -- goldens made by tests/golden/make_golden.py from the reference itself."""
+import numpy as np
+import pytest
+
+from util import Golden, cons_cases, refine_cases, tree_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import kalign_amd
+    c = kalign_amd.Context(0)
+    yield c
+    c.close()
+
+
+def run_refine(ctx, g, first_pass=True):
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    if int(g.n_anchors) > 0:
+        ctx.tree_build_consistency(int(g.n_anchors), float(g.weight))
+    if first_pass:
+        ctx.tree_run()
+        recs, paths, gaps = ctx.tree_download()
+        for got, want in zip(gaps, _split(g.gaps_first, g.lens)):
+            assert np.array_equal(got, want)
+        # the first pass's confidences are sums in a different order: close to, not identical with, the reference's
+        assert np.allclose([r.confidence for r in recs], g.conf_before, rtol=1e-5, atol=1e-6)
+    ctx.tree_refine(int(g.mode), g.conf_before)
+    return ctx.tree_download()
+
+
+def _split(flat, lens):
+    out, o = [], 0
+    for n in lens:
+        out.append(flat[o:o + int(n) + 1])
+        o += int(n) + 1
+    return out
+
+
+@pytest.mark.parametrize("name", refine_cases())
+def test_refinement_matches_reference(ctx, name):
+    """every edge re-aligned with the five flip trials of refine_edge, the best sum-of-pairs trial kept: gap arrays,
+    profile lengths and the kept trial's confidence equal the real reference's, coded paths (convert_raw_path flags)
+    equal the pinned oracle's"""
+    g = Golden(name)
+    recs, paths, gaps = run_refine(ctx, g)
+    for t, r in enumerate(recs):
+        assert r.plen == g.plen_after[g.tasks[t][2]], (name, t)
+        want = g.paths[int(g.path_off[t]):int(g.path_off[t]) + r.plen + 2]
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], want), (name, t)
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+    assert int(g.n_differ) > 0
+
+
+def test_refine_is_repeatable_and_run_returns_to_the_first_pass(ctx):
+    """ka_tree_refine resets the device state like ka_tree_run: refining twice gives the same answer, it does not need
+    a preceding ka_tree_run, and a later ka_tree_run is the plain first pass again"""
+    g = Golden("refine_prot32x200_all")
+    _, _, gaps1 = run_refine(ctx, g, first_pass=False)
+    ctx.tree_refine(1)
+    _, paths2, gaps2 = ctx.tree_download()
+    for a, b, want in zip(gaps1, gaps2, g.gaps_list()):
+        assert np.array_equal(a, want) and np.array_equal(b, want)
+    ctx.tree_run()
+    _, _, gaps3 = ctx.tree_download()
+    for got, want in zip(gaps3, _split(g.gaps_first, g.lens)):
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", [n for n in refine_cases() if n.endswith("_conf")])
+def test_confident_mode_computes_its_own_threshold(ctx, name):
+    """KALIGN_REFINE_CONFIDENT without confidences from the caller: the first pass is repeated depth first, its task
+    confidences are the reference's exact float sums, and the median rule picks the same edges"""
+    g = Golden(name)
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    if int(g.n_anchors) > 0:
+        ctx.tree_build_consistency(int(g.n_anchors), float(g.weight))
+    ctx.tree_refine(2)
+    recs, paths, gaps = ctx.tree_download()
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+
+
+@pytest.mark.parametrize("name", tree_cases() + cons_cases())
+def test_depth_first_pass_has_exact_confidences(ctx, name):
+    """mode 3: the first pass through the depth-first engine -- same paths and gaps as ka_tree_run, and the mean
+    meetup margin of every task bit-identical with the reference's (summed in the reference's order)"""
+    g = Golden(name)
+    cons = hasattr(g, "n_anchors") and int(g.n_anchors) > 0
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    if cons:
+        ctx.tree_build_consistency(int(g.n_anchors), float(g.weight))
+    ctx.tree_refine(3)
+    recs, paths, gaps = ctx.tree_download()
+    for t, r in enumerate(recs):
+        assert r.plen == g.rec("plen")[t] and r.score == g.rec("score")[t]
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), (name, t)
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.rec("confidence").astype(np.float32))
+
+
+def test_refine_rows_match_reference(ctx):
+    """the aligned rows written from the refined gap arrays are the reference's output rows"""
+    g = Golden("refine_cons_prot48_all")
+    run_refine(ctx, g)
+    rows_sorted = ctx.tree_aligned_rows(g.sorted_seqs())
+    rows = [None] * len(rows_sorted)
+    for i, r in enumerate(g.ranks):
+        rows[int(r)] = rows_sorted[i].decode()
+    assert rows == [str(x) for x in g.rows]
+
+
+def test_refine_argument_errors(ctx):
+    from kalign_amd.api import KalignAmdError
+    g = Golden("refine_BB11001_all")
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+    with pytest.raises(KalignAmdError):
+        ctx.tree_refine(4)
+    with pytest.raises(KalignAmdError):
+        ctx.tree_refine(0)
+    with pytest.raises(KalignAmdError):
+        ctx.tree_refine(2, g.conf_before[:-1])
