@@ -119,10 +119,12 @@ int ka_tree_run(ka_ctx* ctx);
    trials (aln_refine.c:199-325: trial 0 is the baseline, trials 1-4 take the second-best meetup round-robin where the
    margin is below the baseline's mean margin; the trial with the best sum-of-pairs score is kept, the first one on
    ties).  mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT (only edges whose first-pass confidence is at or
-   below the median are refined, the others are re-aligned plainly), 3 = no refinement: the first pass again, run depth
-   first like the reference so that every task's confidence is the reference's exact float sum (ka_tree_run adds the
-   same margins level by level: equal within 1e-5).  conf_in[n_tasks]: first-pass task confidences (the reference
-   reads task->confidence); only read for mode 2; NULL = computed here with a mode-3 pass.  Asynchronous like
+   below the median are refined, the others are re-aligned plainly), 3 = KALIGN_REFINE_INLINE
+   (create_msa_tree_inline_refine, aln_run.c:448-790, as aln_wrap.c:222-224 calls it: one pass, three trials on every
+   edge, first-pass path coding, task confidence = the kept trial's sum-of-pairs score), 4 = no refinement: the first
+   pass again, run depth first like the reference so that every task's confidence is the reference's exact float sum
+   (ka_tree_run adds the same margins level by level: equal within 1e-5).  conf_in[n_tasks]: first-pass task
+   confidences (the reference reads task->confidence); only read for mode 2; NULL = computed here with a mode-4 pass.  Asynchronous like
    ka_tree_run; ka_tree_sync / ka_tree_download then return the refined records, paths and gaps (records carry the
    kept trial's confidence). */
 int ka_tree_refine(ka_ctx* ctx, int mode, const float* conf_in);

@@ -188,7 +188,8 @@ class Context:
 
     def tree_refine(self, mode, conf_in=None):
         """refine_alignment (aln_refine.c:34-85) over the uploaded tree: mode 1 = all edges, 2 = edges whose
-        first-pass confidence (conf_in) is at or below the median."""
+        first-pass confidence (conf_in; None: computed on the device) is at or below the median, 3 = inline
+        refinement (create_msa_tree_inline_refine), 4 = the plain first pass, depth first (exact confidences)."""
         cf = None if conf_in is None else np.ascontiguousarray(conf_in, np.float32)
         if cf is not None and len(cf) != self._job["ntasks"]:
             raise KalignAmdError("tree_refine: one confidence per task")

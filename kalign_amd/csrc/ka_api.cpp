@@ -744,9 +744,10 @@ extern "C" int ka_tree_run(ka_ctx* c)
 
 // refine_alignment (aln_refine.c:199-325): a second pass over every edge of the tree with the flip trials of
 // refine_edge; mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT (edges whose first-pass confidence is at or
-// below the median), 3 = the first pass again with the depth-first engine (task confidences are then the reference's
-// exact float sums).  conf_in: the first-pass confidence of every task (the reference reads task->confidence); only
-// read for mode 2, NULL = computed here by a mode-3 pass.  The job keeps its tree, parameters and consistency table.
+// below the median), 3 = KALIGN_REFINE_INLINE (create_msa_tree_inline_refine, aln_run.c:448-790: three trials per edge
+// in one pass), 4 = the first pass again with the depth-first engine (task confidences are then the reference's exact
+// float sums).  conf_in: the first-pass confidence of every task (the reference reads task->confidence); only
+// read for mode 2, NULL = computed here by a mode-4 pass.  The job keeps its tree, parameters and consistency table.
 static int refine_launch(ka_ctx* c, int mode)
 {
         c->refine_mode = mode;
@@ -760,7 +761,7 @@ static int refine_launch(ka_ctx* c, int mode)
 extern "C" int ka_tree_refine(ka_ctx* c, int mode, const float* conf_in)
 {
         if (!c || !c->have_job) return fail("no uploaded job");
-        if (mode < 1 || mode > 3) return fail("ka_tree_refine: mode must be 1 (all), 2 (confident) or 3 (first pass, exact confidences)");
+        if (mode < 1 || mode > 4) return fail("ka_tree_refine: mode must be 1 (all), 2 (confident), 3 (inline) or 4 (first pass, exact confidences)");
         if (c->n_tasks < 1) return fail("ka_tree_refine: no tasks");
         HIPCHK(hipSetDevice(c->device));
         if (c->ran && !c->synced && ka_tree_sync(c)) return KA_FAIL;
@@ -778,7 +779,7 @@ extern "C" int ka_tree_refine(ka_ctx* c, int mode, const float* conf_in)
                 // level-synchronous first pass adds the same margins in another order, so its value can differ in the last
                 // bits -- and the median rule below compares them.  Run the first pass again depth first and read its sums.
                 for (auto& d : c->descs) d.refine = 0;
-                if (refine_launch(c, 3) || ka_tree_sync(c)) return KA_FAIL;
+                if (refine_launch(c, 4) || ka_tree_sync(c)) return KA_FAIL;
                 std::vector<ka_task_rec> r(c->n_tasks);
                 HIPCHK(hipMemcpy(r.data(), c->d_recs.p, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyDeviceToHost));
                 conf.resize(c->n_tasks);

@@ -1803,8 +1803,12 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 __syncthreads();
                 ka_cons_entries(S, D);
         }
-        const bool refine_it = D.refine_mode == 1 || (D.refine_mode == 2 && T.refine != 0);
-        const int n_trials = refine_it ? 5 : 1;
+        // modes: 1 KALIGN_REFINE_ALL, 2 _CONFIDENT (T.refine marks the edges), 3 _INLINE (do_align_inline_refine,
+        // aln_run.c:515-790: three trials on every edge, first-pass path coding, confidence = the best SP score),
+        // 4 = one depth-first trial with first-pass coding (the first pass with the reference's exact confidence sums)
+        const bool inline_mode = D.refine_mode == 3;
+        const bool refine_it = D.refine_mode == 1 || inline_mode || (D.refine_mode == 2 && T.refine != 0);
+        const int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
         if (refine_it) ka_sp_build(S, D, T);
         __syncthreads();
 
@@ -1819,8 +1823,8 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 else if (D.nres <= 5) ka_hirschberg_dfs<KA_PP, 5, NB>(S, lds_waves, tss, k == 0);
                 else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
                 __syncthreads();
-                if (D.refine_mode == 3) ka_code_path(S, (int*)lds_waves);     // the first pass again, depth first (exact confidences)
-                else ka_code_path_refine(S, (int*)lds_waves);
+                if (D.refine_mode >= 3) ka_code_path(S, (int*)lds_waves);     // add_gap_info_to_path_n (aln_run.c:713)
+                else ka_code_path_refine(S, (int*)lds_waves);                 // convert_raw_path (aln_refine.c:243)
                 const float tr_msum = S.rf.msum;
                 const int tr_mcount = S.rf.mcount;
                 bool take = true;
@@ -1868,6 +1872,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 r.gap_scale = T.gap_scale; r.subm_off = T.soff;
                 r.score = S.ctl->top_score;
                 r.confidence = (best_mcount > 0) ? best_msum / (float)best_mcount : 0.0f;
+                if (inline_mode) r.confidence = best_sp;                      // aln_run.c:742
                 r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
                 D.recs[task] = r;
         }

@@ -1,15 +1,17 @@
 /*
  * kalign_amd_glue.c -- the reference-side binding of libkalign_amd.so: the replacement bodies a Kalign
- * maintainer adds for the four call sites of INTEGRATION.md.  This is the text INTEGRATION.md quotes.
+ * maintainer adds for the six call sites of INTEGRATION.md.  This is the text INTEGRATION.md quotes.
  *
  * TEST INFRASTRUCTURE: it is compiled only by `make -C oracle dropin` (build container, where the
- * reference sources lie under /root/reference) into oracle/_ref/libkalign_dropin.so -- the reference's own
- * lib/src compiled where it lies, with the four functions below taken from here instead (the reference's
+ * reference sources lie under /root/reference) into oracle/_ref/dropin/libkalign.so.3 -- the reference's own
+ * lib/src compiled where it lies, with the six functions below taken from here instead (the reference's
  * definitions are renamed at compile time, -Dcreate_msa_tree=kalign_ref_create_msa_tree etc.), linked against
  * libkalign_amd.so and exporting lib/include/kalign/kalign.h unchanged.  The product (kalign_amd/) links
  * nothing from the reference and nothing from here.
  *
  *   create_msa_tree            lib/src/aln_run.c:43-78        -> ka_tree_upload / ka_tree_build_consistency / ka_tree_run
+ *   create_msa_tree_inline_refine  lib/src/aln_run.c:448-475  -> the same with ka_tree_refine(3) in place of ka_tree_run
+ *   refine_alignment           lib/src/aln_refine.c:36-88     -> ka_tree_refine(1 | 2) on the job create_msa_tree left in HBM
  *   anchor_consistency_build   lib/src/anchor_consistency.c:200-275 -> ka_tree_build_consistency (+ a host copy of the table)
  *   build_tree_kmeans          lib/src/bisectingKmeans.c:177-271    -> ka_guide_tree
  *   finalise_alignment         lib/src/msa_op.c:546-576       -> ka_tree_aligned_rows
@@ -31,6 +33,16 @@
 
 /* the reference's own definitions, renamed by the drop-in build (oracle/Makefile) */
 extern int kalign_ref_finalise_alignment(struct msa* msa);
+extern int kalign_ref_refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int refine_mode);
+extern int kalign_ref_create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int n_trials);
+
+/* how often each seam ran on the device / fell back to the reference (tests/test_gpu_dropin.py reads them) */
+enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF, GLUE_N };
+static int glue_counts[GLUE_N];
+int kalign_amd_glue_count(int which)
+{
+        return (which >= 0 && which < GLUE_N) ? glue_counts[which] : -1;
+}
 
 static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
 static const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
@@ -202,7 +214,9 @@ ERROR:
  * seq_distances, the task list; leaves sequences[i]->gaps[], nsip[], sip[][], plen[], task confidence -- exactly
  * the state the reference's dispatcher leaves.  Merged profiles stay in HBM.
  */
-int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
+static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total);
+
+static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int inline_refine)
 {
         struct consistency_table* ct = (struct consistency_table*)msa->consistency_table;
         int n = msa->numseq;
@@ -210,16 +224,12 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
         int* off = NULL;
         int* lens = NULL;
         int* abc = NULL;
-        int* gaps = NULL;
-        int* paths = NULL;
         uint8_t* codes = NULL;
-        ka_task_rec* recs = NULL;
         float subm[23 * 23];
         float scal[6];
         long long total = 0;
-        long long cap;
         int flags = KA_FLAG_DEVICE_GAPS;
-        int i, j, g;
+        int i;
 
         RUN(sort_tasks(t, TASK_ORDER_TREE));             /* as the reference does, aln_run.c:48 */
         RUN(glue_context());
@@ -249,9 +259,34 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
                 }
         }
         glue_ct_resident = ct;                           /* NULL: this upload dropped whatever table there was */
-        if(ka_tree_run(glue_ctx) || ka_tree_sync(glue_ctx)){
+        /* do_align_inline_refine (aln_run.c:515-790) is do_align with three flip trials per edge: mode 3 of ka_tree_refine */
+        if((inline_refine ? ka_tree_refine(glue_ctx, 3, NULL) : ka_tree_run(glue_ctx)) || ka_tree_sync(glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
+        RUN(glue_collect(msa, t, lens, total));
+        glue_counts[inline_refine ? GLUE_INLINE : GLUE_TREE]++;
+        glue_job_msa = msa;
+        glue_job_numseq = n;
+        MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
+        return OK;
+ERROR:
+        if(off) MFREE(off);
+        if(lens) MFREE(lens);
+        if(codes) MFREE(codes);
+        if(abc) MFREE(abc);
+        return FAIL;
+}
+
+/* leave exactly the state do_align leaves (aln_run.c:391-436): gaps[], plen[], nsip[], sip[][], task confidence */
+static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total)
+{
+        int n = msa->numseq;
+        int nt = t->n_tasks;
+        int* gaps = NULL;
+        int* paths = NULL;
+        ka_task_rec* recs = NULL;
+        long long cap;
+        int i, j, g;
         cap = ka_tree_paths_size(glue_ctx);
         MMALLOC(recs, sizeof(ka_task_rec) * nt);
         MMALLOC(gaps, sizeof(int) * (total + n));
@@ -259,8 +294,6 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
         if(ka_tree_download(glue_ctx, recs, paths, cap, gaps)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
-
-        /* leave exactly the state do_align leaves (aln_run.c:391-436) */
         for(i = 0, g = 0; i < n; i++){
                 memcpy(msa->sequences[i]->gaps, gaps + g, sizeof(int) * (lens[i] + 1));
                 g += lens[i] + 1;
@@ -281,18 +314,70 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
                         msa->sip[c][k++] = msa->sip[b][j];
                 }
         }
-        glue_job_msa = msa;
-        glue_job_numseq = n;
-        MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc); MFREE(recs); MFREE(gaps); MFREE(paths);
+        MFREE(recs); MFREE(gaps); MFREE(paths);
         return OK;
 ERROR:
-        if(off) MFREE(off);
-        if(lens) MFREE(lens);
-        if(codes) MFREE(codes);
-        if(abc) MFREE(abc);
         if(recs) MFREE(recs);
         if(gaps) MFREE(gaps);
         if(paths) MFREE(paths);
+        return FAIL;
+}
+
+int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
+{
+        return glue_tree(msa, ap, t, 0);
+}
+
+/*
+ * create_msa_tree_inline_refine (aln_run.c:448-475; KALIGN_REFINE_INLINE, aln_wrap.c:222-224 passes three trials).
+ */
+int create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int n_trials)
+{
+        if(n_trials != 3){
+                glue_job_msa = NULL;
+                return kalign_ref_create_msa_tree_inline_refine(msa, ap, t, n_trials);
+        }
+        return glue_tree(msa, ap, t, 1);
+}
+
+/*
+ * refine_alignment (aln_refine.c:36-88): the second pass over every edge with refine_edge's five flip trials
+ * (:93-346).  The job create_msa_tree uploaded is still in HBM (sequences, tree, parameters, consistency table):
+ * ka_tree_refine runs the pass there.  KALIGN_REFINE_CONFIDENT compares task confidences with their median; the
+ * device recomputes them as the reference's exact float sums (conf_in = NULL) instead of trusting the first pass's
+ * level-order sums.  Anything else -- another msa, ap->adaptive_budget (aln_refine.c:255-282: a trial count per edge
+ * from the baseline's margins; not on the device) -- goes through the reference's own function, which works on the
+ * state create_msa_tree left on the host.
+ */
+int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int refine_mode)
+{
+        int* lens = NULL;
+        long long total = 0;
+        int n = msa->numseq;
+        int i;
+        if(refine_mode == 0){                            /* KALIGN_REFINE_NONE */
+                return OK;
+        }
+        if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx || ap->adaptive_budget || (refine_mode != 1 && refine_mode != 2)){
+                glue_job_msa = NULL;                     /* the host state moves on without the device */
+                glue_counts[GLUE_REFINE_REF]++;
+                return kalign_ref_refine_alignment(msa, ap, t, refine_mode);
+        }
+        RUN(sort_tasks(t, TASK_ORDER_TREE));
+        MMALLOC(lens, sizeof(int) * n);
+        for(i = 0; i < n; i++){
+                lens[i] = msa->sequences[i]->len;
+                total += lens[i];
+        }
+        if(ka_tree_refine(glue_ctx, refine_mode, NULL) || ka_tree_sync(glue_ctx)){
+                ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        RUN(glue_collect(msa, t, lens, total));
+        glue_counts[GLUE_REFINE]++;
+        MFREE(lens);
+        return OK;
+ERROR:
+        if(lens) MFREE(lens);
         return FAIL;
 }
 
@@ -361,8 +446,10 @@ int finalise_alignment(struct msa* msa)
         int width = 0;
         int i;
         if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx){
+                glue_counts[GLUE_FINALISE_REF]++;
                 return kalign_ref_finalise_alignment(msa);
         }
+        glue_counts[GLUE_FINALISE]++;
         glue_job_msa = NULL;                             /* the rows below replace seq->seq: one shot */
         ASSERT(msa->aligned == ALN_STATUS_ALIGNED, "Sequences are not aligned");
         for(i = 0; i < n; i++){

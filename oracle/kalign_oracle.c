@@ -876,7 +876,7 @@ static float* ko_bonus_profile(const ko_cons* ct, const int* lens, int** gaps,
  * anchor-consistency bonus when n_anchors > 0 (aln_wrap.c:207-214, aln_run.c:262-295).
  * Tasks must be in TASK_ORDER_TREE order (children before parents; the last task is the root).
  */
-/* refine_mode 0: create_msa_tree.  1 / 2: refine_alignment (aln_refine.c:36-88; KALIGN_REFINE_ALL / _CONFIDENT) --
+/* refine_mode 0: create_msa_tree.  3: create_msa_tree_inline_refine (see below).  1 / 2: refine_alignment (aln_refine.c:36-88; KALIGN_REFINE_ALL / _CONFIDENT) --
    the same walk over the edges with convert_raw_path coding, and refine_edge's five trials (:93-346) on the edges to
    refine; conf_in = the first pass's task confidences (mode 2: edges at or below their median are refined). */
 static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const int* lens,
@@ -1024,8 +1024,11 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                 }else{
                         /* refine_edge (multi-trial) or replay_edge (one trial); trial 0 is the deterministic baseline,
                            trials 1..4 flip uncertain meetups round-robin with the baseline's mean margin as threshold */
-                        const int refine_it = refine_mode == 1 || (refine_mode == 2 && conf_in[tid] <= conf_threshold);
-                        const int n_trials = refine_it ? 5 : 1;
+                        /* refine_mode 3 = KALIGN_REFINE_INLINE (do_align_inline_refine, aln_run.c:515-790, called with three
+                           trials by aln_wrap.c:222-224): every edge, first-pass path coding, confidence = the best SP score */
+                        const int inline_mode = refine_mode == 3;
+                        const int refine_it = refine_mode == 1 || inline_mode || (refine_mode == 2 && conf_in[tid] <= conf_threshold);
+                        const int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
                         int* cand = malloc(sizeof(int) * (size_t)(len_a + len_b + 3));
                         float best_sp = -F, avg_margin = 0.0F, best_msum = 0.0F;
                         int best_mcount = 0;
@@ -1036,12 +1039,9 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                                 d.flip_threshold = (k == 0) ? 0.0F : avg_margin;
                                 d.flip_trial = k; d.flip_stride = n_trials - 1; d.flip_counter = 0;
                                 ko_align(&d, k == 0 ? &probe : &skip);
-                                if(swapped){
-                                        ko_mirror_path(raw, len_a, len_b, raw2);
-                                        ko_convert_raw_path(raw2, len_a, len_b, cand);
-                                }else{
-                                        ko_convert_raw_path(raw, len_a, len_b, cand);
-                                }
+                                if(swapped) ko_mirror_path(raw, len_a, len_b, raw2);
+                                if(inline_mode) ko_code_path(swapped ? raw2 : raw, len_a, len_b, cand);        /* add_gap_info_to_path_n, aln_run.c:713 */
+                                else ko_convert_raw_path(swapped ? raw2 : raw, len_a, len_b, cand);
                                 if(refine_it){
                                         const float sp = ko_sp_score(codes, off, lens, gaps, cand, sip[a], nsip[a], sip[b], nsip[b], subm, gpo, gpe, tgpe);
                                         if(sp > best_sp){
@@ -1056,6 +1056,7 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                         }
                         d.flip_threshold = 0.0F;
                         task_conf = best_mcount > 0 ? best_msum / (float)best_mcount : 0.0f;
+                        if(inline_mode) task_conf = best_sp;                   /* aln_run.c:742 */
                         free(cand);
                 }
 
@@ -1131,7 +1132,7 @@ int ko_msa_tree_refine(int numseq, const uint8_t* codes, const int* off, const i
                        int n_anchors, float cons_weight, int mode, const float* conf_in,
                        ko_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
 {
-        if(mode != 1 && mode != 2) return 1;
+        if(mode < 1 || mode > 3) return 1;
         if(mode == 2 && !conf_in) return 1;
         return ko_tree_impl(numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, n_anchors, cons_weight,
                             recs, paths_out, paths_cap, gaps_out, -1, NULL, NULL, NULL, NULL, mode, conf_in);

@@ -409,17 +409,33 @@ int refh_run_tree(void* hv, int* gaps_out, double* secs)
 }
 
 /* refine_alignment (aln_refine.c:36-88) after refh_run_tree: the second, multi-trial pass over every edge
-   (mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT).  conf_before / conf_after (n_tasks floats, may be NULL):
-   task.confidence before and after; plen_out (num_profiles ints, may be NULL): msa->plen afterwards. */
+   (mode 1 = KALIGN_REFINE_ALL, 2 = KALIGN_REFINE_CONFIDENT; + 256: ap->adaptive_budget = 1, aln_refine.c:255-282);
+   mode 3 = KALIGN_REFINE_INLINE: the tree aligned again from scratch with create_msa_tree_inline_refine
+   (aln_run.c:448-475, three trials per edge, as aln_wrap.c:222-224 calls it).  conf_before / conf_after (n_tasks
+   floats, may be NULL): task.confidence before and after; plen_out (num_profiles ints, may be NULL): msa->plen
+   afterwards. */
 int refh_refine(void* hv, int mode, int* gaps_out, float* conf_before, float* conf_after, int* plen_out)
 {
         struct refh* h = (struct refh*)hv;
+        const int adaptive = (mode >> 8) & 1;
+        mode &= 255;
         if(sort_tasks(h->tasks, TASK_ORDER_TREE) != OK) return 1;
         if(conf_before) for(int i = 0; i < h->tasks->n_tasks; i++) conf_before[i] = h->tasks->list[i]->confidence;
 #ifdef HAVE_OPENMP
         omp_set_num_threads(h->ap->nthreads < 1 ? 1 : h->ap->nthreads);
 #endif
-        if(refine_alignment(h->msa, h->ap, h->tasks, mode) != OK) return 1;
+        if(mode == KALIGN_REFINE_INLINE){
+                if(clean_aln(h->msa) != OK) return 1;
+                for(int i = 0; i < h->msa->num_profiles; i++){
+                        if(h->tasks->profile[i]){ MFREE(h->tasks->profile[i]); h->tasks->profile[i] = NULL; }
+                }
+                if(create_msa_tree_inline_refine(h->msa, h->ap, h->tasks, 3) != OK) return 1;
+        }else{
+                h->ap->adaptive_budget = adaptive;
+                const int rc = refine_alignment(h->msa, h->ap, h->tasks, mode);
+                h->ap->adaptive_budget = 0;
+                if(rc != OK) return 1;
+        }
         if(conf_after) for(int i = 0; i < h->tasks->n_tasks; i++) conf_after[i] = h->tasks->list[i]->confidence;
         if(plen_out) for(int i = 0; i < h->msa->num_profiles; i++) plen_out[i] = h->msa->plen[i];
         if(gaps_out) collect_gaps(h->msa, gaps_out);

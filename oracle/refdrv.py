@@ -196,7 +196,8 @@ class RefJob:
         return ids, maps
 
     def refine(self, mode=1):
-        """refine_alignment (aln_refine.c:36-88) after run_tree(): mode 1 = KALIGN_REFINE_ALL, 2 = _CONFIDENT.
+        """refine_alignment (aln_refine.c:36-88) after run_tree(): mode 1 = KALIGN_REFINE_ALL, 2 = _CONFIDENT;
+        3 = KALIGN_REFINE_INLINE (create_msa_tree_inline_refine, aln_run.c:448-475, from scratch).
         Returns (gaps per sorted sequence, task.confidence before, after, plen of every node)."""
         g = self._gaps_buf()
         cb = np.zeros(self.ntasks, np.float32)

@@ -169,7 +169,8 @@ def guide_case(name, seqs, n_threads=1, tree_seed=0, tree_noise=0.0):
 
 
 def refine_case(name, seqs, mode, n_anchors=0, weight=2.0, **kw):
-    """refine_alignment (aln_refine.c:36-346) after the first alignment: mode 1 = KALIGN_REFINE_ALL, 2 = _CONFIDENT.
+    """refine_alignment (aln_refine.c:36-346) after the first alignment: mode 1 = KALIGN_REFINE_ALL, 2 = _CONFIDENT;
+    mode 3 = KALIGN_REFINE_INLINE: the tree aligned from scratch by create_msa_tree_inline_refine.
     Everything but `paths` / `path_off` comes from the real reference; the per-task coded paths (the reference frees them)
     are the oracle's, stored only after its gap arrays, confidences and lengths have been found identical to the
     reference's."""
@@ -212,6 +213,17 @@ def refine_cases():
     refine_case("refine_BB30014_conf", synth.read_fasta(os.path.join(data, "BB30014.tfa"))[1], 2)
     refine_case("refine_prot24_scaled_all", synth.dssim(24, 150, seed=11), 1, dist_scale=0.5, use_seq_weights=1.0)
     refine_case("refine_ragged_all", [s[:40 + 13 * i] for i, s in enumerate(synth.dssim(20, 400, seed=13))], 1)
+    inline_cases()
+
+
+def inline_cases():
+    """mode 3 = KALIGN_REFINE_INLINE: create_msa_tree_inline_refine (aln_run.c:448-475) with three trials per edge"""
+    data = os.path.join(HERE, "data")
+    refine_case("refine_prot32x200_inline", synth.dssim(32, 200, seed=1), 3)
+    refine_case("refine_dna16x300_inline", synth.dssim(16, 300, dna=True, seed=1), 3, type_=0)
+    refine_case("refine_cons_prot24_inline", synth.dssim(24, 120, seed=7), 3, n_anchors=3)
+    refine_case("refine_BB30014_inline", synth.read_fasta(os.path.join(data, "BB30014.tfa"))[1], 3)
+    refine_case("refine_prot24_scaled_inline", synth.dssim(24, 150, seed=11), 3, dist_scale=0.5, use_seq_weights=1.0)
 
 
 def realign_case(name, seqs, n_anchors=0, weight=2.0, **kw):
@@ -273,6 +285,8 @@ if __name__ == "__main__":
         realign_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "refine":
         refine_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "inline":
+        inline_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "bpm":
         bpm_case("bpm_mixed", 31)
         guide_cases()

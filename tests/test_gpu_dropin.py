@@ -1,6 +1,6 @@
 """The drop-in boundary, for real: Kalign's own library and CLI with the MI355X dispatcher underneath.
 
-oracle/_ref/dropin/libkalign.so.3 is the reference's lib/src compiled where it lies with four seams replaced by
+oracle/_ref/dropin/libkalign.so.3 is the reference's lib/src compiled where it lies with six seams replaced by
 oracle/dropin/kalign_amd_glue.c (= the text of INTEGRATION.md) and linked against kalign_amd/libkalign_amd.so;
 oracle/_ref/dropin/kalign is the reference's CLI (src/run_kalign.c) on that library.  Built by `make -C oracle dropin`
 in the build container (__graft_entry__.build), shipped prebuilt to the GPU box.  Every result must be byte-identical
@@ -49,10 +49,14 @@ CLI_CASES = [
     ("BB30014.tfa", []), ("BB30014.tfa", ["--fast"]),
     ("BB12006.tfa", []), ("BB12006.tfa", ["--realign", "1"]),
     ("BB30014.tfa", ["--precise"]),
+    # refinement (aln_refine.c) on the device: ka_tree_refine behind refine_alignment
+    ("BB11001.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "confident"]),
+    ("BB12006.tfa", ["--fast", "--refine", "confident"]), ("BB12006.tfa", ["--refine", "all", "--realign", "1"]),
+    ("BB30014.tfa", ["--refine", "all", "--adaptive-budget"]),        # adaptive budget: the glue defers to the reference
 ]
 
 
-@pytest.mark.parametrize("name,flags", CLI_CASES, ids=["%s%s" % (n.split(".")[0], "".join(f).replace("--", "_")) for n, f in CLI_CASES])
+@pytest.mark.parametrize("name,flags", CLI_CASES, ids=["%s%s" % (n.split(".")[0], "_".join([""] + f).replace("--", "").replace("__", "_")) for n, f in CLI_CASES])
 def test_cli_output_is_byte_identical(tmp_path, name, flags):
     """`kalign -i in -o out [flags]`: the aligned FASTA written by the drop-in equals the reference's."""
     inp = os.path.join(DATA, name)
@@ -115,3 +119,34 @@ def test_library_kalign_entry_point():
         assert glen == wlen and got == want
         assert [r.replace("-", "") for r in got] == list(seqs)
         assert all(len(r) == glen for r in got)
+
+
+def _lib_run_file(libname, infile, outfile, refine, n_threads=4):
+    """kalign_read_input + kalign_run + kalign_write_msa of lib/include/kalign/kalign.h:36-50"""
+    L = C.CDLL(_need(libname))
+    L.kalign_read_input.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_int]
+    L.kalign_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int]
+    L.kalign_write_msa.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.kalign_free_msa.argtypes = [C.c_void_p]
+    msa = C.c_void_p()
+    assert L.kalign_read_input(infile.encode(), C.byref(msa), 1) == 0
+    assert L.kalign_run(msa, n_threads, KALIGN_TYPE_UNDEFINED, -1.0, -1.0, -1.0, refine, 0) == 0
+    assert L.kalign_write_msa(msa, outfile.encode(), b"fasta") == 0
+    L.kalign_free_msa(msa)
+    with open(outfile, "rb") as fh:
+        return fh.read(), L
+
+
+@pytest.mark.parametrize("refine", [1, 2, 3], ids=["all", "confident", "inline"])
+def test_library_kalign_run_with_refinement(tmp_path, refine):
+    """kalign_run(..., refine, 0): KALIGN_REFINE_ALL / _CONFIDENT go through refine_alignment, KALIGN_REFINE_INLINE
+    (not reachable from the CLI) through create_msa_tree_inline_refine -- all three on the device in the drop-in"""
+    inp = os.path.join(DATA, "BB30014.tfa")
+    L0 = C.CDLL(_need("dropin/libkalign.so.3"))
+    before = [L0.kalign_amd_glue_count(k) for k in range(6)]
+    got, L = _lib_run_file("dropin/libkalign.so.3", inp, str(tmp_path / "dropin.fa"), refine)
+    want, _ = _lib_run_file("libkalign_ref.so", inp, str(tmp_path / "ref.fa"), refine)
+    assert len(want) > 100 and got == want
+    # which seams ran on the device: (tree, inline tree, refine, refine by the reference, finalise, finalise by the reference)
+    delta = [L.kalign_amd_glue_count(k) - b for k, b in enumerate(before)]
+    assert delta == ([0, 1, 0, 0, 1, 0] if refine == 3 else [1, 0, 1, 0, 1, 0])

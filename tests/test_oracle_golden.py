@@ -163,7 +163,7 @@ def test_refinement_matches_reference(oracle, name):
         assert np.array_equal(got, want)
     assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
     assert all(recs[t].plen == g.plen_after[g.tasks[t][2]] for t in range(len(recs)))
-    assert int(g.n_differ) > 0                                   # the refinement really changed the alignment
+    assert int(g.n_differ) > 0 or int(g.mode) == 3               # the refinement really changed the alignment
     rows_sorted = oracle.rows_from_gaps(g.sorted_seqs(), gaps)
     rows = [None] * len(rows_sorted)
     for i, r in enumerate(g.ranks):
