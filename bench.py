@@ -511,7 +511,7 @@ def main():
     if world > 1 and os.environ.get("KA_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = 0                                             # tests: every rank on the one GPU of the box (gloo)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("KA_BENCH_FORCE_MULTI"):       # (the latter: the RCCL code path on a one-GPU box, world 1)
         return multi_gpu_main(args, rank, world, local_rank)
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -591,9 +591,9 @@ def multi_gpu_main(args, rank, world, local_rank):
     same_gpu = backend != "nccl"
     if same_gpu:
         torch.cuda.set_device(0)
-        kd.init(backend)
+        kd.init(backend, force=True)
     else:
-        kd.init("nccl", device=torch.device("cuda", local_rank))
+        kd.init("nccl", device=torch.device("cuda", local_rank), force=True)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = kalign_amd.Context(0 if same_gpu else local_rank, stream=stream, shared=same_gpu)
     # RCCL: collectives and hand-overs on HBM buffers.  gloo (tests): host tensors -- gloo fills a device tensor from the CPU

@@ -22,11 +22,11 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend=None, device=None):
-    """init_process_group from the torchrun environment; returns (rank, world)."""
+def init(backend=None, device=None, force=False):
+    """init_process_group from the torchrun environment; returns (rank, world).  force: also for a world of one."""
     import torch.distributed as dist
     rank, world, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if device is not None:

@@ -1,0 +1,57 @@
+"""Regenerate section 1 of INTEGRATION.md from oracle/dropin/kalign_amd_glue.c (the compiled glue), so that the
+replacement bodies quoted there are the text that is built and tested.  Usage: python tools/make_integration.py"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLUE = os.path.join(ROOT, "oracle", "dropin", "kalign_amd_glue.c")
+DOC = os.path.join(ROOT, "INTEGRATION.md")
+
+# (heading, functions quoted under it: the comment block in front of the first one is included)
+SEAMS = [
+    ("1a. `create_msa_tree` (`lib/src/aln_run.c:43-78`) and `create_msa_tree_inline_refine` (`lib/src/aln_run.c:448-475`)",
+     ["glue_tree", "glue_collect", "create_msa_tree", "create_msa_tree_inline_refine"]),
+    ("1b. `refine_alignment` (`lib/src/aln_refine.c:36-88`)", ["refine_alignment"]),
+    ("1c. `anchor_consistency_build` (`lib/src/anchor_consistency.c:200-275`)", ["anchor_consistency_build"]),
+    ("1d. `build_tree_kmeans` (`lib/src/bisectingKmeans.c:177-271`)", ["build_tree_kmeans"]),
+    ("1e. `finalise_alignment` (`lib/src/msa_op.c:546-576`)", ["finalise_alignment"]),
+]
+
+
+def function_text(src, name):
+    """the definition of `name` (not a prototype) with the comment block directly above it"""
+    m = None
+    for m in re.finditer(r"^(?:static )?int %s\([^;{]*\)\n\{" % re.escape(name), src, re.M):
+        break
+    assert m, name
+    start = m.start()
+    head = src[:start].rstrip("\n")
+    if head.endswith("*/"):
+        start = head.rindex("/*")
+    depth, i = 0, m.end() - 1
+    while True:
+        if src[i] == "{":
+            depth += 1
+        elif src[i] == "}":
+            depth -= 1
+            if depth == 0:
+                break
+        i += 1
+    return src[start:i + 1]
+
+
+def main():
+    src = open(GLUE).read()
+    doc = open(DOC).read()
+    a = doc.index("### 1a.")
+    b = doc.index("Notes\n", a)
+    parts = []
+    for heading, fns in SEAMS:
+        parts.append("### %s\n\n```c\n%s\n```\n" % (heading, "\n\n".join(function_text(src, f) for f in fns)))
+    doc = doc[:a] + "\n".join(parts) + "\n" + doc[b:]
+    open(DOC, "w").write(doc)
+    print("INTEGRATION.md: section 1 regenerated from", os.path.relpath(GLUE, ROOT))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""Refinement on the device against the reference's refine_alignment: time of ka_tree_refine (modes 1, 2, 3, 4) next to
+the first pass, and -- for sizes the reference finishes -- refine_alignment itself on the host, results compared.
+Usage: python tools/refine_time.py [nseq len [cpu]]   (GPU box; oracle/_ref for the cpu leg)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import kalign_amd  # noqa: E402
+from kalign_amd import guide  # noqa: E402
+
+
+def main():
+    nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    length = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    cpu = len(sys.argv) > 3 and sys.argv[3] == "cpu"
+    ctx = kalign_amd.Context(0)
+    job = bench.make_job(ctx, nseq, length, False, 1)
+    subm, scal = bench.scoring(False)
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    for _ in range(2):
+        ctx.tree_run()
+        ctx.tree_sync()
+    ms0, _ = ctx.tree_kernel_ms()
+    recs, _, gaps0 = ctx.tree_download()
+    cells = float(sum(r.len_a * r.len_b for r in recs))
+    print("first pass %dx%d: %.2f ms kernels, %.1f GCUPS" % (nseq, length, ms0, cells / ms0 / 1e6))
+    out = {}
+    for mode, name in ((4, "depth-first first pass"), (1, "refine all"), (2, "refine confident"), (3, "inline")):
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ctx.tree_refine(mode)
+            ctx.tree_sync()
+            wall = (time.perf_counter() - t0) * 1e3
+        ms, nl = ctx.tree_kernel_ms()
+        r, _, g = ctx.tree_download()
+        out[mode] = (r, g)
+        changed = sum(not np.array_equal(a, b) for a, b in zip(g, gaps0))
+        print("mode %d (%s): %.1f ms kernels (last launch sequence, %d launches), %.1f ms wall incl. set-up; alnlen %d; "
+              "sequences whose gaps differ from the first pass: %d" % (mode, name, ms, nl, wall, r[-1].plen, changed))
+    if cpu:
+        from oracle import refdrv
+        for nt in (16, 1):
+            j = refdrv.EncodedJob(job["codes"], job["tasks"], job["seq_distances"], biotype=0, type_=-1, n_threads=nt)
+            _, secs = j.run_tree()
+            t0 = time.perf_counter()
+            g, cb, ca, plen = j.refine(1)
+            rs = time.perf_counter() - t0
+            j.close()
+            same = all(np.array_equal(a, b) for a, b in zip(g, out[1][1]))
+            print("reference, %d threads: create_msa_tree %.2f s, refine_alignment(ALL) %.2f s; gaps identical to the device: %s"
+                  % (nt, secs, rs, same))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
