@@ -92,7 +92,8 @@ struct ka_ctx {
         std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
         int max_cluster = 8;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
         int refine_mode = 0;                         // the run in flight is a refinement pass (ka_tree_refine): 1 all, 2 confident
-        DevBuf<int2> d_refine_blocks;                   // its workgroup table: one workgroup per task, level after level
+        DevBuf<int2> d_refine_blocks;                   // its workgroup table, level after level (refine_blocks)
+        std::vector<int> refine_off;                    // [levels + 1] first block of every level in it
         int n_cus = 256;                             // compute units of the device (hipDeviceProp)
         bool shared_gpu = false;                     // ka_ctx_set_shared: no multi-workgroup tasks, no chained launch
         bool shared_by_fallback = false;             // shared_gpu was forced by a join watchdog (ka_tree_sync), not by the caller
@@ -164,6 +165,7 @@ struct ka_ctx {
 
 static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out);
 static int setup_colof(ka_ctx* c);
+static int refine_blocks(ka_ctx* c, int mode);
 static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
                               const int* ia, const int* ib, int npairs,
                               const float* subm, float gpo, float gpe, float tgpe, const long long* poff, long long* ptotal_out);
@@ -697,10 +699,8 @@ static int tree_launch(ka_ctx* c)
                 if (!n) continue;
                 if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
                 if (c->refine_mode) {
-                        // refinement pass: the trials of one edge are serial by construction (refine_edge), one workgroup each
-                        size_t o = 0;
-                        for (size_t l = 0; l < L; l++) o += c->levels[l].size();
-                        ka_unit4_launch(&D, c->d_refine_blocks.p + o, n, D.cons_K > 0, c->stream);
+                        // refinement pass: one launch per tree level (see refine_blocks)
+                        ka_unit4_launch(&D, c->d_refine_blocks.p + c->refine_off[L], c->refine_off[L + 1] - c->refine_off[L], D.cons_K > 0, c->stream);
                         c->n_launches++;
                         continue;
                 }
@@ -748,9 +748,36 @@ extern "C" int ka_tree_run(ka_ctx* c)
 // in one pass), 4 = the first pass again with the depth-first engine (task confidences are then the reference's exact
 // float sums).  conf_in: the first-pass confidence of every task (the reference reads task->confidence); only
 // read for mode 2, NULL = computed here by a mode-4 pass.  The job keeps its tree, parameters and consistency table.
+// Workgroup table of a refinement pass.  Within one trial the meetups of an edge are serial by construction (the flip
+// counter walks them in recursion order), so an edge gets ONE workgroup per trial in flight: on a level that leaves CUs
+// idle the flip trials of a refined edge run side by side on 2 or 4 workgroups (ka_task_body_refine), otherwise one
+// workgroup runs them one after the other.
+static int refine_blocks(ka_ctx* c, int mode)
+{
+        std::vector<int2> tbl;
+        c->refine_off.assign(1, 0);
+        const int flips = mode == 3 ? 2 : (mode == 4 ? 0 : 4);
+        for (auto& L : c->levels) {
+                int nref = 0;
+                for (int t : L) nref += (flips > 0 && (mode != 2 || c->descs[t].refine)) ? 1 : 0;
+                int G = 1;
+                if (!c->shared_gpu && !getenv("KA_REFINE_SERIAL"))
+                        while (G * 2 <= flips && (long long)nref * G * 2 + ((long long)L.size() - nref) <= c->n_cus) G *= 2;
+                for (int t : L) {
+                        const int g = (flips > 0 && (mode != 2 || c->descs[t].refine)) ? G : 1;
+                        for (int m = 0; m < g; m++) tbl.push_back(make_int2(t, m | (g << 8)));
+                }
+                c->refine_off.push_back((int)tbl.size());
+        }
+        if (c->d_refine_blocks.alloc(tbl.size())) return fail("hipMalloc failed");
+        HIPCHK(hipMemcpy(c->d_refine_blocks.p, tbl.data(), sizeof(int2) * tbl.size(), hipMemcpyHostToDevice));
+        return KA_OK;
+}
+
 static int refine_launch(ka_ctx* c, int mode)
 {
         c->refine_mode = mode;
+        if (refine_blocks(c, mode)) return KA_FAIL;
         if (upload_plan(c)) return KA_FAIL;
         c->ran = false; c->synced = false;
         if (tree_launch(c)) return KA_FAIL;
@@ -769,10 +796,6 @@ extern "C" int ka_tree_refine(ka_ctx* c, int mode, const float* conf_in)
                 if (setup_colof(c)) return KA_FAIL;
         }
         c->flags |= KA_FLAG_DEVICE_GAPS;
-        std::vector<int2> tbl;
-        for (auto& L : c->levels) for (int t : L) tbl.push_back(make_int2(t, 1 << 8));
-        if (c->d_refine_blocks.alloc(tbl.size())) return fail("hipMalloc failed");
-        HIPCHK(hipMemcpy(c->d_refine_blocks.p, tbl.data(), sizeof(int2) * tbl.size(), hipMemcpyHostToDevice));
         std::vector<float> conf;
         if (mode == 2 && !conf_in) {
                 // task->confidence of the first pass is a float sum in depth-first order (aln_controller.c:194-436): the
@@ -817,6 +840,7 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         if (c->shared_gpu || c->partial) return fail("device watchdog: a wait between workgroups never completed");
                         c->shared_gpu = true; c->shared_by_fallback = true; c->fallback_runs++;
                         if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
+                        if (c->refine_mode && refine_blocks(c, c->refine_mode)) return KA_FAIL;       // one workgroup per edge from here on
                         if (tree_launch(c)) return KA_FAIL;
                         continue;
                 }

@@ -1737,8 +1737,15 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
 // convert_raw_path and, on a refined edge, scored with compute_sp_score; the first best trial's path makes the merged
 // profile (update_n honours its open / extend / close flags) and moves the members' columns.
 // ------------------------------------------------------------------------------------------
+//
+// Trials in parallel (G = 2 or 4 workgroups per refined edge, when the level leaves CUs idle): the flip trials only
+// depend on the baseline's mean margin, so every member runs the baseline itself (same operands, same result -- nothing
+// to exchange), then member m the flip trials m+1, m+1+G, ...; each reports its best (score, trial, margin sum /
+// count) in the task's control block, one barrier, and everybody picks the winner the way the serial loop does (highest
+// score, the earliest trial among equals; aln_refine.c:247-253).  The member that ran the winning trial finishes the
+// task (record, path, merged profile, columns); the others leave.
 template <int NB>
-__device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const int task)
+__device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const int task, const int member, const int G)
 {
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
         TaskShared& S = *(TaskShared*)ka_smem;
@@ -1814,8 +1821,13 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
 
         // P2: the trials
         float best_sp = -KA_F, avg_margin = 0.0f, best_msum = 0.0f;
-        int best_mcount = 0;
+        int best_mcount = 0, best_k = 0;
+        int top_meet0 = -1, top_tr0 = -1;                            // the record carries the baseline's top-level meetup
+        float top_score0 = 0.0f;
+        const int Gt = (refine_it && G > 1) ? G : 1;                 // members that share this edge's flip trials
+        if (member >= Gt) return;
         for (int k = 0; k < n_trials; ++k) {
+                if (k > 0 && (k - 1) % Gt != member) continue;       // another member's trial
                 if (tid == 0) { S.rf.thr = (k == 0) ? 0.0f : avg_margin; S.rf.trial = k; S.rf.stride = max(n_trials - 1, 1); }
                 __syncthreads();
                 if (S.kind == KA_SS) ka_hirschberg_dfs<KA_SS, 23, NB>(S, lds_waves, tss, k == 0);
@@ -1823,6 +1835,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 else if (D.nres <= 5) ka_hirschberg_dfs<KA_PP, 5, NB>(S, lds_waves, tss, k == 0);
                 else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
                 __syncthreads();
+                if (k == 0) { top_meet0 = S.ctl->top_meet; top_tr0 = S.ctl->top_tr; top_score0 = S.ctl->top_score; }
                 if (D.refine_mode >= 3) ka_code_path(S, (int*)lds_waves);     // add_gap_info_to_path_n (aln_run.c:713)
                 else ka_code_path_refine(S, (int*)lds_waves);                 // convert_raw_path (aln_refine.c:243)
                 const float tr_msum = S.rf.msum;
@@ -1834,12 +1847,40 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                         if (take) best_sp = S.sp_value;
                 }
                 if (take) {
-                        best_msum = tr_msum; best_mcount = tr_mcount;
+                        best_msum = tr_msum; best_mcount = tr_mcount; best_k = k;
                         const int n = S.coded[0] + 2;
                         for (int i = tid; i < n; i += KA_NT) { S.best_coded[i] = S.coded[i]; S.best_srcA[i] = S.srcA[i]; S.best_srcB[i] = S.srcB[i]; }
                 }
                 if (k == 0 && tr_mcount > 0) avg_margin = tr_msum / (float)tr_mcount;
                 __syncthreads();
+        }
+        if (Gt > 1) {
+                // report, meet, pick the winner (every member computes the same answer)
+                KaCtl* C = D.ctl + task;
+                int* slot = (int*)&C->lvl[0];                         // 4 ints per member: score, trial, margin sum, margin count
+                if (tid == 0) {
+                        slot[4 * member + 0] = __float_as_int(best_sp); slot[4 * member + 1] = best_k;
+                        slot[4 * member + 2] = __float_as_int(best_msum); slot[4 * member + 3] = best_mcount;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_fetch_add(&C->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int spins = 0;
+                        while (__hip_atomic_load(&C->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)Gt) {
+                                __builtin_amdgcn_s_sleep(8);
+                                if (ka_spin_expired(D.error, ++spins, 1 << 24, 6, true)) break;    // (a member that failed never arrives)
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        float wsp = -KA_F; int wk = 0x7fffffff, wm = 0;
+                        for (int m = 0; m < Gt; ++m) {
+                                const float sp = __int_as_float(__hip_atomic_load(&slot[4 * m + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                const int kk = __hip_atomic_load(&slot[4 * m + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (sp > wsp || (sp == wsp && kk < wk)) { wsp = sp; wk = kk; wm = m; }
+                        }
+                        // the baseline (trial 0) is every member's own: when it wins, member 0 finishes the task
+                        S.dfs_valid = (wk == 0) ? (member == 0) : (wm == member);
+                }
+                __syncthreads();
+                if (!S.dfs_valid) return;
         }
         {
                 const int n = S.best_coded[0] + 2;
@@ -1867,10 +1908,10 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 r.a = T.a; r.b = T.b; r.c = T.c;
                 r.len_a = S.len_a; r.len_b = S.len_b; r.nsip_a = T.nsip_a; r.nsip_b = T.nsip_b;
                 r.plen = alnlen; r.kind = S.kind; r.swapped = S.swapped;
-                r.meet = S.ctl->top_meet; r.transition = S.ctl->top_tr;
+                r.meet = top_meet0; r.transition = top_tr0;
                 r.path_off = (int)po;
                 r.gap_scale = T.gap_scale; r.subm_off = T.soff;
-                r.score = S.ctl->top_score;
+                r.score = top_score0;
                 r.confidence = (best_mcount > 0) ? best_msum / (float)best_mcount : 0.0f;
                 if (inline_mode) r.confidence = best_sp;                      // aln_run.c:742
                 r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
@@ -2070,13 +2111,13 @@ extern "C" int ka_max_g_host(void) { return KA_MAX_G; }
 // refinement pass (unit 4): one workgroup per edge, per-level launches
 __global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
 {
-        const int task = blocks[blockIdx.x].x;
-        if (task >= 0) ka_task_body_refine<0>(D, task);
+        const int2 blk = blocks[blockIdx.x];
+        if (blk.x >= 0) ka_task_body_refine<0>(D, blk.x, blk.y & 0xff, blk.y >> 8);
 }
 __global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
 {
-        const int task = blocks[blockIdx.x].x;
-        if (task >= 0) ka_task_body_refine<KA_NB>(D, task);
+        const int2 blk = blocks[blockIdx.x];
+        if (blk.x >= 0) ka_task_body_refine<KA_NB>(D, blk.x, blk.y & 0xff, blk.y >> 8);
 }
 extern "C" void ka_unit4_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
 {
