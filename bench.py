@@ -458,6 +458,36 @@ def secondary_tree_leg(ctx, name, nseq, length, dna, args, steps=3, warmup=1):
     return out, job
 
 
+def refine_leg(ctx, job, subm, scal, args):
+    """refine_alignment (KALIGN_REFINE_ALL, aln_refine.c:36-346) on the C2 tree: ka_tree_refine on the device next to the
+    reference's own function on the host (both after a first pass; only the refinement is timed), gaps compared."""
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    ctx.tree_refine(1)
+    ctx.tree_sync()                                              # warm-up (arena sizes settle)
+    t0 = time.perf_counter()
+    ctx.tree_refine(1)
+    ctx.tree_sync()
+    wall = time.perf_counter() - t0
+    kms, nl = ctx.tree_kernel_ms()
+    recs, _, gaps = ctx.tree_download()
+    out = {"mode": "KALIGN_REFINE_ALL: every edge re-aligned with five flip trials, best sum-of-pairs trial kept",
+           "device_ms": wall * 1e3, "kernel_ms": kms, "launches": nl, "alnlen": int(recs[-1].plen)}
+    if not args.no_cpu:
+        from oracle import refdrv
+        nt = min(16, host_threads())
+        j = refdrv.EncodedJob(job["codes"], job["tasks"], job["seq_distances"], biotype=1 if job["dna"] else 0,
+                              type_=0 if job["dna"] else -1, n_threads=nt)
+        j.run_tree()
+        t0 = time.perf_counter()
+        g, _, _, _ = j.refine(1)
+        out["reference_refine_alignment_ms"] = (time.perf_counter() - t0) * 1e3
+        out["reference_threads"] = nt
+        j.close()
+        out["gaps_identical_to_reference"] = bool(all(np.array_equal(a, b) for a, b in zip(g, gaps)))
+        out["speedup_vs_reference"] = out["reference_refine_alignment_ms"] / out["device_ms"]
+    return out
+
+
 def c4_single_gpu_leg(ctx, steps=3):
     """The workload `bench.py --gpus N` (N > 1) shards, on ONE GPU: 16384 protein x ~500, default mode -- one step =
     anchor_consistency_build + the task tree, as in multi_gpu_main.  The N = 1 point of the strong-scaling curve."""
@@ -561,6 +591,7 @@ def main():
         out["seqseq_batch"] = pairwise_leg(ctx, c2job["codes"], s2, sc2, args)
         out["end_to_end"] = end_to_end_leg(ctx, c2job["input"], s2, sc2, args)
         out["realign_member"] = realign_leg(ctx, c2job["input"], s2, sc2, args)
+        out["refine_all_c2"] = refine_leg(ctx, c2job, s2, sc2, args)
         bc, bt, bd = make_workload(1024, 400, False, seed=1)
         out["concurrent_sets"] = concurrent_sets_leg(bc, bt, s2, sc2, bd, local_rank)
         if not args.no_c3:

@@ -105,6 +105,47 @@ def test_depth_first_pass_has_exact_confidences(ctx, name):
     assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.rec("confidence").astype(np.float32))
 
 
+@pytest.mark.parametrize("name", ["refine_prot32x200_all", "refine_cons_prot24_conf", "refine_dna16x300_inline"])
+def test_serial_trials_give_the_same_answer(ctx, name, monkeypatch):
+    """small trees leave CUs idle, so the tests above run the flip trials of an edge side by side on several
+    workgroups; KA_REFINE_SERIAL=1 is the one-workgroup-per-edge path big levels take"""
+    import os
+    monkeypatch.setenv("KA_REFINE_SERIAL", "1")
+    assert os.environ["KA_REFINE_SERIAL"] == "1"
+    g = Golden(name)
+    recs, paths, gaps = run_refine(ctx, g, first_pass=False)
+    for t, r in enumerate(recs):
+        want = g.paths[int(g.path_off[t]):int(g.path_off[t]) + r.plen + 2]
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], want), (name, t)
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+
+
+def test_big_tree_parallel_and_serial_trials_agree(ctx, monkeypatch):
+    """512 x 300: the lower levels have more edges than CUs (one workgroup per edge), the upper ones run their trials in
+    parallel; forcing everything serial must not change a single gap"""
+    from kalign_amd import guide, synth
+    import bench
+    seqs = synth.dssim(512, 300, seed=4)
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))
+    seqs = [seqs[i] for i in order]
+    codes = guide.encode(seqs, dna=False)
+    tasks, sd = ctx.guide_tree(guide.encode_tree(seqs, dna=False), n_threads=4)
+    subm, scal = bench.scoring(False)
+    ctx.tree_upload(codes, tasks, subm, scal, sd)
+    ctx.tree_refine(1)
+    recs1, paths1, gaps1 = ctx.tree_download()
+    monkeypatch.setenv("KA_REFINE_SERIAL", "1")
+    ctx.tree_refine(1)
+    recs2, paths2, gaps2 = ctx.tree_download()
+    assert all(np.array_equal(a, b) for a, b in zip(gaps1, gaps2))
+    assert [(r.plen, r.confidence, r.meet, r.score) for r in recs1] == [(r.plen, r.confidence, r.meet, r.score) for r in recs2]
+    ctx.tree_run()
+    _, _, gaps0 = ctx.tree_download()
+    assert any(not np.array_equal(a, b) for a, b in zip(gaps0, gaps1))
+
+
 def test_refine_rows_match_reference(ctx):
     """the aligned rows written from the refined gap arrays are the reference's output rows"""
     g = Golden("refine_cons_prot48_all")
