@@ -167,3 +167,32 @@ def test_refine_argument_errors(ctx):
         ctx.tree_refine(0)
     with pytest.raises(KalignAmdError):
         ctx.tree_refine(2, g.conf_before[:-1])
+
+
+@pytest.mark.parametrize("mode,anchors,nseq,length,dna", [(1, 0, 768, 300, False), (2, 5, 384, 300, False), (3, 0, 384, 250, False),
+                                                          (1, 5, 256, 600, True)],
+                         ids=["all_768x300", "confident_cons_384x300", "inline_384x250", "all_cons_dna256x600"])
+def test_refinement_against_the_live_reference(ctx, mode, anchors, nseq, length, dna):
+    """bigger trees than the goldens (levels with more edges than CUs: serial trials; upper levels: trials in parallel),
+    against refine_alignment / create_msa_tree_inline_refine of the real reference run on the box's host cores: gap arrays,
+    profile lengths and the fp32 task confidences must be identical"""
+    from kalign_amd import synth
+    from oracle import refdrv
+    assert refdrv.available(), "oracle/_ref missing"
+    seqs = synth.dssim(nseq, length, dna=dna, seed=9)
+    job = refdrv.RefJob(seqs, n_threads=16, **({"type_": 0} if dna else {}))
+    if anchors:
+        job.build_consistency(anchors, 2.0)
+    job.run_tree()
+    want_gaps, conf_before, conf_after, plen = job.refine(mode)
+    scal = np.array([job.gpo, job.gpe, job.tgpe, job.dist_scale, job.vsm_amax, job.use_seq_weights], np.float32)
+    ctx.tree_upload(job.codes, job.tasks, job.subm, scal, job.seq_distances)
+    if anchors:
+        ctx.tree_build_consistency(anchors, 2.0)
+    ctx.tree_refine(mode)                                         # (mode 2: the device computes the threshold itself)
+    recs, paths, gaps = ctx.tree_download()
+    job.close()
+    for got, want in zip(gaps, want_gaps):
+        assert np.array_equal(got, want)
+    assert all(recs[t].plen == plen[job.tasks[t][2]] for t in range(len(recs)))
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), conf_after)
