@@ -655,6 +655,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.trace = c->h_trace;
         D.refine_mode = 0;
         D.prof_task = -1;
+        D.wdfs = getenv("KA_NO_WDFS") ? 0 : 1;                         // measurements / tests
         if (const char* e = getenv("KA_PROF_TASK")) D.prof_task = atoi(e);      // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));

@@ -707,13 +707,218 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
 }
 
 // ------------------------------------------------------------------------------------------
+// Depth-first recursion, small subtrees: ONE wave, no workgroup barriers, queues in LDS (ka_wave_dfs).
+//
+// The passes of a sub-problem only need its window, i.e. its parent's decision; only its own decision (which of the two
+// best candidates it takes) needs the flip counter, i.e. everything before it in recursion order.  So when a node is
+// decided, the passes AND the candidate scans of both its children run at once (one packed job of four 16-lane slots,
+// one scan with 32 lanes per child); the left child is decided next, the right child's candidates wait on the stack
+// until the left subtree is through.  A round of passes per decided node instead of per node, no __syncthreads, no
+// work lists in HBM.
+// ------------------------------------------------------------------------------------------
+#define KA_WDFS_ROWS 64                                              // subtrees of at most this many rows run wave-locally
+struct KaWdfsEntry { KaSub sub; float mx, mx2; int key, key2; };
+
+// the meetup candidates of one sub-problem, scanned by GL lanes: same candidates, same order, same arithmetic as ka_meetup
+template <int KIND, int GL>
+__device__ __forceinline__ Best ka_meet_scan(const TaskShared& S, const KaSub& sb, const int lane, const bool valid)
+{
+        const int startb = sb.startb, endb = sb.endb;
+        const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
+        const KaState* f = S.fbuf + sb.roff;
+        const KaState* b = S.bbuf + sb.roff;
+        const float middle = (float)(endb - startb) / 2.0f + (float)startb;
+        const int rrec = mid + 1;
+        float g3, g7, g6n, g6f;
+        if (KIND == KA_SS) {
+                g3 = -S.gpo; g7 = -S.gpo;
+                g6n = (startb == 0) ? -S.tgpe : -S.gpe;
+                g6f = (endb == S.Lb) ? -S.tgpe : -S.gpe;
+        } else {
+                const float* R = S.p1 + ((long long)rrec << 6);
+                g3 = R[55] * S.p1_mult; g7 = R[55 - 64] * S.p1_mult;
+                g6n = (startb == 0) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
+                g6f = (endb == S.Lb) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
+        }
+        Best B = { -KA_F, -KA_F, 0x7fffffff, 0x7fffffff };
+        for (int i = startb + lane; valid && i <= endb; i += GL) {
+                const KaState fi = f[i - startb], bi = b[i - startb];
+                float sub = fabsf(middle - (float)i);
+                sub = sub / 1000.0f;
+                const int kb = (i - startb) * 8;
+                if (i < endb) {
+                        float c2, c5, dummy1, dummy2;
+                        col_terms<KIND>(S, i + 1, c2, dummy1, dummy2);
+                        col_terms<KIND>(S, i, c5, dummy1, dummy2);
+                        best_consider(B, fi.a + bi.a - sub, kb + 0);
+                        best_consider(B, fi.a + bi.ga + c2 - sub, kb + 1);
+                        best_consider(B, fi.a + bi.gb + g3 - sub, kb + 2);
+                        best_consider(B, fi.ga + bi.a + c5 - sub, kb + 3);
+                        best_consider(B, fi.gb + bi.gb + g6n - sub, kb + 4);
+                        best_consider(B, fi.gb + bi.a + g7 - sub, kb + 5);
+                } else {
+                        best_consider(B, fi.a + bi.gb + g3 - sub, kb + 2);
+                        best_consider(B, fi.gb + bi.gb + g6f - sub, kb + 4);
+                }
+        }
+#pragma unroll
+        for (int off = GL / 2; off >= 1; off >>= 1) {
+                const float omx = __shfl_xor(B.mx, off, 64);
+                const float omx2 = __shfl_xor(B.mx2, off, 64);
+                const int okey = __shfl_xor(B.key, off, 64);
+                const int okey2 = __shfl_xor(B.key2, off, 64);
+                best_merge(B, omx, omx2, okey, okey2);
+        }
+        return B;
+}
+
+// The decision of one sub-problem (one lane): margin into the trial's running sum, the flip rule (aln_seqseq.c:376-414),
+// the raw path entries and the two child windows (aln_controller.c:194-436).  Returns the number of non-empty children
+// (c[0] is the one the recursion enters first).
+__device__ __forceinline__ int ka_dfs_decide(TaskShared& S, const KaSub& sb, const Best& B, const bool is_top, KaSub* c)
+{
+        const int startb = sb.startb, endb = sb.endb;
+        const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
+        int meet = -1, tr = -1;
+        if (B.key != 0x7fffffff) {
+                const int ord = B.key & 7;
+                meet = startb + (B.key >> 3);
+                tr = ord + 1 + (ord >= 3 ? 1 : 0);
+        }
+        if (is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
+        if (B.mx2 > -KA_F) { S.rf.msum += B.mx - B.mx2; S.rf.mcount += 1; }
+        if (S.rf.thr > 0.0f && B.key2 != 0x7fffffff && B.mx2 > -KA_F) {
+                const float margin = B.mx - B.mx2;
+                if (margin < S.rf.thr) {
+                        if (S.rf.trial > 0 && S.rf.counter % S.rf.stride == S.rf.trial - 1) {
+                                const int ord2 = B.key2 & 7;
+                                meet = startb + (B.key2 >> 3);
+                                tr = ord2 + 1 + (ord2 >= 3 ? 1 : 0);
+                        }
+                        S.rf.counter += 1;
+                }
+        }
+        if (tr <= 0) return 0;
+        const KaState Z = { 0.0f, -KA_F, -KA_F };
+        const KaState GA = { -KA_F, 0.0f, -KA_F };
+        const KaState GB = { -KA_F, -KA_F, 0.0f };
+        KaSub c1, c2;
+        c1.starta = sb.starta; c1.startb = startb; c1.fin = sb.fin;
+        c2.enda = sb.enda; c2.endb = endb; c2.bin = sb.bin;
+        c1.enda = c1.starta; c1.endb = c1.startb; c1.bin = Z;
+        c2.starta = c2.enda; c2.startb = c2.endb; c2.fin = Z;
+        c1.pad = 0; c2.pad = 0; c1.roff = 0; c2.roff = 0;
+        int* path = S.raw;
+        switch (tr) {
+        case 1:
+                path[mid] = meet; path[mid + 1] = meet + 1;
+                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                break;
+        case 2:
+                path[mid] = meet;
+                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                c2.starta = mid; c2.startb = meet + 1; c2.fin = GA;
+                break;
+        case 3:
+                path[mid] = meet;
+                c1.enda = mid - 1; c1.endb = meet - 1; c1.bin = Z;
+                c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
+                break;
+        case 5:
+                path[mid + 1] = meet + 1;
+                c1.enda = mid; c1.endb = meet - 1; c1.bin = GA;
+                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                break;
+        case 6:
+                c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
+                c2.starta = mid + 1; c2.startb = meet; c2.fin = GB;
+                break;
+        default: /* 7 */
+                path[mid + 1] = meet + 1;
+                c1.enda = mid - 1; c1.endb = meet; c1.bin = GB;
+                c2.starta = mid + 1; c2.startb = meet + 1; c2.fin = Z;
+                break;
+        }
+        int n = 0;
+        if (c1.starta < c1.enda && c1.startb < c1.endb) c[n++] = c1;
+        if (c2.starta < c2.enda && c2.startb < c2.endb) c[n++] = c2;
+        return n;
+}
+
+// The whole subtree below `root` (at most KA_WDFS_ROWS rows), depth first, by the calling wave.  `area`: LDS of an idle
+// wave (stack of KaWdfsEntry, the sub-problems in flight, their pack list); wlds: staging regions for ka_packed.
+template <int KIND, int NRES, int NB>
+__device__ __forceinline__ void ka_wave_dfs(TaskShared& S, const KaSub root, const Best rootB, const bool root_is_top, const int lane,
+                                            char* wlds, const int nreg, const int reg_stride, char* area, const float* tss)
+{
+        KaWdfsEntry* stack = (KaWdfsEntry*)area;                     // <= 2 * log2(rows) + 2 entries
+        KaSub* fly = (KaSub*)(area + 32 * sizeof(KaWdfsEntry));       // the (up to two) sub-problems whose passes run
+        int2* pack = (int2*)(fly + 2);
+        int* ctl = (int*)(pack + 4);                                  // [0] stack height, [1] children of the last decision
+        // the root arrives with its candidates (its passes ran with its sibling's)
+        if (lane == 0) {
+                KaWdfsEntry e; e.sub = root; e.mx = rootB.mx; e.mx2 = rootB.mx2; e.key = rootB.key; e.key2 = rootB.key2;
+                stack[0] = e; ctl[0] = 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        bool top = root_is_top;
+        while (true) {
+                const int h = ((volatile int*)ctl)[0];
+                if (h <= 0) break;
+                // decide the node on top of the stack
+                if (lane == 0) {
+                        const KaWdfsEntry e = stack[h - 1];
+                        const Best B = { e.mx, e.mx2, e.key, e.key2 };
+                        KaSub c[2];
+                        const int n = ka_dfs_decide(S, e.sub, B, top, c);
+                        int row = 0;
+                        for (int k = 0; k < n; ++k) {
+                                c[k].roff = row; row += c[k].endb - c[k].startb + 1;
+                                fly[k] = c[k];
+                                pack[2 * k] = make_int2(k, KA_FWD); pack[2 * k + 1] = make_int2(k, KA_BWD);
+                        }
+                        ctl[0] = h - 1; ctl[1] = n;
+                }
+                top = false;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int n = ((volatile int*)ctl)[1];
+                if (n == 0) continue;
+                // passes of the children (all of them in one job), then their candidates, 32 lanes per child
+                ka_packed<KIND, NRES, 16, NB>(S, fly, pack, 2 * n, 0, lane, tss, KIND != KA_SS ? wlds : nullptr, nreg, reg_stride);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                {
+                        const int g = lane >> 5;
+                        const bool valid = g < n;
+                        const KaSub cs = fly[valid ? g : 0];
+                        const Best B = ka_meet_scan<KIND, 32>(S, cs, lane & 31, valid);
+                        // the child entered first (index 0) must end on top: push the second one first
+                        if ((lane & 31) == 0 && valid) {
+                                const int hh = ((volatile int*)ctl)[0];
+                                KaWdfsEntry e; e.sub = cs; e.mx = B.mx; e.mx2 = B.mx2; e.key = B.key; e.key2 = B.key2;
+                                stack[hh + (n - 1 - g)] = e;
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) ctl[0] = ((volatile int*)ctl)[0] + n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // Depth-first Hirschberg recursion for refinement trials (aln_refine.c:93-346).  A trial flips the n-th uncertain
 // meetup in DFS order, and a flip changes the sub-problems below it: the number of uncertain meetups in the whole left
 // subtree decides what happens in the right one, so the sub-problems of a trial are inherently sequential (as in the
-// reference, aln_controller.c: child 1 completely before child 2).  One sub-problem per iteration: its two passes run
-// as the usual work items (strips pipelined over the waves, packed jobs), then its meetup (wave 0, with the flip rule
-// and the fp32 margin sum of S.rf), then its children go on the stack, right one first.  The stack is S.q[0]; the
-// sub-problem in flight is S.q[1][0], its children arrive in S.q[1][8..9]; row buffers are reused from offset 0.
+// reference, aln_controller.c: child 1 completely before child 2).  But only the DECISIONS are: the passes of a
+// sub-problem need nothing but its window.  One decision per iteration (thread 0: the flip rule, the fp32 margin sum
+// of S.rf, the children's windows), then the passes of BOTH children as the usual work items (strips pipelined over
+// the waves, packed jobs) and their candidate scans (one wave each); both go on the stack with their candidates, the
+// one the recursion enters first on top.  Subtrees of at most KA_WDFS_ROWS rows are handed to one wave (ka_wave_dfs).
+// The stack is S.q[0] (+ candidates), the sub-problems in flight are S.q[1][0..1].
 // ------------------------------------------------------------------------------------------
 template <int KIND, int NRES, int NB>
 __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves, const float* tss, const bool first_trial)
@@ -722,6 +927,8 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
         const int lane = tid & 63;
         const int wave = tid >> 6;
         const int g = max(S.La, S.Lb) + 2;
+        // candidates of the sub-problems on the stack (S.q[0]): four words each, in a work list the depth-first order never fills
+        int4* const cand = (int4*)S.pack[1][0];
         for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;               // init_alnmem / the re-initialisation of refine_edge (:206-215)
         if (tid == 0) {
                 KaSub root;
@@ -730,47 +937,93 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
                 root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.dfs_top = 0;
-                if (S.La > 0 && S.Lb > 0) { S.q[0][0] = root; S.dfs_top = 1; }
                 S.rf.msum = 0.0f; S.rf.mcount = 0; S.rf.counter = 0;
                 S.ctl->msum = 0.0; S.ctl->mcount = 0;
                 if (first_trial) { S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f; }
+                // the root's passes run alone
+                S.dfs_valid = 0;
+                if (S.La > 0 && S.Lb > 0) {
+                        S.q[1][0] = root;
+                        for (int par = 0; par < 2; ++par) {
+                                KaCtl::Lvl& L = S.ctl->lvl[par];
+                                L.nsub = 0; L.rowalloc = 0; L.nitems = 0; L.next_item = 0; L.next_job = 0; L.npack[0] = 0; L.npack[1] = 0;
+                        }
+                        S.ctl->lvl[0].nsub = 1;
+                        S.ctl->lvl[0].rowalloc = S.Lb + 1;
+                        ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La, S.Lb);
+                        S.dfs_valid = 1;
+                }
         }
         __syncthreads();
         bool at_root = true;
         while (true) {
-                if (tid == 0) {
-                        S.dfs_valid = 0;
-                        if (S.dfs_top > 0) {
-                                KaSub cur = S.q[0][--S.dfs_top];
-                                cur.roff = 0;
-                                S.q[1][0] = cur;
-                                for (int par = 0; par < 2; ++par) {
-                                        KaCtl::Lvl& L = S.ctl->lvl[par];
-                                        L.nsub = 0; L.rowalloc = 0; L.nitems = 0; L.next_item = 0; L.next_job = 0; L.npack[0] = 0; L.npack[1] = 0;
+                // ---- the passes and candidate scans of the sub-problems in flight (S.q[1][0 .. n-1]: a decided node's children) ----
+                const int n = S.dfs_valid;
+                if (n > 0) {
+                        const KaSub* qc = S.q[1];
+                        ka_run_items<KIND, NRES, NB>(S, &S.ctl->lvl[0], 0, qc, lds_waves, tss, nullptr);
+                        __syncthreads();
+                        if (wave < n) {
+                                const KaSub cs = qc[wave];
+                                const Best B = ka_meet_scan<KIND, 64>(S, cs, lane, true);
+                                // the child the recursion enters first (index 0) ends on top of the stack
+                                if (lane == 0) {
+                                        const int pos = S.dfs_top + (n - 1 - wave);
+                                        S.q[0][pos] = cs;
+                                        cand[pos] = make_int4(__float_as_int(B.mx), __float_as_int(B.mx2), B.key, B.key2);
                                 }
-                                S.ctl->lvl[0].nsub = 1;
-                                S.ctl->lvl[0].rowalloc = cur.endb - cur.startb + 1;
-                                ka_emit_items(ka_level_out(S, 0, false), 0, cur.starta, cur.enda, cur.endb - cur.startb);
-                                S.dfs_valid = 1;
+                        }
+                        __syncthreads();
+                }
+                // ---- the decision of the node on top of the stack ----
+                if (tid == 0) {
+                        S.dfs_top += n;
+                        S.dfs_valid = -1;                             // stack empty: the trial is complete
+                        if (S.dfs_top > 0) {
+                                const int pos = --S.dfs_top;
+                                const KaSub cur = S.q[0][pos];
+                                const int4 cb = cand[pos];
+                                if (cur.enda - cur.starta <= KA_WDFS_ROWS && !S.dbgskip) {
+                                        S.q[1][0] = cur; cand[pos] = cb;      // (the wave below reads them from here)
+                                        S.q[1][1].pad = pos;
+                                        S.dfs_valid = -2;
+                                } else {
+                                        const Best B = { __int_as_float(cb.x), __int_as_float(cb.y), cb.z, cb.w };
+                                        KaSub c[2];
+                                        const int nc = ka_dfs_decide(S, cur, B, first_trial && at_root, c);
+                                        for (int par = 0; par < 2; ++par) {
+                                                KaCtl::Lvl& L = S.ctl->lvl[par];
+                                                L.nsub = 0; L.rowalloc = 0; L.nitems = 0; L.next_item = 0; L.next_job = 0; L.npack[0] = 0; L.npack[1] = 0;
+                                        }
+                                        const KaLevelOut lo = ka_level_out(S, 0, false);
+                                        int row = 0;
+                                        for (int k = 0; k < nc; ++k) {
+                                                c[k].roff = row; row += c[k].endb - c[k].startb + 1;
+                                                S.q[1][k] = c[k];
+                                                ka_emit_items(lo, k, c[k].starta, c[k].enda, c[k].endb - c[k].startb);
+                                        }
+                                        S.ctl->lvl[0].nsub = nc;
+                                        S.ctl->lvl[0].rowalloc = row;
+                                        S.dfs_valid = nc;
+                                }
                         }
                 }
                 __syncthreads();
-                if (!S.dfs_valid) break;
-                const KaSub* qc = S.q[1];
-                ka_run_items<KIND, NRES, NB>(S, &S.ctl->lvl[0], 0, qc, lds_waves, tss, nullptr);
-                __syncthreads();
-                if (wave == 0) {
-                        const KaLevelOut lout = ka_level_out(S, 1, true);
-                        ka_meetup<KIND, 64, true>(S, qc, 0, 1, S.q[1] + 8, lout, lane, first_trial && at_root);
+                const int st = S.dfs_valid;
+                if (st == -1) break;
+                if (st == -2) {
+                        // a small subtree: wave 0 takes all of it (in a depth-first order the other waves have nothing to do anyway)
+                        if (wave == 0) {
+                                const int4 cb = cand[S.q[1][1].pad];
+                                const Best B = { __int_as_float(cb.x), __int_as_float(cb.y), cb.z, cb.w };
+                                ka_wave_dfs<KIND, NRES, NB>(S, S.q[1][0], B, first_trial && at_root, lane, lds_waves, 4, KA_WAVE_LDS,
+                                                            lds_waves + 7 * KA_WAVE_LDS, tss);
+                        }
+                        __syncthreads();
+                        if (tid == 0) S.dfs_valid = 0;
+                        __syncthreads();
                 }
                 at_root = false;
-                __syncthreads();
-                if (tid == 0) {
-                        // children: the left one is processed first, so it goes on the stack last
-                        const int nchild = S.ctl->lvl[1].nsub;
-                        for (int k = nchild - 1; k >= 0; --k) S.q[0][S.dfs_top++] = S.q[1][8 + k];
-                }
-                __syncthreads();
         }
 }
 
@@ -998,52 +1251,97 @@ __device__ void ka_sp_build(TaskShared& S, const KaTreeDev& D, const KaTaskDesc&
         __syncthreads();
 }
 
-__device__ void ka_sp_score(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+// The walk adds ONE term at a time to ONE float (sp_score.c:134-189): the order of the additions is part of the result
+// and the chain cannot be split.  What can be parallel is everything around the additions: one thread per path column
+// works out its column's terms -- the (i, j) products in the reference's order, then the gap term(s), with the sign
+// folded in (x - y == x + (-y)) -- into an LDS buffer, and one thread adds the buffer up in order (loads run ahead of
+// the dependent adds: the chain costs an add per term instead of a trip to L2 per term).
+// lds: KA_SP_TB floats + 2 * blockDim.x ints.
+#define KA_SP_TB 24576
+__device__ void ka_sp_score(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds)
 {
-        if (threadIdx.x == 0) {
-                const int* path = S.coded;
-                const int* fa0 = S.sp_freq;
-                const int* fb0 = S.sp_freq + 24 * S.len_a;
-                const int nsa = T.nsip_a, nsb = T.nsip_b;
-                const float gpo = T.gpo, gpe = T.gpe, tgpe = T.tgpe;
-                const float* subm = D.subm;
-                float total = 0.0f;
-                int pos_a = 0, pos_b = 0;
-                bool in_a = false, in_b = false;
-                const int plen = path[0];
-                for (int c = 1; c <= plen; ++c) {
-                        const int step = path[c] & 3;
-                        const float pen = (path[c] & 32) ? tgpe : gpe;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        float* const buf = (float*)lds;
+        int* const wtot = (int*)(buf + KA_SP_TB);                     // per-wave totals of the scan
+        const int* path = S.coded;
+        const int* fa0 = S.sp_freq;
+        const int* fb0 = S.sp_freq + 24 * S.len_a;
+        const int nsa = T.nsip_a, nsb = T.nsip_b;
+        const float gpo = T.gpo, gpe = T.gpe, tgpe = T.tgpe;
+        const float* subm = D.subm;
+        const int plen = path[0];
+        float total = 0.0f;                                            // (thread 0's)
+        for (int c0 = 1; c0 <= plen; c0 += KA_NT) {
+                const int c = c0 + tid;
+                const bool in = c <= plen;
+                const int code = in ? path[c] : 0;
+                const int step = code & 3;
+                const float pen = (code & 32) ? tgpe : gpe;
+                const int prev = (in && c > 1) ? (path[c - 1] & 3) : 0;
+                const int* fa = fa0 + 24 * ((in && step != 1) ? S.srcA[c] - 1 : 0);
+                const int* fb = fb0 + 24 * ((in && step != 2) ? S.srcB[c] - 1 : 0);
+                // the column's term count
+                int nza = 0, nzb = 0, cnt = 0;
+                if (in) {
                         if (step == 0) {
-                                const int* fa = fa0 + 24 * pos_a;
-                                const int* fb = fb0 + 24 * pos_b;
-                                for (int i = 0; i < 23; ++i) {
-                                        const int ai = fa[i];
-                                        if (ai == 0) continue;
-                                        for (int j = 0; j < 23; ++j) {
-                                                const int bj = fb[j];
-                                                if (bj == 0) continue;
-                                                total += (float)(ai * bj) * subm[i * 23 + j];
-                                        }
-                                }
-                                const int n_res_a = fa[23], n_res_b = fb[23];
-                                const int n_gap_a = nsa - n_res_a, n_gap_b = nsb - n_res_b;
-                                total -= (float)(n_res_a * n_gap_b + n_gap_a * n_res_b) * pen;
-                                in_a = false; in_b = false; pos_a++; pos_b++;
-                        } else if (step == 1) {
-                                const int n_pairs = nsa * fb0[24 * pos_b + 23];
-                                if (!in_a) total -= (float)n_pairs * gpo;
-                                total -= (float)n_pairs * pen;
-                                in_a = true; in_b = false; pos_b++;
-                        } else {
-                                const int n_pairs = fa0[24 * pos_a + 23] * nsb;
-                                if (!in_b) total -= (float)n_pairs * gpo;
-                                total -= (float)n_pairs * pen;
-                                in_a = false; in_b = true; pos_a++;
-                        }
+                                for (int i = 0; i < 23; ++i) nza += fa[i] != 0;
+                                for (int j = 0; j < 23; ++j) nzb += fb[j] != 0;
+                                cnt = nza * nzb + 1;
+                        } else if (step == 1) cnt = (prev == 1) ? 1 : 2;
+                        else cnt = (prev == 2) ? 1 : 2;
                 }
-                S.sp_value = total;
+                // exclusive scan over the block
+                int sc = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sc, d, 64); if (lane >= d) sc += y; }
+                __syncthreads();                                       // (the previous block's sum is done with buf / wtot)
+                if (lane == 63) wtot[wave] = sc;
+                __syncthreads();
+                int off = sc - cnt, all = 0;
+                for (int w = 0; w < KA_NW; ++w) { const int x = wtot[w]; if (w < wave) off += x; all += x; }
+                for (int base = 0; base < all; base += KA_SP_TB) {
+                        // this thread's terms with a buffer index in [base, base + KA_SP_TB)
+                        if (in && off < base + KA_SP_TB && off + cnt > base) {
+                                int k = off - base;
+                                auto put = [&](float v) { if (k >= 0 && k < KA_SP_TB) buf[k] = v; ++k; };
+                                if (step == 0) {
+                                        for (int i = 0; i < 23; ++i) {
+                                                const int ai = fa[i];
+                                                if (ai == 0) continue;
+                                                for (int j = 0; j < 23; ++j) {
+                                                        const int bj = fb[j];
+                                                        if (bj == 0) continue;
+                                                        put((float)(ai * bj) * subm[i * 23 + j]);
+                                                }
+                                        }
+                                        const int n_res_a = fa[23], n_res_b = fb[23];
+                                        const int n_gap_a = nsa - n_res_a, n_gap_b = nsb - n_res_b;
+                                        put(-((float)(n_res_a * n_gap_b + n_gap_a * n_res_b) * pen));
+                                } else if (step == 1) {
+                                        const int n_pairs = nsa * fb[23];
+                                        if (prev != 1) put(-((float)n_pairs * gpo));
+                                        put(-((float)n_pairs * pen));
+                                } else {
+                                        const int n_pairs = fa[23] * nsb;
+                                        if (prev != 2) put(-((float)n_pairs * gpo));
+                                        put(-((float)n_pairs * pen));
+                                }
+                        }
+                        __syncthreads();
+                        if (tid == 0) {
+                                const int n = min(KA_SP_TB, all - base);
+                                int k = 0;
+                                for (; k + 8 <= n; k += 8) {
+                                        const float4v x = *(const float4v*)(buf + k), y = *(const float4v*)(buf + k + 4);
+                                        total += x.x; total += x.y; total += x.z; total += x.w;
+                                        total += y.x; total += y.y; total += y.z; total += y.w;
+                                }
+                                for (; k < n; ++k) total += buf[k];
+                        }
+                        if (base + KA_SP_TB < all) __syncthreads();        // the buffer is refilled
+                }
         }
+        if (tid == 0) S.sp_value = total;
         __syncthreads();
 }
 
@@ -1753,9 +2051,14 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         char* lds_waves = ka_smem + KA_LDS_WAVES;
         const KaTaskDesc T = D.tasks[task];
         const int tid = threadIdx.x;
+        // KA_FLAG_TIMING: cycles of this member in [0] preparation, [1] SP tables, [2] recursions, [3] path coding, [4] SP scoring,
+        // [5] waiting for the other members, [6] record / path / merged profile / columns, [7] DP cells
+        long long tq[7] = {0, 0, 0, 0, 0, 0, 0};
+        long long tlast = __builtin_amdgcn_s_memtime();
+        auto lap = [&](int k) { const long long now = __builtin_amdgcn_s_memtime(); tq[k] += now - tlast; tlast = now; };
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
-                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = 0; S.prof = nullptr;
+                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = D.wdfs ? 0 : 1; S.prof = nullptr;   // (dbgskip: here "no wave-local subtrees")
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
                 S.profb = D.prof_arena + D.node_prof[T.b];
@@ -1816,8 +2119,10 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         const bool inline_mode = D.refine_mode == 3;
         const bool refine_it = D.refine_mode == 1 || inline_mode || (D.refine_mode == 2 && T.refine != 0);
         const int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
+        lap(0);
         if (refine_it) ka_sp_build(S, D, T);
         __syncthreads();
+        lap(1);
 
         // P2: the trials
         float best_sp = -KA_F, avg_margin = 0.0f, best_msum = 0.0f;
@@ -1835,16 +2140,19 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 else if (D.nres <= 5) ka_hirschberg_dfs<KA_PP, 5, NB>(S, lds_waves, tss, k == 0);
                 else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
                 __syncthreads();
+                lap(2);
                 if (k == 0) { top_meet0 = S.ctl->top_meet; top_tr0 = S.ctl->top_tr; top_score0 = S.ctl->top_score; }
                 if (D.refine_mode >= 3) ka_code_path(S, (int*)lds_waves);     // add_gap_info_to_path_n (aln_run.c:713)
                 else ka_code_path_refine(S, (int*)lds_waves);                 // convert_raw_path (aln_refine.c:243)
+                lap(3);
                 const float tr_msum = S.rf.msum;
                 const int tr_mcount = S.rf.mcount;
                 bool take = true;
                 if (refine_it) {
-                        ka_sp_score(S, D, T);
+                        ka_sp_score(S, D, T, lds_waves);
                         take = S.sp_value > best_sp;
                         if (take) best_sp = S.sp_value;
+                        lap(4);
                 }
                 if (take) {
                         best_msum = tr_msum; best_mcount = tr_mcount; best_k = k;
@@ -1880,6 +2188,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                         S.dfs_valid = (wk == 0) ? (member == 0) : (wm == member);
                 }
                 __syncthreads();
+                lap(5);
                 if (!S.dfs_valid) return;
         }
         {
@@ -1930,6 +2239,15 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T, alnlen);
         ka_update_colof(S, D, T, alnlen);
+        if (D.timing) {
+                __syncthreads();
+                lap(6);
+                if (tid == 0) {
+                        long long* tm = D.timing + 8ll * task;
+                        for (int x = 0; x < 7; ++x) tm[x] = tq[x];
+                        tm[7] = (long long)S.La * S.Lb;
+                }
+        }
 }
 
 // Entry of the task kernels.  blocks[b] = (task, member | launched cluster size << 8); task < 0: padding.

@@ -13,6 +13,15 @@ import kalign_amd  # noqa: E402
 from kalign_amd import guide  # noqa: E402
 
 
+def level_of(tasks, nseq):
+    lvl = np.zeros(2 * nseq - 1, np.int32)
+    out = np.zeros(len(tasks), np.int32)
+    for t, (a, b, c) in enumerate(tasks):
+        lvl[c] = max(lvl[a], lvl[b]) + 1
+        out[t] = lvl[c]
+    return out
+
+
 def main():
     nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     length = int(sys.argv[2]) if len(sys.argv) > 2 else 400
@@ -20,7 +29,8 @@ def main():
     ctx = kalign_amd.Context(0)
     job = bench.make_job(ctx, nseq, length, False, 1)
     subm, scal = bench.scoring(False)
-    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    from kalign_amd import api
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"], flags=api.FLAG_TIMING)
     for _ in range(2):
         ctx.tree_run()
         ctx.tree_sync()
@@ -41,6 +51,17 @@ def main():
         changed = sum(not np.array_equal(a, b) for a, b in zip(g, gaps0))
         print("mode %d (%s): %.1f ms kernels (last launch sequence, %d launches), %.1f ms wall incl. set-up; alnlen %d; "
               "sequences whose gaps differ from the first pass: %d" % (mode, name, ms, nl, wall, r[-1].plen, changed))
+        tm = ctx.tree_timing()
+        if tm is not None:
+            # the finishing member of every task; longest task of every tree level, summed over the levels
+            tm = np.asarray(tm)[:, :7].astype(np.float64) / 2400.0   # s_memtime at 2.4 GHz (as tools/levels_real.py)
+            lv = level_of(job["tasks"], nseq)
+            tot = np.zeros(7)
+            for L in range(1, lv.max() + 1):
+                idx = np.where(lv == L)[0]
+                tot += tm[idx[np.argmax(tm[idx].sum(axis=1))]]
+            print("   longest task per level, summed (us): prep %.0f  sp tables %.0f  recursions %.0f  path coding %.0f  sp scoring %.0f  "
+                  "waiting %.0f  record+merge %.0f" % tuple(tot))
     if cpu:
         from oracle import refdrv
         for nt in (16, 1):
