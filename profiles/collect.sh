@@ -11,6 +11,17 @@ WLS=${@:-headline c2 c3}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 for WL in $WLS; do
+  if [ $WL = refine ]; then
+    # refinement (ka_tree_refine, modes 4 / 1 / 2 / 3 after a first pass) on 1024 x 400: kernel trace only
+    OUT=$ROOT/gpurun_out/prof_${TAG}_refine
+    mkdir -p $OUT
+    cd /tmp
+    timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/refine_time.py 1024 400 > $OUT/kt.log 2>&1
+    cd $ROOT
+    cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+    tail -12 $OUT/kt.log
+    continue
+  fi
   case $WL in
     headline) ARGS="";;
     c2) ARGS="--nseq 1024 --len 400";;
