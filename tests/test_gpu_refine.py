@@ -196,3 +196,33 @@ def test_refinement_against_the_live_reference(ctx, mode, anchors, nseq, length,
         assert np.array_equal(got, want)
     assert all(recs[t].plen == plen[job.tasks[t][2]] for t in range(len(recs)))
     assert np.array_equal(np.array([r.confidence for r in recs], np.float32), conf_after)
+
+
+def test_refine_survives_arena_growth(ctx):
+    """KA_DEBUG_SMALL_ARENAS: the arenas overflow, ka_tree_sync grows them and repeats the refinement pass (not the
+    first pass) -- same answer"""
+    g = Golden("refine_cons_prot48_all")
+    ctx.debug_set_hooks(1)
+    try:
+        recs, paths, gaps = run_refine(ctx, g, first_pass=False)
+    finally:
+        ctx.debug_set_hooks(0)
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+
+
+def test_refine_of_a_forest_equals_separate_jobs(ctx):
+    """two independent alignments as one forest job (n_tasks < numseq - 1, two roots): refining the forest gives each
+    tree the result of its own golden"""
+    from kalign_amd import guide
+    ga, gb = Golden("refine_prot32x200_all"), Golden("refine_ragged_all")
+    assert np.array_equal(ga.subm, gb.subm) and np.array_equal(ga.scal, gb.scal)
+    codes, tasks, dist, spans = guide.forest([(ga.codes, ga.tasks, ga.seq_distances), (gb.codes, gb.tasks, gb.seq_distances)])
+    ctx.tree_upload(codes, tasks, ga.subm, ga.scal, dist)
+    ctx.tree_refine(1)
+    recs, paths, gaps = ctx.tree_download()
+    for g, (s0, t0, ns, nt) in zip((ga, gb), spans):
+        for got, want in zip(gaps[s0:s0 + ns], g.gaps_list()):
+            assert np.array_equal(got, want)
+        assert np.array_equal(np.array([r.confidence for r in recs[t0:t0 + nt]], np.float32), g.conf_after)
