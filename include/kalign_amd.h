@@ -127,6 +127,9 @@ int ka_tree_run(ka_ctx* ctx);
    confidences (the reference reads task->confidence); only read for mode 2; NULL = computed here with a mode-4 pass.  Asynchronous like
    ka_tree_run; ka_tree_sync / ka_tree_download then return the refined records, paths and gaps (records carry the
    kept trial's confidence). */
+#define KA_REFINE_ADAPTIVE 256      /* mode | KA_REFINE_ADAPTIVE: aln_param's adaptive_budget (`kalign --adaptive-budget`,
+                                       aln_refine.c:187-193, 255-282; modes 1 and 2): 1 .. 8 trials per edge, from the share of
+                                       very uncertain meetups of its baseline trial */
 int ka_tree_refine(ka_ctx* ctx, int mode, const float* conf_in);
 int ka_tree_sync(ka_ctx* ctx);
 long long ka_tree_paths_size(ka_ctx* ctx);      /* ints needed for paths_out (valid after run+sync) */

@@ -654,6 +654,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.nres = c->nres;
         D.trace = c->h_trace;
         D.refine_mode = 0;
+        D.refine_adaptive = 0;
         D.prof_task = -1;
         D.wdfs = getenv("KA_NO_WDFS") ? 0 : 1;                         // measurements / tests
         if (const char* e = getenv("KA_PROF_TASK")) D.prof_task = atoi(e);      // measurements only (tools/levels_real.py)
@@ -691,7 +692,8 @@ static int tree_launch(ka_ctx* c)
 {
         if (tree_reset(c)) return KA_FAIL;
         KaTreeDev D = tree_dev(c);
-        D.refine_mode = c->refine_mode;
+        D.refine_mode = c->refine_mode & 255;
+        D.refine_adaptive = (c->refine_mode >> 8) & 1;
         c->partial = false;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
@@ -757,15 +759,16 @@ static int refine_blocks(ka_ctx* c, int mode)
 {
         std::vector<int2> tbl;
         c->refine_off.assign(1, 0);
-        const int flips = mode == 3 ? 2 : (mode == 4 ? 0 : 4);
+        const int base_mode = mode & 255;
+        const int flips = base_mode == 3 ? 2 : (base_mode == 4 ? 0 : 4);      // (adaptive budget: up to 7, shared by at most 4 members)
         for (auto& L : c->levels) {
                 int nref = 0;
-                for (int t : L) nref += (flips > 0 && (mode != 2 || c->descs[t].refine)) ? 1 : 0;
+                for (int t : L) nref += (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? 1 : 0;
                 int G = 1;
                 if (!c->shared_gpu && !getenv("KA_REFINE_SERIAL"))
                         while (G * 2 <= flips && (long long)nref * G * 2 + ((long long)L.size() - nref) <= c->n_cus) G *= 2;
                 for (int t : L) {
-                        const int g = (flips > 0 && (mode != 2 || c->descs[t].refine)) ? G : 1;
+                        const int g = (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? G : 1;
                         for (int m = 0; m < g; m++) tbl.push_back(make_int2(t, m | (g << 8)));
                 }
                 c->refine_off.push_back((int)tbl.size());
@@ -786,10 +789,13 @@ static int refine_launch(ka_ctx* c, int mode)
         return KA_OK;
 }
 
-extern "C" int ka_tree_refine(ka_ctx* c, int mode, const float* conf_in)
+extern "C" int ka_tree_refine(ka_ctx* c, int mode_in, const float* conf_in)
 {
         if (!c || !c->have_job) return fail("no uploaded job");
-        if (mode < 1 || mode > 4) return fail("ka_tree_refine: mode must be 1 (all), 2 (confident), 3 (inline) or 4 (first pass, exact confidences)");
+        const int mode = mode_in & 255, adaptive = mode_in & KA_REFINE_ADAPTIVE;
+        if (mode < 1 || mode > 4 || (mode_in & ~(255 | KA_REFINE_ADAPTIVE)))
+                return fail("ka_tree_refine: mode must be 1 (all), 2 (confident), 3 (inline) or 4 (first pass, exact confidences), optionally | KA_REFINE_ADAPTIVE");
+        if (adaptive && mode != 1 && mode != 2) return fail("ka_tree_refine: KA_REFINE_ADAPTIVE goes with modes 1 and 2 (refine_edge)");
         if (c->n_tasks < 1) return fail("ka_tree_refine: no tasks");
         HIPCHK(hipSetDevice(c->device));
         if (c->ran && !c->synced && ka_tree_sync(c)) return KA_FAIL;
@@ -818,7 +824,7 @@ extern "C" int ka_tree_refine(ka_ctx* c, int mode, const float* conf_in)
                 thr = (n % 2 == 0) ? (v[n / 2 - 1] + v[n / 2]) / 2.0F : v[n / 2];
         }
         for (int t = 0; t < c->n_tasks; t++) c->descs[t].refine = mode == 1 ? 1 : (mode == 2 && conf_in[t] <= thr ? 1 : 0);
-        return refine_launch(c, mode);
+        return refine_launch(c, mode | adaptive);
 }
 
 extern "C" int ka_tree_sync(ka_ctx* c)

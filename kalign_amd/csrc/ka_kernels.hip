@@ -126,6 +126,8 @@ struct TaskShared {
         int dfs_top, dfs_valid;        // ka_hirschberg_dfs: sub-problems on the stack / a sub-problem was popped
         int* best_coded; int* best_srcA; int* best_srcB;   // refinement: the best trial's coded path and column sources
         int* sp_freq;                  // refinement: residue counts [23] + residues per column [1] of both operands (compute_sp_score)
+        float* mlog;                   // refinement, adaptive budget: the margins of the trial in recursion order (first mlog_cap of them), or null
+        int mlog_cap, adapt_trials;
         float sp_value;
         int Gw, member_w;              // cluster size / member index the recursion currently works with
         int split;
@@ -786,7 +788,10 @@ __device__ __forceinline__ int ka_dfs_decide(TaskShared& S, const KaSub& sb, con
                 tr = ord + 1 + (ord >= 3 ? 1 : 0);
         }
         if (is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
-        if (B.mx2 > -KA_F) { S.rf.msum += B.mx - B.mx2; S.rf.mcount += 1; }
+        if (B.mx2 > -KA_F) {
+                if (S.mlog && S.rf.mcount < S.mlog_cap) S.mlog[S.rf.mcount] = B.mx - B.mx2;      // aln_seqseq.c:378-380
+                S.rf.msum += B.mx - B.mx2; S.rf.mcount += 1;
+        }
         if (S.rf.thr > 0.0f && B.key2 != 0x7fffffff && B.mx2 > -KA_F) {
                 const float margin = B.mx - B.mx2;
                 if (margin < S.rf.thr) {
@@ -2118,7 +2123,11 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         // 4 = one depth-first trial with first-pass coding (the first pass with the reference's exact confidence sums)
         const bool inline_mode = D.refine_mode == 3;
         const bool refine_it = D.refine_mode == 1 || inline_mode || (D.refine_mode == 2 && T.refine != 0);
-        const int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
+        int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
+        // --adaptive-budget (aln_refine.c:187-193, 255-282; refine_edge only): the baseline's margins are kept (the first
+        // max(64, min(len_a, len_b) + 1) of them) and the number of trials, 1 .. 8, follows from the share of meetups
+        // whose margin is below a quarter of the mean
+        const bool adaptive_it = D.refine_adaptive && refine_it && !inline_mode;
         lap(0);
         if (refine_it) ka_sp_build(S, D, T);
         __syncthreads();
@@ -2133,7 +2142,12 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         if (member >= Gt) return;
         for (int k = 0; k < n_trials; ++k) {
                 if (k > 0 && (k - 1) % Gt != member) continue;       // another member's trial
-                if (tid == 0) { S.rf.thr = (k == 0) ? 0.0f : avg_margin; S.rf.trial = k; S.rf.stride = max(n_trials - 1, 1); }
+                if (tid == 0) {
+                        S.rf.thr = (k == 0) ? 0.0f : avg_margin; S.rf.trial = k; S.rf.stride = max(n_trials - 1, 1);
+                        S.mlog = (adaptive_it && k == 0) ? (float*)S.raw2 : nullptr;       // (raw2 is idle until the path is coded)
+                        S.mlog_cap = min(max(min(S.len_a, S.len_b) + 1, 64), S.len_a + S.len_b + 8);
+                        S.adapt_trials = 0;
+                }
                 __syncthreads();
                 if (S.kind == KA_SS) ka_hirschberg_dfs<KA_SS, 23, NB>(S, lds_waves, tss, k == 0);
                 else if (S.kind == KA_SP) ka_hirschberg_dfs<KA_SP, 23, NB>(S, lds_waves, tss, k == 0);
@@ -2141,6 +2155,20 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
                 __syncthreads();
                 lap(2);
+                if (k == 0 && adaptive_it) {
+                        const int mc = S.rf.mcount;
+                        if (mc > 0) {
+                                const float vu = (S.rf.msum / (float)mc) * 0.25F;
+                                const int seen = min(mc, S.mlog_cap);
+                                int mine = 0;
+                                for (int i = tid; i < seen; i += KA_NT) mine += (S.mlog[i] < vu) ? 1 : 0;
+                                if (mine) atomicAdd(&S.adapt_trials, mine);
+                                __syncthreads();
+                                const float frac = (float)S.adapt_trials / (float)mc;
+                                n_trials = 1 + (int)(7.0F * frac + 0.5F);
+                        }
+                        __syncthreads();
+                }
                 if (k == 0) { top_meet0 = S.ctl->top_meet; top_tr0 = S.ctl->top_tr; top_score0 = S.ctl->top_score; }
                 if (D.refine_mode >= 3) ka_code_path(S, (int*)lds_waves);     // add_gap_info_to_path_n (aln_run.c:713)
                 else ka_code_path_refine(S, (int*)lds_waves);                 // convert_raw_path (aln_refine.c:243)

@@ -345,9 +345,9 @@ int create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct 
  * (:93-346).  The job create_msa_tree uploaded is still in HBM (sequences, tree, parameters, consistency table):
  * ka_tree_refine runs the pass there.  KALIGN_REFINE_CONFIDENT compares task confidences with their median; the
  * device recomputes them as the reference's exact float sums (conf_in = NULL) instead of trusting the first pass's
- * level-order sums.  Anything else -- another msa, ap->adaptive_budget (aln_refine.c:255-282: a trial count per edge
- * from the baseline's margins; not on the device) -- goes through the reference's own function, which works on the
- * state create_msa_tree left on the host.
+ * level-order sums.  ap->adaptive_budget (aln_refine.c:255-282: a trial count per edge from the baseline's margins) is a
+ * flag of the same call.  Another msa (an alignment the device does not hold) goes through the reference's own
+ * function, which works on the state create_msa_tree left on the host.
  */
 int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int refine_mode)
 {
@@ -358,7 +358,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         if(refine_mode == 0){                            /* KALIGN_REFINE_NONE */
                 return OK;
         }
-        if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx || ap->adaptive_budget || (refine_mode != 1 && refine_mode != 2)){
+        if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx || (refine_mode != 1 && refine_mode != 2)){
                 glue_job_msa = NULL;                     /* the host state moves on without the device */
                 glue_counts[GLUE_REFINE_REF]++;
                 return kalign_ref_refine_alignment(msa, ap, t, refine_mode);
@@ -369,7 +369,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
                 lens[i] = msa->sequences[i]->len;
                 total += lens[i];
         }
-        if(ka_tree_refine(glue_ctx, refine_mode, NULL) || ka_tree_sync(glue_ctx)){
+        if(ka_tree_refine(glue_ctx, refine_mode | (ap->adaptive_budget ? KA_REFINE_ADAPTIVE : 0), NULL) || ka_tree_sync(glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         RUN(glue_collect(msa, t, lens, total));

@@ -55,6 +55,8 @@ typedef struct {
         /* refinement trials (aln_struct.h:32-35; round-robin mode of aln_seqseq.c:385-414) */
         float flip_threshold;
         int flip_trial, flip_stride, flip_counter;
+        float* flip_margins;    /* adaptive budget: the baseline trial's margins (aln_refine.c:187-193) */
+        int flip_margin_alloc;
 } dp_t;
 
 /* ---- gap / score terms --------------------------------- */
@@ -240,6 +242,7 @@ static void ko_meetup(dp_t* d, int startb, int endb, int mid, int* meet, int* tr
         consider(&B, f[i].gb + b[i].gb + g6_far - sub, i, 6);
 
         if(B.max2 > -F){                          /* aln_seqseq.c:376-383 */
+                if(d->flip_margins && d->mcount < d->flip_margin_alloc) d->flip_margins[d->mcount] = B.max - B.max2;
                 d->msum += B.max - B.max2;
                 d->mcount++;
         }
@@ -887,8 +890,10 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                      ko_task_rec* recs, int* paths_out, long long paths_cap,
                      int* gaps_out, int dump_task, float* prof_dump,
                      int* anchor_ids_out, int* maps_out, uint64_t* bonus_hash_out,
-                     int refine_mode, const float* conf_in)
+                     int refine_mode_in, const float* conf_in)
 {
+        const int refine_mode = refine_mode_in & 255;
+        const int adaptive = (refine_mode_in >> 8) & 1;             /* + 256: ap->adaptive_budget */
         const int nprof = 2 * numseq - 1;
         const float gpo0 = scal[0], gpe0 = scal[1], tgpe0 = scal[2];
         const float dist_scale = scal[3], vsm_amax = scal[4], usw = scal[5];
@@ -1028,7 +1033,16 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                            trials by aln_wrap.c:222-224): every edge, first-pass path coding, confidence = the best SP score */
                         const int inline_mode = refine_mode == 3;
                         const int refine_it = refine_mode == 1 || inline_mode || (refine_mode == 2 && conf_in[tid] <= conf_threshold);
-                        const int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
+                        int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
+                        /* adaptive budget (aln_refine.c:187-193, 255-282; refine_edge only): the baseline's margins are kept and
+                           the number of trials follows from the share of very uncertain meetups */
+                        const int adaptive_it = adaptive && refine_it && !inline_mode;
+                        if(adaptive_it){
+                                int est = (len_a < len_b ? len_a : len_b) + 1;
+                                if(est < 64) est = 64;
+                                d.flip_margins = malloc(sizeof(float) * (size_t)est);
+                                d.flip_margin_alloc = est;
+                        }
                         int* cand = malloc(sizeof(int) * (size_t)(len_a + len_b + 3));
                         float best_sp = -F, avg_margin = 0.0F, best_msum = 0.0F;
                         int best_mcount = 0;
@@ -1053,6 +1067,17 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                                         memcpy(coded, cand, sizeof(int) * (size_t)(cand[0] + 2));
                                 }
                                 if(k == 0 && d.mcount > 0) avg_margin = d.msum / (float)d.mcount;
+                                if(k == 0 && adaptive_it){
+                                        if(d.mcount > 0){
+                                                int n_vu = 0;
+                                                const float vu = avg_margin * 0.25F;
+                                                const int seen = d.mcount < d.flip_margin_alloc ? d.mcount : d.flip_margin_alloc;   /* (beyond it the reference reads past its buffer) */
+                                                for(int m_i = 0; m_i < seen; m_i++) if(d.flip_margins[m_i] < vu) n_vu++;
+                                                const float frac = (float)n_vu / (float)d.mcount;
+                                                n_trials = 1 + (int)(7.0F * frac + 0.5F);
+                                        }
+                                        free(d.flip_margins); d.flip_margins = NULL;
+                                }
                         }
                         d.flip_threshold = 0.0F;
                         task_conf = best_mcount > 0 ? best_msum / (float)best_mcount : 0.0f;
@@ -1132,8 +1157,8 @@ int ko_msa_tree_refine(int numseq, const uint8_t* codes, const int* off, const i
                        int n_anchors, float cons_weight, int mode, const float* conf_in,
                        ko_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out)
 {
-        if(mode < 1 || mode > 3) return 1;
-        if(mode == 2 && !conf_in) return 1;
+        if((mode & 255) < 1 || (mode & 255) > 3 || (mode & ~0x1ff)) return 1;      /* + 256: adaptive budget (modes 1, 2) */
+        if((mode & 255) == 2 && !conf_in) return 1;
         return ko_tree_impl(numseq, codes, off, lens, seq_distances, n_tasks, abc, subm, scal, n_anchors, cons_weight,
                             recs, paths_out, paths_cap, gaps_out, -1, NULL, NULL, NULL, NULL, mode, conf_in);
 }

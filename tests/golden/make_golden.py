@@ -214,6 +214,18 @@ def refine_cases():
     refine_case("refine_prot24_scaled_all", synth.dssim(24, 150, seed=11), 1, dist_scale=0.5, use_seq_weights=1.0)
     refine_case("refine_ragged_all", [s[:40 + 13 * i] for i, s in enumerate(synth.dssim(20, 400, seed=13))], 1)
     inline_cases()
+    adaptive_cases()
+
+
+def adaptive_cases():
+    """mode + 256 = --adaptive-budget (aln_refine.c:255-282): the number of trials of an edge (1..8) follows from the share
+    of very uncertain meetups of its baseline trial"""
+    data = os.path.join(HERE, "data")
+    refine_case("refine_prot32x200_all_adaptive", synth.dssim(32, 200, seed=1), 1 + 256)
+    refine_case("refine_cons_prot24_conf_adaptive", synth.dssim(24, 120, seed=7), 2 + 256, n_anchors=3)
+    refine_case("refine_BB30014_all_adaptive", synth.read_fasta(os.path.join(data, "BB30014.tfa"))[1], 1 + 256)
+    refine_case("refine_dna16x300_all_adaptive", synth.dssim(16, 300, dna=True, seed=1), 1 + 256, type_=0)
+    refine_case("refine_ragged_all_adaptive", [s[:40 + 13 * i] for i, s in enumerate(synth.dssim(20, 400, seed=13))], 1 + 256)
 
 
 def inline_cases():
@@ -287,6 +299,8 @@ if __name__ == "__main__":
         refine_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "inline":
         inline_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "adaptive":
+        adaptive_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "bpm":
         bpm_case("bpm_mixed", 31)
         guide_cases()

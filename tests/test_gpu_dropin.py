@@ -52,7 +52,7 @@ CLI_CASES = [
     # refinement (aln_refine.c) on the device: ka_tree_refine behind refine_alignment
     ("BB11001.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "confident"]),
     ("BB12006.tfa", ["--fast", "--refine", "confident"]), ("BB12006.tfa", ["--refine", "all", "--realign", "1"]),
-    ("BB30014.tfa", ["--refine", "all", "--adaptive-budget"]),        # adaptive budget: the glue defers to the reference
+    ("BB30014.tfa", ["--refine", "all", "--adaptive-budget"]), ("BB12006.tfa", ["--refine", "confident", "--adaptive-budget"]),
 ]
 
 

@@ -54,6 +54,7 @@ def test_refinement_matches_reference(ctx, name):
         assert np.array_equal(got, want)
     assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
     assert int(g.n_differ) > 0 or int(g.mode) == 3      # (the inline trials never beat the baseline on these inputs)
+    # mode + 256 = KA_REFINE_ADAPTIVE (--adaptive-budget): 1 .. 8 trials per edge
 
 
 def test_refine_is_repeatable_and_run_returns_to_the_first_pass(ctx):
