@@ -656,7 +656,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.refine_mode = 0;
         D.refine_adaptive = 0;
         D.prof_task = -1;
-        D.wdfs = getenv("KA_NO_WDFS") ? 0 : 1;                         // measurements / tests
+        D.wdfs = (getenv("KA_NO_WDFS") ? 0 : 1) | (getenv("KA_NO_LS0") ? 0 : 2);   // measurements / tests
         if (const char* e = getenv("KA_PROF_TASK")) D.prof_task = atoi(e);      // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));

@@ -72,7 +72,8 @@ struct KaTreeDev {
         long long* timing;             // [n_tasks][8] phase cycle counts (KA_FLAG_TIMING) or null
         int refine_mode;               // refinement pass (ka_tree_refine): 0 none, 1 KALIGN_REFINE_ALL, 2 KALIGN_REFINE_CONFIDENT
         int refine_adaptive;           // ... with aln_param's adaptive_budget (modes 1, 2)
-        int wdfs;                      // refinement: small subtrees of the depth-first recursion run wave-locally (KA_NO_WDFS=1 in the environment: off)
+        int wdfs;                      // refinement: bit 0 small subtrees of the depth-first recursion run wave-locally (KA_NO_WDFS=1 in the
+                                       // environment: off), bit 1 the baseline trial runs level-synchronously (KA_NO_LS0=1: off)
         int prof_task;                 // KA_FLAG_TIMING: the task whose per-level times are kept (-1: the root; KA_PROF_TASK in the environment)
         int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table

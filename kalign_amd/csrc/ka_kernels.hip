@@ -128,6 +128,8 @@ struct TaskShared {
         int* sp_freq;                  // refinement: residue counts [23] + residues per column [1] of both operands (compute_sp_score)
         float* mlog;                   // refinement, adaptive budget: the margins of the trial in recursion order (first mlog_cap of them), or null
         int mlog_cap, adapt_trials;
+        int2* mrec;                    // refinement, level-synchronous baseline trial: (recursion-order key, margin) of every meetup
+        int nrec;
         float sp_value;
         int Gw, member_w;              // cluster size / member index the recursion currently works with
         int split;
@@ -246,9 +248,13 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
 // sub-problems with a handful of columns each.
 // FLIP: a refinement trial (one sub-problem per call, in DFS order): the margins are summed in fp32 in that order and an
 // uncertain meetup may take its runner-up (aln_seqseq.c:376-414, round-robin mode); state in S.rf.
-template <int KIND, int GL, bool FLIP = false>
+// REC (refinement's baseline trial run level-synchronously): every sub-problem carries its place in the reference's
+// depth-first order as a base-3 key in KaSub::pad -- digit 1 / 2 at its depth for the child the recursion enters first /
+// second, zeros below: numeric order of the keys = preorder of the recursion tree -- and every meetup appends (key, margin)
+// to S.mrec; sorted by key afterwards, the margins add up in the reference's order.  kdig: weight of the children's digit.
+template <int KIND, int GL, bool FLIP = false, bool REC = false>
 __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const int k0, const int ncur, KaSub* qnext,
-                                          const KaLevelOut& lout, const int wlane, const bool top_level)
+                                          const KaLevelOut& lout, const int wlane, const bool top_level, const int kdig = 0)
 {
         const int lane = wlane % GL;                                 // lane within the sub-problem's group
         const int ksub = k0 + wlane / GL;
@@ -314,6 +320,10 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 tr = ord + 1 + (ord >= 3 ? 1 : 0);
         }
         if (leader && is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
+        if (REC && leader && B.mx2 > -KA_F) {
+                const int idx = atomicAdd(&S.nrec, 1);
+                S.mrec[idx] = make_int2(sb.pad, __float_as_int(B.mx - B.mx2));
+        }
         if (FLIP && leader) {
                 // the reference's meetups run one after the other in DFS order: fp32 margin sum in that order, and the
                 // running number of uncertain meetups decides which of them a trial flips (round-robin)
@@ -339,7 +349,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         c2.enda = sb.enda; c2.endb = endb; c2.bin = sb.bin;
         c1.enda = c1.starta; c1.endb = c1.startb; c1.bin = Z;          // empty unless a transition fills them in
         c2.starta = c2.enda; c2.startb = c2.endb; c2.fin = Z;
-        c1.pad = 0; c2.pad = 0; c1.roff = 0; c2.roff = 0;
+        c1.pad = REC ? sb.pad + kdig : 0; c2.pad = REC ? sb.pad + 2 * kdig : 0; c1.roff = 0; c2.roff = 0;
         if (tr > 0) {
                 int* path = S.raw;
                 switch (tr) {
@@ -570,7 +580,11 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
         }
 }
 
-template <int KIND, int NRES, int NB>
+__device__ const int ka_pow3[20] = { 1, 3, 9, 27, 81, 243, 729, 2187, 6561, 19683, 59049, 177147, 531441, 1594323, 4782969, 14348907,
+                                     43046721, 129140163, 387420489, 1162261467 };
+#define KA_REC_DEPTH 19                                              // recursion levels the keys of ka_meetup<.., REC> can tell apart
+
+template <int KIND, int NRES, int NB, bool REC = false>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
@@ -677,15 +691,16 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 {
                         const KaLevelOut lout = ka_level_out(S, (level + 1) & 1, true);
                         const int est_cols = S.Lb >> level;          // typical columns per sub-problem at this depth
+                        const int kdig = REC ? ka_pow3[max(KA_REC_DEPTH - 2 - level, 0)] : 0;
                         if (est_cols > 48) {
                                 for (int k = S.member_w * KA_NW + wave; k < ncur; k += KA_NW * S.Gw)
-                                        ka_meetup<KIND, 64>(S, qc, k, ncur, qn, lout, lane, level == 0);
+                                        ka_meetup<KIND, 64, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
                         } else if (est_cols > 6) {
                                 for (int k = (S.member_w * KA_NW + wave) * 4; k < ncur; k += KA_NW * S.Gw * 4)
-                                        ka_meetup<KIND, 16>(S, qc, k, ncur, qn, lout, lane, level == 0);
+                                        ka_meetup<KIND, 16, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
                         } else {
                                 for (int k = (S.member_w * KA_NW + wave) * 16; k < ncur; k += KA_NW * S.Gw * 16)
-                                        ka_meetup<KIND, 4>(S, qc, k, ncur, qn, lout, lane, level == 0);
+                                        ka_meetup<KIND, 4, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
                         }
                 }
                 ka_cluster_sync(S);
@@ -1809,12 +1824,13 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
                 S.priv.b = (KaState*)(pr + x); x += ka_align_up(n * 12, 16);
                 o += (long long)S.G * pb;
         }
-        S.best_coded = nullptr; S.best_srcA = nullptr; S.best_srcB = nullptr; S.sp_freq = nullptr;
+        S.best_coded = nullptr; S.best_srcA = nullptr; S.best_srcB = nullptr; S.sp_freq = nullptr; S.mrec = nullptr;
         if (refine) {
                 S.best_coded = (int*)(base + o); o += ka_align_up(n * 4, 16);
                 S.best_srcA = (int*)(base + o);  o += ka_align_up(n * 4, 16);
                 S.best_srcB = (int*)(base + o);  o += ka_align_up(n * 4, 16);
                 S.sp_freq = (int*)(base + o);    o += ka_align_up(n * 24 * 4, 16);
+                S.mrec = (int2*)(base + o);      o += ka_align_up(n * 8, 16);
         }
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
         if (cons_maxlen > 0) {
@@ -1840,7 +1856,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
         if (g > 1) b += g * ka_private_bytes(la, lb);
-        if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16;
+        if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16 + (n * 8 + 15) / 16 * 16;
         if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 12 + 15) / 16 * 16;
         return b;
 }
@@ -2033,6 +2049,44 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         return 0;
 }
 
+// The margins of a level-synchronous baseline trial (ka_meetup<.., REC>) in the reference's recursion order: sort the
+// (key, margin) records by key in LDS (bitonic, padded to a power of two), then one thread adds them up in fp32 -- and
+// keeps the first mlog_cap of them for the adaptive budget.  Returns false when there are more records than the buffer
+// holds (the caller repeats the trial depth first).
+#define KA_REC_SORT_CAP 8192
+__device__ bool ka_margins_in_order(TaskShared& S, char* lds)
+{
+        const int tid = threadIdx.x;
+        const int n = S.nrec;
+        if (n > KA_REC_SORT_CAP) return false;
+        int2* buf = (int2*)lds;
+        int m = 1;
+        while (m < n) m <<= 1;
+        for (int i = tid; i < m; i += KA_NT) buf[i] = (i < n) ? S.mrec[i] : make_int2(0x7fffffff, 0);
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < m; i += KA_NT) {
+                                const int l = i ^ j;
+                                if (l > i) {
+                                        const int2 a = buf[i], b = buf[l];
+                                        const bool up = (i & k) == 0;
+                                        if ((a.x > b.x) == up) { buf[i] = b; buf[l] = a; }
+                                }
+                        }
+                        __syncthreads();
+                }
+        }
+        if (S.mlog) for (int i = tid; i < min(n, S.mlog_cap); i += KA_NT) S.mlog[i] = __int_as_float(buf[i].y);
+        if (tid == 0) {
+                float sum = 0.0f;
+                for (int i = 0; i < n; ++i) sum += __int_as_float(buf[i].y);
+                S.rf.msum = sum; S.rf.mcount = n; S.rf.counter = 0;
+        }
+        __syncthreads();
+        return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // Refinement pass (refine_alignment, aln_refine.c:36-346): one workgroup per edge.  Operand preparation as in
 // ka_task_body; then refine_edge's trials -- trial 0 without flips, trials 1..4 with the baseline's mean margin as the
@@ -2063,7 +2117,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         auto lap = [&](int k) { const long long now = __builtin_amdgcn_s_memtime(); tq[k] += now - tlast; tlast = now; };
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
-                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = D.wdfs ? 0 : 1; S.prof = nullptr;   // (dbgskip: here "no wave-local subtrees")
+                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = (D.wdfs & 1) ? 0 : 1; S.prof = nullptr;   // (dbgskip: here "no wave-local subtrees")
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
                 S.profb = D.prof_arena + D.node_prof[T.b];
@@ -2149,10 +2203,25 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                         S.adapt_trials = 0;
                 }
                 __syncthreads();
-                if (S.kind == KA_SS) ka_hirschberg_dfs<KA_SS, 23, NB>(S, lds_waves, tss, k == 0);
-                else if (S.kind == KA_SP) ka_hirschberg_dfs<KA_SP, 23, NB>(S, lds_waves, tss, k == 0);
-                else if (D.nres <= 5) ka_hirschberg_dfs<KA_PP, 5, NB>(S, lds_waves, tss, k == 0);
-                else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
+                // The baseline trial has no flips: its sub-problems are independent and run level-synchronously (all waves busy,
+                // a fifth of the depth-first time); the margins are put back into recursion order afterwards.
+                bool done = false;
+                if (k == 0 && (D.wdfs & 2) && S.La < (1 << 17)) {
+                        if (tid == 0) S.nrec = 0;
+                        __syncthreads();
+                        if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
+                        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
+                        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, true>(S, nullptr, lds_waves, tss, D.trace);
+                        else ka_hirschberg<KA_PP, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
+                        __syncthreads();
+                        done = ka_margins_in_order(S, lds_waves);
+                }
+                if (!done) {
+                        if (S.kind == KA_SS) ka_hirschberg_dfs<KA_SS, 23, NB>(S, lds_waves, tss, k == 0);
+                        else if (S.kind == KA_SP) ka_hirschberg_dfs<KA_SP, 23, NB>(S, lds_waves, tss, k == 0);
+                        else if (D.nres <= 5) ka_hirschberg_dfs<KA_PP, 5, NB>(S, lds_waves, tss, k == 0);
+                        else ka_hirschberg_dfs<KA_PP, 23, NB>(S, lds_waves, tss, k == 0);
+                }
                 __syncthreads();
                 lap(2);
                 if (k == 0 && adaptive_it) {
