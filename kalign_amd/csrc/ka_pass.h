@@ -173,12 +173,15 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const int lastl = nl - 1;                                     // lane holding the strip's last row
         const bool last_is_b = (nr & 1) == 0;
         const bool first = (k == 0);
-        // Hand-over batches: a strip starts 63 columns (the lane skew) plus one batch behind the strip above it.  Inside a
-        // workgroup the batch is 16 columns (start delay 79 instead of 127 columns); across workgroups it stays at 64 --
-        // every batch costs an agent-scope release there.
-        // (declared below: first = strip 0 of its pass has no strip above; the last strip's row is read after the level's barrier)
-        const int CBM = (acq_agent || k == 0) ? 63 : 15;              // consumer side: batch mask of the strip above
-        const int PBM = (rel_agent || k + 1 >= ka_strips_of(nrows)) ? 63 : 15;   // producer side
+        // Hand-over batches: a strip starts 63 columns (the lane skew) plus one batch behind the strip above it, and every
+        // hand-over is an event step on both sides (a flush behind a release fence; a wait and a reload) that breaks the
+        // branch-free step pairs.  64 columns per batch, inside a workgroup as well as across workgroups: 16-column batches
+        // inside a workgroup (start delay 79 instead of 127 columns) measured 4 % slower on the 4096 x 400 tree and 12 %
+        // slower on 4096 x 2000 nucleotides -- consumers run behind their producers anyway, so the start delay is not
+        // what a pass waits for, the event steps are.  (Tried on top, no gain: a 16-column FIRST batch, fetching the next
+        // batch one batch early, raising a batch's flag one batch late.)
+        const int CBM = 63;                                           // consumer side: batch mask of the strip above
+        const int PBM = 63;                                           // producer side
         // acq_agent: the strip above (k-1) runs in ANOTHER workgroup of the cluster; rel_agent: the strip below (k+1) does
         // (or may: work items beyond the statically dealt ones are pulled by whoever is free).  Neighbours inside this
         // workgroup hand over at workgroup scope: no L2 write-back, no L1 invalidate.

@@ -14,7 +14,7 @@ pre = "%s_%s" % (tag, wl)
 
 def find(sub, suffix):
     hits = glob.glob(os.path.join(d, sub, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None      # (a re-collected directory keeps the older runs' files)
 
 
 def rows(path):
