@@ -89,3 +89,15 @@ def test_member_on_context_call_sequence():
                        ("aln_guide_tree",), ("upload", "tasks4", "sd4", keep), ("run",), ("rows",),
                        ("aln_guide_tree",), ("upload", "tasks8", "sd8", keep), ("run",), ("rows",)]
     assert rows == ["row11"]
+
+
+def test_integration_md_quotes_the_compiled_glue():
+    """INTEGRATION.md section 1 must be, verbatim, the functions of oracle/dropin/kalign_amd_glue.c that `make -C oracle
+    dropin` compiles (tools/make_integration.py regenerates it)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_integration", os.path.join(root, "tools", "make_integration.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.render() == open(os.path.join(root, "INTEGRATION.md")).read()

@@ -40,7 +40,8 @@ def function_text(src, name):
     return src[start:i + 1]
 
 
-def main():
+def render():
+    """INTEGRATION.md with section 1 regenerated from the glue file"""
     src = open(GLUE).read()
     doc = open(DOC).read()
     a = doc.index("### 1a.")
@@ -48,7 +49,17 @@ def main():
     parts = []
     for heading, fns in SEAMS:
         parts.append("### %s\n\n```c\n%s\n```\n" % (heading, "\n\n".join(function_text(src, f) for f in fns)))
-    doc = doc[:a] + "\n".join(parts) + "\n" + doc[b:]
+    return doc[:a] + "\n".join(parts) + "\n" + doc[b:]
+
+
+def main():
+    import sys
+    doc = render()
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        if doc != open(DOC).read():
+            sys.exit("INTEGRATION.md section 1 is not the text of %s: run python tools/make_integration.py" % os.path.relpath(GLUE, ROOT))
+        print("INTEGRATION.md section 1 == the compiled glue")
+        return
     open(DOC, "w").write(doc)
     print("INTEGRATION.md: section 1 regenerated from", os.path.relpath(GLUE, ROOT))
 
