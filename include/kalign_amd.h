@@ -280,6 +280,13 @@ int ka_run_encoded(ka_ctx* ctx, int numseq, const uint8_t* tree_codes, const uin
                    const int* off, const int* lens, const float* subm, const float* scal,
                    int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads,
                    uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out);
+/* The same with refinement (kalign_run_seeded / kalign_run_realign's `refine` argument): refine_mode 0 none, 1 / 2
+   (optionally | KA_REFINE_ADAPTIVE) refine_alignment after the last alignment (aln_wrap.c:229-232, :506-509), 3
+   KALIGN_REFINE_INLINE: every alignment of the run is create_msa_tree_inline_refine (:222-226, :498-502). */
+int ka_run_encoded_refine(ka_ctx* ctx, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
+                   const int* off, const int* lens, const float* subm, const float* scal,
+                   int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads, int refine_mode,
+                   uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out);
 
 /*
  * Guide tree: build_tree_kmeans (lib/src/bisectingKmeans.c:177-271) -- anchors by length

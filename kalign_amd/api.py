@@ -46,7 +46,7 @@ EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
            "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
            "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from",
-           "ka_aln_guide_tree", "ka_run_encoded"]
+           "ka_aln_guide_tree", "ka_run_encoded", "ka_run_encoded_refine"]
 
 
 def lib_path():
@@ -112,6 +112,8 @@ def load_library():
     L.ka_tree_aligned_rows.argtypes = [vp, vp, C.c_ubyte, vp, C.c_longlong, vp]
     L.ka_run_encoded.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, C.c_int,
                                  C.c_ubyte, vp, C.c_longlong, vp]
+    L.ka_run_encoded_refine.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, C.c_int, C.c_int,
+                                        C.c_ubyte, vp, C.c_longlong, vp]
     L.ka_aln_guide_tree.argtypes = [vp, C.c_int, vp, C.c_longlong, C.c_int, C.c_ubyte, vp, vp, vp]
     L.ka_guide_tree.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]
     L.ka_guide_tree_from.argtypes = [C.c_int, vp, DIST_FN, vp, C.c_int, vp, vp, vp]
@@ -478,8 +480,9 @@ Context.aln_guide_tree = _aln_guide_tree
 
 
 def _run_encoded(self, tree_codes, codes, letters, subm, scal, n_anchors=0, weight=2.0, realign=0, dm_scale=None,
-                 n_threads=1, gap=b"-"):
-    """ka_run_encoded: guide tree, (consistency,) alignment, `realign` realignment iterations, rows -- one call.
+                 n_threads=1, gap=b"-", refine=0):
+    """ka_run_encoded(_refine): guide tree, (consistency,) alignment, `realign` realignment iterations, (refinement,)
+    rows -- one call.  refine: 0, 1, 2 (| 256 adaptive budget) or 3, as kalign_run_seeded's argument.
     Returns the aligned rows (bytes) in the order of the input sequences."""
     tflat, off, lens = _flatten(tree_codes)
     cflat, _, _ = _flatten(codes)
@@ -493,7 +496,10 @@ def _run_encoded(self, tree_codes, codes, letters, subm, scal, n_anchors=0, weig
     alen = np.zeros(n, np.int32)
     args = (self.h, n, _ptr(tflat), _ptr(cflat), _ptr(lflat), _ptr(off), _ptr(lens), _ptr(sub), _ptr(sc),
             int(n_anchors), float(weight), int(realign), _ptr(dms), int(n_threads), gap[0])
-    self._chk(self.L.ka_run_encoded(*args, None, 0, _ptr(alen)))            # the alignment stays in HBM: how long is it?
+    if refine:
+        self._chk(self.L.ka_run_encoded_refine(*args[:14], int(refine), args[14], None, 0, _ptr(alen)))
+    else:
+        self._chk(self.L.ka_run_encoded(*args, None, 0, _ptr(alen)))        # the alignment stays in HBM: how long is it?
     self._job = dict(lens=lens, ntasks=n - 1, n=n)
     return self.tree_aligned_rows(letters, gap=gap)
 

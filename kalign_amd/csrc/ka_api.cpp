@@ -1096,11 +1096,44 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
 // ---- kalign_run_seeded / kalign_run_realign between "sequences encoded" and "rows finalised" (aln_wrap.c:144-251,361-527)
 //      as one call: the composition of the entry points above, with the intermediate rows of realignment passes
 //      never leaving HBM ----
+// refine_mode: 0 none; 1 / 2 (| KA_REFINE_ADAPTIVE) refine_alignment after the last alignment (aln_wrap.c:229-232, :506-509);
+// 3 KALIGN_REFINE_INLINE: every alignment is create_msa_tree_inline_refine instead of create_msa_tree (:222-226, :498-502)
+static int run_encoded(ka_ctx* c, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
+                       const int* off, const int* lens, const float* subm, const float* scal,
+                       int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads, int refine_mode,
+                       uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out);
+
 extern "C" int ka_run_encoded(ka_ctx* c, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
                               const int* off, const int* lens, const float* subm, const float* scal,
                               int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads,
                               uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out)
 {
+        return run_encoded(c, numseq, tree_codes, codes, letters, off, lens, subm, scal, n_anchors, weight, realign_iterations, dm_scale,
+                           n_threads, 0, gap_char, rows_out, row_stride, alnlen_out);
+}
+
+extern "C" int ka_run_encoded_refine(ka_ctx* c, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
+                                     const int* off, const int* lens, const float* subm, const float* scal,
+                                     int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads,
+                                     int refine_mode, uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out)
+{
+        const int base = refine_mode & 255;
+        if (refine_mode < 0 || base > 3 || (refine_mode & ~(255 | KA_REFINE_ADAPTIVE)) || ((refine_mode & KA_REFINE_ADAPTIVE) && base != 1 && base != 2))
+                return fail("ka_run_encoded_refine: refine_mode must be 0, 1, 2 (optionally | KA_REFINE_ADAPTIVE) or 3");
+        return run_encoded(c, numseq, tree_codes, codes, letters, off, lens, subm, scal, n_anchors, weight, realign_iterations, dm_scale,
+                           n_threads, refine_mode, gap_char, rows_out, row_stride, alnlen_out);
+}
+
+static int run_encoded(ka_ctx* c, int numseq, const uint8_t* tree_codes, const uint8_t* codes, const uint8_t* letters,
+                       const int* off, const int* lens, const float* subm, const float* scal,
+                       int n_anchors, float weight, int realign_iterations, const float* dm_scale, int n_threads, int refine_mode,
+                       uint8_t gap_char, uint8_t* rows_out, long long row_stride, int* alnlen_out)
+{
+        const bool inline_refine = (refine_mode & 255) == 3;
+        auto align = [&]() -> int {
+                if (inline_refine ? ka_tree_refine(c, 3, nullptr) : ka_tree_run(c)) return KA_FAIL;
+                return ka_tree_sync(c);
+        };
         if (!c) return fail("null ctx");
         if (numseq < 2 || !tree_codes || !codes || !letters || !off || !lens || !subm || !scal || (!rows_out && !alnlen_out))
                 return fail("ka_run_encoded: bad arguments");
@@ -1109,7 +1142,7 @@ extern "C" int ka_run_encoded(ka_ctx* c, int numseq, const uint8_t* tree_codes, 
         if (ka_guide_tree(c, numseq, tree_codes, off, lens, n_threads, dm_scale, tasks.data(), sd.data())) return KA_FAIL;
         if (ka_tree_upload(c, numseq, codes, off, lens, sd.data(), numseq - 1, tasks.data(), subm, scal, KA_FLAG_DEVICE_GAPS)) return KA_FAIL;
         if (n_anchors > 0 && ka_tree_build_consistency(c, n_anchors, weight)) return KA_FAIL;
-        if (ka_tree_run(c) || ka_tree_sync(c)) return KA_FAIL;
+        if (align()) return KA_FAIL;
         std::vector<int> alen;
         int widest = 0;
         for (int it = 0; it < realign_iterations; it++) {
@@ -1117,7 +1150,10 @@ extern "C" int ka_run_encoded(ka_ctx* c, int numseq, const uint8_t* tree_codes, 
                 if (ka_aln_guide_tree(c, numseq, nullptr, 0, 0, 0, tasks.data(), sd.data(), nullptr)) return KA_FAIL;
                 if (ka_tree_upload(c, numseq, codes, off, lens, sd.data(), numseq - 1, tasks.data(), subm, scal,
                                    KA_FLAG_DEVICE_GAPS | KA_FLAG_KEEP_CONSISTENCY)) return KA_FAIL;
-                if (ka_tree_run(c) || ka_tree_sync(c)) return KA_FAIL;
+                if (align()) return KA_FAIL;
+        }
+        if ((refine_mode & 255) == 1 || (refine_mode & 255) == 2) {
+                if (ka_tree_refine(c, refine_mode, nullptr) || ka_tree_sync(c)) return KA_FAIL;
         }
         if (rows_prepare(c, letters, alen, &widest)) return KA_FAIL;
         if (alnlen_out) memcpy(alnlen_out, alen.data(), sizeof(int) * numseq);

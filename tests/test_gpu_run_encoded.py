@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from util import GOLDEN, Golden, cons_cases, tree_cases
+from util import GOLDEN, Golden, cons_cases, refine_cases, tree_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -35,6 +35,17 @@ def test_run_seeded(ctx, name):
     k = int(g.n_anchors) if hasattr(g, "n_anchors") else 0
     rows = ctx.run_encoded(g.tree_seqs, g.codes, g.sorted_seqs(), g.subm, g.scal, n_anchors=k,
                            weight=float(g.weight) if k else 2.0, n_threads=2)
+    assert input_order(g.ranks, rows) == [str(x) for x in g.rows]
+
+
+@pytest.mark.parametrize("name", refine_cases())
+def test_run_seeded_with_refinement(ctx, name):
+    """kalign_run_seeded(..., refine, adaptive_budget): KALIGN_REFINE_ALL / _CONFIDENT (with and without the adaptive
+    budget) after the alignment, KALIGN_REFINE_INLINE instead of it -- one call, rows of the real reference"""
+    g = Golden(name)
+    k = int(g.n_anchors)
+    rows = ctx.run_encoded(g.tree_seqs, g.codes, g.sorted_seqs(), g.subm, g.scal, n_anchors=k,
+                           weight=float(g.weight) if k else 2.0, n_threads=2, refine=int(g.mode))
     assert input_order(g.ranks, rows) == [str(x) for x in g.rows]
 
 
