@@ -181,7 +181,7 @@ int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_task_rec* r
 int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats);
 /* Per-task phase timings of the last run (KA_FLAG_TIMING): out[8*t + k], shader-clock cycles:
    0 operand prep, 1 Hirschberg, 2 path coding, 3 profile merge, 4 passes, 5 meetups, 6 recursion
-   levels, 7 DP rows*cols; followed by 16 x (sub-problems, pass cycles, meetup cycles) per
+   levels | workgroups used << 8 | workgroups offered << 16, 7 DP rows*cols; followed by 16 x (sub-problems, pass cycles, meetup cycles) per
    recursion level of the root task, followed by 512 values that only profiling builds (-DKA_PROF) fill:
    out must hold 8*n_tasks + 48 + 512 values. */
 int ka_tree_get_timing(ka_ctx* ctx, long long* out);
@@ -191,6 +191,9 @@ int ka_tree_get_timing(ka_ctx* ctx, long long* out);
 #define KA_DEBUG_SMALL_ARENAS 1
 #define KA_DEBUG_STARVE_ROOT_JOIN 2
 int ka_debug_set_hooks(ka_ctx* ctx, int hooks);
+/* Tools and tests: the KA_* environment switches (experiments and measurements; none is needed in production) are read
+   once, at ka_ctx_create.  This reads them again and rebuilds the launch plan of the uploaded job. */
+int ka_debug_reload_env(ka_ctx* ctx);
 /* Debug: 64 breadcrumb words written by workgroup 0 (context created with KA_TRACE=1 in the
    environment); readable while a kernel is still running. */
 int ka_debug_trace(ka_ctx* ctx, int* out64);
@@ -199,6 +202,9 @@ double ka_tree_cells(ka_ctx* ctx);
 /* Milliseconds spent in the DP kernels of the last ka_tree_run, measured with HIP events
    on the launch stream; n_launches receives the number of kernel launches. */
 int ka_tree_kernel_ms(ka_ctx* ctx, float* ms, int* n_launches);
+/* Measurements: the duration of every launch of the last run (needs KA_LAUNCH_EV=1 in the environment when the
+   context is created); returns the number of values written (<= cap), -1 on error. */
+int ka_tree_launch_ms(ka_ctx* ctx, float* ms, int cap);
 
 /*
  * Anchor consistency = the reference's default mode (anchor_consistency_build, anchor_consistency.c:194-275,

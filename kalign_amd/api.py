@@ -39,9 +39,9 @@ class TaskRec(C.Structure):
 DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
 EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_consistency_part",
-           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
+           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_debug_reload_env", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_refine", "ka_tree_sync", "ka_tree_paths_size",
-           "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms",
+           "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms", "ka_tree_launch_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
            "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
@@ -73,6 +73,7 @@ def load_library():
     L.ka_ctx_set_shared.argtypes = [vp, C.c_int]
     L.ka_last_error.restype = C.c_char_p
     L.ka_debug_set_hooks.argtypes = [vp, C.c_int]
+    L.ka_debug_reload_env.argtypes = [vp]
     L.ka_tree_profile_dev.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]
     L.ka_tree_reserve_profile_dev.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.ka_tree_build_consistency_part.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.c_int]
@@ -97,6 +98,7 @@ def load_library():
     L.ka_tree_cells.argtypes = [vp]
     L.ka_tree_cells.restype = C.c_double
     L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.ka_tree_launch_ms.argtypes = [vp, vp, C.c_int]
     L.ka_tree_run_tasks.argtypes = [vp, vp, C.c_int]
     L.ka_tree_reset.argtypes = [vp]
     L.ka_tree_node_len.argtypes = [vp, C.c_int]
@@ -167,6 +169,10 @@ class Context:
         """tests only: ka_debug_set_hooks (KA_DEBUG_SMALL_ARENAS = 1, KA_DEBUG_STARVE_ROOT_JOIN = 2)"""
         self._chk(self.L.ka_debug_set_hooks(self.h, int(hooks)))
 
+    def reload_env(self):
+        """tools / tests: the KA_* environment switches are read once at context creation; read them again"""
+        self._chk(self.L.ka_debug_reload_env(self.h))
+
     def fallback_runs(self):
         return int(self.L.ka_ctx_fallback_runs(self.h))
 
@@ -204,6 +210,14 @@ class Context:
         ms, n = C.c_float(0), C.c_int(0)
         self._chk(self.L.ka_tree_kernel_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def tree_launch_ms(self):
+        """per-launch kernel times of the last run (KA_LAUNCH_EV=1 when the context was created / reload_env)"""
+        out = np.zeros(96, np.float32)
+        n = self.L.ka_tree_launch_ms(self.h, _ptr(out), 96)
+        if n < 0:
+            raise RuntimeError(self.L.ka_last_error().decode())
+        return out[:n].tolist()
 
     def tree_cells(self):
         return self.L.ka_tree_cells(self.h)

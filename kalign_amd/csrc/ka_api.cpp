@@ -76,7 +76,34 @@ struct DevBuf {
         void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// The KA_* environment switches (experiments, measurements and tests; none is needed in production), read ONCE when the
+// context is created -- ka_debug_reload_env re-reads them for tools and tests that flip a switch on a live context.
+struct KaEnv {
+        bool trace = false, no_chain = false, no_queue = false, no_half = false, no_lean = false, chain_g1 = false, no_crit = false;
+        bool no_staging = false, no_wdfs = false, no_ls0 = false, refine_serial = false;
+        int chain_tasks = 0;           // KA_CHAIN_TASKS: the chained launch starts at the first level with at most this many tasks (0: CUs - 8)
+        int max_cluster = 0;           // KA_MAX_CLUSTER: workgroups one task may use (0: the default, 16)
+        int crit_top = 0;              // KA_CRIT_TOP: workgroups of the chain entry with the longest way to the root (0: default)
+        int prof_task = -1;            // KA_PROF_TASK: the task whose per-level times KA_FLAG_TIMING keeps (-1: the root)
+        int q1 = 1;                    // KA_Q1: 64-row strips (KaTreeDev::q1_mode)
+        int lean4 = 0;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU
+        bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
+};
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static void read_env(KaEnv& v)
+{
+        v = KaEnv();
+        v.trace = getenv("KA_TRACE") != nullptr; v.no_chain = getenv("KA_NO_CHAIN") != nullptr; v.no_queue = getenv("KA_NO_QUEUE") != nullptr;
+        v.no_half = getenv("KA_NO_HALF") != nullptr; v.no_lean = getenv("KA_NO_LEAN") != nullptr; v.chain_g1 = getenv("KA_CHAIN_G1") != nullptr;
+        v.no_crit = getenv("KA_NO_CRIT") != nullptr; v.no_staging = getenv("KA_NO_STAGING") != nullptr;
+        v.no_wdfs = getenv("KA_NO_WDFS") != nullptr; v.no_ls0 = getenv("KA_NO_LS0") != nullptr; v.refine_serial = getenv("KA_REFINE_SERIAL") != nullptr;
+        v.chain_tasks = env_int("KA_CHAIN_TASKS", 0); v.max_cluster = env_int("KA_MAX_CLUSTER", 0); v.crit_top = env_int("KA_CRIT_TOP", 0);
+        v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", 1); v.lean4 = env_int("KA_LEAN4", 0);
+        v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
+}
+
 struct ka_ctx {
+        KaEnv env;
         int device = 0;
         hipStream_t stream = nullptr;
         // ---- tree job ----
@@ -90,7 +117,7 @@ struct ka_ctx {
         std::vector<int2> blocks_flat;               // per level: (task, member | cluster size << 8) per workgroup
         std::vector<int> blocks_off;
         std::vector<int> level_lean;                 // level consists of seq-seq tasks only -> lean kernel
-        int max_cluster = 8;                         // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
+        int max_cluster = 16;                        // KA_MAX_CLUSTER env: workgroups (CUs) one task may use
         int refine_mode = 0;                         // the run in flight is a refinement pass (ka_tree_refine): 1 all, 2 confident
         DevBuf<int2> d_refine_blocks;                   // its workgroup table, level after level (refine_blocks)
         std::vector<int> refine_off;                    // [levels + 1] first block of every level in it
@@ -124,6 +151,7 @@ struct ka_ctx {
         DevBuf<ka_task_rec> d_recs;
         long long prof_cap = 0, path_cap = 0, scratch_cap = 0, dbg_cap = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        std::vector<hipEvent_t> launch_ev;           // KA_LAUNCH_EV: one event behind every launch of the last run
         // two pinned bounce buffers for large downloads into the caller's (pageable) memory
         char* pin[2] = { nullptr, nullptr };
         hipEvent_t pin_ev[2] = { nullptr, nullptr };
@@ -164,6 +192,8 @@ struct ka_ctx {
 };
 
 static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>& tbl, int* lean_out);
+static int plan_launches(ka_ctx* c);
+static int upload_plan(ka_ctx* c);
 static int setup_colof(ka_ctx* c);
 static int refine_blocks(ka_ctx* c, int mode);
 static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, const int* lens, int numseq,
@@ -188,7 +218,8 @@ extern "C" int ka_ctx_create(int device, ka_ctx** out)
         }
         hipError_t e = hipEventCreate(&c->ev0);
         if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-        if (e == hipSuccess && getenv("KA_TRACE")) {
+        read_env(c->env);
+        if (e == hipSuccess && c->env.trace) {
                 e = hipHostMalloc((void**)&c->h_trace, 64 * sizeof(int), hipHostMallocMapped);
                 if (e == hipSuccess) memset(c->h_trace, 0xff, 64 * sizeof(int));
         }
@@ -205,6 +236,21 @@ extern "C" int ka_debug_set_hooks(ka_ctx* c, int hooks)
 {
         if (!c) return fail("null ctx");
         c->test_hooks = hooks;
+        return KA_OK;
+}
+
+// Tools and tests that flip a KA_* switch on a live context: the environment is otherwise read once, at ka_ctx_create.
+// The launch plan of an uploaded job is rebuilt.
+extern "C" int ka_debug_reload_env(ka_ctx* c)
+{
+        if (!c) return fail("null ctx");
+        read_env(c->env);
+        if (c->have_job) {
+                if (c->ran && !c->synced && ka_tree_sync(c)) return KA_FAIL;
+                for (auto& d : c->descs) d.refine = 0;
+                c->refine_mode = 0;
+                if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
+        }
         return KA_OK;
 }
 
@@ -230,6 +276,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         c->d_cons_map_off.release(); c->d_sip_off.release();
         for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
         if (c->h_trace) (void)hipHostFree(c->h_trace);
+        for (hipEvent_t e : c->launch_ev) (void)hipEventDestroy(e);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -299,11 +346,13 @@ static int plan_launches(ka_ctx* c)
                 }
                 c->n_trees = numseq - n_tasks;
                 c->chain_level = -1;
-                if (!getenv("KA_NO_CHAIN") && !c->shared_gpu) {
+                if (!c->env.no_chain && !c->shared_gpu) {
                         for (int L = 0; L + 1 < max_level; L++) {
                                 bool all_ss = true;
                                 for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
-                                if (!all_ss && (int)c->levels[L].size() <= c->n_cus - 8) { c->chain_level = L; break; }   // one workgroup per CU, all resident
+                                int chain_tasks = c->n_cus - 8;
+                                if (c->env.chain_tasks > 0) chain_tasks = std::min(chain_tasks, c->env.chain_tasks);   // experiments
+                                if (!all_ss && (int)c->levels[L].size() <= chain_tasks) { c->chain_level = L; break; }   // one workgroup per CU, all resident
                         }
                 }
                 if (c->chain_level >= 0) {
@@ -325,7 +374,7 @@ static int plan_launches(ka_ctx* c)
                 // KA_NO_QUEUE=1 keeps one launch per level.
                 for (int t = 0; t < n_tasks; t++) { c->descs[t].qa = -1; c->descs[t].qb = -1; }
                 c->queue_first = -1;
-                if (c->chain_level >= 1 && !getenv("KA_NO_QUEUE") && !getenv("KA_NO_HALF")) {
+                if (c->chain_level >= 1 && !c->env.no_queue && !c->env.no_half) {
                         int L0 = 0;
                         while (L0 < c->chain_level) {                       // skip the leading seq-seq levels (lean kernel)
                                 bool all_ss = true;
@@ -334,7 +383,7 @@ static int plan_launches(ka_ctx* c)
                                 L0++;
                         }
                         bool ok = c->chain_level - L0 >= 2;                 // one level alone gains nothing
-                        for (int L = L0; ok && L < c->chain_level; L++) if ((int)c->levels[L].size() <= c->n_cus) ok = false;
+                        if ((int)c->levels[L0].size() <= c->n_cus) ok = false;   // (the queue's first level must fill the GPU; later ones need not)
                         if (ok) {
                                 c->queue_first = L0;
                                 for (int t = 0; t < n_tasks; t++) {
@@ -348,7 +397,7 @@ static int plan_launches(ka_ctx* c)
         }
 
         // ---- workgroup tables, one per dependency level (build_blocks) ----
-        if (const char* e = getenv("KA_MAX_CLUSTER")) c->max_cluster = std::max(1, std::min(8, atoi(e)));
+        c->max_cluster = c->env.max_cluster > 0 ? std::min(16, c->env.max_cluster) : 16;
         if (c->shared_gpu) c->max_cluster = 1;
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
         for (auto& L : c->levels) {
@@ -389,11 +438,52 @@ static int plan_launches(ka_ctx* c)
                 // one column = one XCD.
                 int G0 = 1;
                 while (G0 * 2 <= c->max_cluster && 8 * m * G0 * 2 <= c->n_cus) G0 *= 2;
-                if (getenv("KA_CHAIN_G1")) G0 = 1;
-                c->chain_blocks.assign((size_t)8 * m * G0, make_int2(-1, 0));
-                for (int r = 0; r < (int)order.size(); r++)
+                if (c->env.chain_g1) G0 = 1;
+                // The CUs this leaves idle go to the entries whose way to the root is the longest (estimated wavefront steps
+                // of the tasks above them): clusters only grow where subtrees of the SAME launch meet, and the critical path
+                // of a k-means tree is a caterpillar that absorbs small subtrees finished by earlier launches -- its tasks
+                // would run on the one workgroup their entry started with while most of the GPU waits at join points.  A
+                // cluster keeps its workgroups all the way up (surplus members climb with it), so a workgroup given to an
+                // entry serves every task on that entry's path.  Extra members sit behind the regular table, in the
+                // entry's XCD column.
+                std::vector<int> extra(order.size(), 0);
+                int spare = (c->n_cus - 8 * m * G0) / 8 * 8;
+                if (!c->env.no_crit && spare > 0 && !order.empty()) {
+                        std::vector<double> len(2 * numseq - 1, 0.0), up(n_tasks, 0.0);
+                        for (int i = 0; i < numseq; i++) len[i] = c->lens[i];
+                        for (int t = 0; t < n_tasks; t++) len[abc[3 * t + 2]] = 1.1 * std::max(len[abc[3 * t]], len[abc[3 * t + 1]]);
+                        for (int t = n_tasks - 1; t >= 0; t--) {               // parents come after their children in the task list
+                                const double la = len[abc[3 * t]], lb = len[abc[3 * t + 1]];
+                                up[t] = 2.0 * std::max(la, lb) + std::min(la, lb) + (c->descs[t].parent >= 0 ? up[c->descs[t].parent] : 0.0);
+                        }
+                        std::vector<int> by_up(order.size());
+                        for (size_t r = 0; r < order.size(); r++) by_up[r] = (int)r;
+                        std::stable_sort(by_up.begin(), by_up.end(), [&](int x, int y) { return up[order[x]] > up[order[y]]; });
+                        int top_g = 4;
+                        if (c->env.crit_top > 0) top_g = std::min(c->max_cluster, c->env.crit_top);   // experiments
+                        for (size_t i = 0; i < by_up.size() && spare > 0; i++) {
+                                const int want = std::min(spare, std::max(0, (i == 0 ? top_g : 2 * G0) - G0));
+                                extra[by_up[i]] = want; spare -= want;
+                        }
+                }
+                int n_extra = 0;
+                std::vector<int> col_need(8, 0);
+                for (size_t r = 0; r < order.size(); r++) { n_extra += extra[r]; col_need[r / m] += extra[r]; }
+                int extra_rows = *std::max_element(col_need.begin(), col_need.end());
+                const bool by_column = 8 * m * G0 + 8 * extra_rows <= c->n_cus;       // else: packed densely, any XCD
+                if (!by_column) extra_rows = (n_extra + 7) / 8;
+                c->chain_blocks.assign((size_t)8 * m * G0 + (size_t)8 * extra_rows, make_int2(-1, 0));
+                std::vector<int> col_fill(8, 0);
+                int dense = 0;
+                for (int r = 0; r < (int)order.size(); r++) {
+                        const int Gr = G0 + extra[r];
                         for (int g = 0; g < G0; g++)
-                                c->chain_blocks[((size_t)(r % m) * G0 + g) * 8 + (r / m)] = make_int2(order[r], g | (G0 << 8));
+                                c->chain_blocks[((size_t)(r % m) * G0 + g) * 8 + (r / m)] = make_int2(order[r], g | (Gr << 8));
+                        for (int g = G0; g < Gr; g++) {
+                                const size_t pos = (size_t)8 * m * G0 + (by_column ? (size_t)8 * col_fill[r / m]++ + (r / m) : (size_t)dense++);
+                                c->chain_blocks[pos] = make_int2(order[r], g | (Gr << 8));
+                        }
+                }
                 c->chain_blocks_off = (int)c->blocks_flat.size();
                 c->blocks_flat.insert(c->blocks_flat.end(), c->chain_blocks.begin(), c->chain_blocks.end());
         }
@@ -586,7 +676,7 @@ static int upload_plan(ka_ctx* c)
 static int copy_to_host(ka_ctx* c, void* dst, const void* src, size_t bytes)
 {
         const size_t CH = (size_t)1 << 20;
-        bool staged = bytes >= 2 * CH && !getenv("KA_NO_STAGING");
+        bool staged = bytes >= 2 * CH && !c->env.no_staging;
         for (int k = 0; staged && k < 2; k++) {
                 if (!c->pin[k] && hipHostMalloc((void**)&c->pin[k], CH, hipHostMallocDefault) != hipSuccess) { c->pin[k] = nullptr; staged = false; }
                 if (staged && !c->pin_ev[k] && hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming) != hipSuccess) { c->pin_ev[k] = nullptr; staged = false; }
@@ -656,10 +746,12 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.refine_mode = 0;
         D.refine_adaptive = 0;
         D.prof_task = -1;
-        D.wdfs = (getenv("KA_NO_WDFS") ? 0 : 1) | (getenv("KA_NO_LS0") ? 0 : 2);   // measurements / tests
-        if (const char* e = getenv("KA_PROF_TASK")) D.prof_task = atoi(e);      // measurements only (tools/levels_real.py)
+        D.wdfs = (c->env.no_wdfs ? 0 : 1) | (c->env.no_ls0 ? 0 : 2);   // measurements / tests
+        D.prof_task = c->env.prof_task;                                 // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
+        D.q1_mode = c->env.q1;
+        D.lean4 = c->env.lean4;
         D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;
         D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
         D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
@@ -676,8 +768,8 @@ static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector
         const int nt = (int)L.size();
         int lean = 1;                                    // launch kind: 0 = 8 waves, 1 = lean, 2 = half
         for (int t : L) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) lean = 0;
-        if (getenv("KA_NO_LEAN")) lean = 0;
-        if (!lean && nt > c->n_cus && !getenv("KA_NO_HALF")) lean = 2;   // more tasks than CUs: two 4-wave workgroups per CU
+        if (c->env.no_lean) lean = 0;
+        if (!lean && nt > c->n_cus && !c->env.no_half) lean = 2;   // more tasks than CUs: two 4-wave workgroups per CU
         int G = 1;
         while (lean == 0 && G * 2 <= c->max_cluster && nt * G * 2 <= c->n_cus) G *= 2;
         const int groups = (nt + 7) / 8;
@@ -686,6 +778,15 @@ static void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector
                 for (int m = 0; m < G; m++)
                         tbl[(size_t)(j % 8) + 8 * ((size_t)m + (size_t)G * (j / 8))] = make_int2(L[j], m | (G << 8));
         *lean_out = lean;
+}
+
+// KA_LAUNCH_EV: an event behind launch number c->n_launches of the run (measurements; ka_tree_launch_ms)
+static int mark_launch(ka_ctx* c)
+{
+        if (!c->env.launch_ev) return KA_OK;
+        while ((int)c->launch_ev.size() < c->n_launches) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->launch_ev.push_back(e); }
+        HIPCHK(hipEventRecord(c->launch_ev[c->n_launches - 1], c->stream));
+        return KA_OK;
 }
 
 static int tree_launch(ka_ctx* c)
@@ -704,25 +805,25 @@ static int tree_launch(ka_ctx* c)
                 if (c->refine_mode) {
                         // refinement pass: one launch per tree level (see refine_blocks)
                         ka_unit4_launch(&D, c->d_refine_blocks.p + c->refine_off[L], c->refine_off[L + 1] - c->refine_off[L], D.cons_K > 0, c->stream);
-                        c->n_launches++;
+                        c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         continue;
                 }
                 if ((int)L == c->queue_first) {
                         // levels queue_first .. chain_level-1: one launch, two workgroups per CU pulling from the ordered list
                         const int nwg = std::min(c->queue_n, 2 * c->n_cus);
                         ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
-                        c->n_launches++;
+                        c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         L = (size_t)c->chain_level - 1;
                         continue;
                 }
                 if ((int)L == c->chain_level) {
                         // this level and everything above it: one launch, tasks chained through their join points
                         ka_launch_task_level(&D, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, c->stream);
-                        c->n_launches++;
+                        c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         break;
                 }
                 ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->level_lean[L], 0, c->stream);
-                c->n_launches++;
+                c->n_launches++; if (mark_launch(c)) return KA_FAIL;
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -765,7 +866,7 @@ static int refine_blocks(ka_ctx* c, int mode)
                 int nref = 0;
                 for (int t : L) nref += (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? 1 : 0;
                 int G = 1;
-                if (!c->shared_gpu && !getenv("KA_REFINE_SERIAL"))
+                if (!c->shared_gpu && !c->env.refine_serial)
                         while (G * 2 <= flips && (long long)nref * G * 2 + ((long long)L.size() - nref) <= c->n_cus) G *= 2;
                 for (int t : L) {
                         const int g = (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? G : 1;
@@ -1421,6 +1522,18 @@ extern "C" int ka_tree_kernel_ms(ka_ctx* c, float* ms, int* n_launches)
         HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
         if (n_launches) *n_launches = c->n_launches;
         return KA_OK;
+}
+
+// Measurements: the duration of every launch of the last run (context created with KA_LAUNCH_EV=1 in the environment);
+// returns the number of launches written, -1 on error.
+extern "C" int ka_tree_launch_ms(ka_ctx* c, float* ms, int cap)
+{
+        if (!c || !c->synced) { fail("run + sync first"); return -1; }
+        if (!c->env.launch_ev || (int)c->launch_ev.size() < c->n_launches) { fail("ka_tree_launch_ms: no launch events (KA_LAUNCH_EV=1)"); return -1; }
+        const int n = std::min(cap, c->n_launches);
+        for (int i = 0; i < n; i++)
+                if (hipEventElapsedTime(ms + i, i ? c->launch_ev[i - 1] : c->ev0, c->launch_ev[i]) != hipSuccess) { fail("hipEventElapsedTime"); return -1; }
+        return n;
 }
 
 

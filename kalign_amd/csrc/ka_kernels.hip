@@ -115,6 +115,7 @@ struct TaskShared {
         KaCtl* lctl;                   // level counters + margin sums of the recursion: == ctl until a cluster SPLITS, then -> ctl_lds
         KaCtl ctl_lds;
         int G, member;                 // cluster size / this workgroup's index in it
+        int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
         // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
         // over the workgroups, agent-scope hand-over, two cluster barriers per level).  As soon as a level has at least
         // G sub-problems (or single-strip passes) the cluster SPLITS: every workgroup takes its share of the
@@ -202,7 +203,7 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
 // than 32 rows becomes strip items (its strips are contiguous and ascending, so strip k-1 is
 // always pulled before strip k); smaller passes go to the packed lists (16-lane slots for up
 // to 32 rows, 4-lane slots for up to 8 rows).
-struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; };
+struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; int srows; };
 
 // A thin but long pass (few rows, many columns -- gap-rich regions of deep profiles produce them) also runs
 // as a strip: its ncols + nrows/2 dependent steps are the level's critical path, a strip step costs about
@@ -213,7 +214,7 @@ __device__ __forceinline__ bool ka_pass_is_strip(int nrows, int ncols) { return 
 __device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows, int ncols)
 {
         if (ka_pass_is_strip(nrows, ncols)) {
-                const int ns = ka_strips_of(nrows);
+                const int ns = ka_strips_of(nrows, o.srows);
                 const int base = atomicAdd(o.nitems, ns);
                 for (int k = 0; k < ns; ++k) { o.items[base + k] = make_int2(slot, (dir << 16) | k); o.prog[base + k] = 0; }
         } else if (nrows > 8) {
@@ -241,6 +242,7 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         o.n4 = &S.lctl->lvl[parity].npack[1];
         o.nsub = &S.lctl->lvl[parity].nsub;
         o.rowalloc = &S.lctl->lvl[parity].rowalloc;
+        o.srows = S.srows;
         return o;
 }
 
@@ -399,7 +401,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
                 if (!((x < 2) ? v1 : v2)) continue;
-                if (ka_pass_is_strip(pr[x], pc[x])) need[2] += ka_strips_of(pr[x]);
+                if (ka_pass_is_strip(pr[x], pc[x])) need[2] += ka_strips_of(pr[x], lout.srows);
                 else if (pr[x] > 8) need[3] += 1;
                 else need[4] += 1;
         }
@@ -444,7 +446,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 for (int x = 0; x < 2; ++x) {
                         const int nrows = pr[2 * ch + x], ncols = pc[2 * ch + x], dir = x ? KA_BWD : KA_FWD;
                         if (ka_pass_is_strip(nrows, ncols)) {
-                                const int ns = ka_strips_of(nrows);
+                                const int ns = ka_strips_of(nrows, lout.srows);
                                 for (int k = 0; k < ns; ++k) { lout.items[ip + k] = make_int2(slot, (dir << 16) | k); lout.prog[ip + k] = 0; }
                                 ip += ns;
                         } else if (nrows > 8) {
@@ -486,7 +488,8 @@ __device__ void ka_cluster_sync(TaskShared& S)
 #define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
 
 // The passes of one recursion level: its work items (strips, packed jobs) dealt to / pulled by the waves of the team.
-template <int KIND, int NRES, int NB>
+// Q1: the kernel also carries the one-row-per-lane strip (TaskShared::srows == 64 selects it per task)
+template <int KIND, int NRES, int NB, bool Q1 = false>
 __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cur, const int level, const KaSub* qc, char* lds_waves,
                                              const float* tss, long long* pslot)
 {
@@ -569,13 +572,19 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
                                 const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
                                 const int mid_ = ((ea - sa) / 2) + sa;
-                                const int ns = ka_strips_of(dir == KA_FWD ? mid_ - sa : ea - mid_);
+                                const int srows = __builtin_amdgcn_readfirstlane(S.srows);
+                                const int ns = ka_strips_of(dir == KA_FWD ? mid_ - sa : ea - mid_, srows);
                                 const bool st_me = it < nstatic;
                                 const bool prod_local = k > 0 && st_me && (it - 1) / per == member_w;
                                 const bool cons_local = k + 1 < ns && st_me && it + 1 < nstatic && (it + 1) / per == member_w;
-                                ka_strip<KIND, NRES, NB>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
-                                                     (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
-                                                     lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
+                                if (Q1 && srows == KA_STRIP1_ROWS)
+                                        ka_strip<KIND, NRES, NB, 1>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                                             (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
+                                                             lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
+                                else
+                                        ka_strip<KIND, NRES, NB, 2>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                                             (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
+                                                             lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
                         }
         }
 }
@@ -584,7 +593,7 @@ __device__ const int ka_pow3[20] = { 1, 3, 9, 27, 81, 243, 729, 2187, 6561, 1968
                                      43046721, 129140163, 387420489, 1162261467 };
 #define KA_REC_DEPTH 19                                              // recursion levels the keys of ka_meetup<.., REC> can tell apart
 
-template <int KIND, int NRES, int NB, bool REC = false>
+template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
@@ -620,7 +629,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 if (S.G > 1 && !did_split && level >= 1) {
                         const int nshared = S.ctl->lvl[level & 1].nsub;
                         // every member sees the same numbers here (the barrier that ended the previous level published them)
-                        if (nshared >= S.G || (S.La >> (level + 1)) <= KA_STRIP_ROWS / 2) {
+                        if (nshared >= S.G || (S.La >> (level + 1)) <= S.srows / 2) {
                                 did_split = true;
                                 __syncthreads();
                                 if (tid == 0) {
@@ -671,7 +680,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
 #ifdef KA_PROF
                 if (S.prof && lead && level < 8) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; } }
 #endif
-                ka_run_items<KIND, NRES, NB>(S, cur, level, qc, lds_waves, tss, pslot);
+                ka_run_items<KIND, NRES, NB, Q1>(S, cur, level, qc, lds_waves, tss, pslot);
 #ifdef KA_PROF
                 if (pslot && lane == 0) pslot[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1780,7 +1789,7 @@ __device__ __host__ inline long long ka_private_bytes(long long la, long long lb
 {
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 20;
-        const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
+        const long long ni = 2 * nq + 2 * (n / KA_STRIP1_ROWS + 2);
         return 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16) + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16);
 }
@@ -1800,7 +1809,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         const long long nq = (long long)(la < lb ? la : lb) + 20;
         S.q[0] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
         S.q[1] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
-        const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
+        const long long ni = 2 * nq + 2 * (n / KA_STRIP1_ROWS + 2);
         S.items[0] = (int2*)(base + o); o += ka_align_up(ni * 8, 16);
         S.items[1] = (int2*)(base + o); o += ka_align_up(ni * 8, 16);
         S.prog[0] = (int*)(base + o); o += ka_align_up(ni * 4, 16);
@@ -1850,7 +1859,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 {
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 20;
-        const long long ni = 2 * nq + 2 * (n / KA_STRIP_ROWS + 2);
+        const long long ni = 2 * nq + 2 * (n / KA_STRIP1_ROWS + 2);
         long long b = 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
@@ -1868,7 +1877,8 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
 // ring, <=128 VGPRs -> four workgroups per CU instead of one.
 // Returns 0 when this workgroup took part in the task to its end, 1 when the task failed (arena overflow),
 // 2 when the workgroup was surplus to the task's cluster (the task is too small for all of them).
-template <bool LEAN, int NB>
+// Q1: the 8-wave kernels also carry the one-row-per-lane strip (ka_strip<.., Q = 1>) for tasks that own idle SIMDs.
+template <bool LEAN, int NB, bool Q1 = false>
 __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, const int member, const int g_launch)
 {
         // all LDS lives in the dynamic region (16-B aligned carve-outs, guide section 6 G17)
@@ -1925,7 +1935,17 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // how many of the launched workgroups this task really uses (every member derives the
                 // same number from the operand lengths): one CU saturates at about 8 strips in flight
                 int g_eff = (S.La >= 1536) ? 8 : ((S.La >= 1152) ? 6 : ((S.La >= 768) ? 4 : ((S.La >= 320) ? 2 : 1)));
+                // The strip shape: 64-row strips (one DP row per lane, about half the instructions per step) when the
+                // cluster has a SIMD for every strip of the two top-level passes -- the number of strips in flight stays
+                // about the same down the recursion (rows halve, passes double) -- else 128-row strips.
+                int srows = KA_STRIP_ROWS;
+                if (Q1 && D.q1_mode) {
+                        const int s1 = ka_strips_of(S.La / 2, KA_STRIP1_ROWS) + ka_strips_of(S.La - S.La / 2, KA_STRIP1_ROWS);
+                        const int g1 = (s1 + 3) / 4;
+                        if (g1 <= g_launch || (D.q1_mode >= 2 && (s1 + 7) / 8 <= g_launch) || D.q1_mode >= 3) { srows = KA_STRIP1_ROWS; g_eff = g1; }
+                }
                 if (g_eff > g_launch) g_eff = g_launch;
+                S.srows = srows;
                 S.G = g_eff; S.member = member; S.bar_phase = 0;
                 S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
@@ -1974,13 +1994,13 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
 
         // P2
-        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB>(S, s_dbg, lds_waves, tss, D.trace);
+        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         // no B / Z / X in the job (the usual case): every profile's counts [20..22] are zero and the reference skips
         // zero counts (aln_profileprofile.c:70-77) -- 20 terms per cell instead of 23
-        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB>(S, s_dbg, lds_waves, tss, D.trace);
-        else ka_hirschberg<KA_PP, 23, NB>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else ka_hirschberg<KA_PP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         tk2 = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 3);
@@ -2035,7 +2055,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 if (tid == 0) {
                         long long* tm = D.timing + 8ll * task;
                         tm[0] = tk1 - tk0; tm[1] = tk2 - tk1; tm[2] = tk3 - tk2; tm[3] = __builtin_amdgcn_s_memtime() - tk3;
-                        tm[4] = S.t_pass; tm[5] = S.t_meet; tm[6] = S.n_levels; tm[7] = (long long)S.La * S.Lb;
+                        tm[4] = S.t_pass; tm[5] = S.t_meet; tm[6] = S.n_levels | (S.G << 8) | (g_launch << 16); tm[7] = (long long)S.La * S.Lb;
                         if (D.prof_task >= 0 ? task == D.prof_task : T.is_root) {
                                 long long* lv = D.timing + 8ll * (D.numseq - 1);
                                 for (int l = 0; l < 16; ++l) {
@@ -2148,7 +2168,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.p2_mult = swapped ? (float)T.nsip_b : (float)T.nsip_a;
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
-                S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0;
+                S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS;
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true);
@@ -2356,7 +2376,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
 // as soon as both operands exist instead of at the next launch, clusters grow as the tree narrows, and the
 // whole upper tree is one launch.  All workgroups are resident from the start (<= one per CU), so the waits
 // cannot starve anybody; they are bounded all the same (device watchdog).
-#define KA_MAX_G 8
+#define KA_MAX_G 16
 template <bool LEAN, int NB>
 __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __restrict__ blocks, const int chain)
 {
@@ -2368,7 +2388,7 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
         int member = blk.y & 0xff, g = blk.y >> 8;
         const int tid = threadIdx.x;
         while (true) {
-                const int st = ka_task_body<LEAN, NB>(D, task, member, g);
+                const int st = ka_task_body<LEAN, NB, !LEAN>(D, task, member, g);
                 if (!chain || st == 1) return;
                 // A workgroup the task had no use for stays with its cluster: it skips the task, waits for the cluster's
                 // role at the parent and moves up with it -- a bigger task further up may need it (in a chain-like
@@ -2600,9 +2620,19 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 3) void ka_task_kernel_lean_cons(con
 {
         ka_task_entry<true, KA_NB>(D, blocks, 0);
 }
+// the same body with 4 waves: four workgroups per CU, the shape ka_pair_kernel runs the same alignments in (experiment: KA_LEAN4=1)
+__global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_task_kernel_lean4(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<true, 0>(D, blocks, 0);
+}
 extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
 {
-        static bool done0 = false, done1 = false;
+        static bool done0 = false, done1 = false, done2 = false;
+        if (!cons && D->lean4) {
+                if (ka_optin(ka_task_kernel_lean4, KA_LDS_PAIR, &done2) != hipSuccess) return;
+                hipLaunchKernelGGL(ka_task_kernel_lean4, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+                return;
+        }
         if (cons) {
                 if (ka_optin(ka_task_kernel_lean_cons, KA_LDS_PAIR, &done1) != hipSuccess) return;
                 hipLaunchKernelGGL(ka_task_kernel_lean_cons, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
@@ -2627,7 +2657,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int i = P.ia[k], j = P.ib[k];
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
-                S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0;
+                S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;

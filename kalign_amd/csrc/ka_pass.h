@@ -28,7 +28,8 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-#define KA_STRIP_ROWS 128
+#define KA_STRIP_ROWS 128                                       // Q = 2: two DP rows per lane
+#define KA_STRIP1_ROWS 64                                       // Q = 1: one DP row per lane (narrow step, see ka_strip)
 #define KA_RING_BATCH 32
 #define KA_RING_SLOTS 4
 #define KA_REC_CHUNKS 7                                         // 7 x 16 B = profile fields [32..59]
@@ -93,7 +94,8 @@ __device__ __forceinline__ float wave_rol1(float x)
 template <int NRES>
 __device__ __forceinline__ constexpr bool ka_chunk_used(int ch) { return ch * 4 < NRES || ch >= 5; }
 
-__device__ __forceinline__ int ka_strips_of(int nrows) { return nrows <= 0 ? 1 : (nrows + KA_STRIP_ROWS - 1) / KA_STRIP_ROWS; }
+// srows: rows per strip of the task (TaskShared::srows: 128 or 64)
+__device__ __forceinline__ int ka_strips_of(int nrows, int srows) { return nrows <= 0 ? 1 : (nrows + srows - 1) / srows; }
 
 // NB > 0: anchor-consistency build -- every DP row carries NB (column, value) bonus entries with distinct
 // columns (ka_cons_prepare); the cell at s-index j adds the value of the entry whose column is j, which
@@ -119,7 +121,12 @@ struct KaBonus {
         }
 };
 
-template <int KIND, int NRES, int NB>
+// Q: DP rows per lane.  Q = 2 (128-row strips) is the throughput shape: ~100 instructions per 128 cells.  Q = 1 (64-row
+// strips) is the latency shape for tasks that own idle SIMDs: ~55 instructions per step -- a lone wave issues one
+// instruction per ~5 cycles, so the step, and with it the C + R/Q + hand-over steps of a pass, costs about half -- at
+// twice the waves.  The profile-profile dot product then packs two RESIDUES per v_pk_mul_f32 (the counts of residues
+// 2i, 2i+1 against the matching half of the column record's float4) and adds the two products one after the other.
+template <int KIND, int NRES, int NB, int Q = 2>
 __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
                                          const float inj_a, const float inj_ga, const float inj_gb,
                                          const int dir, const int k, KaState* rows, int* prog,
@@ -167,11 +174,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const float m1 = ka_uniform_f(S.p1_mult), m2 = ka_uniform_f(S.p2_mult);
         ka_gfloat* const grows = (ka_gfloat*)rows;
 
-        const int u0 = k * KA_STRIP_ROWS;
-        const int nr = min(KA_STRIP_ROWS, nrows - u0);
-        const int nl = (nr + 1) >> 1;
+        constexpr int SROWS = 64 * Q;
+        const int u0 = k * SROWS;
+        const int nr = min(SROWS, nrows - u0);
+        const int nl = (Q == 2) ? ((nr + 1) >> 1) : nr;
         const int lastl = nl - 1;                                     // lane holding the strip's last row
-        const bool last_is_b = (nr & 1) == 0;
+        const bool last_is_b = (Q == 2) && (nr & 1) == 0;
         const bool first = (k == 0);
         // Hand-over batches: a strip starts 63 columns (the lane skew) plus one batch behind the strip above it, and every
         // hand-over is an event step on both sides (a flush behind a release fence; a wait and a reload) that breaks the
@@ -185,9 +193,9 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // acq_agent: the strip above (k-1) runs in ANOTHER workgroup of the cluster; rel_agent: the strip below (k+1) does
         // (or may: work items beyond the statically dealt ones are pulled by whoever is free).  Neighbours inside this
         // workgroup hand over at workgroup scope: no L2 write-back, no L1 invalidate.
-        const bool actB = 2 * lane + 1 < nr;
-        const int uA = u0 + min(2 * lane, nr - 1);
-        const int uB = u0 + min(2 * lane + 1, nr - 1);
+        const bool actB = (Q == 2) && 2 * lane + 1 < nr;
+        const int uA = u0 + min(Q * lane, nr - 1);
+        const int uB = u0 + min(Q * lane + 1, nr - 1);              // (Q = 1: row B does not exist; its operand loads are dead code)
         const int iA = (dir == KA_FWD) ? (r0 + uA) : (r1 - 1 - uA);
         const int iB = (dir == KA_FWD) ? (r0 + uB) : (r1 - 1 - uB);
         const int recA = iA + 1, recB = iB + 1;
@@ -217,7 +225,10 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         }
         // ---- stationary row operand ----
         float oA, eA, tA, oB, eB, tB, orpA, orpB;
-        float2v p1v[NRES];
+        float2v p1v[Q == 2 ? NRES : 1];                               // Q = 2: the counts of residue c in rows (A, B)
+        constexpr int NPAIR = NRES / 2;
+        float2v p1p[Q == 1 ? (NPAIR > 0 ? NPAIR : 1) : 1];            // Q = 1: the counts of residues (2i, 2i+1) in row A
+        float p1last = 0.0f;                                          // Q = 1, odd alphabets: the count of residue NRES-1
         int res1A = 0, res1B = 0;
         if (KIND == KA_SS) {
                 oA = oB = -S.gpo; eA = eB = -S.gpe; tA = tB = -S.tgpe; orpA = orpB = -S.gpo;
@@ -233,29 +244,45 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         // the NRES counts of a row are the head of its 256-B record: 16-B loads (a dword load per count made
                         // 2 x NRES load instructions of 64 scattered lines each at the start of every strip)
                         constexpr int NV = (NRES + 3) / 4;
-                        float4v va[NV], vb[NV];
+                        if constexpr (Q == 2) {
+                                float4v va[NV], vb[NV];
 #pragma unroll
-                        for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
+                                for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
 #pragma unroll
-                        for (int c = 0; c < NRES; ++c) {
-                                p1v[c].x = va[c >> 2][c & 3];
-                                p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
+                                for (int c = 0; c < NRES; ++c) {
+                                        p1v[c].x = va[c >> 2][c & 3];
+                                        p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
+                                }
+                        } else {
+                                float4v va[NV];
+#pragma unroll
+                                for (int i = 0; i < NV; ++i) va[i] = ((const float4v*)pA)[i];
+#pragma unroll
+                                for (int i = 0; i < NPAIR; ++i) { p1p[i].x = va[(2 * i) >> 2][(2 * i) & 3]; p1p[i].y = va[(2 * i + 1) >> 2][(2 * i + 1) & 3]; }
+                                if (NRES & 1) p1last = va[(NRES - 1) >> 2][(NRES - 1) & 3];
                         }
                 } else {
                         // seq-profile: score = P1[row][32 + residue], residue varies per step ->
-                        // keep this lane's two score rows in its private LDS lines
-                        float* tA_ = sp_tbl + (2 * lane) * KA_SP_STRIDE;
-                        float* tB_ = tA_ + KA_SP_STRIDE;
-                        float4v sa[6], sb[6];
+                        // keep this lane's score rows (two, or one with Q = 1) in its private LDS lines
+                        float* tA_ = sp_tbl + (Q * lane) * KA_SP_STRIDE;
+                        float4v sa[6];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) { sa[i] = ((const float4v*)(pA + 32))[i]; sb[i] = ((const float4v*)(pB + 32))[i]; }
+                        for (int i = 0; i < 6; ++i) sa[i] = ((const float4v*)(pA + 32))[i];
 #pragma unroll
-                        for (int c = 0; c < 23; ++c) { tA_[c] = sa[c >> 2][c & 3]; tB_[c] = sb[c >> 2][c & 3]; }
+                        for (int c = 0; c < 23; ++c) tA_[c] = sa[c >> 2][c & 3];
+                        if constexpr (Q == 2) {
+                                float* tB_ = tA_ + KA_SP_STRIDE;
+                                float4v sb[6];
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) sb[i] = ((const float4v*)(pB + 32))[i];
+#pragma unroll
+                                for (int c = 0; c < 23; ++c) tB_[c] = sb[c >> 2][c & 3];
+                        }
                 }
         }
 
         KaBonus<NB> bonA, bonB;
-        if (NB) { bonA.load(S.ent, iA); bonB.load(S.ent, iB); }
+        if (NB) { bonA.load(S.ent, iA); if (Q == 2) bonB.load(S.ent, iB); }
 
         // sequence columns: the three column gap terms are task constants.  Read them from the LDS-resident
         // TaskShared ONCE -- inside the step the compiler re-loads them (ds_read + s_waitcnt) every step.
@@ -285,7 +312,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // for the loads just issued for the next step (lgkmcnt is a plain in-order counter), exposing
         // the full LDS latency every step.  ring_wait() is the matching manual wait; it takes the
         // registers as in/out operands so that no use can be scheduled above it.
-        auto ring_read = [&](float4v* dstq, int vcol, float2v& dep) {
+        auto ring_read = [&](float4v* dstq, int vcol, auto& dep) {
                 // (the wave's LDS region is 2048-B aligned: OR instead of ADD)
                 const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
                 if (NRES <= 8) {
@@ -330,8 +357,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // of the residue batch would otherwise sit in every step of a lone wave).  resn = batch of
                 // columns 64m+1+lane, fetched 64 steps before it is rotated in.
                 resn = ((ka_gbytec*)S.s2)[REC(min(1 + lane, ncols)) - 1];
-                if (KIND == KA_SS) { scA = tss[res1A]; scB = tss[res1B]; }        // step 0: no lane is at a real column yet
-                else { scA = sp_tbl[(2 * lane) * KA_SP_STRIDE]; scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE]; }
+                if (KIND == KA_SS) { scA = tss[res1A]; if (Q == 2) scB = tss[res1B]; }        // step 0: no lane is at a real column yet
+                else { scA = sp_tbl[(Q * lane) * KA_SP_STRIDE]; if (Q == 2) scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE]; }
         }
 
 #ifdef KA_PROF
@@ -339,7 +366,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 #endif
         // One wavefront step.
         //   ST   : steady state, every active lane is strictly inside the column range (no edge cases)
-        //   FULL : the strip has all 128 rows (64 active lanes, last row = row B of lane 63)
+        //   FULL : the strip has all 64 * Q rows (64 active lanes, last row = the last row of lane 63)
         //   P    : which half of q[] holds this step's column record (the other half receives the next)
         //   EV   : this step may carry a periodic event (ring batch hand-over, boundary / residue batch
         //          reload, flush of the output batch); EV = false steps are branch-free
@@ -369,8 +396,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 resb = __builtin_amdgcn_update_dpp(resb, resb, 0x134, 0xf, 0xf, false);   // wave_rol:1
                         }
                         res2 = __builtin_amdgcn_update_dpp(resb, res2, 0x138, 0xf, 0xf, false);
-                        if (KIND == KA_SS) { scA = tss[res1A + res2]; scB = tss[res1B + res2]; }
-                        else { scA = sp_tbl[(2 * lane) * KA_SP_STRIDE + res2]; scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2]; }
+                        if (KIND == KA_SS) { scA = tss[res1A + res2]; if (Q == 2) scB = tss[res1B + res2]; }
+                        else { scA = sp_tbl[(Q * lane) * KA_SP_STRIDE + res2]; if (Q == 2) scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE + res2]; }
                 }
 
                 // ---- state of the row above A: lane l-1's row B, lane 0 takes the boundary ----
@@ -419,94 +446,152 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // batch is rotated for the NEXT step before it is used: its registers then die at the DPP that
                 // splices lane 0 in (the `old` operand is tied to the destination) and no copy is needed.
                 float upa, upga, upgb;
+                // (the lane's last row: B, or A when a lane owns one row)
+                const float lra = (Q == 2) ? cBa : cAa, lrga = (Q == 2) ? cBga : cAga, lrgb = (Q == 2) ? cBgb : cAgb;
                 if (FIRST) {
-                        upa = wave_shr1_old(bta, cBa); upga = wave_shr1_old(btga, cBga); upgb = wave_shr1_old(btgb, cBgb);
+                        upa = wave_shr1_old(bta, lra); upga = wave_shr1_old(btga, lrga); upgb = wave_shr1_old(btgb, lrgb);
                 } else {
                         const float nbta = wave_rol1(bta), nbtga = wave_rol1(btga), nbtgb = wave_rol1(btgb);
-                        upa = wave_shr1_old(bta, cBa); upga = wave_shr1_old(btga, cBga); upgb = wave_shr1_old(btgb, cBgb);
+                        upa = wave_shr1_old(bta, lra); upga = wave_shr1_old(btga, lrga); upgb = wave_shr1_old(btgb, lrgb);
                         bta = nbta; btga = nbtga; btgb = nbtgb;
                 }
 
-                // ---- the two cells of this lane ----
-                float2v acc;
-                acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
-                acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
-                if (KIND == KA_SS) {
-                        acc.x += scA_cur;
-                        acc.y += scB_cur;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
-                } else if (KIND == KA_SP) {
-                        acc.x += scA_cur;
-                        acc.y += scB_cur;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
-                } else {
-                        // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
-                        // v_pk_add of the chain instead of an s_nop
-                        float2v prod;
-                        prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
-#pragma unroll
-                        for (int c = NRES - 1; c >= 1; --c) {
-                                float2v nprod;
-                                switch ((c - 1) & 3) {                  // (compile-time after unrolling)
-                                case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
-                                case 1: nprod = ka_mul_bcast<1>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
-                                case 2: nprod = ka_mul_bcast<2>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
-                                default: nprod = ka_mul_bcast<3>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                if constexpr (Q == 2) {
+                        // ---- the two cells of this lane ----
+                        float2v acc;
+                        acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
+                        acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
+                        if (KIND == KA_SS) {
+                                acc.x += scA_cur;
+                                acc.y += scB_cur;
+                                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
+                        } else if (KIND == KA_SP) {
+                                acc.x += scA_cur;
+                                acc.y += scB_cur;
+                                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
+                        } else {
+                                // products one term ahead of the (dependent) sums: keeps a v_pk_mul between two
+                                // v_pk_add of the chain instead of an s_nop
+                                float2v prod;
+                                prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
+        #pragma unroll
+                                for (int c = NRES - 1; c >= 1; --c) {
+                                        float2v nprod;
+                                        switch ((c - 1) & 3) {                  // (compile-time after unrolling)
+                                        case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        case 1: nprod = ka_mul_bcast<1>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        case 2: nprod = ka_mul_bcast<2>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        default: nprod = ka_mul_bcast<3>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        }
+                                        acc = acc + prod;
+                                        prod = nprod;
                                 }
                                 acc = acc + prod;
-                                prod = nprod;
+                                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
+                                // Fetch the next step's column record into the other half of q.  The loads must
+                                // stay AFTER the dot products: placed above them, the s_waitcnt for this step's
+                                // half (loaded one step ago) also waits for the fresh loads and exposes the whole
+                                // LDS latency every step.  sched_barrier pins the machine scheduler; the fake
+                                // dependency on acc keeps the IR passes from sinking the chain below the loads.
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int tn = t + 1;
+                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
+                                        __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
+                                        ring_issue((tn >> 5) + 1);
+                                }
+                                ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
+                                __builtin_amdgcn_sched_barrier(0);
                         }
-                        acc = acc + prod;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
-                        // Fetch the next step's column record into the other half of q.  The loads must
-                        // stay AFTER the dot products: placed above them, the s_waitcnt for this step's
-                        // half (loaded one step ago) also waits for the fresh loads and exposes the whole
-                        // LDS latency every step.  sched_barrier pins the machine scheduler; the fake
-                        // dependency on acc keeps the IR passes from sinking the chain below the loads.
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int tn = t + 1;
-                        if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
-                                __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
-                                ring_issue((tn >> 5) + 1);
+                        float nAa, nAga, nAgb, nBa, nBga, nBgb;
+                        if (ST) {
+                                nAa = acc.x;
+                                nAga = kmax(cAga + cext, cAa + copen);
+                                nAgb = kmax(upgb + eA, upa + oA);
+                                nBa = acc.y;
+                                nBga = kmax(cBga + cext, cBa + copen);
+                                nBgb = kmax(nAgb + eB, nAa + oB);
+                        } else {
+                                const bool at0 = (v == 0), atN = (v == ncols);
+                                const bool edge = at0 || atN;
+                                const bool term = (at0 && near_t) || (atN && far_t);
+                                nAa = at0 ? -KA_F : acc.x;
+                                nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
+                                nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
+                                // B: the row above is A's fresh state
+                                nBa = at0 ? -KA_F : acc.y;
+                                nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
+                                nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
                         }
-                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
-                        __builtin_amdgcn_sched_barrier(0);
-                }
-                float nAa, nAga, nAgb, nBa, nBga, nBgb;
-                if (ST) {
-                        nAa = acc.x;
-                        nAga = kmax(cAga + cext, cAa + copen);
-                        nAgb = kmax(upgb + eA, upa + oA);
-                        nBa = acc.y;
-                        nBga = kmax(cBga + cext, cBa + copen);
-                        nBgb = kmax(nAgb + eB, nAa + oB);
+                        // No predication on "this lane is inside its row/column range": state only flows DOWN the lanes
+                        // (lane l -> l+1) and a lane's first real column (v = 0) rebuilds all six states from the lane above,
+                        // so whatever lanes outside the range compute is never consumed by a lane inside it; the last-row
+                        // collection below reads an active lane and is range-checked itself.
+                        cAa = nAa; cAga = nAga; cAgb = nAgb;
+                        cBa = nBa; cBga = nBga; cBgb = nBgb;
+                        dga = upa; dgga = upga; dggb = upgb;
+                        copen_prev = copen;
+
                 } else {
-                        const bool at0 = (v == 0), atN = (v == ncols);
-                        const bool edge = at0 || atN;
-                        const bool term = (at0 && near_t) || (atN && far_t);
-                        nAa = at0 ? -KA_F : acc.x;
-                        nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
-                        nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
-                        // B: the row above is A's fresh state
-                        nBa = at0 ? -KA_F : acc.y;
-                        nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
-                        nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
+                        // ---- the one cell of this lane (Q = 1) ----
+                        float a1 = kmax3(dga, dgga + copen_prev, dggb + orpA);
+                        if (KIND != KA_PP) {
+                                a1 += scA_cur;
+                                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); a1 += bonA.template at<!ST>(jb); }
+                        } else {
+                                // residue NRES-1 first (aln_profileprofile.c:99-107 walks the non-zero counts downwards); a pair of
+                                // residues per v_pk_mul_f32, products one pair ahead of the (dependent) sums
+                                if (NRES & 1) a1 += p1last * q[P][(NRES - 1) >> 2][(NRES - 1) & 3];
+                                if (NPAIR > 0) {
+                                        auto qpair = [&](int i) -> float2v {
+                                                const float4v& w = q[P][(2 * i) >> 2];
+                                                return ((2 * i) & 3) ? __builtin_shufflevector(w, w, 2, 3) : __builtin_shufflevector(w, w, 0, 1);
+                                        };
+                                        float2v prod = p1p[NPAIR - 1] * qpair(NPAIR - 1);
+#pragma unroll
+                                        for (int i = NPAIR - 1; i >= 1; --i) {
+                                                const float2v nprod = p1p[i - 1] * qpair(i - 1);
+                                                a1 += prod.y;
+                                                a1 += prod.x;
+                                                prod = nprod;
+                                        }
+                                        a1 += prod.y;
+                                        a1 += prod.x;
+                                }
+                                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); a1 += bonA.template at<!ST>(jb); }
+                                // next step's column record: after the chain, as in the two-row step
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int tn = t + 1;
+                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
+                                        __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
+                                        ring_issue((tn >> 5) + 1);
+                                }
+                                ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), a1);
+                                __builtin_amdgcn_sched_barrier(0);
+                        }
+                        float nAa, nAga, nAgb;
+                        if (ST) {
+                                nAa = a1;
+                                nAga = kmax(cAga + cext, cAa + copen);
+                                nAgb = kmax(upgb + eA, upa + oA);
+                        } else {
+                                const bool at0 = (v == 0), atN = (v == ncols);
+                                const bool edge = at0 || atN;
+                                const bool term = (at0 && near_t) || (atN && far_t);
+                                nAa = at0 ? -KA_F : a1;
+                                nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
+                                nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
+                        }
+                        cAa = nAa; cAga = nAga; cAgb = nAgb;
+                        dga = upa; dgga = upga; dggb = upgb;
+                        copen_prev = copen;
                 }
-                // No predication on "this lane is inside its row/column range": state only flows DOWN the lanes
-                // (lane l -> l+1) and a lane's first real column (v = 0) rebuilds all six states from the lane above,
-                // so whatever lanes outside the range compute is never consumed by a lane inside it; the last-row
-                // collection below reads an active lane and is range-checked itself.
-                cAa = nAa; cAga = nAga; cAgb = nAgb;
-                cBa = nBa; cBga = nBga; cBgb = nBgb;
-                dga = upa; dgga = upga; dggb = upgb;
-                copen_prev = copen;
 
                 // ---- collect the strip's last row and hand it on 64 columns at a time ----
                 const int vL = t - lastl;
                 if (ST || (vL >= 0 && vL <= ncols)) {
                         if (FULL) {
                                 // shift register: lane 63 (the last row's owner) feeds its fresh state in
-                                oba = wave_shl1_old(cBa, oba); obga = wave_shl1_old(cBga, obga); obgb = wave_shl1_old(cBgb, obgb);
+                                oba = wave_shl1_old(Q == 2 ? cBa : cAa, oba); obga = wave_shl1_old(Q == 2 ? cBga : cAga, obga); obgb = wave_shl1_old(Q == 2 ? cBgb : cAgb, obgb);
                         } else {
                                 const float la = lane_bcast(last_is_b ? cBa : cAa, lastl);
                                 const float lga = lane_bcast(last_is_b ? cBga : cAga, lastl);
@@ -591,7 +676,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 run_steady(t, t_steady1, full_tag, first_tag);
                 run(t, nsteps, std::false_type(), full_tag, first_tag);
         };
-        if (nr == KA_STRIP_ROWS) {
+        if (nr == SROWS) {
                 if (first) phases(std::true_type(), std::true_type());
                 else phases(std::true_type(), std::false_type());
         } else {

@@ -113,8 +113,13 @@ def test_serial_trials_give_the_same_answer(ctx, name, monkeypatch):
     import os
     monkeypatch.setenv("KA_REFINE_SERIAL", "1")
     assert os.environ["KA_REFINE_SERIAL"] == "1"
+    ctx.reload_env()                                   # (the environment is read once per context)
     g = Golden(name)
-    recs, paths, gaps = run_refine(ctx, g, first_pass=False)
+    try:
+        recs, paths, gaps = run_refine(ctx, g, first_pass=False)
+    finally:
+        monkeypatch.delenv("KA_REFINE_SERIAL")
+        ctx.reload_env()
     for t, r in enumerate(recs):
         want = g.paths[int(g.path_off[t]):int(g.path_off[t]) + r.plen + 2]
         assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], want), (name, t)
@@ -138,8 +143,11 @@ def test_big_tree_parallel_and_serial_trials_agree(ctx, monkeypatch):
     ctx.tree_refine(1)
     recs1, paths1, gaps1 = ctx.tree_download()
     monkeypatch.setenv("KA_REFINE_SERIAL", "1")
+    ctx.reload_env()
     ctx.tree_refine(1)
     recs2, paths2, gaps2 = ctx.tree_download()
+    monkeypatch.delenv("KA_REFINE_SERIAL")
+    ctx.reload_env()
     assert all(np.array_equal(a, b) for a, b in zip(gaps1, gaps2))
     assert [(r.plen, r.confidence, r.meet, r.score) for r in recs1] == [(r.plen, r.confidence, r.meet, r.score) for r in recs2]
     ctx.tree_run()

@@ -50,12 +50,29 @@ for r, t in zip(recs, tot):
     start[r.c] = max(done[r.a], done[r.b])
 by_c = {r.c: (r, t, tmr) for r, t, tmr in zip(recs, tot, tm)}
 node = recs[-1].c
+crit = []
 print('critical path (root first): node lens nsip kind  start_us  total_us  prep hirsch[pass meet levels] code merge')
 while node in by_c:
     r, t, x = by_c[node]
-    print('  %6d %5dx%-5d %4d+%-4d k%d  %8.0f %7.0f   %5.0f %6.0f [%6.0f %5.0f %2d] %4.0f %5.0f' % (
-        node, r.len_a, r.len_b, r.nsip_a, r.nsip_b, r.kind, start[node], t/GHZ/1e3, x[0]/GHZ/1e3, x[1]/GHZ/1e3, x[4]/GHZ/1e3, x[5]/GHZ/1e3, x[6], x[2]/GHZ/1e3, x[3]/GHZ/1e3))
+    print('  %6d %5dx%-5d %4d+%-4d k%d  %8.0f %7.0f   %5.0f %6.0f [%6.0f %5.0f %2d] %4.0f %5.0f  G %d of %d  L%d' % (
+        node, r.len_a, r.len_b, r.nsip_a, r.nsip_b, r.kind, start[node], t/GHZ/1e3, x[0]/GHZ/1e3, x[1]/GHZ/1e3, x[4]/GHZ/1e3, x[5]/GHZ/1e3, int(x[6]) & 255, x[2]/GHZ/1e3, x[3]/GHZ/1e3,
+        (int(x[6]) >> 8) & 255, int(x[6]) >> 16, lvl[node]))
+    crit.append(node)
     node = r.a if done[r.a] >= done[r.b] else r.b
 print('%s task, per Hirschberg level: sub-problems, pass us, meetup us' % (os.environ.get('KA_PROF_TASK', 'root')))
 for l, (nsub, cp, cm) in enumerate(ctx.root_levels):
     if nsub: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
+
+# per-level times of more tasks on the critical path (KA_PROF_TASK): tree levels given as the 7th argument, e.g. 8,12,16
+if len(sys.argv) > 6:
+    idx_of = {r.c: i for i, r in enumerate(recs)}
+    for want in [int(v) for v in sys.argv[6].split(',')]:
+        nodes = [nd for nd in crit if lvl[nd] == want]
+        if not nodes: continue
+        os.environ['KA_PROF_TASK'] = str(idx_of[nodes[0]])
+        ctx.reload_env()
+        ctx.tree_run(); ctx.tree_sync(); ctx.tree_timing()
+        r = recs[idx_of[nodes[0]]]
+        print('task of node %d (tree level %d, %dx%d, nsip %d+%d, kind %d), per Hirschberg level:' % (nodes[0], want, r.len_a, r.len_b, r.nsip_a, r.nsip_b, r.kind))
+        for l, (nsub, cp, cm) in enumerate(ctx.root_levels):
+            if nsub: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
