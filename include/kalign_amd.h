@@ -190,6 +190,7 @@ int ka_tree_get_timing(ka_ctx* ctx, long long* out);
    KA_DEBUG_STARVE_ROOT_JOIN makes the root's join wait for a workgroup that never comes (watchdog -> re-plan). */
 #define KA_DEBUG_SMALL_ARENAS 1
 #define KA_DEBUG_STARVE_ROOT_JOIN 2
+#define KA_DEBUG_STARVE_REFINE_MEMBER 4   /* ka_tree_refine: a member of the first multi-workgroup edge never starts (watchdog -> re-plan) */
 int ka_debug_set_hooks(ka_ctx* ctx, int hooks);
 /* Tools and tests: the KA_* environment switches (experiments and measurements; none is needed in production) are read
    once, at ka_ctx_create.  This reads them again and rebuilds the launch plan of the uploaded job. */

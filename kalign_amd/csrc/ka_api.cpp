@@ -85,8 +85,9 @@ struct KaEnv {
         int max_cluster = 0;           // KA_MAX_CLUSTER: workgroups one task may use (0: the default, 16)
         int crit_top = 0;              // KA_CRIT_TOP: workgroups of the chain entry with the longest way to the root (0: default)
         int prof_task = -1;            // KA_PROF_TASK: the task whose per-level times KA_FLAG_TIMING keeps (-1: the root)
-        int q1 = 1;                    // KA_Q1: 64-row strips (KaTreeDev::q1_mode)
-        int lean4 = 0;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU
+        int q1 = 0;                    // KA_Q1: 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
+        int lean4 = 1;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU (1.60 -> 1.28 ms on the 4096 x 400 leaf level)
+        int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -98,8 +99,9 @@ static void read_env(KaEnv& v)
         v.no_crit = getenv("KA_NO_CRIT") != nullptr; v.no_staging = getenv("KA_NO_STAGING") != nullptr;
         v.no_wdfs = getenv("KA_NO_WDFS") != nullptr; v.no_ls0 = getenv("KA_NO_LS0") != nullptr; v.refine_serial = getenv("KA_REFINE_SERIAL") != nullptr;
         v.chain_tasks = env_int("KA_CHAIN_TASKS", 0); v.max_cluster = env_int("KA_MAX_CLUSTER", 0); v.crit_top = env_int("KA_CRIT_TOP", 0);
-        v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", 1); v.lean4 = env_int("KA_LEAN4", 0);
+        v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", 0); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
+        v.subtree = env_int("KA_SUBTREE", 1);
 }
 
 struct ka_ctx {
@@ -341,7 +343,8 @@ static int plan_launches(ka_ctx* c)
                                 len[cc] = 1.1 * std::max(len[a], len[b]);
                                 cells[cc] = cells[a] + cells[b] + len[a] * len[b];
                                 c->descs[t].wait_mult = 1 + (int)std::min(63.0, cells[cc] / 4e9);
-                                c->descs[t].refine = 0;
+                                // (descs[t].refine -- the edges a KALIGN_REFINE_CONFIDENT pass refines -- is not part of the plan: it is
+                                // set by ka_tree_refine and must survive the re-plan of a watchdog fallback, ka_tree_sync)
                         }
                 }
                 c->n_trees = numseq - n_tasks;
@@ -752,6 +755,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
         D.q1_mode = c->env.q1;
         D.lean4 = c->env.lean4;
+        D.sub_mode = c->env.subtree;
         D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;
         D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
         D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
@@ -862,6 +866,7 @@ static int refine_blocks(ka_ctx* c, int mode)
         c->refine_off.assign(1, 0);
         const int base_mode = mode & 255;
         const int flips = base_mode == 3 ? 2 : (base_mode == 4 ? 0 : 4);      // (adaptive budget: up to 7, shared by at most 4 members)
+        bool starved = false;
         for (auto& L : c->levels) {
                 int nref = 0;
                 for (int t : L) nref += (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? 1 : 0;
@@ -870,7 +875,11 @@ static int refine_blocks(ka_ctx* c, int mode)
                         while (G * 2 <= flips && (long long)nref * G * 2 + ((long long)L.size() - nref) <= c->n_cus) G *= 2;
                 for (int t : L) {
                         const int g = (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? G : 1;
-                        for (int m = 0; m < g; m++) tbl.push_back(make_int2(t, m | (g << 8)));
+                        // tests: one member of the first multi-workgroup edge never starts -- its member barrier starves, the
+                        // watchdog reports it and ka_tree_sync re-plans with one workgroup per edge (the refine marks must survive)
+                        const bool starve = (c->test_hooks & KA_DEBUG_STARVE_REFINE_MEMBER) && g > 1 && !starved;
+                        if (starve) starved = true;
+                        for (int m = 0; m < g; m++) tbl.push_back(starve && m == g - 1 ? make_int2(-1, 0) : make_int2(t, m | (g << 8)));
                 }
                 c->refine_off.push_back((int)tbl.size());
         }

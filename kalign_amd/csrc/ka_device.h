@@ -79,6 +79,7 @@ struct KaTreeDev {
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table
         // ---- anchor consistency (anchor_consistency.c); cons_K == 0: off ----
         int max_g;                     // workgroups one task may use when clusters merge up the chained launch
+        int sub_mode;                  // wave-local subtrees in LDS (ka_subtree.h); 0: off (KA_SUBTREE=0, experiments)
         int lean4;                     // leaf levels (seq-seq tasks only) on 4-wave workgroups, four per CU (KA_LEAN4)
         int q1_mode;                   // 64-row strips (one DP row per lane): 0 never, 1 for tasks whose cluster has a SIMD per top-level strip,
                                        // 2 also at two strips per SIMD, 3 always (experiments; KA_Q1 in the environment)

@@ -115,6 +115,8 @@ struct TaskShared {
         KaCtl* lctl;                   // level counters + margin sums of the recursion: == ctl until a cluster SPLITS, then -> ctl_lds
         KaCtl ctl_lds;
         int G, member;                 // cluster size / this workgroup's index in it
+        int sub_ok, nres_t, sub_stride; // wave-local subtrees (ka_subtree.h): enabled for this task / alphabet class (5, 20, 23) / bytes per wave
+        char* sub_base;                //   ... and where the waves' LDS regions start
         int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
         // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
         // over the workgroups, agent-scope hand-over, two cluster barriers per level).  As soon as a level has at least
@@ -199,11 +201,20 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
         }
 }
 
+#include "ka_subtree.h"
+
 // Queue the two passes of sub-problem `slot` for the next recursion level.  A pass with more
 // than 32 rows becomes strip items (its strips are contiguous and ascending, so strip k-1 is
 // always pulled before strip k); smaller passes go to the packed lists (16-lane slots for up
 // to 32 rows, 4-lane slots for up to 8 rows).
-struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; int srows; };
+struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; int srows;
+                    int sub_ok, kind, nres, sub_bytes; };       // wave-local subtrees (ka_subtree.h): allowed / what decides whether a window fits
+#define KA_ITEM_SUBTREE 2                                      // `dir` of a work item that is a whole subtree
+
+__device__ __forceinline__ bool ka_child_is_subtree(const KaLevelOut& o, int rows, int cols)
+{
+        return o.sub_ok && rows <= KA_SUB_MAXROWS && ka_sub_bytes(o.kind, o.nres, rows, cols) <= o.sub_bytes && cols < 4096;
+}
 
 // A thin but long pass (few rows, many columns -- gap-rich regions of deep profiles produce them) also runs
 // as a strip: its ncols + nrows/2 dependent steps are the level's critical path, a strip step costs about
@@ -224,8 +235,13 @@ __device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int 
         }
 }
 
-__device__ __forceinline__ void ka_emit_items(const KaLevelOut& o, int slot, int starta, int enda, int ncols)
+__device__ __forceinline__ void ka_emit_items(const KaLevelOut& o, int slot, int starta, int enda, int ncols, bool allow_sub = true)
 {
+        if (allow_sub && ka_child_is_subtree(o, enda - starta, ncols)) {
+                const int base = atomicAdd(o.nitems, 1);
+                o.items[base] = make_int2(slot, KA_ITEM_SUBTREE << 16); o.prog[base] = 0;
+                return;
+        }
         const int mid = ((enda - starta) / 2) + starta;
         ka_emit_pass(o, slot, KA_FWD, mid - starta, ncols);
         ka_emit_pass(o, slot, KA_BWD, enda - mid, ncols);
@@ -243,6 +259,7 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         o.nsub = &S.lctl->lvl[parity].nsub;
         o.rowalloc = &S.lctl->lvl[parity].rowalloc;
         o.srows = S.srows;
+        o.sub_ok = S.sub_ok; o.kind = S.kind; o.nres = S.nres_t; o.sub_bytes = S.sub_stride;
         return o;
 }
 
@@ -398,9 +415,14 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         }
         if (v1) { need[0] += 1; need[1] += c1.endb - c1.startb + 1; }
         if (v2) { need[0] += 1; need[1] += c2.endb - c2.startb + 1; }
+        // a child small enough for one wave's LDS is ONE work item: the whole subtree below it (ka_subtree.h)
+        const bool st1 = !FLIP && !REC && v1 && ka_child_is_subtree(lout, c1.enda - c1.starta, c1.endb - c1.startb);
+        const bool st2 = !FLIP && !REC && v2 && ka_child_is_subtree(lout, c2.enda - c2.starta, c2.endb - c2.startb);
+        if (st1) need[2] += 1;
+        if (st2) need[2] += 1;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-                if (!((x < 2) ? v1 : v2)) continue;
+                if (!((x < 2) ? v1 : v2) || ((x < 2) ? st1 : st2)) continue;
                 if (ka_pass_is_strip(pr[x], pc[x])) need[2] += ka_strips_of(pr[x], lout.srows);
                 else if (pr[x] > 8) need[3] += 1;
                 else need[4] += 1;
@@ -442,6 +464,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 if (!(ch ? v2 : v1)) continue;
                 cs.roff = row; row += cs.endb - cs.startb + 1;
                 qnext[slot] = cs;
+                if (ch ? st2 : st1) { lout.items[ip] = make_int2(slot, KA_ITEM_SUBTREE << 16); lout.prog[ip] = 0; ++ip; ++slot; continue; }
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                         const int nrows = pr[2 * ch + x], ncols = pc[2 * ch + x], dir = x ? KA_BWD : KA_FWD;
@@ -563,6 +586,10 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const int dk = __builtin_amdgcn_readfirstlane(item.y);
                                 const KaSub* sp = qc + subi;
                                 const int dir = dk >> 16, k = dk & 0xffff;
+                                if (dir == KA_ITEM_SUBTREE) {
+                                        ka_subtree<KIND, NRES>(S, *sp, lane, S.sub_base + wave * S.sub_stride, tss);
+                                        continue;
+                                }
                                 const int sa = __builtin_amdgcn_readfirstlane(sp->starta);
                                 const int ea = __builtin_amdgcn_readfirstlane(sp->enda);
                                 const int sbb = __builtin_amdgcn_readfirstlane(sp->startb);
@@ -616,7 +643,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 S.ctl->lvl[0].nsub = (S.La > 0 && S.Lb > 0) ? 1 : 0;
                 S.ctl->lvl[0].rowalloc = S.Lb + 1;
                 S.lctl = S.ctl;
-                if (S.ctl->lvl[0].nsub) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La, S.Lb);
+                if (S.ctl->lvl[0].nsub) ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La, S.Lb, false);   // (the top level keeps its rows in HBM: records, tests)
                 S.ctl->msum = 0.0; S.ctl->mcount = 0;
                 S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f;
                 S.t_pass = 0; S.t_meet = 0; S.n_levels = 0;
@@ -1768,8 +1795,10 @@ static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table ov
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
 #define KA_HALF_BLOCK 256
 #define KA_LDS_HALF (KA_LDS_WAVES + (KA_HALF_BLOCK / 64) * KA_WAVE_LDS)   // 4 rings: two workgroups per CU
-#define KA_LDS_PAIR (KA_LDS_WAVES + (2 * KA_PAIR_BLOCK + 16) * 4)   // seq-seq: only the path-coding scratch follows the table
-#define KA_LDS_LEAN (KA_LDS_WAVES + (2 * KA_LEAN_BLOCK + 16) * 4)
+// seq-seq kernels: the path-coding scratch, then a small region per wave for wave-local subtrees (ka_subtree.h)
+#define KA_LEAN_SCRATCH(nt_) ((((2 * (nt_) + 16) * 4) + 15) & ~15)
+#define KA_LDS_PAIR (KA_LDS_WAVES + KA_LEAN_SCRATCH(KA_PAIR_BLOCK) + (KA_PAIR_BLOCK / 64) * KA_WAVE_LDS_LEAN)
+#define KA_LDS_LEAN (KA_LDS_WAVES + KA_LEAN_SCRATCH(KA_LEAN_BLOCK) + (KA_LEAN_BLOCK / 64) * KA_WAVE_LDS_LEAN)
 static_assert(sizeof(TaskShared) <= KA_LDS_DBG, "TaskShared outgrew its LDS slot");
 static_assert(KA_LDS_WAVES % 16 == 0, "wave regions must be 16-B aligned");
 
@@ -1946,6 +1975,11 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 }
                 if (g_eff > g_launch) g_eff = g_launch;
                 S.srows = srows;
+                // wave-local subtrees (ka_subtree.h): every kernel shape has a region per wave behind the workgroup's scratch
+                S.sub_ok = (NB == 0 && D.sub_mode) ? 1 : 0;
+                S.nres_t = (D.nres <= 5) ? 5 : ((D.nres <= 20) ? 20 : 23);
+                S.sub_stride = LEAN ? KA_WAVE_LDS_LEAN : KA_WAVE_LDS;
+                S.sub_base = LEAN ? (lds_waves + KA_LEAN_SCRATCH(KA_NT)) : lds_waves;
                 S.G = g_eff; S.member = member; S.bar_phase = 0;
                 S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
@@ -2169,6 +2203,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
                 S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS;
+                S.sub_ok = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr;     // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true);
@@ -2485,7 +2520,8 @@ __device__ __forceinline__ void ka_task_queue_entry(const KaTreeDev& D, const in
                                         int spins = 0;
                                         while (__hip_atomic_load(&D.join[dep[k]].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                                                 __builtin_amdgcn_s_sleep(16);
-                                                if (ka_spin_expired(D.error, ++spins, 1 << 22, 6, true)) break;
+                                                // (the bound scales with the DP cells below the producer, like the joins of the chained launch)
+                                                if (ka_spin_expired(D.error, ++spins, (1 << 22) * max(1, min(D.tasks[dep[k]].wait_mult, 64)), 6, true)) break;
                                         }
                                         waited = true;
                                 }
@@ -2658,6 +2694,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS;
+                S.sub_ok = 1; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT);
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;

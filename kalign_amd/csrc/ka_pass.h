@@ -34,7 +34,9 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 #define KA_RING_SLOTS 4
 #define KA_REC_CHUNKS 7                                         // 7 x 16 B = profile fields [32..59]
 #define KA_SLOT_BYTES (KA_REC_CHUNKS * KA_RING_BATCH * 16)      // 3584
-#define KA_WAVE_LDS (KA_RING_SLOTS * KA_SLOT_BYTES)             // 14336 B per wave
+#define KA_RING_BYTES (KA_RING_SLOTS * KA_SLOT_BYTES)           // 14336 B: the column ring of a strip wave
+#define KA_WAVE_LDS 18432                                       // per-wave LDS region: the ring, or the staging area of a wave-local subtree (ka_subtree.h)
+#define KA_WAVE_LDS_LEAN 6144                                   // the same in the seq-seq kernels (no ring; residues instead of records)
 #define KA_SP_STRIDE 25                                         // floats per row in the seq-profile score table
 #define KA_T_STRIDE 24                                          // floats per row in the seq-seq score table
 

@@ -235,3 +235,27 @@ def test_refine_of_a_forest_equals_separate_jobs(ctx):
         for got, want in zip(gaps[s0:s0 + ns], g.gaps_list()):
             assert np.array_equal(got, want)
         assert np.array_equal(np.array([r.confidence for r in recs[t0:t0 + nt]], np.float32), g.conf_after)
+
+
+def test_confident_marks_survive_a_watchdog_fallback():
+    """KALIGN_REFINE_CONFIDENT with a member of a multi-workgroup edge that never starts (what a non-resident workgroup
+    looks like from the device): the member barrier's watchdog reports it, ka_tree_sync re-plans with one workgroup per
+    edge and repeats the pass -- and the repeated pass must still refine exactly the edges at or below the median
+    confidence (the marks are not part of the launch plan)."""
+    import kalign_amd
+    g = Golden("refine_cons_prot24_conf")
+    c = kalign_amd.Context(0)
+    try:
+        c.debug_set_hooks(4)                                 # KA_DEBUG_STARVE_REFINE_MEMBER
+        recs, paths, gaps = run_refine(c, g, first_pass=False)
+        assert c.fallback_runs() == 1
+    finally:
+        c.debug_set_hooks(0)
+        c.close()
+    for t, r in enumerate(recs):
+        want = g.paths[int(g.path_off[t]):int(g.path_off[t]) + r.plen + 2]
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], want), t
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+    assert int(g.n_differ) > 0
