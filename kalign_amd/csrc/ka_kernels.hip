@@ -210,6 +210,7 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
 struct KaLevelOut { int2* items; int* prog; int* nitems; int2* pack16; int2* pack4; int* n16; int* n4; int* nsub; int* rowalloc; int srows;
                     int sub_ok, kind, nres, sub_bytes; };       // wave-local subtrees (ka_subtree.h): allowed / what decides whether a window fits
 #define KA_ITEM_SUBTREE 2                                      // `dir` of a work item that is a whole subtree
+#define KA_SUB_MARK 0x7fffffff                                 // KaSub::pad of such a sub-problem: its level's meetups skip it (the wave that ran it did them)
 
 __device__ __forceinline__ bool ka_child_is_subtree(const KaLevelOut& o, int rows, int cols)
 {
@@ -277,8 +278,10 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
 {
         const int lane = wlane % GL;                                 // lane within the sub-problem's group
         const int ksub = k0 + wlane / GL;
-        const bool valid = ksub < ncur;
-        const KaSub sb = qc[valid ? ksub : k0];
+        const bool in_range = ksub < ncur;
+        const KaSub sb = qc[in_range ? ksub : k0];
+        // (a wave-local subtree is already complete: path entries written, margins added, no children left)
+        const bool valid = in_range && (FLIP || REC || sb.pad != KA_SUB_MARK);
         const bool is_top = top_level && ksub == 0;
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
@@ -463,8 +466,12 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 KaSub& cs = ch ? c2 : c1;
                 if (!(ch ? v2 : v1)) continue;
                 cs.roff = row; row += cs.endb - cs.startb + 1;
+                if (ch ? st2 : st1) cs.pad = KA_SUB_MARK;
                 qnext[slot] = cs;
-                if (ch ? st2 : st1) { lout.items[ip] = make_int2(slot, KA_ITEM_SUBTREE << 16); lout.prog[ip] = 0; ++ip; ++slot; continue; }
+                if (ch ? st2 : st1) {
+                        lout.items[ip] = make_int2(slot, KA_ITEM_SUBTREE << 16); lout.prog[ip] = 0; ++ip; ++slot;
+                        continue;
+                }
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                         const int nrows = pr[2 * ch + x], ncols = pc[2 * ch + x], dir = x ? KA_BWD : KA_FWD;
@@ -682,7 +689,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                                 sb.roff = L.rowalloc;
                                                 L.rowalloc += sb.endb - sb.startb + 1;
                                                 S.q[level & 1][L.nsub] = sb;
-                                                ka_emit_items(lo, L.nsub, sb.starta, sb.enda, sb.endb - sb.startb);
+                                                ka_emit_items(lo, L.nsub, sb.starta, sb.enda, sb.endb - sb.startb, sb.pad == KA_SUB_MARK);
                                                 L.nsub += 1;
                                         }
                                         S.Gw = 1; S.member_w = 0; S.split = 1;
