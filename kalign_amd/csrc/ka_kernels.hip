@@ -117,6 +117,8 @@ struct TaskShared {
         int G, member;                 // cluster size / this workgroup's index in it
         int sub_ok, nres_t, sub_stride; // wave-local subtrees (ka_subtree.h): enabled for this task / alphabet class (5, 20, 23) / bytes per wave
         char* sub_base;                //   ... and where the waves' LDS regions start
+        int sub_tm;                    // KA_FLAG_TIMING, the profiled task: subtree phase times are accumulated in sub_t
+        unsigned long long sub_t[7];   //   subtrees, staging / pass / meetup / total cycles (sums over the workgroup's subtrees), longest one, sum of level*1e6 + R*1e3 + C
         int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
         // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
         // over the workgroups, agent-scope hand-over, two cluster barriers per level).  As soon as a level has at least
@@ -1795,8 +1797,8 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 }
 
 // dynamic-LDS layout of a workgroup
-#define KA_LDS_DBG 1008
-#define KA_LDS_TSS 1024
+#define KA_LDS_DBG 1200
+#define KA_LDS_TSS 1216
 #define KA_LDS_WAVES 4096                                           // per-wave regions: 2048-B aligned (ring addressing ORs the column offset in)
 static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table overlaps the wave regions");
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
@@ -1987,6 +1989,8 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 S.nres_t = (D.nres <= 5) ? 5 : ((D.nres <= 20) ? 20 : 23);
                 S.sub_stride = LEAN ? KA_WAVE_LDS_LEAN : KA_WAVE_LDS;
                 S.sub_base = LEAN ? (lds_waves + KA_LEAN_SCRATCH(KA_NT)) : lds_waves;
+                S.sub_tm = (D.timing && (D.prof_task >= 0 ? task == D.prof_task : T.is_root)) ? 1 : 0;
+                for (int x = 0; x < 7; ++x) S.sub_t[x] = 0;
                 S.G = g_eff; S.member = member; S.bar_phase = 0;
                 S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
@@ -2104,6 +2108,8 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                                         lv[3 * l + 1] = l < S.n_levels ? S.lvl_pass[l] : 0;
                                         lv[3 * l + 2] = l < S.n_levels ? S.lvl_meet[l] : 0;
                                 }
+                                // (the leading workgroup's wave-local subtrees: the last seven of the 48 level slots)
+                                if (S.n_levels <= 13) for (int x = 0; x < 7; ++x) lv[41 + x] = (long long)S.sub_t[x];
                         }
                 }
         }
@@ -2210,7 +2216,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
                 S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS;
-                S.sub_ok = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr;     // (flip trials decide in recursion order: no wave-local subtrees)
+                S.sub_ok = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true);
@@ -2701,7 +2707,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS;
-                S.sub_ok = 1; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT);
+                S.sub_ok = 1; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;

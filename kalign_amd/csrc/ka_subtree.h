@@ -50,6 +50,54 @@ __device__ __forceinline__ bool ka_sub_fits(int kind, int nres, int R, int C)
         return R >= 1 && R <= KA_SUB_MAXROWS && C >= 1 && C < 4096 && ka_sub_bytes(kind, nres, R, C) <= KA_WAVE_LDS;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP only (row_shr 1 / 2 / 4 / 8 inside rows of 16, then row_bcast:15 and
+// row_bcast:31 carry the row totals up; no LDS crossbar trips)
+__device__ __forceinline__ int ka_wave_scan_incl(int x)
+{
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+        return x;
+}
+
+// maximum over the 64 lanes, wave-uniform result (same DPP ladder; the last lane ends with the total)
+__device__ __forceinline__ int ka_wave_max_i(int x)
+{
+        x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false));
+        x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false));
+        x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false));
+        x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false));
+        x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));
+        x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false));
+        return __builtin_amdgcn_readlane(x, 63);
+}
+
+template <int ctrl, int row_mask>
+__device__ __forceinline__ double ka_dpp_f64(double x)
+{
+        // lanes the DPP move does not write (no source lane / masked row) read 0.0
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), ctrl, row_mask, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), ctrl, row_mask, 0xf, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 64 lanes (lane 63's total, broadcast)
+__device__ __forceinline__ double ka_wave_sum_f64(double x)
+{
+        x += ka_dpp_f64<0x111, 0xf>(x);
+        x += ka_dpp_f64<0x112, 0xf>(x);
+        x += ka_dpp_f64<0x114, 0xf>(x);
+        x += ka_dpp_f64<0x118, 0xf>(x);
+        x += ka_dpp_f64<0x142, 0xa>(x);
+        x += ka_dpp_f64<0x143, 0xc>(x);
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ void ka_wave_lds_sync()
 {
         // written and read by different lanes of THIS wave only (LDS executes a wave's operations in order)
@@ -83,16 +131,21 @@ __device__ __forceinline__ KaState ka_sub_state(const int code, const KaState ro
         return s;
 }
 
-// The passes pass0 .. pass0 + 64/SLOT - 1 of the current level (pass p = sub-problem p / 2, direction p & 1), SLOT lanes
-// apiece, two DP rows per lane, in lock-step.  Same cell code as ka_packed.
-template <int KIND, int NRES, int SLOT>
-__device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, const int npass, const int pass0, const int lane, const float* tss)
+// The passes pass0 .. pass0 + (64 >> sshift) - 1 of the current level (pass p = sub-problem p / 2, direction p & 1),
+// 1 << sshift lanes apiece, ONE DP row per lane (the level's passes have at most 1 << sshift rows), in lock-step.
+// The cell is ka_packed's; the profile-profile dot product packs two residues per v_pk_mul_f32 and adds the two
+// products one after the other (as ka_strip<.., Q = 1>).  The column record of the NEXT step is fetched behind the
+// dot-product chain with untracked ds_read_b128 (the compiler's own wait for this step's record would otherwise
+// also wait for the fresh loads: lgkmcnt is one in-order counter).
+template <int KIND, int NRES>
+__device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, const int npass, const int pass0, const int sshift, const int lane, const float* tss)
 {
         constexpr int RW = (KIND == KA_PP) ? 4 * ((NRES + 3) / 4) + 4 : (KIND == KA_SP ? 28 : 0);
         constexpr int G0 = RW - 4;                                     // the gap chunk of a record
         constexpr int NV = (NRES + 3) / 4;
-        const int p = pass0 + lane / SLOT;
-        const int ls = lane % SLOT;
+        constexpr int NPAIR = NRES / 2;
+        const int p = pass0 + (lane >> sshift);
+        const int ls = lane & ((1 << sshift) - 1);
         const bool live = p < npass;
         const KaSubL e = ka_subl_load(qc, live ? (p >> 1) : 0);
         const int dir = p & 1;
@@ -102,8 +155,7 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
         const int mid = ((ea - sa) / 2) + sa;
         const int r0 = (dir == KA_FWD) ? sa : mid;
         const int r1 = (dir == KA_FWD) ? mid : ea;
-        const int nrows = r1 - r0;                                    // 0 .. 2 * SLOT
-        const int nl = (nrows + 1) >> 1;
+        const int nrows = r1 - r0;                                    // 0 .. 1 << sshift
         const bool near_t = (dir == KA_FWD) ? (X.b0 + sb == 0) : (X.b0 + eb == X.Lb);
         const bool far_t = (dir == KA_FWD) ? (X.b0 + eb == X.Lb) : (X.b0 + sb == 0);
         const KaState inj = (dir == KA_FWD) ? ka_sub_state((e.c >> 16) & 3, X.rfin) : ka_sub_state((e.c >> 18) & 3, X.rbin);
@@ -112,78 +164,86 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
 #define SREC(v_) ((dir == KA_FWD) ? (sb + (v_)) : (eb + 1 - (v_)))     /* column record, relative to b0 */
 #define SIDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
 
-        const bool writer = live && (ls == (nl > 0 ? nl - 1 : 0));
-        const bool last_is_b = (nrows & 1) == 0;
-        const int uA = min(2 * ls, max(nrows - 1, 0));
-        const int uB = min(2 * ls + 1, max(nrows - 1, 0));
-        const bool actB = live && (2 * ls + 1 < nrows);
-        const int iA = (dir == KA_FWD) ? (r0 + uA) : (r1 - 1 - uA);   // DP rows, relative to a0
-        const int iB = (dir == KA_FWD) ? (r0 + uB) : (r1 - 1 - uB);
-        const int recA = min(max(iA + 1, 0), X.R + 1), recB = min(max(iB + 1, 0), X.R + 1);
+        const bool writer = live && (ls == max(nrows - 1, 0));        // owner of the pass's last row (or of the init row)
+        const int uA = min(ls, max(nrows - 1, 0));
+        const int iA = (dir == KA_FWD) ? (r0 + uA) : (r1 - 1 - uA);   // DP row, relative to a0
+        const int recA = min(max(iA + 1, 0), X.R + 1);
         const int prevA = min(max((dir == KA_FWD) ? recA - 1 : recA + 1, 0), X.R + 1);
-        const int prevB = min(max((dir == KA_FWD) ? recB - 1 : recB + 1, 0), X.R + 1);
 
-        float oA, eA, tA, oB, eB, tB, orpA, orpB;
-        float2v p1v[KIND == KA_PP ? NRES : 1];
-        int res1A = 0, res1B = 0;
+        float oA, eA, tA, orpA;
+        float2v p1p[KIND == KA_PP ? (NPAIR > 0 ? NPAIR : 1) : 1];     // the counts of residues (2i, 2i+1)
+        float p1last = 0.0f;
+        int res1A = 0;
         const ka_lf* srowA = nullptr;
-        const ka_lf* srowB = nullptr;
         if (KIND == KA_SS) {
-                oA = oB = -X.gpo; eA = eB = -X.gpe; tA = tB = -X.tgpe; orpA = orpB = -X.gpo;
-                res1A = X.rowres[min(max(iA, 0), X.R - 1)] * KA_T_STRIDE; res1B = X.rowres[min(max(iB, 0), X.R - 1)] * KA_T_STRIDE;
+                oA = -X.gpo; eA = -X.gpe; tA = -X.tgpe; orpA = -X.gpo;
+                res1A = X.rowres[min(max(iA, 0), X.R - 1)] * KA_T_STRIDE;
         } else {
                 const ka_lf* pA = X.rowsL + recA * RW;
-                const ka_lf* pB = X.rowsL + recB * RW;
-                const float4v ga = *(const ka_lf4*)(pA + G0), gb = *(const ka_lf4*)(pB + G0);
-                oA = ga.x; eA = ga.y; tA = ga.z; oB = gb.x; eB = gb.y; tB = gb.z;
-                orpA = X.rowsL[prevA * RW + G0]; orpB = X.rowsL[prevB * RW + G0];
+                const float4v ga = *(const ka_lf4*)(pA + G0);
+                oA = ga.x; eA = ga.y; tA = ga.z;
+                orpA = X.rowsL[prevA * RW + G0];
                 if (KIND == KA_PP) {
-                        float4v va[NV], vb[NV];
+                        float4v va[NV];
 #pragma unroll
-                        for (int i = 0; i < NV; ++i) { va[i] = ((const ka_lf4*)pA)[i]; vb[i] = ((const ka_lf4*)pB)[i]; }
+                        for (int i = 0; i < NV; ++i) va[i] = ((const ka_lf4*)pA)[i];
 #pragma unroll
-                        for (int c = 0; c < NRES; ++c) {
-                                p1v[c].x = va[c >> 2][c & 3];
-                                p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
-                        }
+                        for (int i = 0; i < NPAIR; ++i) { p1p[i].x = va[(2 * i) >> 2][(2 * i) & 3]; p1p[i].y = va[(2 * i + 1) >> 2][(2 * i + 1) & 3]; }
+                        if (NRES & 1) p1last = va[(NRES - 1) >> 2][(NRES - 1) & 3];
                 } else {
-                        srowA = pA; srowB = pB;                       // seq-profile: the score rows stay in LDS, indexed by the column's residue
+                        srowA = pA;                                   // seq-profile: the score row stays in LDS, indexed by the column's residue
                 }
         }
 
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
-        float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
         float dga = -KA_F, dgga = -KA_F, dggb = -KA_F;
         float inia = inj.a, iniga = inj.ga, inigb = inj.gb;
         float copen_prev = 0.0f;
         float4v q[2][KIND == KA_PP ? NV + 1 : 1];
         int resq[2] = {0, 0};
 
-        auto fetch = [&](float4v* dstq, int& dstres, int vcol) {
-                const int vv = min(max(vcol, 0), ncols);
-                if (KIND == KA_PP) {
-                        const ka_lf4* src = (const ka_lf4*)(X.colsL + SREC(vv) * RW);
-#pragma unroll
-                        for (int ch = 0; ch < NV + 1; ++ch) dstq[ch] = src[ch];
+        // profile columns: the record of column counter vcol (clamped), untracked reads + a manual wait (see ka_strip)
+        const unsigned cols_u = (unsigned)(unsigned long long)X.colsL;
+        auto rec_addr = [&](int vcol) -> unsigned { const int vv = min(max(vcol, 0), ncols); return cols_u + (unsigned)(SREC(vv) * (RW * 4)); };
+        auto pp_read = [&](float4v* dstq, unsigned a, auto& dep) {
+                if (NV == 2) {
+                        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32"
+                                     : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "+v"(dep) : "v"(a) : "memory");
+                } else if (NV == 5) {
+                        asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:32\n\t"
+                                     "ds_read_b128 %3, %7 offset:48\n\tds_read_b128 %4, %7 offset:64\n\tds_read_b128 %5, %7 offset:80"
+                                     : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "=&v"(dstq[3]), "=&v"(dstq[4]), "=&v"(dstq[5]), "+v"(dep) : "v"(a) : "memory");
                 } else {
-                        // residue of column record rec sits at rec - 1 of the sequence (clamped like ka_packed does)
-                        dstres = X.colres[min(max(SREC(max(vv, 1)) - 1, 0), X.C - 1) + 1];
+                        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                                     "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                                     "ds_read_b128 %6, %8 offset:96"
+                                     : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "=&v"(dstq[3]), "=&v"(dstq[4]), "=&v"(dstq[5]), "=&v"(dstq[6]), "+v"(dep) : "v"(a) : "memory");
                 }
         };
-        fetch(q[0], resq[0], -ls);
+        auto pp_wait = [&](float4v* qq) {
+                if (NV == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]) : : "memory");
+                else if (NV == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]) : : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");
+        };
+        static_assert(KIND != KA_PP || NV == 2 || NV == 5 || NV == 6, "alphabets of 5, 20 and 23 residues");
+        auto res_fetch = [&](int vcol) -> int {
+                // residue of column record rec sits at rec - 1 of the sequence (clamped like ka_packed does)
+                const int vv = min(max(vcol, 0), ncols);
+                return X.colres[min(max(SREC(max(vv, 1)) - 1, 0), X.C - 1) + 1];
+        };
+        if (KIND == KA_PP) { float nodep = 0.0f; pp_read(q[0], rec_addr(-ls), nodep); }
+        else resq[0] = res_fetch(-ls);
 
-        int nsteps = live ? (ncols + max(nl, 1)) : 0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, off, 64));
+        const int nsteps = ka_wave_max_i(live ? (ncols + max(nrows, 1)) : 0);
 
         auto step = [&](const int t, auto par_tag) {
                 constexpr int P = decltype(par_tag)::value;
                 const int v = t - ls;
                 const bool vin = live && (v >= 0) && (v <= ncols);
-                fetch(q[1 - P], resq[1 - P], v + 1);
+                if (KIND != KA_PP) resq[1 - P] = res_fetch(v + 1);
 
                 float copen, cext, ctext;
-                if (KIND == KA_PP) { copen = q[P][NV].x; cext = q[P][NV].y; ctext = q[P][NV].z; }
+                if (KIND == KA_PP) { pp_wait(q[P]); copen = q[P][NV].x; cext = q[P][NV].y; ctext = q[P][NV].z; }
                 else { copen = X.kc_open; cext = X.kc_ext; ctext = X.kc_text; }
                 {
                         const float gx = near_t ? ctext : cext, gy = near_t ? ctext : copen;
@@ -193,47 +253,53 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                         iniga = v0 ? inj.ga : (vmid ? g : -KA_F);
                         inigb = v0 ? inj.gb : -KA_F;
                 }
-                float upa = wave_shr1(cBa), upga = wave_shr1(cBga), upgb = wave_shr1(cBgb);
-                if (ls == 0) { upa = inia; upga = iniga; upgb = inigb; }
+                const float sha = wave_shr1(cAa), shga = wave_shr1(cAga), shgb = wave_shr1(cAgb);
+                const float upa = (ls == 0) ? inia : sha, upga = (ls == 0) ? iniga : shga, upgb = (ls == 0) ? inigb : shgb;
 
-                float2v acc;
-                acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
-                acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
+                float a1 = kmax3(dga, dgga + copen_prev, dggb + orpA);
                 if (KIND == KA_SS) {
-                        acc.x += tss[res1A + resq[P]];
-                        acc.y += tss[res1B + resq[P]];
+                        a1 += tss[res1A + resq[P]];
                 } else if (KIND == KA_SP) {
-                        acc.x += srowA[resq[P]];
-                        acc.y += srowB[resq[P]];
+                        a1 += srowA[resq[P]];
                 } else {
+                        if (NRES & 1) a1 += p1last * q[P][(NRES - 1) >> 2][(NRES - 1) & 3];
+                        if (NPAIR > 0) {
+                                auto qpair = [&](int i) -> float2v {
+                                        const float4v& w = q[P][(2 * i) >> 2];
+                                        return ((2 * i) & 3) ? __builtin_shufflevector(w, w, 2, 3) : __builtin_shufflevector(w, w, 0, 1);
+                                };
+                                float2v prod = p1p[NPAIR - 1] * qpair(NPAIR - 1);
 #pragma unroll
-                        for (int c = NRES - 1; c >= 0; --c) {
-                                const float sc = q[P][c >> 2][c & 3];
-                                float2v w; w.x = sc; w.y = sc;
-                                acc = acc + p1v[c] * w;
+                                for (int i = NPAIR - 1; i >= 1; --i) {
+                                        const float2v nprod = p1p[i - 1] * qpair(i - 1);
+                                        a1 += prod.y;
+                                        a1 += prod.x;
+                                        prod = nprod;
+                                }
+                                a1 += prod.y;
+                                a1 += prod.x;
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        pp_read(q[1 - P], rec_addr(v + 1), a1);
+                        __builtin_amdgcn_sched_barrier(0);
                 }
                 const bool at0 = (v == 0), atN = (v == ncols);
                 const bool edge = at0 || atN;
                 const bool term = (at0 && near_t) || (atN && far_t);
-                const float nAa = at0 ? -KA_F : acc.x;
-                const float nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
-                const float nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
-                const float nBa = at0 ? -KA_F : acc.y;
-                const float nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
-                const float nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
+                // selects only (a branchy cell costs more than the arithmetic it skips); max(x, y) + c == max(x + c, y + c) bit
+                // for bit (rounding is monotonic), so the terminal and the inner form of the gb state share one expression
+                const float nAa = at0 ? -KA_F : a1;
+                const float ga_in = kmax(cAga + cext, cAa + copen);
+                const float nAga = edge ? -KA_F : ga_in;
+                const float gbx = term ? tA : eA, gby = term ? tA : oA;
+                const float nAgb = kmax(upgb + gbx, upa + gby);
                 cAa = nAa; cAga = nAga; cAgb = nAgb;
-                cBa = nBa; cBga = nBga; cBgb = nBgb;
                 dga = upa; dgga = upga; dggb = upgb;
                 copen_prev = copen;
+                const float wa = (nrows == 0) ? inia : cAa, wga = (nrows == 0) ? iniga : cAga, wgb = (nrows == 0) ? inigb : cAgb;
                 if (vin && writer) {
                         ka_lf* w = rowbuf + 3 * SIDX(v);
-                        if (nrows == 0) { w[0] = inia; w[1] = iniga; w[2] = inigb; }
-                        else {
-                                w[0] = last_is_b ? cBa : cAa;
-                                w[1] = last_is_b ? cBga : cAga;
-                                w[2] = last_is_b ? cBgb : cAgb;
-                        }
+                        w[0] = wa; w[1] = wga; w[2] = wgb;
                 }
         };
         int t = 0;
@@ -242,6 +308,7 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                 step(t + 1, std::integral_constant<int, 1>());
         }
         if (t < nsteps) step(t, std::integral_constant<int, 0>());
+        if (KIND == KA_PP) pp_wait(q[nsteps & 1]);                    // nothing of this pass is in flight when the LDS is reused
 #undef SREC
 #undef SIDX
 }
@@ -299,14 +366,22 @@ __device__ __forceinline__ void ka_sub_meet(TaskShared& S, const KaSubCtx& X, co
                         best_consider(Bt, fgb + bgb + g6f - sub, kb + 4);
                 }
         }
-#pragma unroll
-        for (int off = GL / 2; off >= 1; off >>= 1) {
-                const float omx = __shfl_xor(Bt.mx, off, 64);
-                const float omx2 = __shfl_xor(Bt.mx2, off, 64);
-                const int okey = __shfl_xor(Bt.key, off, 64);
-                best_merge(Bt, omx, omx2, okey);
+        // group reduction with DPP shifts towards the higher lanes (no LDS crossbar trips): the LAST lane of the group ends
+        // with the group's answer -- lanes without a source lane merge the identity; what the other lanes hold is not used
+#define KA_BEST_STEP(ctrl_, rmask_)                                                                                           \
+        {                                                                                                                     \
+                const float omx = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-KA_F), __float_as_int(Bt.mx), ctrl_, rmask_, 0xf, false));   \
+                const float omx2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-KA_F), __float_as_int(Bt.mx2), ctrl_, rmask_, 0xf, false)); \
+                const int okey = __builtin_amdgcn_update_dpp(0x7fffffff, Bt.key, ctrl_, rmask_, 0xf, false);                   \
+                best_merge(Bt, omx, omx2, okey);                                                                              \
         }
-        const bool leader = (lane == 0) && valid;
+        if (GL >= 2) KA_BEST_STEP(0x111, 0xf)
+        if (GL >= 4) KA_BEST_STEP(0x112, 0xf)
+        if (GL >= 8) KA_BEST_STEP(0x114, 0xf)
+        if (GL >= 16) KA_BEST_STEP(0x118, 0xf)
+        if (GL >= 64) { KA_BEST_STEP(0x142, 0xa) KA_BEST_STEP(0x143, 0xc) }
+#undef KA_BEST_STEP
+        const bool leader = (lane == GL - 1) && valid;
         int meet = -1, tr = -1;
         if (leader && Bt.key != 0x7fffffff) {
                 const int ord = Bt.key & 7;
@@ -356,13 +431,11 @@ __device__ __forceinline__ void ka_sub_meet(TaskShared& S, const KaSubCtx& X, co
         // queue slots and row-buffer cells of the children: exclusive scans over the wave
         const int nsl = (v1 ? 1 : 0) + (v2 ? 1 : 0);
         const int nrw = (v1 ? c1eb - c1sb + 1 : 0) + (v2 ? c2eb - c2sb + 1 : 0);
-        int sc1 = nsl, sc2 = nrw;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-                const int y1 = __shfl_up(sc1, d, 64), y2 = __shfl_up(sc2, d, 64);
-                if (wlane >= d) { sc1 += y1; sc2 += y2; }
-        }
-        const int tot1 = __shfl(sc1, 63, 64), tot2 = __shfl(sc2, 63, 64);
+        // (both counts in one word: at most 128 slots and < 65536 row cells per level)
+        const int sc = ka_wave_scan_incl(nsl | (nrw << 8));
+        const int sc1 = sc & 0xff, sc2 = sc >> 8;
+        const int tots = __builtin_amdgcn_readlane(sc, 63);
+        const int tot1 = tots & 0xff, tot2 = tots >> 8;
         int slot = n_next + sc1 - nsl, row = row_next + sc2 - nrw;
         if (v1) {
                 KaSubL c; c.a = c1sa | (c1ea << 16); c.b = c1sb | (c1eb << 16); c.c = row | (fcode << 16) | (c1bc << 18);
@@ -374,11 +447,9 @@ __device__ __forceinline__ void ka_sub_meet(TaskShared& S, const KaSubCtx& X, co
         }
         n_next += tot1; row_next += tot2;
         // margins (best - second best) of the meetups that had a second candidate
-        double m = (leader && Bt.mx2 > -KA_F) ? (double)(Bt.mx - Bt.mx2) : 0.0;
-        int mc = (leader && Bt.mx2 > -KA_F) ? 1 : 0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { m += __shfl_xor(m, d, 64); mc += __shfl_xor(mc, d, 64); }
-        msum += m; mcount += mc;
+        const bool has2 = leader && Bt.mx2 > -KA_F;
+        msum += ka_wave_sum_f64(has2 ? (double)(Bt.mx - Bt.mx2) : 0.0);
+        mcount += __builtin_popcountll(__ballot(has2));
 }
 
 // The whole subtree below `root` by the calling wave.  area: the wave's LDS region (KA_WAVE_LDS bytes).
@@ -411,37 +482,45 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
         X.F = (ka_lf*)(area + o); o += rbytes;
         X.B = (ka_lf*)(area + o);
 
-        // ---- stage the operand windows ----
+        const bool tmg = S.sub_tm != 0;                               // KA_FLAG_TIMING on the profiled task: where a subtree's time goes
+        long long tq0 = 0, tq1 = 0, tpass = 0, tmeet = 0;
+        if (tmg) tq0 = __builtin_amdgcn_s_memtime();
+        // ---- stage the operand windows: 16-byte chunks, four loads in flight per lane before their LDS writes ----
         const float m1 = ka_uniform_f(S.p1_mult), m2 = ka_uniform_f(S.p2_mult);
+        // one record = `per` chunks: nsc chunks of 4 floats from field `src0` on, then (open, ext, text) * mult
+        auto stage = [&](const float* prof, const int rec0, const int nrec, const int src0, const int nsc, const float mult, ka_lf* dst) {
+                const int per = nsc + 1;
+                const int nit = nrec * per;
+                for (int base = 0; base < nit; base += 256) {
+                        float4v val[4];
+                        int off[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                                const int it = min(base + 64 * u + lane, nit - 1);
+                                const int k = it / per, ch = it - k * per;
+                                const float* rec = prof + ((long long)(rec0 + k) << 6);
+                                if (ch < nsc) val[u] = *(const float4v*)(rec + src0 + 4 * ch);
+                                else { val[u].x = rec[55]; val[u].y = rec[56]; val[u].z = rec[57]; val[u].w = 0.0f; }
+                                off[u] = (ch < nsc) ? (k * RW + 4 * ch) : -(k * RW + G0) - 1;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                                if (base + 64 * u + lane >= nit) continue;
+                                float4v w = val[u];
+                                int o2 = off[u];
+                                if (o2 < 0) { o2 = -o2 - 1; w.x = w.x * mult; w.y = w.y * mult; w.z = w.z * mult; }
+                                *(ka_lf4*)(dst + o2) = w;
+                        }
+                }
+        };
         if (KIND == KA_SS) {
                 for (int i = lane; i < X.R; i += 64) X.rowres[i] = S.s1[X.a0 + i];
         } else {
-                // records a0 .. a0 + R + 1 of the row profile: chunk NV carries the gap terms times nsip of the other operand
-                const int src0 = (KIND == KA_PP) ? 0 : 32;              // PP rows: the counts; SP rows: the scores
-                constexpr int NVR = (KIND == KA_PP) ? NV : 6;
-                static_assert(KIND != KA_SP || RW == 28, "seq-profile row records are 24 scores + the gap chunk");
-                const int per = NVR + 1;
-                const int nit = (X.R + 2) * per;
-                for (int it = lane; it < nit; it += 64) {
-                        const int k = it / per, ch = it % per;
-                        const float* rec = S.p1 + ((long long)(X.a0 + k) << 6);
-                        float4v val;
-                        if (ch < NVR) val = *(const float4v*)(rec + src0 + 4 * ch);
-                        else { val.x = rec[55] * m1; val.y = rec[56] * m1; val.z = rec[57] * m1; val.w = 0.0f; }
-                        *(ka_lf4*)(X.rowsL + k * RW + (ch < NVR ? 4 * ch : G0)) = val;
-                }
+                // records a0 .. a0 + R + 1 of the row profile: PP rows carry the counts, SP rows the 23 scores
+                stage(S.p1, X.a0, X.R + 2, (KIND == KA_PP) ? 0 : 32, (KIND == KA_PP) ? NV : 6, m1, X.rowsL);
         }
         if (KIND == KA_PP) {
-                const int per = NV + 1;
-                const int nit = (X.C + 2) * per;
-                for (int it = lane; it < nit; it += 64) {
-                        const int k = it / per, ch = it % per;
-                        const float* rec = S.p2 + ((long long)(X.b0 + k) << 6);
-                        float4v val;
-                        if (ch < NV) val = *(const float4v*)(rec + 32 + 4 * ch);
-                        else { val.x = rec[55] * m2; val.y = rec[56] * m2; val.z = rec[57] * m2; val.w = 0.0f; }
-                        *(ka_lf4*)(X.colsL + k * RW + (ch < NV ? 4 * ch : G0)) = val;
-                }
+                stage(S.p2, X.b0, X.C + 2, 32, NV, m2, X.colsL);
         } else {
                 // colres[1 + j] = residue at position b0 + j of the column sequence, j = 0 .. C-1 (ka_sub_pass clamps into that range)
                 for (int i = lane; i < X.C; i += 64) X.colres[1 + i] = S.s2[X.b0 + i];
@@ -451,6 +530,7 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
                 ka_subl_store(X.q[0], 0, e);
         }
         ka_wave_lds_sync();
+        if (tmg) tq1 = __builtin_amdgcn_s_memtime();
 
         int ncur = 1, level = 0;
         double msum = 0.0;
@@ -461,13 +541,16 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
                 // ---- passes: the slot size follows the level's longest pass ----
                 int maxrows = 0;
                 for (int k = lane; k < ncur; k += 64) { const KaSubL e = ka_subl_load(qc, k); const int r = (e.a >> 16) - (e.a & 0xffff); maxrows = max(maxrows, r - r / 2); }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) maxrows = max(maxrows, __shfl_xor(maxrows, off, 64));
+                maxrows = ka_wave_max_i(maxrows);
                 const int npass = 2 * ncur;
-                if (maxrows > 8) { for (int p0 = 0; p0 < npass; p0 += 4) ka_sub_pass<KIND, NRES, 16>(X, qc, npass, p0, lane, tss); }
-                else if (maxrows > 2) { for (int p0 = 0; p0 < npass; p0 += 16) ka_sub_pass<KIND, NRES, 4>(X, qc, npass, p0, lane, tss); }
-                else { for (int p0 = 0; p0 < npass; p0 += 64) ka_sub_pass<KIND, NRES, 1>(X, qc, npass, p0, lane, tss); }
+                // slot = the power of two that holds the level's longest pass, one row per lane
+                int sshift = 0;
+                while ((1 << sshift) < maxrows) ++sshift;
+                long long tl0 = 0, tl1 = 0;
+                if (tmg) tl0 = __builtin_amdgcn_s_memtime();
+                for (int p0 = 0; p0 < npass; p0 += 64 >> sshift) ka_sub_pass<KIND, NRES>(X, qc, npass, p0, sshift, lane, tss);
                 ka_wave_lds_sync();
+                if (tmg) tl1 = __builtin_amdgcn_s_memtime();
                 // ---- meetups and children ----
                 int n_next = 0, row_next = 0;
                 if (ncur <= 1) { ka_sub_meet<KIND, NRES, 64>(S, X, qc, ncur, 0, qn, n_next, row_next, msum, mcount, lane); }
@@ -475,8 +558,16 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
                 else if (ncur <= 16) { ka_sub_meet<KIND, NRES, 4>(S, X, qc, ncur, 0, qn, n_next, row_next, msum, mcount, lane); }
                 else { for (int k0 = 0; k0 < ncur; k0 += 64) ka_sub_meet<KIND, NRES, 1>(S, X, qc, ncur, k0, qn, n_next, row_next, msum, mcount, lane); }
                 ka_wave_lds_sync();
+                if (tmg) { const long long tl2 = __builtin_amdgcn_s_memtime(); tpass += tl1 - tl0; tmeet += tl2 - tl1; }
                 ncur = n_next;
                 ++level;
+        }
+        if (tmg && lane == 0) {
+                const long long tot = __builtin_amdgcn_s_memtime() - tq0;
+                atomicAdd(&S.sub_t[0], 1ull); atomicAdd(&S.sub_t[1], (unsigned long long)(tq1 - tq0));
+                atomicAdd(&S.sub_t[2], (unsigned long long)tpass); atomicAdd(&S.sub_t[3], (unsigned long long)tmeet);
+                atomicAdd(&S.sub_t[4], (unsigned long long)tot); atomicMax(&S.sub_t[5], (unsigned long long)tot);
+                atomicAdd(&S.sub_t[6], (unsigned long long)(level * 1000000 + X.R * 1000 + min(X.C, 999)));
         }
         if (lane == 0 && mcount) { atomicAdd(&S.lctl->msum, msum); atomicAdd(&S.lctl->mcount, mcount); }
 }

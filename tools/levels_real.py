@@ -75,4 +75,8 @@ if len(sys.argv) > 6:
         r = recs[idx_of[nodes[0]]]
         print('task of node %d (tree level %d, %dx%d, nsip %d+%d, kind %d), per Hirschberg level:' % (nodes[0], want, r.len_a, r.len_b, r.nsip_a, r.nsip_b, r.kind))
         for l, (nsub, cp, cm) in enumerate(ctx.root_levels):
-            if nsub: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
+            if nsub and l < 13: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
+        st = ctx.root_levels.reshape(-1)[41:48]
+        if st[0]:
+            print('  wave-local subtrees of the leading workgroup: %d, mean us: staging %.1f passes %.1f meetups %.1f total %.1f; longest %.1f; mean levels/rows/cols code %.0f' % (
+                st[0], st[1]/st[0]/GHZ/1e3, st[2]/st[0]/GHZ/1e3, st[3]/st[0]/GHZ/1e3, st[4]/st[0]/GHZ/1e3, st[5]/GHZ/1e3, st[6]/st[0]))
