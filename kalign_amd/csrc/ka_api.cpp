@@ -115,6 +115,8 @@ struct ka_ctx {
         std::vector<int> abc;
         std::vector<KaTaskDesc> descs;
         std::vector<std::vector<int>> levels;        // task ids per dependency level
+        std::vector<std::vector<int>> plan_levels;   // ... of the tasks the current launch plan covers (plan_launches)
+        std::vector<char> plan_active;               // the tasks it covers (empty: the whole job) -- ka_tree_plan_tasks
         std::vector<int> level_ids_flat, level_off;
         std::vector<int2> blocks_flat;               // per level: (task, member | cluster size << 8) per workgroup
         std::vector<int> blocks_off;
@@ -320,6 +322,13 @@ static int plan_launches(ka_ctx* c)
         const int numseq = c->numseq, n_tasks = c->n_tasks;
         const int* abc = c->abc.data();
         const int max_level = (int)c->levels.size();
+        // the tasks this plan covers: all of them, or the subset of ka_tree_plan_tasks (a rank's subtrees of a sharded
+        // tree: closed under descendants).  A task outside the plan is neither a parent nor a producer in it.
+        const bool subset = !c->plan_active.empty();
+        auto act = [&](int t) { return !subset || c->plan_active[t] != 0; };
+        c->plan_levels.assign(max_level, std::vector<int>());
+        for (int L = 0; L < max_level; L++) for (int t : c->levels[L]) if (act(t)) c->plan_levels[L].push_back(t);
+        const std::vector<std::vector<int>>& levels = c->plan_levels;
         // ---- parents, and the level from which the rest of the tree runs as ONE chained launch: the first
         // non-leaf level with at most one task per CU (all its workgroups resident at once; levels only get
         // narrower above it).  KA_NO_CHAIN=1 keeps one launch per level.
@@ -327,12 +336,13 @@ static int plan_launches(ka_ctx* c)
                 std::vector<int> task_of((2 * numseq - 1), -1);
                 for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
                 for (int t = 0; t < n_tasks; t++) { c->descs[t].parent = -1; c->descs[t].chain_need = 0; }
+                for (int t = 0; t < n_tasks; t++) c->descs[t].is_root = 1;
                 for (int t = 0; t < n_tasks; t++) {
                         const int a = abc[3 * t], b = abc[3 * t + 1];
-                        if (a >= numseq) c->descs[task_of[a]].parent = t;
-                        if (b >= numseq) c->descs[task_of[b]].parent = t;
+                        // (is_root is a property of the tree: the root's task builds no profile.  parent is one of the plan.)
+                        if (a >= numseq) { c->descs[task_of[a]].is_root = 0; if (act(t) && act(task_of[a])) c->descs[task_of[a]].parent = t; }
+                        if (b >= numseq) { c->descs[task_of[b]].is_root = 0; if (act(t) && act(task_of[b])) c->descs[task_of[b]].parent = t; }
                 }
-                for (int t = 0; t < n_tasks; t++) c->descs[t].is_root = (c->descs[t].parent < 0);
                 {
                         // join watchdog of the chained launch: ~2 s per 4e9 estimated DP cells below the task (a healthy
                         // sibling subtree of a huge job may legitimately take longer than the base bound)
@@ -352,19 +362,19 @@ static int plan_launches(ka_ctx* c)
                 if (!c->env.no_chain && !c->shared_gpu) {
                         for (int L = 0; L + 1 < max_level; L++) {
                                 bool all_ss = true;
-                                for (int t : c->levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
+                                for (int t : levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
                                 int chain_tasks = c->n_cus - 8;
                                 if (c->env.chain_tasks > 0) chain_tasks = std::min(chain_tasks, c->env.chain_tasks);   // experiments
-                                if (!all_ss && (int)c->levels[L].size() <= chain_tasks) { c->chain_level = L; break; }   // one workgroup per CU, all resident
+                                if (!all_ss && (int)levels[L].size() <= chain_tasks) { c->chain_level = L; break; }   // one workgroup per CU, all resident
                         }
                 }
                 if (c->chain_level >= 0) {
                         for (int t = 0; t < n_tasks; t++) {
-                                if (c->task_level[t] <= c->chain_level) continue;
+                                if (c->task_level[t] <= c->chain_level || !act(t)) continue;
                                 int need = 0;
                                 for (int k = 0; k < 2; k++) {
                                         const int ch = abc[3 * t + k];
-                                        if (ch >= numseq && c->task_level[task_of[ch]] >= c->chain_level) need++;
+                                        if (ch >= numseq && act(task_of[ch]) && c->task_level[task_of[ch]] >= c->chain_level) need++;
                                 }
                                 c->descs[t].chain_need = need;
                         }
@@ -381,19 +391,19 @@ static int plan_launches(ka_ctx* c)
                         int L0 = 0;
                         while (L0 < c->chain_level) {                       // skip the leading seq-seq levels (lean kernel)
                                 bool all_ss = true;
-                                for (int t : c->levels[L0]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
+                                for (int t : levels[L0]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
                                 if (!all_ss) break;
                                 L0++;
                         }
                         bool ok = c->chain_level - L0 >= 2;                 // one level alone gains nothing
-                        if ((int)c->levels[L0].size() <= c->n_cus) ok = false;   // (the queue's first level must fill the GPU; later ones need not)
+                        if ((int)levels[L0].size() <= c->n_cus) ok = false;   // (the queue's first level must fill the GPU; later ones need not)
                         if (ok) {
                                 c->queue_first = L0;
                                 for (int t = 0; t < n_tasks; t++) {
-                                        if (c->task_level[t] < L0 || c->task_level[t] >= c->chain_level) continue;
+                                        if (c->task_level[t] < L0 || c->task_level[t] >= c->chain_level || !act(t)) continue;
                                         const int a = abc[3 * t], b = abc[3 * t + 1];
-                                        if (a >= numseq && c->task_level[task_of[a]] >= L0) c->descs[t].qa = task_of[a];
-                                        if (b >= numseq && c->task_level[task_of[b]] >= L0) c->descs[t].qb = task_of[b];
+                                        if (a >= numseq && act(task_of[a]) && c->task_level[task_of[a]] >= L0) c->descs[t].qa = task_of[a];
+                                        if (b >= numseq && act(task_of[b]) && c->task_level[task_of[b]] >= L0) c->descs[t].qb = task_of[b];
                                 }
                         }
                 }
@@ -403,7 +413,7 @@ static int plan_launches(ka_ctx* c)
         c->max_cluster = c->env.max_cluster > 0 ? std::min(16, c->env.max_cluster) : 16;
         if (c->shared_gpu) c->max_cluster = 1;
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
-        for (auto& L : c->levels) {
+        for (auto& L : levels) {
                 std::vector<int2> tbl;
                 int lean = 0;
                 build_blocks(c, L, tbl, &lean);
@@ -415,7 +425,7 @@ static int plan_launches(ka_ctx* c)
         c->queue_off = (int)c->blocks_flat.size(); c->queue_n = 0;
         if (c->queue_first >= 0) {
                 for (int L = c->queue_first; L < c->chain_level; L++)
-                        for (int t : c->levels[L]) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
+                        for (int t : levels[L]) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
         }
         if (c->chain_level >= 0) {
                 // Every task of the chain's first level starts on a single workgroup; clusters form on the way up.
@@ -425,13 +435,15 @@ static int plan_launches(ka_ctx* c)
                 std::vector<int> task_of((2 * numseq - 1), -1), order;
                 for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
                 std::vector<int> stack;
-                for (int t = n_tasks - 1; t >= 0; t--) if (c->descs[t].parent < 0 && c->task_level[t] >= c->chain_level) stack.push_back(t);   // every root above the cut
+                for (int t = n_tasks - 1; t >= 0; t--) if (act(t) && c->descs[t].parent < 0 && c->task_level[t] >= c->chain_level) stack.push_back(t);   // every root above the cut
                 while (!stack.empty()) {
                         const int t = stack.back(); stack.pop_back();
-                        if (c->task_level[t] == c->chain_level) { order.push_back(t); continue; }
+                        // an entry of the chain: no child of it runs inside the launch (the chain's first level; in a plan over a
+                        // subset also a task whose children were all run before)
+                        if (c->task_level[t] == c->chain_level || c->descs[t].chain_need == 0) { order.push_back(t); continue; }
                         for (int k = 1; k >= 0; k--) {
                                 const int ch = abc[3 * t + k];
-                                if (ch >= numseq && c->task_level[task_of[ch]] >= c->chain_level) stack.push_back(task_of[ch]);
+                                if (ch >= numseq && act(task_of[ch]) && c->task_level[task_of[ch]] >= c->chain_level) stack.push_back(task_of[ch]);
                         }
                 }
                 const int m = ((int)order.size() + 7) / 8;
@@ -611,6 +623,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
 
         c->task_level.assign(n_tasks, 0);
         for (int t = 0; t < n_tasks; t++) c->task_level[t] = level[abc[3 * t + 2]] - 1;
+        c->plan_active.clear();
         if (plan_launches(c)) return KA_FAIL;
 
         // ---- arenas ----
@@ -793,19 +806,21 @@ static int mark_launch(ka_ctx* c)
         return KA_OK;
 }
 
-static int tree_launch(ka_ctx* c)
+// reset: start from the leaves (a whole-tree run); false: a planned subset on top of what the context already holds
+static int tree_launch(ka_ctx* c, bool reset = true)
 {
-        if (tree_reset(c)) return KA_FAIL;
+        if (reset ? tree_reset(c) : (!c->state_valid && tree_reset(c))) return KA_FAIL;
         KaTreeDev D = tree_dev(c);
         D.refine_mode = c->refine_mode & 255;
         D.refine_adaptive = (c->refine_mode >> 8) & 1;
-        c->partial = false;
+        c->partial = !reset;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
-        for (size_t L = 0; L < c->levels.size(); L++) {
-                const int n = (int)c->levels[L].size();
+        for (size_t L = 0; L < c->plan_levels.size(); L++) {
+                const int n = (int)c->plan_levels[L].size();
                 if (!n) continue;
-                if (L) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                if (L || !reset) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                if (!reset && (int)L == c->queue_first) HIPCHK(hipMemsetAsync(c->d_counters.p + 4, 0, sizeof(unsigned long long), c->stream));   // (the queue's head)
                 if (c->refine_mode) {
                         // refinement pass: one launch per tree level (see refine_blocks)
                         ka_unit4_launch(&D, c->d_refine_blocks.p + c->refine_off[L], c->refine_off[L + 1] - c->refine_off[L], D.cons_K > 0, c->stream);
@@ -831,7 +846,7 @@ static int tree_launch(ka_ctx* c)
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev1, c->stream));
-        std::fill(c->task_done.begin(), c->task_done.end(), 1);
+        for (auto& L : c->plan_levels) for (int t : L) c->task_done[t] = 1;
         return KA_OK;
 }
 
@@ -840,6 +855,10 @@ extern "C" int ka_tree_run(ka_ctx* c)
         if (!c || !c->have_job) return fail("no uploaded job");
         HIPCHK(hipSetDevice(c->device));
         c->ran = false; c->synced = false;
+        if (!c->plan_active.empty()) {                   // the last plan covered a subset (ka_tree_plan_tasks): plan the whole tree again
+                c->plan_active.clear();
+                if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
+        }
         if (c->refine_mode) {                            // the plan on the device carries the refine marks of the last ka_tree_refine
                 c->refine_mode = 0;
                 for (auto& d : c->descs) d.refine = 0;
@@ -890,6 +909,7 @@ static int refine_blocks(ka_ctx* c, int mode)
 
 static int refine_launch(ka_ctx* c, int mode)
 {
+        if (!c->plan_active.empty()) { c->plan_active.clear(); if (plan_launches(c)) return KA_FAIL; }
         c->refine_mode = mode;
         if (refine_blocks(c, mode)) return KA_FAIL;
         if (upload_plan(c)) return KA_FAIL;
@@ -1885,3 +1905,428 @@ extern "C" int ka_bpm_batch(ka_ctx* c, const uint8_t* codes, const int* off, con
         HIPCHK(hipMemcpy(dist_out, c->b_dist.p, sizeof(int) * npairs, hipMemcpyDeviceToHost));
         return KA_OK;
 }
+
+// =================================================================================================================
+// One alignment over the GPUs of a node: one process per GPU, RCCL over xGMI, driven from C.
+//
+//   * anchor_consistency_build: every rank aligns its share of the N x K seq-seq batch and fills their position maps
+//     in its copy of the table; every rank's range is then broadcast IN PLACE, HBM to HBM (ncclBroadcast, all ranges in
+//     one group);
+//   * the guide tree is cut ONCE per job into one subtree per rank (balanced by estimated DP cells); a rank's subtrees
+//     run as ONE planned run (queued / chained launches, like a whole tree: ka_tree_plan_tasks); above the cut the
+//     profile of the smaller child moves device to device (ncclSend / ncclRecv: a two-int header, the records from
+//     where they lie in the source's arena into room reserved in the destination's, and -- default mode -- the
+//     residue -> column table of the moved subtree, packed and unpacked on the device) to the rank that holds the other
+//     child, which runs the parent on up to 16 CUs;
+//   * records and coded paths: every rank scatters its own into the job-wide layout on the device and ONE all-reduce
+//     each (disjoint ranges, zeros elsewhere: the sum of integers words is exact) leaves every rank with everything.
+// Results do not depend on the number of ranks: tasks are position-addressed and a task's DP is the same code wherever
+// it runs -- the reference's thread-count invariance (lib/src/aln_run.c:95-109, independent subtrees).
+// RCCL is loaded at run time (dlopen): the single-GPU library has no link-time dependency on it.
+// =================================================================================================================
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+extern "C" void ka_launch_cols_pack(int* colof, const int* seq_off, const int* seq_len, const int* members, const long long* moff, int nmem,
+                                    int* buf, int unpack, hipStream_t stream);
+extern "C" void ka_launch_path_counts(const ka_task_rec* recs, const char* mine, int n_tasks, int* counts, hipStream_t stream);
+extern "C" void ka_launch_path_scatter(const ka_task_rec* recs, const char* mine, int n_tasks, const int* arena, const long long* goff, int* out, hipStream_t stream);
+
+namespace {
+struct Rccl {
+        void* lib = nullptr;
+        ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+        ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+        ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+        ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+        ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+        ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+        ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+        ncclResult_t (*GroupStart)() = nullptr;
+        ncclResult_t (*GroupEnd)() = nullptr;
+        const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+        if (g_rccl.lib) return KA_OK;
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        void* h = nullptr;
+        for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!h) return fail(std::string("ka_dist: cannot load RCCL (librccl.so.1): ") + dlerror());
+#define KA_SYM(field_, name_) *(void**)(&g_rccl.field_) = dlsym(h, name_); if (!g_rccl.field_) return fail(std::string("ka_dist: RCCL lacks ") + name_)
+        KA_SYM(GetUniqueId, "ncclGetUniqueId"); KA_SYM(CommInitRank, "ncclCommInitRank"); KA_SYM(CommDestroy, "ncclCommDestroy");
+        KA_SYM(Broadcast, "ncclBroadcast"); KA_SYM(AllReduce, "ncclAllReduce"); KA_SYM(Send, "ncclSend"); KA_SYM(Recv, "ncclRecv");
+        KA_SYM(GroupStart, "ncclGroupStart"); KA_SYM(GroupEnd, "ncclGroupEnd"); KA_SYM(GetErrorString, "ncclGetErrorString");
+#undef KA_SYM
+        g_rccl.lib = h;
+        return KA_OK;
+}
+#define NCCLCHK(x)                                                                                         \
+        do {                                                                                               \
+                ncclResult_t r_ = (x);                                                                     \
+                if (r_ != ncclSuccess) return fail(std::string(#x) + ": " + g_rccl.GetErrorString(r_));     \
+        } while (0)
+}  // namespace
+
+// A child profile that changes GPUs above the cut
+struct KaMove {
+        int task, child, src, dst;
+        int nmem = 0;                  // default mode: the child's member sequences ...
+        long long ncols = 0;           // ... and the ints of their residue -> column tables
+        DevBuf<int> d_members; DevBuf<long long> d_moff;
+};
+struct ka_dist {
+        ka_ctx* c = nullptr;
+        int rank = 0, world = 1;
+        ncclComm_t comm = nullptr;
+        bool planned = false;
+        std::vector<int> run_rank, top, mine_sub;        // rank of every task; the tasks above the cut (tree order); this rank's subtree tasks
+        std::vector<KaMove> moves;                       // in the order the top tasks need them
+        std::vector<std::vector<int>> top_moves;         // per top task: indices into moves
+        std::vector<DevBuf<int2>> top_blocks;            // per top task this rank runs: its workgroup table
+        DevBuf<char> d_mine; DevBuf<int> d_counts, d_gpaths, d_colbuf; DevBuf<long long> d_goff;
+        std::vector<char> mine;
+        std::vector<ka_task_rec> h_recs;
+        std::vector<int> h_paths;
+        std::vector<long long> goff;
+        int* h_head = nullptr;                           // pinned: the two-int header of an incoming profile
+        double last_ms = 0.0, last_kernel_wait_ms = 0.0;
+};
+
+// Pure planning (no device, no communicator): cut the tree into at most `world` subtrees balanced by estimated DP cells;
+// run_rank[t] = the rank that runs task t, top[0 .. *n_top) = the tasks above the cut in tree order.  Every rank derives
+// the same plan from the same inputs.
+extern "C" int ka_dist_plan_subtrees(int numseq, const int* lens, int n_tasks, const int* abc, int world, int* run_rank, int* top, int* n_top)
+{
+        if (numseq < 2 || n_tasks < 1 || world < 1 || !lens || !abc || !run_rank || !top || !n_top) return fail("ka_dist_plan_subtrees: bad arguments");
+        const int nprof = 2 * numseq - 1;
+        std::vector<int> task_of(nprof, -1), members(nprof, 0);
+        std::vector<double> est(nprof, 0.0), work(nprof, 0.0);
+        for (int i = 0; i < numseq; i++) { est[i] = lens[i]; members[i] = 1; }
+        for (int t = 0; t < n_tasks; t++) {
+                const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                if (a < 0 || b < 0 || cc < numseq || a >= nprof || b >= nprof || cc >= nprof) return fail("ka_dist_plan_subtrees: bad task list");
+                task_of[cc] = t;
+                est[cc] = 1.05 * std::max(est[a], est[b]);
+                work[cc] = work[a] + work[b] + est[a] * est[b];
+                members[cc] = members[a] + members[b];
+        }
+        const int root = abc[3 * (n_tasks - 1) + 2];
+        std::vector<int> frontier(1, root), tops;
+        auto internal = [&](const std::vector<int>& f) { int n = 0; for (int x : f) n += x >= numseq; return n; };
+        while (internal(frontier) < world) {
+                int best = -1;
+                for (int x : frontier) if (x >= numseq && (best < 0 || work[x] > work[best] || (work[x] == work[best] && x < best))) best = x;
+                if (best < 0) break;
+                const int t = task_of[best];
+                const int kids = (abc[3 * t] >= numseq) + (abc[3 * t + 1] >= numseq);
+                if (kids == 0) break;                            // splitting would not add a subtree (both children are leaves)
+                frontier.erase(std::find(frontier.begin(), frontier.end(), best));
+                frontier.push_back(abc[3 * t]); frontier.push_back(abc[3 * t + 1]);
+                tops.push_back(t);
+        }
+        std::sort(tops.begin(), tops.end());
+        std::vector<int> roots;
+        for (int x : frontier) if (x >= numseq) roots.push_back(x);
+        std::sort(roots.begin(), roots.end(), [&](int x, int y) { return work[x] > work[y] || (work[x] == work[y] && x < y); });
+        for (int t = 0; t < n_tasks; t++) run_rank[t] = -1;
+        std::vector<int> holder(nprof, -1);
+        for (size_t r = 0; r < roots.size(); r++) {
+                std::vector<int> stack(1, roots[r]);
+                while (!stack.empty()) {
+                        const int v = stack.back(); stack.pop_back();
+                        if (v < numseq) continue;
+                        const int t = task_of[v];
+                        run_rank[t] = (int)(r % world);
+                        stack.push_back(abc[3 * t]); stack.push_back(abc[3 * t + 1]);
+                }
+                holder[roots[r]] = (int)(r % world);
+        }
+        for (int t : tops) {                                     // tree order: children first
+                const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                const int ha = holder[a], hb = holder[b];
+                int r;
+                if (ha < 0 && hb < 0) r = 0;
+                else if (ha < 0 || (hb >= 0 && members[b] > members[a])) r = hb;
+                else r = ha;
+                run_rank[t] = r;
+                holder[cc] = r;
+        }
+        for (size_t i = 0; i < tops.size(); i++) top[i] = tops[i];
+        *n_top = (int)tops.size();
+        return KA_OK;
+}
+
+extern "C" int ka_dist_unique_id(void* id128)
+{
+        if (!id128) return fail("null id");
+        if (rccl_load()) return KA_FAIL;
+        static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+        ncclUniqueId id;
+        NCCLCHK(g_rccl.GetUniqueId(&id));
+        memcpy(id128, &id, sizeof(id));
+        return KA_OK;
+}
+
+extern "C" void ka_dist_destroy(ka_dist* d)
+{
+        if (!d) return;
+        if (d->c) (void)hipSetDevice(d->c->device);
+        if (d->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d->comm);
+        for (auto& m : d->moves) { m.d_members.release(); m.d_moff.release(); }
+        for (auto& b : d->top_blocks) b.release();
+        d->d_mine.release(); d->d_counts.release(); d->d_gpaths.release(); d->d_colbuf.release(); d->d_goff.release();
+        if (d->h_head) (void)hipHostFree(d->h_head);
+        delete d;
+}
+
+// id128: the 128 bytes rank 0 got from ka_dist_unique_id, handed to every rank by the launcher (a file, MPI, torch...).
+// world == 1: no communicator is made (every step degenerates to the local run) -- the code path is the same.
+extern "C" int ka_dist_create(ka_ctx* c, int rank, int world, const void* id128, ka_dist** out)
+{
+        if (!c || !out || world < 1 || rank < 0 || rank >= world) return fail("ka_dist_create: bad arguments");
+        HIPCHK(hipSetDevice(c->device));
+        ka_dist* d = new ka_dist();
+        d->c = c; d->rank = rank; d->world = world;
+        if (hipHostMalloc((void**)&d->h_head, 64, hipHostMallocDefault) != hipSuccess) { delete d; return fail("hipHostMalloc failed"); }
+        if (world > 1 || id128) {
+                if (!id128 || rccl_load()) { ka_dist_destroy(d); return id128 ? KA_FAIL : fail("ka_dist_create: a world of several ranks needs the unique id"); }
+                ncclUniqueId id;
+                memcpy(&id, id128, sizeof(id));
+                ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, id, rank);
+                if (r != ncclSuccess) { const std::string m = g_rccl.GetErrorString(r); ka_dist_destroy(d); return fail("ncclCommInitRank: " + m); }
+        }
+        *out = d;
+        return KA_OK;
+}
+
+// Once per uploaded job: the cut, who runs what, the hand-overs above the cut, this rank's subtrees planned as one run.
+extern "C" int ka_dist_plan(ka_dist* d)
+{
+        if (!d || !d->c || !d->c->have_job) return fail("ka_dist_plan: no uploaded job");
+        ka_ctx* c = d->c;
+        HIPCHK(hipSetDevice(c->device));
+        if (c->n_tasks != c->numseq - 1) return fail("ka_dist_plan: one guide tree per job");
+        const int n_tasks = c->n_tasks, numseq = c->numseq;
+        d->run_rank.assign(n_tasks, -1);
+        d->top.assign(n_tasks, 0);
+        int n_top = 0;
+        if (ka_dist_plan_subtrees(numseq, c->lens.data(), n_tasks, c->abc.data(), d->world, d->run_rank.data(), d->top.data(), &n_top)) return KA_FAIL;
+        d->top.resize(n_top);
+        std::vector<char> is_top(n_tasks, 0);
+        for (int t : d->top) is_top[t] = 1;
+        d->mine_sub.clear();
+        d->mine.assign(n_tasks, 0);
+        for (int t = 0; t < n_tasks; t++) {
+                if (d->run_rank[t] == d->rank) d->mine[t] = 1;
+                if (d->run_rank[t] == d->rank && !is_top[t]) d->mine_sub.push_back(t);
+        }
+        // the hand-overs: a child of a top task that sits on another rank than the one running the parent
+        for (auto& m : d->moves) { m.d_members.release(); m.d_moff.release(); }
+        for (auto& b : d->top_blocks) b.release();
+        d->moves.clear(); d->top_moves.assign(n_top, std::vector<int>()); d->top_blocks.clear(); d->top_blocks.resize(n_top);
+        std::vector<int> holder(2 * numseq - 1, -1);
+        for (int t = 0; t < n_tasks; t++) if (!is_top[t]) holder[c->abc[3 * t + 2]] = d->run_rank[t];
+        long long max_cols = 0;
+        for (int i = 0; i < n_top; i++) {
+                const int t = d->top[i], dst = d->run_rank[t];
+                for (int k = 0; k < 2; k++) {
+                        const int child = c->abc[3 * t + k];
+                        const int src = child >= numseq ? holder[child] : -1;
+                        if (child < numseq || src < 0 || src == dst) continue;
+                        d->moves.emplace_back();
+                        KaMove& m = d->moves.back();
+                        m.task = t; m.child = child; m.src = src; m.dst = dst;
+                        if (d->rank == src || d->rank == dst) {
+                                long long lo, hi;
+                                node_members(c, child, &lo, &hi);
+                                std::vector<int> mem(c->sip_flat.begin() + lo, c->sip_flat.begin() + hi);
+                                std::vector<long long> off(mem.size());
+                                long long o = 0;
+                                for (size_t q = 0; q < mem.size(); q++) { off[q] = o; o += c->lens[mem[q]]; }
+                                m.nmem = (int)mem.size(); m.ncols = o;
+                                max_cols = std::max(max_cols, o);
+                                if (m.d_members.alloc(mem.size()) || m.d_moff.alloc(off.size())) return fail("hipMalloc failed");
+                                HIPCHK(hipMemcpy(m.d_members.p, mem.data(), sizeof(int) * mem.size(), hipMemcpyHostToDevice));
+                                HIPCHK(hipMemcpy(m.d_moff.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
+                        }
+                        d->top_moves[i].push_back((int)d->moves.size() - 1);
+                }
+                holder[c->abc[3 * t + 2]] = dst;
+                if (dst == d->rank) {
+                        std::vector<int2> tbl;
+                        int lean = 0;
+                        build_blocks(c, std::vector<int>(1, t), tbl, &lean);
+                        if (d->top_blocks[i].alloc(tbl.size())) return fail("hipMalloc failed");
+                        HIPCHK(hipMemcpy(d->top_blocks[i].p, tbl.data(), sizeof(int2) * tbl.size(), hipMemcpyHostToDevice));
+                }
+        }
+        if (d->d_mine.alloc(n_tasks) || d->d_counts.alloc(n_tasks) || d->d_goff.alloc(n_tasks) || d->d_colbuf.alloc((size_t)std::max<long long>(max_cols, 1)))
+                return fail("hipMalloc failed");
+        HIPCHK(hipMemcpy(d->d_mine.p, d->mine.data(), n_tasks, hipMemcpyHostToDevice));
+        // this rank's subtrees as ONE planned run (queued / chained launches where they apply)
+        c->plan_active.assign(n_tasks, 0);
+        for (int t : d->mine_sub) c->plan_active[t] = 1;
+        if (d->mine_sub.empty()) c->plan_active.assign(n_tasks, 0);
+        // (an all-zero mask is a plan over nothing: every level empty)
+        if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
+        d->planned = true;
+        return KA_OK;
+}
+
+extern "C" int ka_dist_get_plan(ka_dist* d, int* run_rank, int* top, int* n_top, int* n_moves)
+{
+        if (!d || !d->planned) return fail("ka_dist_get_plan: plan first");
+        if (run_rank) memcpy(run_rank, d->run_rank.data(), sizeof(int) * d->run_rank.size());
+        if (top) memcpy(top, d->top.data(), sizeof(int) * d->top.size());
+        if (n_top) *n_top = (int)d->top.size();
+        if (n_moves) *n_moves = (int)d->moves.size();
+        return KA_OK;
+}
+
+// anchor_consistency_build over the ranks: this rank's share of the N x K batch, then every share broadcast in place.
+extern "C" int ka_dist_consistency(ka_dist* d, int n_anchors, float weight)
+{
+        if (!d || !d->c) return fail("ka_dist_consistency: null");
+        ka_ctx* c = d->c;
+        HIPCHK(hipSetDevice(c->device));
+        // a part that cannot be built (e.g. it holds only anchors) must not leave the other ranks waiting in a collective:
+        // every rank reduces the outcome first
+        int rc = ka_tree_build_consistency_part(c, n_anchors, weight, d->rank, d->world);
+        const std::string why = rc ? g_err : std::string();
+        if (d->world > 1) {
+                int* flag = (int*)d->d_counts.p;
+                if (!flag && d->d_counts.alloc(std::max(c->n_tasks, 1))) return fail("hipMalloc failed");
+                flag = d->d_counts.p;
+                const int mine = rc ? 1 : 0;
+                HIPCHK(hipMemcpyAsync(flag, &mine, sizeof(int), hipMemcpyHostToDevice, c->stream));
+                NCCLCHK(g_rccl.AllReduce(flag, flag, 1, ncclInt32, ncclMax, d->comm, c->stream));
+                int any = 0;
+                HIPCHK(hipMemcpyAsync(&any, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (any) return fail(rc ? why : std::string("ka_dist_consistency: another rank could not build its part"));
+                if (c->cons_K <= 0) return KA_OK;                    // the job declined on every rank alike (fewer than 3 sequences ...)
+                NCCLCHK(g_rccl.GroupStart());
+                for (int r = 0; r < d->world; r++) {
+                        long long lo = 0, hi = 0;
+                        if (ka_tree_consistency_part_range(c, r, d->world, &lo, &hi)) { (void)g_rccl.GroupEnd(); return KA_FAIL; }
+                        if (hi > lo) NCCLCHK(g_rccl.Broadcast(c->d_cons_maps.p + lo, c->d_cons_maps.p + lo, (size_t)(hi - lo), ncclInt32, r, d->comm, c->stream));
+                }
+                NCCLCHK(g_rccl.GroupEnd());
+        } else if (rc) return KA_FAIL;
+        return KA_OK;
+}
+
+// One step of the sharded tree: from the leaves to every rank holding every record and coded path.
+extern "C" int ka_dist_tree_run(ka_dist* d)
+{
+        if (!d || !d->planned) return fail("ka_dist_tree_run: plan first");
+        ka_ctx* c = d->c;
+        HIPCHK(hipSetDevice(c->device));
+        const auto t_begin = std::chrono::steady_clock::now();
+        const int n_tasks = c->n_tasks;
+        if (c->plan_active.empty()) return fail("ka_dist_tree_run: the context's plan was replaced by a whole-tree run; call ka_dist_plan again");
+        c->ran = false; c->synced = false;
+        if (tree_reset(c)) return KA_FAIL;                          // (keeps the consistency table; residue -> column tables back to the leaves)
+        if (tree_launch(c, false)) return KA_FAIL;                  // this rank's subtrees
+        const KaTreeDev D = tree_dev(c);
+        for (size_t i = 0; i < d->top.size(); i++) {
+                const int t = d->top[i], dst = d->run_rank[t];
+                for (int mi : d->top_moves[i]) {
+                        KaMove& m = d->moves[mi];
+                        if (d->rank != m.src && d->rank != m.dst) continue;
+                        const bool cols = c->have_colof && m.ncols > 0 && (c->cons_K > 0 || (c->flags & KA_FLAG_DEVICE_GAPS));
+                        if (d->rank == m.src) {
+                                // header (plen) straight from the node table, the records from where they lie in the arena
+                                HIPCHK(hipMemcpyAsync(d->h_head, c->d_node_len.p + m.child, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(hipMemcpyAsync(d->h_head + 2, c->d_node_prof.p + m.child, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(hipStreamSynchronize(c->stream));
+                                const int plen = d->h_head[0];
+                                long long po; memcpy(&po, d->h_head + 2, sizeof(po));
+                                if (plen < 1 || po < 0) return fail("ka_dist_tree_run: a subtree root has no profile");
+                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_seq_len_dev(), m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 0, c->stream);
+                                NCCLCHK(g_rccl.GroupStart());
+                                NCCLCHK(g_rccl.Send(c->d_node_len.p + m.child, 1, ncclInt32, m.dst, d->comm, c->stream));
+                                NCCLCHK(g_rccl.Send(c->d_prof_arena.p + po, (size_t)(plen + 2) * KA_REC, ncclFloat32, m.dst, d->comm, c->stream));
+                                if (cols) NCCLCHK(g_rccl.Send(d->d_colbuf.p, (size_t)m.ncols, ncclInt32, m.dst, d->comm, c->stream));
+                                NCCLCHK(g_rccl.GroupEnd());
+                        } else {
+                                // the header first: it sizes the room the records get in this rank's arena
+                                NCCLCHK(g_rccl.Recv(c->d_node_len.p + m.child, 1, ncclInt32, m.src, d->comm, c->stream));
+                                HIPCHK(hipMemcpyAsync(d->h_head, c->d_node_len.p + m.child, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(hipMemcpyAsync(d->h_head + 2, c->d_counters.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(hipStreamSynchronize(c->stream));
+                                const int plen = d->h_head[0];
+                                unsigned long long top_; memcpy(&top_, d->h_head + 2, sizeof(top_));
+                                const unsigned long long need = (unsigned long long)(plen + 2) * KA_REC;
+                                if (plen < 1 || (long long)(top_ + need) > c->prof_cap) return fail("ka_dist_tree_run: profile arena too small for an incoming profile");
+                                const long long po = (long long)top_;
+                                top_ += need;
+                                memcpy(d->h_head + 4, &top_, sizeof(top_)); memcpy(d->h_head + 6, &po, sizeof(po));
+                                HIPCHK(hipMemcpyAsync(c->d_counters.p, d->h_head + 4, sizeof(top_), hipMemcpyHostToDevice, c->stream));
+                                HIPCHK(hipMemcpyAsync(c->d_node_prof.p + m.child, d->h_head + 6, sizeof(po), hipMemcpyHostToDevice, c->stream));
+                                NCCLCHK(g_rccl.GroupStart());
+                                NCCLCHK(g_rccl.Recv(c->d_prof_arena.p + po, (size_t)need, ncclFloat32, m.src, d->comm, c->stream));
+                                if (cols) NCCLCHK(g_rccl.Recv(d->d_colbuf.p, (size_t)m.ncols, ncclInt32, m.src, d->comm, c->stream));
+                                NCCLCHK(g_rccl.GroupEnd());
+                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_seq_len_dev(), m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 1, c->stream);
+                                HIPCHK(hipStreamSynchronize(c->stream));          // (h_head is reused by the next hand-over)
+                                c->injected.push_back(m.child);
+                        }
+                }
+                if (dst == d->rank) {
+                        HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                        ka_launch_task_level(&D, d->top_blocks[i].p, (int)d->top_blocks[i].n, 0, 0, c->stream);
+                        c->n_launches++;
+                        c->task_done[t] = 1;
+                }
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        c->ran = true; c->partial = true;
+        // ---- every rank ends with every record and every coded path ----
+        if (ka_tree_sync(c)) return KA_FAIL;                        // (arena overflow, watchdogs: partial runs do not re-run)
+        ka_launch_path_counts(c->d_recs.p, d->d_mine.p, n_tasks, d->d_counts.p, c->stream);
+        if (d->world > 1) NCCLCHK(g_rccl.AllReduce(d->d_counts.p, d->d_counts.p, (size_t)n_tasks, ncclInt32, ncclSum, d->comm, c->stream));
+        std::vector<int> counts(n_tasks);
+        HIPCHK(hipMemcpyAsync(counts.data(), d->d_counts.p, sizeof(int) * n_tasks, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        d->goff.assign(n_tasks, 0);
+        long long total = 0;
+        for (int t = 0; t < n_tasks; t++) { d->goff[t] = total; total += counts[t]; }
+        if (d->d_gpaths.alloc((size_t)std::max<long long>(total, 1))) return fail("hipMalloc failed");
+        HIPCHK(hipMemcpyAsync(d->d_goff.p, d->goff.data(), sizeof(long long) * n_tasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(d->d_gpaths.p, 0, sizeof(int) * (size_t)total, c->stream));
+        ka_launch_path_scatter(c->d_recs.p, d->d_mine.p, n_tasks, c->d_path_arena.p, d->d_goff.p, d->d_gpaths.p, c->stream);
+        if (d->world > 1) {
+                static_assert(sizeof(ka_task_rec) % 4 == 0, "records are reduced as 32-bit words");
+                NCCLCHK(g_rccl.GroupStart());
+                NCCLCHK(g_rccl.AllReduce(d->d_gpaths.p, d->d_gpaths.p, (size_t)total, ncclInt32, ncclSum, d->comm, c->stream));
+                NCCLCHK(g_rccl.AllReduce(c->d_recs.p, c->d_recs.p, (size_t)n_tasks * (sizeof(ka_task_rec) / 4), ncclInt32, ncclSum, d->comm, c->stream));
+                NCCLCHK(g_rccl.GroupEnd());
+        }
+        d->h_recs.resize(n_tasks);
+        d->h_paths.resize((size_t)total);
+        HIPCHK(hipMemcpyAsync(d->h_recs.data(), c->d_recs.p, sizeof(ka_task_rec) * n_tasks, hipMemcpyDeviceToHost, c->stream));
+        if (copy_to_host(c, d->h_paths.data(), d->d_gpaths.p, sizeof(int) * (size_t)total)) return KA_FAIL;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int t = 0; t < n_tasks; t++) d->h_recs[t].path_off = (int)d->goff[t];
+        d->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return KA_OK;
+}
+
+// Records (task order, path_off into paths) and coded paths of the last ka_dist_tree_run; *used = ints written.
+extern "C" int ka_dist_download(ka_dist* d, ka_task_rec* recs, int* paths, long long paths_cap, long long* used)
+{
+        if (!d || d->h_recs.empty()) return fail("ka_dist_download: run first");
+        if ((long long)d->h_paths.size() > paths_cap) { g_err = "paths_out too small"; return KA_ERR_PATHS_CAP; }
+        memcpy(recs, d->h_recs.data(), sizeof(ka_task_rec) * d->h_recs.size());
+        memcpy(paths, d->h_paths.data(), sizeof(int) * d->h_paths.size());
+        if (used) *used = (long long)d->h_paths.size();
+        return KA_OK;
+}
+
+extern "C" long long ka_dist_paths_size(ka_dist* d) { return d ? (long long)d->h_paths.size() : -1; }
+extern "C" double ka_dist_last_ms(ka_dist* d) { return d ? d->last_ms : -1.0; }

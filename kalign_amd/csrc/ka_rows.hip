@@ -5,6 +5,7 @@
 // N x alnlen bytes it writes; one workgroup per sequence.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "kalign_amd.h"
 
 // Thread p owns residue p of its sequence: the gap run in front of it (columns colof[p-1]+1 .. colof[p]-1), the
 // letter itself, and -- the last residue -- the trailing gaps and the terminator.  Every byte of the row is
@@ -284,4 +285,52 @@ extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys
         hipLaunchKernelGGL(ka_upgma_init_kernel, dim3(blocks), dim3(256), 0, stream, U);
         for (int step = 0; step < n - 1; ++step)
                 hipLaunchKernelGGL(ka_upgma_step_kernel, dim3(blocks), dim3(256), 0, stream, U, step);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Helpers of the sharded tree (ka_dist_*, ka_api.cpp): all byte / index work, one launch each.
+// ------------------------------------------------------------------------------------------------
+// The residue -> column table of a subtree's member sequences (scattered over `colof` like the sequences are), packed
+// into one contiguous buffer for the hand-over to another GPU, or unpacked from it.  One workgroup per member.
+__global__ void __launch_bounds__(256) ka_cols_pack_kernel(int* __restrict__ colof, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
+                                                           const int* __restrict__ members, const long long* __restrict__ moff, int* __restrict__ buf,
+                                                           const int unpack)
+{
+        const int m = members[blockIdx.x];
+        int* tbl = colof + seq_off[m];
+        int* b = buf + moff[blockIdx.x];
+        const int n = seq_len[m];
+        if (unpack) for (int i = threadIdx.x; i < n; i += blockDim.x) tbl[i] = b[i];
+        else for (int i = threadIdx.x; i < n; i += blockDim.x) b[i] = tbl[i];
+}
+extern "C" void ka_launch_cols_pack(int* colof, const int* seq_off, const int* seq_len, const int* members, const long long* moff, int nmem,
+                                    int* buf, int unpack, hipStream_t stream)
+{
+        if (nmem > 0) hipLaunchKernelGGL(ka_cols_pack_kernel, dim3(nmem), dim3(256), 0, stream, colof, seq_off, seq_len, members, moff, buf, unpack);
+}
+
+// plen + 2 of every task this rank ran (0 for the others): what the all-reduce turns into every rank's path layout
+__global__ void __launch_bounds__(256) ka_path_counts_kernel(const ka_task_rec* __restrict__ recs, const char* __restrict__ mine, int n_tasks, int* __restrict__ counts)
+{
+        const int t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < n_tasks) counts[t] = mine[t] ? recs[t].plen + 2 : 0;
+}
+// this rank's coded paths from its own arena into the job-wide layout (goff[t], task order); other ranks' ranges stay zero
+__global__ void __launch_bounds__(256) ka_path_scatter_kernel(const ka_task_rec* __restrict__ recs, const char* __restrict__ mine,
+                                                              const int* __restrict__ arena, const long long* __restrict__ goff, int* __restrict__ out)
+{
+        const int t = blockIdx.x;
+        if (!mine[t]) return;
+        const int n = recs[t].plen + 2;
+        const int* src = arena + recs[t].path_off;
+        int* dst = out + goff[t];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+extern "C" void ka_launch_path_counts(const ka_task_rec* recs, const char* mine, int n_tasks, int* counts, hipStream_t stream)
+{
+        hipLaunchKernelGGL(ka_path_counts_kernel, dim3((n_tasks + 255) / 256), dim3(256), 0, stream, recs, mine, n_tasks, counts);
+}
+extern "C" void ka_launch_path_scatter(const ka_task_rec* recs, const char* mine, int n_tasks, const int* arena, const long long* goff, int* out, hipStream_t stream)
+{
+        hipLaunchKernelGGL(ka_path_scatter_kernel, dim3(n_tasks), dim3(256), 0, stream, recs, mine, arena, goff, out);
 }
