@@ -701,7 +701,33 @@ def multi_gpu_main(args, rank, world, local_rank):
     anchors = 0 if args.scale_fast else 5
     ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
 
+    # The C multi-GPU layer (ka_dist_*: the cut planned once per job, a rank's subtrees as ONE planned run, RCCL called from
+    # C on HBM buffers) whenever the backend is RCCL; the torch.distributed path of kalign_amd/dist.py for the gloo tests
+    # (and as the fall-back should the C layer fail to come up: `dist_layer` says which one ran).
+    cd, dist_layer = None, "python (kalign_amd/dist.py over torch.distributed)"
+    if not same_gpu and not os.environ.get("KA_BENCH_PYDIST"):
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.as_tensor(api.dist_unique_id()))
+            dist.broadcast(uid, src=0)
+            torch.cuda.synchronize()
+            cd = api.Dist(ctx, rank, world, uid.cpu().numpy())
+            cd.plan()
+            dist_layer = "C (ka_dist_*: RCCL from C, one planned run per rank)"
+        except Exception as e:                                     # pragma: no cover
+            sys.stderr.write("rank %d: C multi-GPU layer unavailable (%s): torch.distributed path\n" % (rank, e))
+            cd = None
+        ok = kd.reduce_scalar(1.0 if cd is not None else 0.0, "sum", device=coll_dev) >= world - 0.5
+        if not ok and cd is not None:                              # (all ranks take the same path)
+            cd.close(); cd = None
+
     def step():
+        if cd is not None:
+            if anchors:
+                cd.consistency(anchors, 2.0)
+            cd.tree_run()
+            return None, None
         ctx.tree_reset()
         if anchors:
             kd.sharded_consistency(ctx, anchors, 2.0, rank, world)
@@ -720,6 +746,8 @@ def multi_gpu_main(args, rank, world, local_rank):
         recs, paths = step()
     barrier()
     elapsed = kd.reduce_scalar(time.perf_counter() - t0, "max", device=coll_dev)
+    if cd is not None:
+        recs, paths = cd.download()                                # (every rank holds every record and path after each step)
     cells = float(sum(r.len_a * r.len_b for r in recs))
     pair_cells = 0.0
     if anchors:
@@ -731,9 +759,16 @@ def multi_gpu_main(args, rank, world, local_rank):
     same_as_one_gpu = None
     if rank == 0:
         # the same job as ONE whole-tree run on this rank's GPU (outside the timed region): results must not depend on N
-        if anchors:
-            ctx.tree_build_consistency(anchors, 2.0)
-        ctx.tree_run()
+        def single():
+            if anchors:
+                ctx.tree_build_consistency(anchors, 2.0)
+            ctx.tree_run()
+            ctx.tree_sync()
+        single()
+        ts = time.perf_counter()
+        for _ in range(2):
+            single()
+        single_ms = (time.perf_counter() - ts) / 2 * 1e3
         r1, p1, _ = ctx.tree_download(want_gaps=False)
         diff = [t for t, (a, b) in enumerate(zip(r1, recs))
                 if a.plen != b.plen or not np.array_equal(p1[a.path_off:a.path_off + a.plen + 2], paths[b.path_off:b.path_off + b.plen + 2])]
@@ -758,8 +793,15 @@ def multi_gpu_main(args, rank, world, local_rank):
                        "useful_cells_tree": cells, "useful_cells_consistency_batch": pair_cells,
                        "guide_tree_ms_every_rank": job["guide_tree_ms"],
                        "identical_results_on_all_ranks": bool(chk_max == float(chk)),
-                       "identical_to_a_single_gpu_run": same_as_one_gpu},
+                       "identical_to_a_single_gpu_run": same_as_one_gpu,
+                       "dist_layer": dist_layer},
+            # the same job as one whole-tree run on rank 0's GPU (no sharding layer at all), timed after the steps; at
+            # N = 1 (KA_BENCH_FORCE_MULTI=1) the difference is what the sharding layer itself costs
+            "single_gpu_step_ms": single_ms,
+            "sharding_overhead_ms": (elapsed / args.steps * 1e3 - single_ms) if world == 1 else None,
         }))
+    if cd is not None:
+        cd.close()
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()

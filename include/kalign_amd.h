@@ -161,6 +161,12 @@ int ka_tree_aligned_rows(ka_ctx* ctx, const uint8_t* letters, uint8_t gap_char, 
  *     recs[t] needs a, b, c, path_off.
  */
 int ka_tree_run_tasks(ka_ctx* ctx, const int* task_ids, int n);
+/* The listed tasks as ONE planned run -- queued and chained launches where they apply, like a whole tree (what a rank of
+ * a sharded tree does with its subtrees; ka_tree_run_tasks launches level by level).  The set must be closed under
+ * descendants among the tasks not run yet.  task_ids == NULL plans the whole tree again (ka_tree_run does that itself).
+ * ka_tree_run_planned runs the planned tasks on top of what the context holds; no reset. */
+int ka_tree_plan_tasks(ka_ctx* ctx, const int* task_ids, int n);
+int ka_tree_run_planned(ka_ctx* ctx);
 /* The same hand-over without the host: ka_tree_profile_dev says where the (plen+2)*64 floats of a node's profile lie in
  * this context's HBM, ka_tree_reserve_profile_dev reserves room for an incoming profile of `plen` columns on the
  * receiving context and makes the node available to ka_tree_run_tasks; the caller moves the bytes device to device
@@ -322,6 +328,42 @@ int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user,
 
 /* Kernel time (HIP events on the launch stream) of the last ka_pairwise_batch / ka_bpm_batch, milliseconds. */
 float ka_pairwise_kernel_ms(ka_ctx* ctx);
+
+
+/*
+ * ONE alignment over the GPUs of a node, driven from C (the reference's unit of parallelism is the
+ * independent subtree, lib/src/aln_run.c:95-109): one process per GPU, RCCL (ncclBroadcast / ncclSend / ncclRecv /
+ * ncclAllReduce over xGMI), loaded at run time -- the single-GPU library has no link-time dependency on it.
+ *   ka_dist_unique_id   rank 0: the 128-byte ncclUniqueId; the launcher hands it to every rank (file, MPI, torch ...).
+ *   ka_dist_create      the communicator of this rank's context (ncclCommInitRank).  world == 1 and id == NULL: none.
+ *   ka_dist_plan        once per uploaded job (every rank uploads the same job): the tree is cut into one subtree per
+ *                       rank, balanced by estimated DP cells; the hand-overs above the cut; this rank's subtrees planned
+ *                       as one run (ka_tree_plan_tasks).  ka_dist_plan_subtrees is the pure planning function.
+ *   ka_dist_consistency anchor_consistency_build sharded: this rank's share of the N x K batch, every share broadcast
+ *                       in place, HBM to HBM; fails on every rank alike when one part cannot be built.
+ *   ka_dist_tree_run    one step: subtrees, the merges above the cut (profiles -- and in default mode the residue ->
+ *                       column tables, packed on the device -- move device to device), then every rank holds every
+ *                       record and coded path (one all-reduce each over disjoint ranges).
+ *   ka_dist_download    records in task order (path_off into paths) and the coded paths, identical on every rank and for
+ *                       every world size.
+ */
+typedef struct ka_dist ka_dist;
+int ka_dist_unique_id(void* id128);
+int ka_dist_create(ka_ctx* ctx, int rank, int world, const void* id128, ka_dist** out);
+void ka_dist_destroy(ka_dist* d);
+int ka_dist_plan_subtrees(int numseq, const int* lens, int n_tasks, const int* tasks_abc, int world, int* run_rank, int* top, int* n_top);
+int ka_dist_plan(ka_dist* d);
+int ka_dist_get_plan(ka_dist* d, int* run_rank, int* top, int* n_top, int* n_moves);
+int ka_dist_consistency(ka_dist* d, int n_anchors, float weight);
+int ka_dist_tree_run(ka_dist* d);
+long long ka_dist_paths_size(ka_dist* d);
+int ka_dist_download(ka_dist* d, ka_task_rec* recs, int* paths, long long paths_cap, long long* used);
+double ka_dist_last_ms(ka_dist* d);
+/* Tests: the ranks as threads of ONE process, each with its own context on the same GPU (RCCL refuses two ranks on one
+   device): an in-process stand-in for the communicator with the same call sequence, host-synchronous. */
+void* ka_dist_loopback_new(int world);
+void ka_dist_loopback_free(void* loopback);
+int ka_dist_create_loopback(ka_ctx* ctx, int rank, int world, void* loopback, ka_dist** out);
 
 #ifdef __cplusplus
 }

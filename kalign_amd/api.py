@@ -46,7 +46,10 @@ EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_
            "ka_tree_run_tasks", "ka_tree_reset", "ka_tree_node_len", "ka_tree_set_profile", "ka_tree_download_tasks", "ka_weave_gaps",
            "ka_tree_node_cols_size", "ka_tree_get_node_cols", "ka_tree_set_node_cols", "ka_bpm_batch",
            "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from",
-           "ka_aln_guide_tree", "ka_run_encoded", "ka_run_encoded_refine"]
+           "ka_aln_guide_tree", "ka_run_encoded", "ka_run_encoded_refine", "ka_tree_plan_tasks", "ka_tree_run_planned",
+           "ka_dist_unique_id", "ka_dist_create", "ka_dist_destroy", "ka_dist_plan_subtrees", "ka_dist_plan", "ka_dist_get_plan",
+           "ka_dist_consistency", "ka_dist_tree_run", "ka_dist_paths_size", "ka_dist_download", "ka_dist_last_ms",
+           "ka_dist_loopback_new", "ka_dist_loopback_free", "ka_dist_create_loopback"]
 
 
 def lib_path():
@@ -100,6 +103,27 @@ def load_library():
     L.ka_tree_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.ka_tree_launch_ms.argtypes = [vp, vp, C.c_int]
     L.ka_tree_run_tasks.argtypes = [vp, vp, C.c_int]
+    L.ka_tree_plan_tasks.argtypes = [vp, vp, C.c_int]
+    L.ka_tree_run_planned.argtypes = [vp]
+    L.ka_dist_unique_id.argtypes = [vp]
+    L.ka_dist_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.ka_dist_destroy.argtypes = [vp]
+    L.ka_dist_destroy.restype = None
+    L.ka_dist_plan_subtrees.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.POINTER(C.c_int)]
+    L.ka_dist_plan.argtypes = [vp]
+    L.ka_dist_get_plan.argtypes = [vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ka_dist_consistency.argtypes = [vp, C.c_int, C.c_float]
+    L.ka_dist_tree_run.argtypes = [vp]
+    L.ka_dist_paths_size.argtypes = [vp]
+    L.ka_dist_paths_size.restype = C.c_longlong
+    L.ka_dist_download.argtypes = [vp, vp, vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.ka_dist_last_ms.argtypes = [vp]
+    L.ka_dist_last_ms.restype = C.c_double
+    L.ka_dist_loopback_new.argtypes = [C.c_int]
+    L.ka_dist_loopback_new.restype = vp
+    L.ka_dist_loopback_free.argtypes = [vp]
+    L.ka_dist_loopback_free.restype = None
+    L.ka_dist_create_loopback.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.ka_tree_reset.argtypes = [vp]
     L.ka_tree_node_len.argtypes = [vp, C.c_int]
     L.ka_tree_set_profile.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -210,6 +234,17 @@ class Context:
         ms, n = C.c_float(0), C.c_int(0)
         self._chk(self.L.ka_tree_kernel_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def tree_plan_tasks(self, task_ids):
+        """the listed tasks as ONE planned run (queued / chained launches); None = the whole tree again"""
+        if task_ids is None:
+            self._chk(self.L.ka_tree_plan_tasks(self.h, None, 0))
+        else:
+            ids = np.ascontiguousarray(task_ids, np.int32)
+            self._chk(self.L.ka_tree_plan_tasks(self.h, _ptr(ids), len(ids)))
+
+    def tree_run_planned(self):
+        self._chk(self.L.ka_tree_run_planned(self.h))
 
     def tree_launch_ms(self):
         """per-launch kernel times of the last run (KA_LAUNCH_EV=1 when the context was created / reload_env)"""
@@ -574,3 +609,78 @@ def pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe, device=0):
         return ctx.pairwise_batch(codes, ia, ib, subm, gpo, gpe, tgpe)
     finally:
         ctx.close()
+
+
+def dist_plan_subtrees(lens, tasks, world):
+    """ka_dist_plan_subtrees: (run_rank[n_tasks], top task ids) -- pure host logic, needs no GPU"""
+    L = load_library()
+    lens = np.ascontiguousarray(lens, np.int32)
+    tasks = np.ascontiguousarray(tasks, np.int32)
+    run_rank = np.zeros(len(tasks), np.int32)
+    top = np.zeros(len(tasks), np.int32)
+    n_top = C.c_int(0)
+    if L.ka_dist_plan_subtrees(len(lens), _ptr(lens), len(tasks), _ptr(tasks), int(world), _ptr(run_rank), _ptr(top), C.byref(n_top)):
+        raise RuntimeError(L.ka_last_error().decode())
+    return run_rank, top[:n_top.value].tolist()
+
+
+def dist_unique_id():
+    """rank 0: the 128 bytes every rank hands to Dist (ncclGetUniqueId)"""
+    L = load_library()
+    buf = np.zeros(128, np.uint8)
+    if L.ka_dist_unique_id(_ptr(buf)):
+        raise RuntimeError(L.ka_last_error().decode())
+    return buf
+
+
+class Dist:
+    """Thin caller of the C multi-GPU layer (ka_dist_*): ONE alignment over the GPUs of a node, RCCL driven from C.
+    unique_id: the 128 bytes of dist_unique_id() from rank 0 (None with world == 1: no communicator)."""
+
+    def __init__(self, ctx, rank, world, unique_id=None, loopback=None):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = C.c_void_p()
+        if loopback is not None:                      # tests: threads of one process (ka_dist_loopback_new)
+            rc = self.L.ka_dist_create_loopback(ctx.h, int(rank), int(world), loopback, C.byref(self.h))
+        else:
+            uid = None if unique_id is None else np.ascontiguousarray(unique_id, np.uint8)
+            rc = self.L.ka_dist_create(ctx.h, int(rank), int(world), _ptr(uid) if uid is not None else None, C.byref(self.h))
+        if rc:
+            raise RuntimeError(self.L.ka_last_error().decode())
+
+    def _chk(self, rc):
+        if rc:
+            raise RuntimeError(self.L.ka_last_error().decode())
+
+    def plan(self):
+        self._chk(self.L.ka_dist_plan(self.h))
+
+    def get_plan(self):
+        n = self.ctx._job["ntasks"]
+        run_rank, top = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        n_top, n_moves = C.c_int(0), C.c_int(0)
+        self._chk(self.L.ka_dist_get_plan(self.h, _ptr(run_rank), _ptr(top), C.byref(n_top), C.byref(n_moves)))
+        return run_rank, top[:n_top.value].tolist(), n_moves.value
+
+    def consistency(self, n_anchors, weight):
+        self._chk(self.L.ka_dist_consistency(self.h, int(n_anchors), float(weight)))
+
+    def tree_run(self):
+        self._chk(self.L.ka_dist_tree_run(self.h))
+
+    def download(self):
+        n = self.ctx._job["ntasks"]
+        recs = (TaskRec * n)()
+        cap = int(self.L.ka_dist_paths_size(self.h))
+        paths = np.zeros(max(cap, 1), np.int32)
+        used = C.c_longlong(0)
+        self._chk(self.L.ka_dist_download(self.h, recs, _ptr(paths), cap, C.byref(used)))
+        return list(recs), paths[:used.value]
+
+    def last_ms(self):
+        return float(self.L.ka_dist_last_ms(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.ka_dist_destroy(self.h)
+            self.h = C.c_void_p()

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1344,6 +1345,50 @@ extern "C" int ka_tree_run_tasks(ka_ctx* c, const int* task_ids, int n)
         return KA_OK;
 }
 
+// The listed tasks as ONE planned run: queued and chained launches where they apply, as for a whole tree -- what a rank
+// of a sharded tree does with its subtrees.  The set must be closed under descendants among the tasks not run yet (a
+// task's internal children are in the set, already run, or injected).  task_ids == NULL: plan the whole tree again.
+extern "C" int ka_tree_plan_tasks(ka_ctx* c, const int* task_ids, int n)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        HIPCHK(hipSetDevice(c->device));
+        if (c->ran && !c->synced && ka_tree_sync(c)) return KA_FAIL;
+        if (!task_ids) c->plan_active.clear();
+        else {
+                c->plan_active.assign(c->n_tasks, 0);
+                for (int i = 0; i < n; i++) {
+                        if (task_ids[i] < 0 || task_ids[i] >= c->n_tasks) return fail("task id out of range");
+                        c->plan_active[task_ids[i]] = 1;
+                }
+        }
+        for (auto& d : c->descs) d.refine = 0;
+        c->refine_mode = 0;
+        return (plan_launches(c) || upload_plan(c)) ? KA_FAIL : KA_OK;
+}
+
+// Run the planned tasks on top of what the context holds (leaves, tasks run earlier, injected profiles); no reset.
+extern "C" int ka_tree_run_planned(ka_ctx* c)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (c->plan_active.empty()) return fail("ka_tree_run_planned: no task subset planned (ka_tree_plan_tasks)");
+        HIPCHK(hipSetDevice(c->device));
+        if (!c->state_valid && tree_reset(c)) return KA_FAIL;
+        std::vector<char> have(2 * c->numseq - 1, 0);
+        for (int i = 0; i < c->numseq; i++) have[i] = 1;
+        for (int t = 0; t < c->n_tasks; t++) if (c->task_done[t]) have[c->descs[t].c] = 1;
+        for (int node : c->injected) have[node] = 1;
+        for (auto& L : c->plan_levels)
+                for (int t : L) {
+                        if (c->task_done[t]) return fail("task already run");
+                        if (!have[c->descs[t].a] || !have[c->descs[t].b]) return fail("a task's operand is neither computed, planned nor injected on this context");
+                        have[c->descs[t].c] = 1;
+                }
+        c->ran = false; c->synced = false;
+        if (tree_launch(c, false)) return KA_FAIL;
+        c->ran = true;
+        return KA_OK;
+}
+
 // Forget every computed / injected node: the next ka_tree_run_tasks starts from the leaves again.
 extern "C" int ka_tree_reset(ka_ctx* c)
 {
@@ -1925,6 +1970,11 @@ extern "C" int ka_bpm_batch(ka_ctx* c, const uint8_t* codes, const int* off, con
 // RCCL is loaded at run time (dlopen): the single-GPU library has no link-time dependency on it.
 // =================================================================================================================
 #include <dlfcn.h>
+#include <climits>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <rccl/rccl.h>
 
 extern "C" void ka_launch_cols_pack(int* colof, const int* seq_off, const int* seq_len, const int* members, const long long* moff, int nmem,
@@ -1968,6 +2018,26 @@ int rccl_load()
                 ncclResult_t r_ = (x);                                                                     \
                 if (r_ != ncclSuccess) return fail(std::string(#x) + ": " + g_rccl.GetErrorString(r_));     \
         } while (0)
+
+// An in-process stand-in for the communicator (tests): the ranks are threads of ONE process, each with its own context on
+// the SAME GPU -- RCCL refuses two ranks on one device, and the pool's GPU boxes have one.  Host-synchronous, FIFO per
+// (source, destination) pair; collectives meet at a barrier and reduce through the host.  Same call sequence as RCCL.
+struct KaLoopback {
+        int world = 1;
+        std::mutex m;
+        std::condition_variable cv;
+        struct Msg { const void* ptr; size_t bytes; bool taken; };
+        std::map<std::pair<int, int>, std::deque<Msg*>> box;
+        std::vector<void*> bufs;
+        int arrived = 0;
+        long long gen = 0;
+        void barrier(std::unique_lock<std::mutex>& lk)
+        {
+                const long long g = gen;
+                if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); }
+                else cv.wait(lk, [&] { return gen != g; });
+        }
+};
 }  // namespace
 
 // A child profile that changes GPUs above the cut
@@ -1981,7 +2051,15 @@ struct ka_dist {
         ka_ctx* c = nullptr;
         int rank = 0, world = 1;
         ncclComm_t comm = nullptr;
+        KaLoopback* loop = nullptr;                      // tests: threads of one process instead of RCCL
         bool planned = false;
+        // ---- the five transport operations (RCCL on the context's stream, or the loopback) ----
+        int all_reduce_i32(int* buf, size_t count, bool take_max);
+        int broadcast_i32(int* buf, size_t count, int root);
+        int send(const void* buf, size_t bytes, int peer);
+        int recv(void* buf, size_t bytes, int peer);
+        int group_start() { if (loop || world == 1) return KA_OK; ncclResult_t r = g_rccl.GroupStart(); return r == ncclSuccess ? KA_OK : fail(std::string("ncclGroupStart: ") + g_rccl.GetErrorString(r)); }
+        int group_end() { if (loop || world == 1) return KA_OK; ncclResult_t r = g_rccl.GroupEnd(); return r == ncclSuccess ? KA_OK : fail(std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r)); }
         std::vector<int> run_rank, top, mine_sub;        // rank of every task; the tasks above the cut (tree order); this rank's subtree tasks
         std::vector<KaMove> moves;                       // in the order the top tasks need them
         std::vector<std::vector<int>> top_moves;         // per top task: indices into moves
@@ -1994,6 +2072,84 @@ struct ka_dist {
         int* h_head = nullptr;                           // pinned: the two-int header of an incoming profile
         double last_ms = 0.0, last_kernel_wait_ms = 0.0;
 };
+
+int ka_dist::all_reduce_i32(int* buf, size_t count, bool take_max)
+{
+        if (world == 1 && !comm) return KA_OK;
+        if (!loop) { NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclInt32, take_max ? ncclMax : ncclSum, comm, c->stream)); return KA_OK; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::unique_lock<std::mutex> lk(loop->m);
+        loop->bufs[rank] = buf;
+        loop->barrier(lk);
+        std::vector<int> acc(count, take_max ? INT_MIN : 0), tmp(count);
+        for (int r = 0; r < world; r++) {
+                HIPCHK(hipMemcpy(tmp.data(), loop->bufs[r], sizeof(int) * count, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < count; i++) acc[i] = take_max ? std::max(acc[i], tmp[i]) : acc[i] + tmp[i];
+        }
+        loop->barrier(lk);                                          // everybody has read every buffer
+        HIPCHK(hipMemcpy(buf, acc.data(), sizeof(int) * count, hipMemcpyHostToDevice));
+        return KA_OK;
+}
+int ka_dist::broadcast_i32(int* buf, size_t count, int root)
+{
+        if (world == 1 && !comm) return KA_OK;
+        if (!loop) { NCCLCHK(g_rccl.Broadcast(buf, buf, count, ncclInt32, root, comm, c->stream)); return KA_OK; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::unique_lock<std::mutex> lk(loop->m);
+        loop->bufs[rank] = buf;
+        loop->barrier(lk);
+        if (rank != root) HIPCHK(hipMemcpy(buf, loop->bufs[root], sizeof(int) * count, hipMemcpyDeviceToDevice));
+        loop->barrier(lk);
+        return KA_OK;
+}
+int ka_dist::send(const void* buf, size_t bytes, int peer)
+{
+        if (!loop) { NCCLCHK(g_rccl.Send(buf, bytes, ncclInt8, peer, comm, c->stream)); return KA_OK; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        KaLoopback::Msg msg = { buf, bytes, false };
+        std::unique_lock<std::mutex> lk(loop->m);
+        loop->box[std::make_pair(rank, peer)].push_back(&msg);
+        loop->cv.notify_all();
+        loop->cv.wait(lk, [&] { return msg.taken; });
+        return KA_OK;
+}
+int ka_dist::recv(void* buf, size_t bytes, int peer)
+{
+        if (!loop) { NCCLCHK(g_rccl.Recv(buf, bytes, ncclInt8, peer, comm, c->stream)); return KA_OK; }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::unique_lock<std::mutex> lk(loop->m);
+        auto& q = loop->box[std::make_pair(peer, rank)];
+        loop->cv.wait(lk, [&] { return !q.empty(); });
+        KaLoopback::Msg* msg = q.front();
+        q.pop_front();
+        if (msg->bytes != bytes) { msg->taken = true; loop->cv.notify_all(); return fail("ka_dist loopback: message size mismatch"); }
+        const hipError_t e = hipMemcpy(buf, msg->ptr, bytes, hipMemcpyDeviceToDevice);
+        msg->taken = true;
+        loop->cv.notify_all();
+        if (e != hipSuccess) return fail(std::string("ka_dist loopback: ") + hipGetErrorString(e));
+        return KA_OK;
+}
+
+// Tests: a loopback "communicator" for `world` ranks living in one process (threads), each with its own context.
+extern "C" void* ka_dist_loopback_new(int world)
+{
+        if (world < 1) return nullptr;
+        KaLoopback* l = new KaLoopback();
+        l->world = world;
+        l->bufs.assign(world, nullptr);
+        return l;
+}
+extern "C" void ka_dist_loopback_free(void* l) { delete (KaLoopback*)l; }
+extern "C" int ka_dist_create_loopback(ka_ctx* c, int rank, int world, void* loopback, ka_dist** out)
+{
+        if (!c || !out || !loopback || world < 1 || rank < 0 || rank >= world || ((KaLoopback*)loopback)->world != world) return fail("ka_dist_create_loopback: bad arguments");
+        HIPCHK(hipSetDevice(c->device));
+        ka_dist* d = new ka_dist();
+        d->c = c; d->rank = rank; d->world = world; d->loop = (KaLoopback*)loopback;
+        if (hipHostMalloc((void**)&d->h_head, 64, hipHostMallocDefault) != hipSuccess) { delete d; return fail("hipHostMalloc failed"); }
+        *out = d;
+        return KA_OK;
+}
 
 // Pure planning (no device, no communicator): cut the tree into at most `world` subtrees balanced by estimated DP cells;
 // run_rank[t] = the rank that runs task t, top[0 .. *n_top) = the tasks above the cut in tree order.  Every rank derives
@@ -2196,25 +2352,25 @@ extern "C" int ka_dist_consistency(ka_dist* d, int n_anchors, float weight)
         // every rank reduces the outcome first
         int rc = ka_tree_build_consistency_part(c, n_anchors, weight, d->rank, d->world);
         const std::string why = rc ? g_err : std::string();
-        if (d->world > 1) {
+        if (d->world > 1 || d->comm) {
                 int* flag = (int*)d->d_counts.p;
                 if (!flag && d->d_counts.alloc(std::max(c->n_tasks, 1))) return fail("hipMalloc failed");
                 flag = d->d_counts.p;
                 const int mine = rc ? 1 : 0;
                 HIPCHK(hipMemcpyAsync(flag, &mine, sizeof(int), hipMemcpyHostToDevice, c->stream));
-                NCCLCHK(g_rccl.AllReduce(flag, flag, 1, ncclInt32, ncclMax, d->comm, c->stream));
+                if (d->all_reduce_i32(flag, 1, true)) return KA_FAIL;
                 int any = 0;
                 HIPCHK(hipMemcpyAsync(&any, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
                 if (any) return fail(rc ? why : std::string("ka_dist_consistency: another rank could not build its part"));
                 if (c->cons_K <= 0) return KA_OK;                    // the job declined on every rank alike (fewer than 3 sequences ...)
-                NCCLCHK(g_rccl.GroupStart());
+                if (d->group_start()) return KA_FAIL;
                 for (int r = 0; r < d->world; r++) {
                         long long lo = 0, hi = 0;
-                        if (ka_tree_consistency_part_range(c, r, d->world, &lo, &hi)) { (void)g_rccl.GroupEnd(); return KA_FAIL; }
-                        if (hi > lo) NCCLCHK(g_rccl.Broadcast(c->d_cons_maps.p + lo, c->d_cons_maps.p + lo, (size_t)(hi - lo), ncclInt32, r, d->comm, c->stream));
+                        if (ka_tree_consistency_part_range(c, r, d->world, &lo, &hi)) { (void)d->group_end(); return KA_FAIL; }
+                        if (hi > lo && d->broadcast_i32(c->d_cons_maps.p + lo, (size_t)(hi - lo), r)) { (void)d->group_end(); return KA_FAIL; }
                 }
-                NCCLCHK(g_rccl.GroupEnd());
+                if (d->group_end()) return KA_FAIL;
         } else if (rc) return KA_FAIL;
         return KA_OK;
 }
@@ -2246,15 +2402,15 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
                                 const int plen = d->h_head[0];
                                 long long po; memcpy(&po, d->h_head + 2, sizeof(po));
                                 if (plen < 1 || po < 0) return fail("ka_dist_tree_run: a subtree root has no profile");
-                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_seq_len_dev(), m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 0, c->stream);
-                                NCCLCHK(g_rccl.GroupStart());
-                                NCCLCHK(g_rccl.Send(c->d_node_len.p + m.child, 1, ncclInt32, m.dst, d->comm, c->stream));
-                                NCCLCHK(g_rccl.Send(c->d_prof_arena.p + po, (size_t)(plen + 2) * KA_REC, ncclFloat32, m.dst, d->comm, c->stream));
-                                if (cols) NCCLCHK(g_rccl.Send(d->d_colbuf.p, (size_t)m.ncols, ncclInt32, m.dst, d->comm, c->stream));
-                                NCCLCHK(g_rccl.GroupEnd());
+                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_node_len.p, m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 0, c->stream);
+                                // (plain stream-ordered point-to-point operations, matched in order with the receiver's: every rank
+                                // walks the hand-overs in the same order, so no two ranks ever wait for each other crosswise)
+                                if (d->send(c->d_node_len.p + m.child, sizeof(int), m.dst)) return KA_FAIL;
+                                if (d->send(c->d_prof_arena.p + po, sizeof(float) * (size_t)(plen + 2) * KA_REC, m.dst)) return KA_FAIL;
+                                if (cols && d->send(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.dst)) return KA_FAIL;
                         } else {
                                 // the header first: it sizes the room the records get in this rank's arena
-                                NCCLCHK(g_rccl.Recv(c->d_node_len.p + m.child, 1, ncclInt32, m.src, d->comm, c->stream));
+                                if (d->recv(c->d_node_len.p + m.child, sizeof(int), m.src)) return KA_FAIL;
                                 HIPCHK(hipMemcpyAsync(d->h_head, c->d_node_len.p + m.child, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                                 HIPCHK(hipMemcpyAsync(d->h_head + 2, c->d_counters.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
                                 HIPCHK(hipStreamSynchronize(c->stream));
@@ -2267,11 +2423,9 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
                                 memcpy(d->h_head + 4, &top_, sizeof(top_)); memcpy(d->h_head + 6, &po, sizeof(po));
                                 HIPCHK(hipMemcpyAsync(c->d_counters.p, d->h_head + 4, sizeof(top_), hipMemcpyHostToDevice, c->stream));
                                 HIPCHK(hipMemcpyAsync(c->d_node_prof.p + m.child, d->h_head + 6, sizeof(po), hipMemcpyHostToDevice, c->stream));
-                                NCCLCHK(g_rccl.GroupStart());
-                                NCCLCHK(g_rccl.Recv(c->d_prof_arena.p + po, (size_t)need, ncclFloat32, m.src, d->comm, c->stream));
-                                if (cols) NCCLCHK(g_rccl.Recv(d->d_colbuf.p, (size_t)m.ncols, ncclInt32, m.src, d->comm, c->stream));
-                                NCCLCHK(g_rccl.GroupEnd());
-                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_seq_len_dev(), m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 1, c->stream);
+                                if (d->recv(c->d_prof_arena.p + po, sizeof(float) * (size_t)need, m.src)) return KA_FAIL;
+                                if (cols && d->recv(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.src)) return KA_FAIL;
+                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_node_len.p, m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 1, c->stream);
                                 HIPCHK(hipStreamSynchronize(c->stream));          // (h_head is reused by the next hand-over)
                                 c->injected.push_back(m.child);
                         }
@@ -2289,7 +2443,7 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
         // ---- every rank ends with every record and every coded path ----
         if (ka_tree_sync(c)) return KA_FAIL;                        // (arena overflow, watchdogs: partial runs do not re-run)
         ka_launch_path_counts(c->d_recs.p, d->d_mine.p, n_tasks, d->d_counts.p, c->stream);
-        if (d->world > 1) NCCLCHK(g_rccl.AllReduce(d->d_counts.p, d->d_counts.p, (size_t)n_tasks, ncclInt32, ncclSum, d->comm, c->stream));
+        if (d->all_reduce_i32(d->d_counts.p, (size_t)n_tasks, false)) return KA_FAIL;
         std::vector<int> counts(n_tasks);
         HIPCHK(hipMemcpyAsync(counts.data(), d->d_counts.p, sizeof(int) * n_tasks, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -2300,13 +2454,11 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
         HIPCHK(hipMemcpyAsync(d->d_goff.p, d->goff.data(), sizeof(long long) * n_tasks, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemsetAsync(d->d_gpaths.p, 0, sizeof(int) * (size_t)total, c->stream));
         ka_launch_path_scatter(c->d_recs.p, d->d_mine.p, n_tasks, c->d_path_arena.p, d->d_goff.p, d->d_gpaths.p, c->stream);
-        if (d->world > 1) {
-                static_assert(sizeof(ka_task_rec) % 4 == 0, "records are reduced as 32-bit words");
-                NCCLCHK(g_rccl.GroupStart());
-                NCCLCHK(g_rccl.AllReduce(d->d_gpaths.p, d->d_gpaths.p, (size_t)total, ncclInt32, ncclSum, d->comm, c->stream));
-                NCCLCHK(g_rccl.AllReduce(c->d_recs.p, c->d_recs.p, (size_t)n_tasks * (sizeof(ka_task_rec) / 4), ncclInt32, ncclSum, d->comm, c->stream));
-                NCCLCHK(g_rccl.GroupEnd());
-        }
+        static_assert(sizeof(ka_task_rec) % 4 == 0, "records are reduced as 32-bit words");
+        if (d->group_start()) return KA_FAIL;
+        if (d->all_reduce_i32(d->d_gpaths.p, (size_t)total, false)) return KA_FAIL;
+        if (d->all_reduce_i32((int*)c->d_recs.p, (size_t)n_tasks * (sizeof(ka_task_rec) / 4), false)) return KA_FAIL;
+        if (d->group_end()) return KA_FAIL;
         d->h_recs.resize(n_tasks);
         d->h_paths.resize((size_t)total);
         HIPCHK(hipMemcpyAsync(d->h_recs.data(), c->d_recs.p, sizeof(ka_task_rec) * n_tasks, hipMemcpyDeviceToHost, c->stream));

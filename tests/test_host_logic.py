@@ -101,3 +101,19 @@ def test_integration_md_quotes_the_compiled_glue():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.render() == open(os.path.join(root, "INTEGRATION.md")).read()
+
+
+def test_c_subtree_plan_matches_the_python_plan():
+    """ka_dist_plan_subtrees (the C layer's planning function, pure host logic) against kalign_amd.dist.plan_subtrees on
+    seeded random guide trees: same rank for every task, same tasks above the cut -- for 1 .. 8 ranks"""
+    import numpy as np
+    from kalign_amd import api, dist, guide
+    rng = np.random.RandomState(7)
+    for n in (3, 5, 17, 64, 257):
+        lens = rng.randint(40, 700, n)
+        for world in (1, 2, 3, 4, 8):
+            tasks = guide.bisecting_tree(n, seed=int(rng.randint(1 << 30)), jitter=0.3)
+            rr_py, top_py = dist.plan_subtrees(tasks, lens, world)
+            rr_c, top_c = api.dist_plan_subtrees(lens, tasks, world)
+            assert list(rr_c) == [int(x) for x in rr_py], (n, world)
+            assert top_c == [int(t) for t in top_py], (n, world)
