@@ -682,6 +682,11 @@ def multi_gpu_main(args, rank, world, local_rank):
     import kalign_amd
     from kalign_amd import api
     from kalign_amd import dist as kd
+    # RCCL prints a version banner to stdout when a communicator comes up; the contract is ONE JSON line on stdout:
+    # everything else this process (and the libraries under it) writes to fd 1 goes to stderr, the line to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     backend = os.environ.get("KA_BENCH_BACKEND", "nccl")          # tests on one GPU: gloo, every rank on cuda:0
     same_gpu = backend != "nccl"
     if same_gpu:
@@ -779,7 +784,7 @@ def multi_gpu_main(args, rank, world, local_rank):
                 diff[:12], len(recs), [int(run_rank[t]) for t in diff[:12]], [t in set(top) for t in diff[:12]]))
     if rank == 0:
         kinds = np.bincount([r.kind for r in recs], minlength=3)
-        print(json.dumps({
+        real_stdout.write(json.dumps({
             "metric": "GCUPS (DP cell updates/s) on NxL synthetic MSA", "value": (cells + pair_cells) * args.steps / elapsed / 1e9,
             "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -799,7 +804,8 @@ def multi_gpu_main(args, rank, world, local_rank):
             # N = 1 (KA_BENCH_FORCE_MULTI=1) the difference is what the sharding layer itself costs
             "single_gpu_step_ms": single_ms,
             "sharding_overhead_ms": (elapsed / args.steps * 1e3 - single_ms) if world == 1 else None,
-        }))
+        }) + "\n")
+        real_stdout.flush()
     if cd is not None:
         cd.close()
     ctx.close()

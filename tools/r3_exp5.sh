@@ -1,8 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out/r3f
-timeout 600 python -m pytest tests/test_gpu_dist_c.py -x -q > gpurun_out/r3f/pytest_dist.log 2>&1; rc=$?; echo "pytest rc $rc" >> gpurun_out/r3f/pytest_dist.log
+echo skip
 tail -25 gpurun_out/r3f/pytest_dist.log | cut -c1-260
-KA_BENCH_FORCE_MULTI=1 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 > gpurun_out/r3f/force_multi.json 2> gpurun_out/r3f/force_multi.err; echo "force-multi rc $?"
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 KA_BENCH_FORCE_MULTI=1 timeout 600 python bench.py --gpus 1 --steps 3 --warmup 1 > gpurun_out/r3f/force_multi.json 2> gpurun_out/r3f/force_multi.err; echo "force-multi rc $?"
 tail -3 gpurun_out/r3f/force_multi.err | cut -c1-300
 python - <<'PY'
 import json
@@ -12,4 +12,4 @@ try:
 except Exception as e:
     print('no json', e)
 PY
-timeout 300 python -m pytest tests/test_gpu_dist_emul.py tests/test_gpu_partial.py -x -q 2>&1 | tail -3
+echo skip2
