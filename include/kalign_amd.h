@@ -130,6 +130,8 @@ int ka_tree_run(ka_ctx* ctx);
 #define KA_REFINE_ADAPTIVE 256      /* mode | KA_REFINE_ADAPTIVE: aln_param's adaptive_budget (`kalign --adaptive-budget`,
                                        aln_refine.c:187-193, 255-282; modes 1 and 2): 1 .. 8 trials per edge, from the share of
                                        very uncertain meetups of its baseline trial */
+#define KA_REFINE_TRIALS(n) (((n) & 255) << 16)   /* 3 | KA_REFINE_TRIALS(n): create_msa_tree_inline_refine with n trials per edge
+                                                     (lib/src/aln_run.c:448-475 takes any count; kalign_run passes 3, the default here) */
 int ka_tree_refine(ka_ctx* ctx, int mode, const float* conf_in);
 int ka_tree_sync(ka_ctx* ctx);
 long long ka_tree_paths_size(ka_ctx* ctx);      /* ints needed for paths_out (valid after run+sync) */

@@ -88,6 +88,7 @@ struct KaEnv {
         int prof_task = -1;            // KA_PROF_TASK: the task whose per-level times KA_FLAG_TIMING keeps (-1: the root)
         int q1 = 0;                    // KA_Q1: 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
         int lean4 = 1;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU (1.60 -> 1.28 ms on the 4096 x 400 leaf level)
+        int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
 };
@@ -103,6 +104,7 @@ static void read_env(KaEnv& v)
         v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", 0); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
+        v.mw = env_int("KA_MW", 1);
 }
 
 struct ka_ctx {
@@ -762,6 +764,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.trace = c->h_trace;
         D.refine_mode = 0;
         D.refine_adaptive = 0;
+        D.refine_trials = 3;
         D.prof_task = -1;
         D.wdfs = (c->env.no_wdfs ? 0 : 1) | (c->env.no_ls0 ? 0 : 2);   // measurements / tests
         D.prof_task = c->env.prof_task;                                 // measurements only (tools/levels_real.py)
@@ -770,6 +773,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
+        D.mw_mode = c->env.mw;
         D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;
         D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
         D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
@@ -814,6 +818,7 @@ static int tree_launch(ka_ctx* c, bool reset = true)
         KaTreeDev D = tree_dev(c);
         D.refine_mode = c->refine_mode & 255;
         D.refine_adaptive = (c->refine_mode >> 8) & 1;
+        D.refine_trials = (c->refine_mode >> 16) & 255 ? (c->refine_mode >> 16) & 255 : 3;
         c->partial = !reset;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
@@ -885,7 +890,8 @@ static int refine_blocks(ka_ctx* c, int mode)
         std::vector<int2> tbl;
         c->refine_off.assign(1, 0);
         const int base_mode = mode & 255;
-        const int flips = base_mode == 3 ? 2 : (base_mode == 4 ? 0 : 4);      // (adaptive budget: up to 7, shared by at most 4 members)
+        const int trials3 = (mode >> 16) & 255 ? (mode >> 16) & 255 : 3;
+        const int flips = base_mode == 3 ? trials3 - 1 : (base_mode == 4 ? 0 : 4);      // (adaptive budget: up to 7, shared by at most 4 members)
         bool starved = false;
         for (auto& L : c->levels) {
                 int nref = 0;
@@ -923,9 +929,10 @@ static int refine_launch(ka_ctx* c, int mode)
 extern "C" int ka_tree_refine(ka_ctx* c, int mode_in, const float* conf_in)
 {
         if (!c || !c->have_job) return fail("no uploaded job");
-        const int mode = mode_in & 255, adaptive = mode_in & KA_REFINE_ADAPTIVE;
-        if (mode < 1 || mode > 4 || (mode_in & ~(255 | KA_REFINE_ADAPTIVE)))
+        const int mode = mode_in & 255, adaptive = mode_in & KA_REFINE_ADAPTIVE, trials = mode_in & KA_REFINE_TRIALS(255);
+        if (mode < 1 || mode > 4 || (mode_in & ~(255 | KA_REFINE_ADAPTIVE | KA_REFINE_TRIALS(255))))
                 return fail("ka_tree_refine: mode must be 1 (all), 2 (confident), 3 (inline) or 4 (first pass, exact confidences), optionally | KA_REFINE_ADAPTIVE");
+        if (trials && mode != 3) return fail("ka_tree_refine: KA_REFINE_TRIALS goes with mode 3 (create_msa_tree_inline_refine)");
         if (adaptive && mode != 1 && mode != 2) return fail("ka_tree_refine: KA_REFINE_ADAPTIVE goes with modes 1 and 2 (refine_edge)");
         if (c->n_tasks < 1) return fail("ka_tree_refine: no tasks");
         HIPCHK(hipSetDevice(c->device));
@@ -955,7 +962,7 @@ extern "C" int ka_tree_refine(ka_ctx* c, int mode_in, const float* conf_in)
                 thr = (n % 2 == 0) ? (v[n / 2 - 1] + v[n / 2]) / 2.0F : v[n / 2];
         }
         for (int t = 0; t < c->n_tasks; t++) c->descs[t].refine = mode == 1 ? 1 : (mode == 2 && conf_in[t] <= thr ? 1 : 0);
-        return refine_launch(c, mode | adaptive);
+        return refine_launch(c, mode | adaptive | trials);
 }
 
 extern "C" int ka_tree_sync(ka_ctx* c)

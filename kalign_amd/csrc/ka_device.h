@@ -72,6 +72,7 @@ struct KaTreeDev {
         long long* timing;             // [n_tasks][8] phase cycle counts (KA_FLAG_TIMING) or null
         int refine_mode;               // refinement pass (ka_tree_refine): 0 none, 1 KALIGN_REFINE_ALL, 2 KALIGN_REFINE_CONFIDENT
         int refine_adaptive;           // ... with aln_param's adaptive_budget (modes 1, 2)
+        int refine_trials;             // ... mode 3 (KALIGN_REFINE_INLINE): trials per edge (create_msa_tree_inline_refine's n_trials; 3 in kalign_run)
         int wdfs;                      // refinement: bit 0 small subtrees of the depth-first recursion run wave-locally (KA_NO_WDFS=1 in the
                                        // environment: off), bit 1 the baseline trial runs level-synchronously (KA_NO_LS0=1: off)
         int prof_task;                 // KA_FLAG_TIMING: the task whose per-level times are kept (-1: the root; KA_PROF_TASK in the environment)
@@ -79,6 +80,7 @@ struct KaTreeDev {
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table
         // ---- anchor consistency (anchor_consistency.c); cons_K == 0: off ----
         int max_g;                     // workgroups one task may use when clusters merge up the chained launch
+        int mw_mode;                   // the top-level meetup scans are shared by the waves of the leading workgroup (KA_MW=0: off)
         int sub_mode;                  // wave-local subtrees in LDS (ka_subtree.h); 0: off (KA_SUBTREE=0, experiments)
         int lean4;                     // leaf levels (seq-seq tasks only) on 4-wave workgroups, four per CU (KA_LEAN4)
         int q1_mode;                   // 64-row strips (one DP row per lane): 0 never, 1 for tasks whose cluster has a SIMD per top-level strip,

@@ -117,6 +117,9 @@ struct TaskShared {
         int G, member;                 // cluster size / this workgroup's index in it
         int sub_ok, nres_t, sub_stride; // wave-local subtrees (ka_subtree.h): enabled for this task / alphabet class (5, 20, 23) / bytes per wave
         char* sub_base;                //   ... and where the waves' LDS regions start
+        float mw_mx[8], mw_mx2[8];     // multi-wave meetup scan: the waves' partial (best, second best, key of the best)
+        int mw_key[8];
+        int mw_ok;                     //   ... enabled (KaTreeDev::mw_mode)
         int sub_tm;                    // KA_FLAG_TIMING, the profiled task: subtree phase times are accumulated in sub_t
         unsigned long long sub_t[7];   //   subtrees, staging / pass / meetup / total cycles (sums over the workgroup's subtrees), longest one, sum of level*1e6 + R*1e3 + C
         int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
@@ -274,10 +277,15 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
 // depth-first order as a base-3 key in KaSub::pad -- digit 1 / 2 at its depth for the child the recursion enters first /
 // second, zeros below: numeric order of the keys = preorder of the recursion tree -- and every meetup appends (key, margin)
 // to S.mrec; sorted by key afterwards, the margins add up in the reference's order.  kdig: weight of the children's digit.
-template <int KIND, int GL, bool FLIP = false, bool REC = false>
+// MW (GL = 64 only; all waves of the workgroup call it together): the top recursion levels have one or two sub-problems with
+// thousands of candidate columns -- every wave scans every NW-th block of 64 columns, the partial (best, second best)
+// pairs meet in TaskShared::mw_* behind a workgroup barrier, and wave 0 merges them (the merge ranks by value and scan
+// position, so it does not depend on who found what) and carries on alone: decision, path entries, children.
+template <int KIND, int GL, bool FLIP = false, bool REC = false, bool MW = false>
 __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const int k0, const int ncur, KaSub* qnext,
                                           const KaLevelOut& lout, const int wlane, const bool top_level, const int kdig = 0)
 {
+        static_assert(!MW || GL == 64, "the multi-wave scan works on 64-lane groups");
         const int lane = wlane % GL;                                 // lane within the sub-problem's group
         const int ksub = k0 + wlane / GL;
         const bool in_range = ksub < ncur;
@@ -303,7 +311,8 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 g6f = (endb == S.Lb) ? R[57] * S.p1_mult : R[56] * S.p1_mult;
         }
         Best B = { -KA_F, -KA_F, 0x7fffffff, 0x7fffffff };
-        for (int i = startb + lane; valid && i <= endb; i += GL) {
+        const int mw_wave = MW ? (int)(threadIdx.x >> 6) : 0, mw_nw = MW ? KA_NW : 1;
+        for (int i = startb + lane + GL * mw_wave; valid && i <= endb; i += GL * mw_nw) {
                 const KaState fi = f[i - startb], bi = b[i - startb];
                 float sub = fabsf(middle - (float)i);
                 sub = sub / 1000.0f;
@@ -331,6 +340,14 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 const int okey = __shfl_xor(B.key, off, 64);
                 const int okey2 = FLIP ? __shfl_xor(B.key2, off, 64) : 0x7fffffff;
                 best_merge(B, omx, omx2, okey, okey2);
+        }
+        if (MW) {
+                // (the caller's barrier in front of this call separates the previous use of mw_* from these stores)
+                if (lane == 0) { S.mw_mx[mw_wave] = B.mx; S.mw_mx2[mw_wave] = B.mx2; S.mw_key[mw_wave] = B.key; }
+                __syncthreads();
+                if (mw_wave != 0) return;
+                B.mx = -KA_F; B.mx2 = -KA_F; B.key = 0x7fffffff; B.key2 = 0x7fffffff;
+                for (int w = 0; w < mw_nw; ++w) best_merge(B, S.mw_mx[w], S.mw_mx2[w], S.mw_key[w]);
         }
         // ---- aln_continue for the group's sub-problem (its lane 0 = "leader"), wave-cooperatively: the level's
         // counters live in HBM when a cluster shares the task, and per-sub-problem atomics on five addresses
@@ -737,7 +754,15 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const KaLevelOut lout = ka_level_out(S, (level + 1) & 1, true);
                         const int est_cols = S.Lb >> level;          // typical columns per sub-problem at this depth
                         const int kdig = REC ? ka_pow3[max(KA_REC_DEPTH - 2 - level, 0)] : 0;
-                        if (est_cols > 48) {
+                        if (est_cols > 128 && ncur <= 2 && S.mw_ok) {
+                                // one or two sub-problems with thousands of columns: the leading workgroup's waves share each scan
+                                // (every wave of it takes part in both barriers of a round; the other members have nothing to do)
+                                if (S.member_w == 0)
+                                        for (int k = 0; k < ncur; ++k) {
+                                                __syncthreads();
+                                                ka_meetup<KIND, 64, false, REC, true>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
+                                        }
+                        } else if (est_cols > 48) {
                                 for (int k = S.member_w * KA_NW + wave; k < ncur; k += KA_NW * S.Gw)
                                         ka_meetup<KIND, 64, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
                         } else if (est_cols > 6) {
@@ -1797,8 +1822,8 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 }
 
 // dynamic-LDS layout of a workgroup
-#define KA_LDS_DBG 1200
-#define KA_LDS_TSS 1216
+#define KA_LDS_DBG 1400
+#define KA_LDS_TSS 1408
 #define KA_LDS_WAVES 4096                                           // per-wave regions: 2048-B aligned (ring addressing ORs the column offset in)
 static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table overlaps the wave regions");
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
@@ -1989,6 +2014,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 S.nres_t = (D.nres <= 5) ? 5 : ((D.nres <= 20) ? 20 : 23);
                 S.sub_stride = LEAN ? KA_WAVE_LDS_LEAN : KA_WAVE_LDS;
                 S.sub_base = LEAN ? (lds_waves + KA_LEAN_SCRATCH(KA_NT)) : lds_waves;
+                S.mw_ok = D.mw_mode;
                 S.sub_tm = (D.timing && (D.prof_task >= 0 ? task == D.prof_task : T.is_root)) ? 1 : 0;
                 for (int x = 0; x < 7; ++x) S.sub_t[x] = 0;
                 S.G = g_eff; S.member = member; S.bar_phase = 0;
@@ -2216,7 +2242,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
                 S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS;
-                S.sub_ok = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
+                S.sub_ok = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true);
@@ -2245,7 +2271,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         // 4 = one depth-first trial with first-pass coding (the first pass with the reference's exact confidence sums)
         const bool inline_mode = D.refine_mode == 3;
         const bool refine_it = D.refine_mode == 1 || inline_mode || (D.refine_mode == 2 && T.refine != 0);
-        int n_trials = inline_mode ? 3 : refine_it ? 5 : 1;
+        int n_trials = inline_mode ? max(D.refine_trials, 1) : refine_it ? 5 : 1;      // (create_msa_tree_inline_refine takes any number of trials, aln_run.c:448-475)
         // --adaptive-budget (aln_refine.c:187-193, 255-282; refine_edge only): the baseline's margins are kept (the first
         // max(64, min(len_a, len_b) + 1) of them) and the number of trials, 1 .. 8, follows from the share of meetups
         // whose margin is below a quarter of the mean
@@ -2707,7 +2733,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS;
-                S.sub_ok = 1; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0;
+                S.sub_ok = 1; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0; S.mw_ok = 1;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;

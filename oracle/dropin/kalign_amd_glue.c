@@ -14,7 +14,13 @@
  *   refine_alignment           lib/src/aln_refine.c:36-88     -> ka_tree_refine(1 | 2) on the job create_msa_tree left in HBM
  *   anchor_consistency_build   lib/src/anchor_consistency.c:200-275 -> ka_tree_build_consistency (+ a host copy of the table)
  *   build_tree_kmeans          lib/src/bisectingKmeans.c:177-271    -> ka_guide_tree
+ *   build_tree_kmeans_noisy    lib/src/bisectingKmeans.c:76-175     -> ka_guide_tree with the noise multipliers (ensemble members)
+ *   compute_aln_pairwise_dist  lib/src/aln_apair_dist.c:9-86        -> ka_aln_guide_tree: identity distances AND the UPGMA tree, on the
+ *   build_tree_from_pairwise   lib/src/bisectingKmeans.c:1150-1200     rows finalise_alignment left in HBM (`--precise`, `--realign`)
  *   finalise_alignment         lib/src/msa_op.c:546-576       -> ka_tree_aligned_rows
+ *
+ * KALIGN_AMD_GLUE_REPORT=1 in the environment prints, at exit, how often every seam ran on the device and how often it
+ * handed the call to the reference's own function (stderr, one line).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -28,6 +34,7 @@
 #include "task.h"
 #include "aln_param.h"
 #include "anchor_consistency.h"
+#include "tlrng.h"
 
 #include "kalign_amd.h"
 
@@ -35,13 +42,28 @@
 extern int kalign_ref_finalise_alignment(struct msa* msa);
 extern int kalign_ref_refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int refine_mode);
 extern int kalign_ref_create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int n_trials);
+extern int kalign_ref_compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr);
+extern int kalign_ref_build_tree_from_pairwise(struct msa* msa, struct aln_tasks** tasks, float** dm);
+extern int kalign_ref_anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchors, float weight, struct consistency_table** ct_out);
 
 /* how often each seam ran on the device / fell back to the reference (tests/test_gpu_dropin.py reads them) */
-enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF, GLUE_N };
+enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF,
+       GLUE_CONS, GLUE_CONS_REF, GLUE_KMEANS, GLUE_KMEANS_NOISY, GLUE_ALNDIST, GLUE_ALNDIST_REF, GLUE_ALNTREE, GLUE_ALNTREE_REF, GLUE_INLINE_REF, GLUE_N };
+static const char* glue_names[GLUE_N] = { "tree", "inline", "refine", "refine_ref", "finalise", "finalise_ref",
+                                          "cons", "cons_ref", "kmeans", "kmeans_noisy", "alndist", "alndist_ref", "alntree", "alntree_ref", "inline_ref" };
 static int glue_counts[GLUE_N];
 int kalign_amd_glue_count(int which)
 {
         return (which >= 0 && which < GLUE_N) ? glue_counts[which] : -1;
+}
+static void glue_report(void)
+{
+        int i;
+        fprintf(stderr, "kalign_amd_glue:");
+        for(i = 0; i < GLUE_N; i++){
+                fprintf(stderr, " %s=%d", glue_names[i], glue_counts[i]);
+        }
+        fprintf(stderr, "\n");
 }
 
 static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
@@ -50,6 +72,13 @@ static int glue_job_numseq = 0;
 
 static int glue_context(void)
 {
+        static int registered = 0;
+        if(!registered){
+                registered = 1;
+                if(getenv("KALIGN_AMD_GLUE_REPORT")){
+                        atexit(glue_report);
+                }
+        }
         if(!glue_ctx && ka_ctx_create(0, &glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
@@ -161,8 +190,13 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         glue_ct_resident = NULL;
         if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0) ||
            ka_tree_build_consistency(glue_ctx, K, weight)){
-                ERROR_MSG("kalign_amd: %s", ka_last_error());
+                /* a request the library does not take (more than 5 anchors ...): the reference's own function, like every
+                   other seam; the dispatcher then rebuilds the table it needs or declines alike (glue_ct_resident stays NULL) */
+                MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc);
+                glue_counts[GLUE_CONS_REF]++;
+                return kalign_ref_anchor_consistency_build(msa, ap, n_anchors, weight, ct_out);
         }
+        glue_counts[GLUE_CONS]++;
         MMALLOC(ct, sizeof(struct consistency_table));
         ct->pos_maps = NULL;
         ct->map_lengths = NULL;
@@ -216,6 +250,7 @@ ERROR:
  */
 static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total);
 
+/* inline_refine: 0 = create_msa_tree, n > 0 = create_msa_tree_inline_refine with n trials per edge */
 static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int inline_refine)
 {
         struct consistency_table* ct = (struct consistency_table*)msa->consistency_table;
@@ -260,7 +295,7 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         }
         glue_ct_resident = ct;                           /* NULL: this upload dropped whatever table there was */
         /* do_align_inline_refine (aln_run.c:515-790) is do_align with three flip trials per edge: mode 3 of ka_tree_refine */
-        if((inline_refine ? ka_tree_refine(glue_ctx, 3, NULL) : ka_tree_run(glue_ctx)) || ka_tree_sync(glue_ctx)){
+        if((inline_refine ? ka_tree_refine(glue_ctx, 3 | KA_REFINE_TRIALS(inline_refine), NULL) : ka_tree_run(glue_ctx)) || ka_tree_sync(glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         RUN(glue_collect(msa, t, lens, total));
@@ -333,11 +368,12 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
  */
 int create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int n_trials)
 {
-        if(n_trials != 3){
+        if(n_trials < 1 || n_trials > 255){
                 glue_job_msa = NULL;
+                glue_counts[GLUE_INLINE_REF]++;
                 return kalign_ref_create_msa_tree_inline_refine(msa, ap, t, n_trials);
         }
-        return glue_tree(msa, ap, t, 1);
+        return glue_tree(msa, ap, t, n_trials);
 }
 
 /*
@@ -386,7 +422,7 @@ ERROR:
  * UPGMA between them on the host in the reference's fp32 order -- the same task list and seq_distances, bit for bit.
  * msa->sequences[i]->s holds the tree alphabet at this point (aln_wrap.c:155-160).
  */
-int build_tree_kmeans(struct msa* msa, struct aln_tasks** tasks)
+static int glue_kmeans(struct msa* msa, struct aln_tasks** tasks, const float* dm_scale)
 {
         struct aln_tasks* t = *tasks;
         int n = msa->numseq;
@@ -410,7 +446,7 @@ int build_tree_kmeans(struct msa* msa, struct aln_tasks** tasks)
         if(msa->seq_distances == NULL){
                 MMALLOC(msa->seq_distances, sizeof(float) * n);
         }
-        if(ka_guide_tree(glue_ctx, n, codes, off, lens, n_threads, NULL, abc, msa->seq_distances)){
+        if(ka_guide_tree(glue_ctx, n, codes, off, lens, n_threads, dm_scale, abc, msa->seq_distances)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         for(i = 0; i < n - 1; i++){
@@ -427,6 +463,149 @@ ERROR:
         if(lens) MFREE(lens);
         if(abc) MFREE(abc);
         if(codes) MFREE(codes);
+        return FAIL;
+}
+
+int build_tree_kmeans(struct msa* msa, struct aln_tasks** tasks)
+{
+        glue_counts[GLUE_KMEANS]++;
+        return glue_kmeans(msa, tasks, NULL);
+}
+
+/*
+ * build_tree_kmeans_noisy (bisectingKmeans.c:76-175; the guide trees of ensemble members): the same tree builder on
+ * distances multiplied by Gaussian noise.  The multipliers are the caller's: drawn here from the reference's own
+ * generator in the reference's order (one per (sequence, anchor), :105-115) and handed to the device with the batch.
+ */
+int build_tree_kmeans_noisy(struct msa* msa, struct aln_tasks** tasks, uint64_t seed, float noise_sigma)
+{
+        float* scale = NULL;
+        int n = msa->numseq;
+        int na = n < 32 ? n : 32;                        /* pick_anchor, bisectingKmeans.c */
+        int i, j, rc;
+        if(seed == 0 || noise_sigma <= 0.0f){
+                glue_counts[GLUE_KMEANS_NOISY]++;
+                return glue_kmeans(msa, tasks, NULL);
+        }
+        MMALLOC(scale, sizeof(float) * (size_t)n * na);
+        {
+                struct rng_state* rng = init_rng(seed);
+                for(i = 0; i < n; i++){
+                        for(j = 0; j < na; j++){
+                                double noise = tl_random_gaussian(rng, 1.0, (double)noise_sigma);
+                                if(noise < 0.1) noise = 0.1;
+                                scale[(size_t)i * na + j] = (float)noise;
+                        }
+                }
+                free_rng(rng);
+        }
+        glue_counts[GLUE_KMEANS_NOISY]++;
+        rc = glue_kmeans(msa, tasks, scale);
+        MFREE(scale);
+        return rc;
+ERROR:
+        return FAIL;
+}
+
+/*
+ * compute_aln_pairwise_dist (aln_apair_dist.c:9-86) and build_tree_from_pairwise (bisectingKmeans.c:1150-1200): the
+ * realignment loop of kalign_run_realign (aln_wrap.c:449-504; `--precise`, `--realign n`).  The rows finalise_alignment
+ * just made are still in HBM: ONE device call computes the N x N identity distances and the UPGMA tree on them
+ * (ka_aln_guide_tree).  The reference's interface splits that in two, so the first seam returns the distances in the
+ * reference's layout and keeps the tree; the second hands the tree over when it is asked about that very matrix.
+ */
+static float** glue_dm = NULL;                   /* the matrix the last compute_aln_pairwise_dist returned */
+static int* glue_dm_abc = NULL;
+static float* glue_dm_sd = NULL;
+static int glue_dm_n = 0;
+static const struct msa* glue_rows_msa = NULL;   /* the msa whose finalised rows the device holds */
+
+int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
+{
+        float** dm = NULL;
+        float* flat = NULL;
+        uint8_t* rows = NULL;
+        int n = msa->numseq;
+        int i;
+        if(!glue_ctx || msa->aligned != ALN_STATUS_FINAL || n < 2){
+                glue_counts[GLUE_ALNDIST_REF]++;
+                return kalign_ref_compute_aln_pairwise_dist(msa, dm_ptr);
+        }
+        if(glue_dm_abc){ MFREE(glue_dm_abc); glue_dm_abc = NULL; }
+        if(glue_dm_sd){ MFREE(glue_dm_sd); glue_dm_sd = NULL; }
+        glue_dm = NULL;
+        MMALLOC(flat, sizeof(float) * (size_t)n * n);
+        MMALLOC(glue_dm_abc, sizeof(int) * 3 * (n - 1));
+        MMALLOC(glue_dm_sd, sizeof(float) * n);
+        if(msa == glue_rows_msa){
+                /* the rows are where ka_tree_aligned_rows left them */
+                if(ka_aln_guide_tree(glue_ctx, n, NULL, 0, 0, '-', glue_dm_abc, glue_dm_sd, flat)){
+                        ERROR_MSG("kalign_amd: %s", ka_last_error());
+                }
+        }else{
+                long long stride = (long long)msa->alnlen + 1;
+                MMALLOC(rows, (size_t)n * stride);
+                for(i = 0; i < n; i++){
+                        memcpy(rows + (size_t)i * stride, msa->sequences[i]->seq, msa->alnlen);
+                        rows[(size_t)i * stride + msa->alnlen] = 0;
+                }
+                if(ka_aln_guide_tree(glue_ctx, n, rows, stride, msa->alnlen, '-', glue_dm_abc, glue_dm_sd, flat)){
+                        ERROR_MSG("kalign_amd: %s", ka_last_error());
+                }
+                MFREE(rows); rows = NULL;
+        }
+        MMALLOC(dm, sizeof(float*) * n);
+        for(i = 0; i < n; i++){
+                dm[i] = NULL;
+        }
+        for(i = 0; i < n; i++){
+                MMALLOC(dm[i], sizeof(float) * n);
+                memcpy(dm[i], flat + (size_t)i * n, sizeof(float) * n);
+        }
+        MFREE(flat);
+        glue_dm = dm; glue_dm_n = n;
+        glue_counts[GLUE_ALNDIST]++;
+        *dm_ptr = dm;
+        return OK;
+ERROR:
+        if(flat) MFREE(flat);
+        if(rows) MFREE(rows);
+        if(dm){
+                for(i = 0; i < n; i++){
+                        if(dm[i]) MFREE(dm[i]);
+                }
+                MFREE(dm);
+        }
+        return FAIL;
+}
+
+int build_tree_from_pairwise(struct msa* msa, struct aln_tasks** tasks, float** dm)
+{
+        struct aln_tasks* t = *tasks;
+        int n = msa->numseq;
+        int i;
+        if(dm == NULL || dm != glue_dm || n != glue_dm_n || !glue_dm_abc){
+                glue_counts[GLUE_ALNTREE_REF]++;
+                return kalign_ref_build_tree_from_pairwise(msa, tasks, dm);
+        }
+        if(!t){
+                RUN(alloc_tasks(&t, n));
+        }
+        if(msa->seq_distances == NULL){
+                MMALLOC(msa->seq_distances, sizeof(float) * n);
+        }
+        memcpy(msa->seq_distances, glue_dm_sd, sizeof(float) * n);
+        for(i = 0; i < n - 1; i++){
+                t->list[i]->a = glue_dm_abc[3 * i];
+                t->list[i]->b = glue_dm_abc[3 * i + 1];
+                t->list[i]->c = glue_dm_abc[3 * i + 2];
+        }
+        t->n_tasks = n - 1;
+        *tasks = t;
+        glue_dm = NULL;                                  /* (the caller frees the matrix next; its address may come back) */
+        glue_counts[GLUE_ALNTREE]++;
+        return OK;
+ERROR:
         return FAIL;
 }
 
@@ -447,10 +626,12 @@ int finalise_alignment(struct msa* msa)
         int i;
         if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx){
                 glue_counts[GLUE_FINALISE_REF]++;
+                glue_rows_msa = NULL;
                 return kalign_ref_finalise_alignment(msa);
         }
         glue_counts[GLUE_FINALISE]++;
         glue_job_msa = NULL;                             /* the rows below replace seq->seq: one shot */
+        glue_rows_msa = msa;                             /* ... and stay in HBM for the realignment loop's distances */
         ASSERT(msa->aligned == ALN_STATUS_ALIGNED, "Sequences are not aligned");
         for(i = 0; i < n; i++){
                 total += msa->sequences[i]->len;

@@ -29,13 +29,42 @@ def _need(name):
     return p
 
 
-def _cli(binary, infile, outfile, *flags):
-    env = dict(os.environ, OMP_NUM_THREADS="8")
+def _cli(binary, infile, outfile, *flags, counters=None):
+    """counters: a dict that receives the seam counters the drop-in prints at exit (KALIGN_AMD_GLUE_REPORT=1): how often
+    every seam ran on the device and how often it handed the call to the reference's own function"""
+    env = dict(os.environ, OMP_NUM_THREADS="8", KALIGN_AMD_GLUE_REPORT="1")
     r = subprocess.run([_need(binary), "-i", infile, "-o", outfile, "-n", "8"] + list(flags), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
+    if counters is not None:
+        lines = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("kalign_amd_glue:")]
+        assert lines, "the drop-in did not report its seam counters:\n" + r.stderr.decode()[-1500:]
+        counters.update({k: int(v) for k, v in (kv.split("=") for kv in lines[-1].split()[1:])})
     with open(outfile, "rb") as fh:
         return fh.read()
+
+
+def _device_ran(c, flags):
+    """the seams a run with these CLI flags must have taken ON THE DEVICE -- a byte-identical FASTA alone would also come out
+    of a run that silently fell back to the reference's own functions"""
+    for k in ("refine_ref", "finalise_ref", "cons_ref", "alndist_ref", "alntree_ref", "inline_ref"):
+        assert c[k] == 0, (k, c)
+    precise = "--precise" in flags
+    realign = int(flags[flags.index("--realign") + 1]) if "--realign" in flags else (1 if precise else 0)
+    # --precise: ensemble of 3 + one realignment (src/run_kalign.c:375-383)
+    ens = [f for f in flags if f.startswith("--ensemble=")]
+    members = int(ens[0].split("=")[1]) if ens else (3 if precise else 1)
+    assert c["tree"] + c["inline"] >= members * (1 + realign), c
+    assert c["finalise"] >= members * (1 + realign), c
+    assert c["kmeans"] + c["kmeans_noisy"] >= members, c
+    if members > 1 and not realign:
+        assert c["kmeans_noisy"] >= 1, c                      # kalign_run_seeded: members after the first build their trees on noisy distances
+    if realign:
+        assert c["alndist"] >= members * realign and c["alntree"] == c["alndist"], c
+    if "--fast" not in flags and members == 1:
+        assert c["cons"] >= 1, c                               # default mode: the N x K batch and the position maps
+    if "--refine" in flags:
+        assert c["refine"] >= 1, c
 
 
 def _write_fasta(path, seqs):
@@ -45,7 +74,8 @@ def _write_fasta(path, seqs):
 
 
 CLI_CASES = [
-    ("BB11001.tfa", []), ("BB11001.tfa", ["--fast"]),
+    ("BB11001.tfa", []), ("BB11001.tfa", ["--fast"]), ("BB11001.tfa", ["--precise"]), ("BB12006.tfa", ["--fast", "--realign", "2"]),
+    ("BB11001.tfa", ["--ensemble=3"]),
     ("BB30014.tfa", []), ("BB30014.tfa", ["--fast"]),
     ("BB12006.tfa", []), ("BB12006.tfa", ["--realign", "1"]),
     ("BB30014.tfa", ["--precise"]),
@@ -60,9 +90,11 @@ CLI_CASES = [
 def test_cli_output_is_byte_identical(tmp_path, name, flags):
     """`kalign -i in -o out [flags]`: the aligned FASTA written by the drop-in equals the reference's."""
     inp = os.path.join(DATA, name)
-    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags)
+    c = {}
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags, counters=c)
     want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), *flags)
     assert len(want) > 100 and got == want
+    _device_ran(c, flags)
 
 
 @pytest.mark.parametrize("dna,n,length,flags", [(False, 32, 200, []), (False, 32, 200, ["--fast"]),
@@ -71,9 +103,11 @@ def test_cli_on_dssim_sets(tmp_path, dna, n, length, flags):
     from kalign_amd import synth
     inp = str(tmp_path / "in.fa")
     _write_fasta(inp, synth.dssim(n, length, dna=dna, seed=1))
-    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags)
+    c = {}
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags, counters=c)
     want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), *flags)
     assert got == want
+    _device_ran(c, flags)
 
 
 def _lib_kalign(libname, seqs, type_, n_threads=4):
