@@ -52,6 +52,12 @@ extern "C" {
                                    sequences with a new task list keep the consistency table ka_tree_build_consistency
                                    built for the previous job of this context (no table then: none now); fails if the
                                    sequences differ */
+#define KA_FLAG_EXACT_CONFIDENCE 16 /* task confidence as the reference's float, bit for bit: the reference adds a task's meetup
+                                   margins in recursion order (aln_run.c:391-395, aln_controller.c:194-436), the level-synchronous
+                                   first pass in level order (equal within 1e-5).  With this flag every meetup records its margin with
+                                   its place in the recursion order; sorted and added in fp32 after the recursion.  Costs a sort per
+                                   task and the wave-local subtrees (the records are not kept there); tasks with more than 8192
+                                   recorded meetups keep the level-order sum. */
 
 typedef struct ka_ctx ka_ctx;
 

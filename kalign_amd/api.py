@@ -15,6 +15,7 @@ FLAG_DEBUG_ROWS = 1
 FLAG_TIMING = 2
 FLAG_DEVICE_GAPS = 4
 FLAG_KEEP_CONSISTENCY = 8
+FLAG_EXACT_CONFIDENCE = 16
 
 
 class KalignAmdError(RuntimeError):

@@ -74,7 +74,7 @@ struct KaCtl {
         int alnlen;
         int fail;
         unsigned int bar;               // cluster barrier: arrivals so far (monotonic)
-        int pad;
+        int nrec;                       // (recursion-order key, margin) records appended so far (exact confidences; all members of a cluster)
         long long scratch_off;          // cluster: scratch block allocated by member 0
         long long newp_off;             // merged profile offset in the arena (-1: root / none)
         long long path_off;             // coded path offset in the path arena
@@ -137,7 +137,7 @@ struct TaskShared {
         float* mlog;                   // refinement, adaptive budget: the margins of the trial in recursion order (first mlog_cap of them), or null
         int mlog_cap, adapt_trials;
         int2* mrec;                    // refinement, level-synchronous baseline trial: (recursion-order key, margin) of every meetup
-        int nrec;
+        int rec_on;                    // first pass with exact confidences (KA_FLAG_EXACT_CONFIDENCE): every meetup records (key, margin)
         float sp_value;
         int Gw, member_w;              // cluster size / member index the recursion currently works with
         int split;
@@ -291,7 +291,8 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         const bool in_range = ksub < ncur;
         const KaSub sb = qc[in_range ? ksub : k0];
         // (a wave-local subtree is already complete: path entries written, margins added, no children left)
-        const bool valid = in_range && (FLIP || REC || sb.pad != KA_SUB_MARK);
+        const bool rec = REC || S.rec_on;                             // (REC: refinement's baseline trial; rec_on: the first pass with exact confidences)
+        const bool valid = in_range && (FLIP || rec || sb.pad != KA_SUB_MARK);
         const bool is_top = top_level && ksub == 0;
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
@@ -361,8 +362,8 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
                 tr = ord + 1 + (ord >= 3 ? 1 : 0);
         }
         if (leader && is_top) { S.ctl->top_meet = meet; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
-        if (REC && leader && B.mx2 > -KA_F) {
-                const int idx = atomicAdd(&S.nrec, 1);
+        if (rec && leader && B.mx2 > -KA_F) {
+                const int idx = atomicAdd(&S.ctl->nrec, 1);
                 S.mrec[idx] = make_int2(sb.pad, __float_as_int(B.mx - B.mx2));
         }
         if (FLIP && leader) {
@@ -390,7 +391,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         c2.enda = sb.enda; c2.endb = endb; c2.bin = sb.bin;
         c1.enda = c1.starta; c1.endb = c1.startb; c1.bin = Z;          // empty unless a transition fills them in
         c2.starta = c2.enda; c2.startb = c2.endb; c2.fin = Z;
-        c1.pad = REC ? sb.pad + kdig : 0; c2.pad = REC ? sb.pad + 2 * kdig : 0; c1.roff = 0; c2.roff = 0;
+        c1.pad = rec ? sb.pad + kdig : 0; c2.pad = rec ? sb.pad + 2 * kdig : 0; c1.roff = 0; c2.roff = 0;
         if (tr > 0) {
                 int* path = S.raw;
                 switch (tr) {
@@ -438,8 +439,8 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         if (v1) { need[0] += 1; need[1] += c1.endb - c1.startb + 1; }
         if (v2) { need[0] += 1; need[1] += c2.endb - c2.startb + 1; }
         // a child small enough for one wave's LDS is ONE work item: the whole subtree below it (ka_subtree.h)
-        const bool st1 = !FLIP && !REC && v1 && ka_child_is_subtree(lout, c1.enda - c1.starta, c1.endb - c1.startb);
-        const bool st2 = !FLIP && !REC && v2 && ka_child_is_subtree(lout, c2.enda - c2.starta, c2.endb - c2.startb);
+        const bool st1 = !FLIP && !rec && v1 && ka_child_is_subtree(lout, c1.enda - c1.starta, c1.endb - c1.startb);
+        const bool st2 = !FLIP && !rec && v2 && ka_child_is_subtree(lout, c2.enda - c2.starta, c2.endb - c2.startb);
         if (st1) need[2] += 1;
         if (st2) need[2] += 1;
 #pragma unroll
@@ -753,7 +754,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 {
                         const KaLevelOut lout = ka_level_out(S, (level + 1) & 1, true);
                         const int est_cols = S.Lb >> level;          // typical columns per sub-problem at this depth
-                        const int kdig = REC ? ka_pow3[max(KA_REC_DEPTH - 2 - level, 0)] : 0;
+                        const int kdig = (REC || S.rec_on) ? ka_pow3[max(KA_REC_DEPTH - 2 - level, 0)] : 0;
                         if (est_cols > 128 && ncur <= 2 && S.mw_ok) {
                                 // one or two sub-problems with thousands of columns: the leading workgroup's waves share each scan
                                 // (every wave of it takes part in both barriers of a round; the other members have nothing to do)
@@ -1858,7 +1859,7 @@ __device__ __host__ inline long long ka_private_bytes(long long la, long long lb
 }
 
 // carve the per-task scratch region (cons_maxlen > 0: the job has a consistency table)
-__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen, bool refine = false)
+__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen, bool refine = false, bool rec = false)
 {
         const long long n = (long long)la + lb + 8;
         long long o = 0;
@@ -1904,6 +1905,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
                 S.sp_freq = (int*)(base + o);    o += ka_align_up(n * 24 * 4, 16);
                 S.mrec = (int2*)(base + o);      o += ka_align_up(n * 8, 16);
         }
+        if (rec && !refine) { S.mrec = (int2*)(base + o); o += ka_align_up(n * 8, 16); }
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
         if (cons_maxlen > 0) {
                 S.ent = (int2*)(base + o);    o += ka_align_up(n * 8 * KA_NB, 16);
@@ -1918,7 +1920,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         return o;
 }
 
-__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1, bool refine = false)
+__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1, bool refine = false, bool rec = false)
 {
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 20;
@@ -1929,8 +1931,47 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
         if (g > 1) b += g * ka_private_bytes(la, lb);
         if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16 + (n * 8 + 15) / 16 * 16;
+        if (rec && !refine) b += (n * 8 + 15) / 16 * 16;
         if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 12 + 15) / 16 * 16;
         return b;
+}
+
+// The margins of a level-synchronous baseline trial (ka_meetup<.., REC>) in the reference's recursion order: sort the
+// (key, margin) records by key in LDS (bitonic, padded to a power of two), then one thread adds them up in fp32 -- and
+// keeps the first mlog_cap of them for the adaptive budget.  Returns false when there are more records than the buffer
+// holds (the caller repeats the trial depth first).
+#define KA_REC_SORT_CAP 8192
+__device__ bool ka_margins_in_order(TaskShared& S, char* lds, const int cap = KA_REC_SORT_CAP)
+{
+        const int tid = threadIdx.x;
+        const int n = S.ctl->nrec;
+        int2* buf = (int2*)lds;
+        int m = 1;
+        while (m < n) m <<= 1;
+        if (m > cap) return false;                                  // (uniform: n comes from the control block)
+        for (int i = tid; i < m; i += KA_NT) buf[i] = (i < n) ? S.mrec[i] : make_int2(0x7fffffff, 0);
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < m; i += KA_NT) {
+                                const int l = i ^ j;
+                                if (l > i) {
+                                        const int2 a = buf[i], b = buf[l];
+                                        const bool up = (i & k) == 0;
+                                        if ((a.x > b.x) == up) { buf[i] = b; buf[l] = a; }
+                                }
+                        }
+                        __syncthreads();
+                }
+        }
+        if (S.mlog) for (int i = tid; i < min(n, S.mlog_cap); i += KA_NT) S.mlog[i] = __int_as_float(buf[i].y);
+        if (tid == 0) {
+                float sum = 0.0f;
+                for (int i = 0; i < n; ++i) sum += __int_as_float(buf[i].y);
+                S.rf.msum = sum; S.rf.mcount = n; S.rf.counter = 0;
+        }
+        __syncthreads();
+        return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2010,7 +2051,11 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 if (g_eff > g_launch) g_eff = g_launch;
                 S.srows = srows;
                 // wave-local subtrees (ka_subtree.h): every kernel shape has a region per wave behind the workgroup's scratch
-                S.sub_ok = (NB == 0 && D.sub_mode) ? 1 : 0;
+                // exact task confidences (aln_run.c:391-395 adds the margins in recursion order): every meetup records its margin
+                // with its place in that order; sorted and added up in fp32 after the recursion (ka_margins_in_order).  The
+                // wave-local subtrees do not keep those records: off.
+                S.rec_on = (D.flags & KA_FLAG_EXACT_CONFIDENCE) ? 1 : 0;
+                S.sub_ok = (NB == 0 && D.sub_mode && !S.rec_on) ? 1 : 0;
                 S.nres_t = (D.nres <= 5) ? 5 : ((D.nres <= 20) ? 20 : 23);
                 S.sub_stride = LEAN ? KA_WAVE_LDS_LEAN : KA_WAVE_LDS;
                 S.sub_base = LEAN ? (lds_waves + KA_LEAN_SCRATCH(KA_NT)) : lds_waves;
@@ -2021,10 +2066,10 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
                 S.lctl = S.ctl;
-                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; }
+                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.nrec = 0; }
                 s_dbg = nullptr;
                 if (member == 0) {
-                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff);
+                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff, false, (D.flags & KA_FLAG_EXACT_CONFIDENCE) != 0);
                         const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                         if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
                         // an earlier task of this run already failed (arena overflow): its outputs -- possibly this
@@ -2043,7 +2088,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         if (S.member >= S.G) return 2;                       // surplus workgroup of an over-provisioned cluster
         ka_cluster_sync(S);
         if (S.ctl->fail) return 1;
-        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0);
+        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0, false, S.rec_on != 0);
 
         // P1
         ka_build_tss(tss, D.subm, T.soff);
@@ -2073,6 +2118,14 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         else ka_hirschberg<KA_PP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
+        // exact confidence: the cluster's last barrier (inside ka_hirschberg) has published every member's records
+        bool conf_exact = false;
+        if (S.rec_on && S.member == 0 && S.n_levels < KA_REC_DEPTH) {   // (deeper: the keys no longer tell the levels apart)
+                if (tid == 0) { S.mlog = nullptr; S.mlog_cap = 0; }
+                __syncthreads();
+                const int cap = (int)min((long long)KA_REC_SORT_CAP, (LEAN ? (long long)KA_NW * KA_WAVE_LDS_LEAN + KA_LEAN_SCRATCH(KA_NT) : (long long)KA_NW * KA_WAVE_LDS) / 8);
+                conf_exact = ka_margins_in_order(S, lds_waves, cap);
+        }
         tk2 = __builtin_amdgcn_s_memtime();
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 3);
 #undef s_dbg
@@ -2103,6 +2156,8 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         r.gap_scale = T.gap_scale; r.subm_off = T.soff;
                         r.score = S.ctl->top_score;
                         r.confidence = (S.ctl->mcount > 0) ? (float)S.ctl->msum / (float)S.ctl->mcount : 0.0f;
+                        // (the reference: m->margin_sum / (float)m->margin_count, both summed in recursion order, aln_run.c:391-395)
+                        if (conf_exact) r.confidence = (S.rf.mcount > 0) ? S.rf.msum / (float)S.rf.mcount : 0.0f;
                         r.prof_hash = 0; r.fhash = 0; r.bhash = 0;
                         D.recs[task] = r;
                 }
@@ -2140,44 +2195,6 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 }
         }
         return 0;
-}
-
-// The margins of a level-synchronous baseline trial (ka_meetup<.., REC>) in the reference's recursion order: sort the
-// (key, margin) records by key in LDS (bitonic, padded to a power of two), then one thread adds them up in fp32 -- and
-// keeps the first mlog_cap of them for the adaptive budget.  Returns false when there are more records than the buffer
-// holds (the caller repeats the trial depth first).
-#define KA_REC_SORT_CAP 8192
-__device__ bool ka_margins_in_order(TaskShared& S, char* lds)
-{
-        const int tid = threadIdx.x;
-        const int n = S.nrec;
-        if (n > KA_REC_SORT_CAP) return false;
-        int2* buf = (int2*)lds;
-        int m = 1;
-        while (m < n) m <<= 1;
-        for (int i = tid; i < m; i += KA_NT) buf[i] = (i < n) ? S.mrec[i] : make_int2(0x7fffffff, 0);
-        __syncthreads();
-        for (int k = 2; k <= m; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                        for (int i = tid; i < m; i += KA_NT) {
-                                const int l = i ^ j;
-                                if (l > i) {
-                                        const int2 a = buf[i], b = buf[l];
-                                        const bool up = (i & k) == 0;
-                                        if ((a.x > b.x) == up) { buf[i] = b; buf[l] = a; }
-                                }
-                        }
-                        __syncthreads();
-                }
-        }
-        if (S.mlog) for (int i = tid; i < min(n, S.mlog_cap); i += KA_NT) S.mlog[i] = __int_as_float(buf[i].y);
-        if (tid == 0) {
-                float sum = 0.0f;
-                for (int i = 0; i < n; ++i) sum += __int_as_float(buf[i].y);
-                S.rf.msum = sum; S.rf.mcount = n; S.rf.counter = 0;
-        }
-        __syncthreads();
-        return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2242,7 +2259,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
                 S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS;
-                S.sub_ok = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
+                S.sub_ok = 0; S.rec_on = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true);
@@ -2301,7 +2318,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 // a fifth of the depth-first time); the margins are put back into recursion order afterwards.
                 bool done = false;
                 if (k == 0 && (D.wdfs & 2) && S.La < (1 << 17)) {
-                        if (tid == 0) S.nrec = 0;
+                        if (tid == 0) S.ctl->nrec = 0;
                         __syncthreads();
                         if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
                         else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
@@ -2733,7 +2750,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS;
-                S.sub_ok = 1; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0; S.mw_ok = 1;
+                S.sub_ok = 1; S.rec_on = 0; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0; S.mw_ok = 1;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
                 S.watchdog = P.error; S.trace = nullptr; S.dbgskip = 0; S.prof = nullptr;

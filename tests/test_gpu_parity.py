@@ -6,7 +6,7 @@ within 1e-5 relative (it is a mean whose summation order differs)."""
 import numpy as np
 import pytest
 
-from util import Golden, compare_recs, pair_cases, tree_cases
+from util import Golden, compare_recs, cons_cases, pair_cases, tree_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +41,27 @@ def test_tree_matches_reference_golden(ctx, oracle, name):
     if t < len(recs) - 1:
         prof = ctx.tree_profile(recs[t].c, recs[t].plen)
         assert np.array_equal(prof[:len(g.dump)].view(np.uint32), g.dump.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", tree_cases() + cons_cases())
+def test_tree_exact_confidence_flag(ctx, name):
+    """KA_FLAG_EXACT_CONFIDENCE: ka_tree_run's task confidences are the reference's floats bit for bit (the meetup
+    margins sorted into the recursion order before they are added), next to everything in EXACT"""
+    from kalign_amd import api
+    g = Golden(name)
+    cons = hasattr(g, "n_anchors") and int(g.n_anchors) > 0
+    ctx.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, flags=api.FLAG_EXACT_CONFIDENCE | api.FLAG_DEVICE_GAPS)
+    if cons:
+        ctx.tree_build_consistency(int(g.n_anchors), float(g.weight))
+    ctx.tree_run()
+    ctx.tree_sync()
+    recs, paths, gaps = ctx.tree_download()
+    fields = [f for f in EXACT if f not in ("fhash", "bhash")] + ["confidence"]
+    assert compare_recs(g, recs, paths, fields, tol_fields=()) == []
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.rec("confidence").astype(np.float32))
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert ctx.fallback_runs() == 0
 
 
 @pytest.mark.parametrize("name", pair_cases())
