@@ -39,7 +39,7 @@ extern "C" void ka_launch_posmaps(const int* paths, const long long* poff, const
                                   int numseq, int K, int* maps, hipStream_t stream);
 extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int alnlen, int n, uint8_t gap, float* dm, float* means,
                                    hipStream_t stream);
-extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, hipStream_t stream);
+extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, int mode, hipStream_t stream);
 int ka_tasks_from_merges(int numseq, const int* merges_ab, int* tasks_abc);      // ka_guide.cpp
 extern "C" void ka_launch_rows(const uint8_t* letters, const int* off, const int* lens, const int* colof, const int* alnlen,
                                int numseq, uint8_t gap, uint8_t* rows, long long stride, hipStream_t stream);
@@ -91,6 +91,7 @@ struct KaEnv {
         int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
+        bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
 };
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static void read_env(KaEnv& v)
@@ -105,6 +106,7 @@ static void read_env(KaEnv& v)
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
         v.mw = env_int("KA_MW", 1);
+        v.upgma_launches = getenv("KA_UPGMA_LAUNCHES") != nullptr;
 }
 
 struct ka_ctx {
@@ -1223,7 +1225,7 @@ extern "C" int ka_aln_guide_tree(ka_ctx* c, int numseq, const uint8_t* rows, lon
         if (seq_distances) HIPCHK(hipMemcpyAsync(seq_distances, c->d_amean.p, sizeof(float) * numseq, hipMemcpyDeviceToHost, c->stream));
         std::vector<int> ones(numseq, 1);
         HIPCHK(hipMemcpyAsync(c->d_uactive.p, ones.data(), sizeof(int) * numseq, hipMemcpyHostToDevice, c->stream));
-        ka_launch_upgma(c->d_adm.p, c->d_uactive.p, c->d_ucand.p, c->d_umerges.p, numseq, c->stream);
+        ka_launch_upgma(c->d_adm.p, c->d_uactive.p, c->d_ucand.p, c->d_umerges.p, numseq, c->env.upgma_launches ? 1 : 0, c->stream);
         HIPCHK(hipGetLastError());
         std::vector<int> merges(2 * (size_t)numseq);
         HIPCHK(hipMemcpyAsync(merges.data(), c->d_umerges.p, sizeof(int2) * (numseq - 1), hipMemcpyDeviceToHost, c->stream));

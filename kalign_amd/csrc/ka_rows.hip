@@ -272,15 +272,202 @@ extern "C" void ka_launch_aln_dist(const uint8_t* rows, long long stride, int al
         hipLaunchKernelGGL(ka_row_mean_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dm, n, means);
 }
 
-// ---- launching the n - 1 dependent merge steps ----
-// One launch per step, ~11 us each, of which the step's own work is a few.  Measured alternatives on MI355X, both
-// bit-identical and neither faster: the loop replayed as one hipGraph of n kernel nodes (12 us per node: the cost is the
-// dependent dispatch on the GPU, not the host-side launch), and one persistent kernel of 64 workgroups with a barrier
-// in HBM between steps (21 us per step: an agent-scope release/acquire pair across the eight XCDs' L2s costs more than
-// a kernel boundary).  keys: 2 * n words, active: n ones, merges: n - 1 pairs.
-extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, hipStream_t stream)
+// ---- all n - 1 merges in ONE launch of ONE workgroup ----
+// The merges depend on each other, so the loop is a latency chain: per launch it costs the dependent dispatch (~11 us),
+// per cluster-wide barrier in HBM a release/acquire pair across the XCDs' L2s (~21 us, measured in round 2).  One
+// workgroup of 8 waves needs neither: its waves share one L1 and meet at s_barrier.  Row keys, activity flags and the
+// rescan list live in LDS; the matrix is kept symmetric, so the two COLUMNS a step reads (a and b, a stride-n walk)
+// are read as ROWS a and b (coalesced).  One step = LDS work + ONE round trip to the matrix:
+//   A  all threads reduce the n row keys to the pair (a, b)                                             [LDS]
+//   L  thread i lists row i for a rescan if its minimum sat in column a or b                            [LDS]
+//   B  loads in flight together: rows a and b (thread i: elements i), and for each listed row its columns > i.
+//      v = (dm[a][i] + dm[b][i]) * 0.5 + 0.001 (the operands and their order are the reference's
+//      dm[i][a] + dm[i][b], bisectingKmeans.c:1027-1040) goes to dm[a][i] (coalesced) and to its mirror dm[i][a]
+//      (the step's only strided access, a store nobody waits for until the next step's loads); row i's key takes
+//      the new candidate (i < a); row a's key is the minimum over the v of the columns > a
+//   C  one wave per listed row: the key from the columns loaded in B, with v in place of column a.
+// Barriers between the phases wait for LDS only; the one in front of B also waits for the previous step's stores.
+#define KA_UPGMA_NT 512
+#define KA_UPGMA_ONE_WG_MAX 6144
+#define KA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long ka_dpp_min_u64(const unsigned long long v)
+{
+        // (lanes without a source, or in a masked row, keep the identity)
+        const unsigned int olo = (unsigned int)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)(unsigned int)v, CTRL, ROW_MASK, 0xf, false);
+        const unsigned int ohi = (unsigned int)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)(unsigned int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+        const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+        return o < v ? o : v;
+}
+// minimum over the wave, in every lane (VALU only: a butterfly of 64-bit shuffles is 12 trips through the LDS crossbar)
+__device__ __forceinline__ unsigned long long ka_wave_min_u64(unsigned long long v)
+{
+        v = ka_dpp_min_u64<0x111, 0xf>(v);                            // row_shr:1
+        v = ka_dpp_min_u64<0x112, 0xf>(v);                            // row_shr:2
+        v = ka_dpp_min_u64<0x114, 0xf>(v);                            // row_shr:4
+        v = ka_dpp_min_u64<0x118, 0xf>(v);                            // row_shr:8   -> lane 15 of every row: the row's minimum
+        v = ka_dpp_min_u64<0x142, 0xa>(v);                            // row_bcast:15 into rows 1 and 3
+        v = ka_dpp_min_u64<0x143, 0xc>(v);                            // row_bcast:31 into rows 2 and 3 -> lane 63: everything
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, 63);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), 63);
+        return ((unsigned long long)hi << 32) | lo;
+}
+
+// PER: rows per thread (n <= PER * KA_UPGMA_NT); SV * 64: columns of a listed row per round trip
+template <int PER, int SV>
+__global__ void __launch_bounds__(KA_UPGMA_NT) ka_upgma_one_wg_kernel(KaUpgma U)
+{
+        extern __shared__ __attribute__((aligned(16))) unsigned char ka_upgma_lds[];
+        __shared__ unsigned long long red[KA_UPGMA_NT / 64], red_a[KA_UPGMA_NT / 64];
+        __shared__ int nlist;
+        const int n = U.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        constexpr int nw = KA_UPGMA_NT / 64;
+        unsigned long long* keys = (unsigned long long*)ka_upgma_lds;  // n row keys
+        int* list = (int*)(keys + n);                                 // rows to rescan in this step
+        float* listv = (float*)(list + n);                            // [row] their new value in column a
+        unsigned char* act = (unsigned char*)(listv + n);             // [row] still a cluster of its own
+        for (int i = tid; i < n; i += KA_UPGMA_NT) act[i] = U.active[i] != 0;
+        __syncthreads();
+        // key of row i from the columns in sv (loaded by the caller) and, beyond SV * 64 columns, from the matrix
+        auto row_key = [&](const int i, const float* sv, const int a) {
+                const float* row = U.dm + (long long)i * n;
+                unsigned long long best = ~0ull;
+                // (flags first, all reads in flight together: a flag read inside a branch costs an LDS round trip per column)
+                unsigned char ac[SV];
+#pragma unroll
+                for (int u = 0; u < SV; ++u) { const int j = i + 1 + lane + 64 * u; ac[u] = act[j < n ? j : n - 1]; }
+                const float lv = a >= 0 ? listv[i] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < SV; ++u) {
+                        const int j = i + 1 + lane + 64 * u;
+                        const unsigned long long k = ka_upgma_key(j == a ? lv : sv[u], (unsigned int)(i * n + j));
+                        const unsigned long long kk = (j < n && ac[u]) ? k : ~0ull;
+                        best = kk < best ? kk : best;
+                }
+                for (int j0 = i + 1 + lane + 64 * SV; j0 < n; j0 += 64 * SV) {
+                        float v[SV];
+#pragma unroll
+                        for (int u = 0; u < SV; ++u) { const int j = j0 + 64 * u; v[u] = row[j < n ? j : n - 1]; }
+#pragma unroll
+                        for (int u = 0; u < SV; ++u) { const int j = j0 + 64 * u; ac[u] = act[j < n ? j : n - 1]; }
+#pragma unroll
+                        for (int u = 0; u < SV; ++u) {
+                                const int j = j0 + 64 * u;
+                                const unsigned long long k = ka_upgma_key(j == a ? lv : v[u], (unsigned int)(i * n + j));
+                                const unsigned long long kk = (j < n && ac[u]) ? k : ~0ull;
+                                best = kk < best ? kk : best;
+                        }
+                }
+                best = ka_wave_min_u64(best);
+                if (lane == 0) keys[i] = best;
+        };
+        auto row_load = [&](const int i, float* sv) {
+                const float* row = U.dm + (long long)i * n;
+#pragma unroll
+                for (int u = 0; u < SV; ++u) { const int j = i + 1 + lane + 64 * u; sv[u] = row[j < n ? j : n - 1]; }
+        };
+        for (int i = wave; i < n; i += nw) { float sv[SV]; row_load(i, sv); row_key(i, sv, -1); }
+        __syncthreads();
+        for (int step = 0; step < n - 1; ++step) {
+                // A
+                unsigned long long best = ~0ull;
+                for (int i = tid; i < n; i += KA_UPGMA_NT) { const unsigned long long k = keys[i]; best = k < best ? k : best; }
+                best = ka_wave_min_u64(best);
+                if (lane == 0) red[wave] = best;
+                if (tid == 0) nlist = 0;
+                KA_LDS_BARRIER();
+                best = ka_wave_min_u64(red[lane & (nw - 1)]);
+                const unsigned int idx = (unsigned int)(best & 0xffffffffull);
+                const int a = (int)(idx / (unsigned int)n), b = (int)(idx % (unsigned int)n);
+                // L
+                unsigned long long kq[PER]; unsigned char aq[PER];
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                        const int i = tid + u * KA_UPGMA_NT, ii = i < n ? i : n - 1;
+                        kq[u] = keys[ii]; aq[u] = act[ii];
+                }
+                bool listed[PER];
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                        const int i = tid + u * KA_UPGMA_NT;
+                        const int jmin = (int)(unsigned int)(kq[u] & 0xffffffffull) - i * n;   // (row i's key: index i * n + j)
+                        listed[u] = i < n && i != a && i != b && aq[u] && kq[u] != ~0ull && (jmin == a || jmin == b);
+                        if (listed[u]) list[atomicAdd(&nlist, 1)] = i;
+                }
+                if (tid == 0) { U.merges[step] = make_int2(a, b); act[b] = 0; keys[b] = ~0ull; }
+                __syncthreads();                                      // (also: the previous step's stores have landed)
+                // B
+                const int nl = nlist;
+                float sv[SV];
+                if (wave < nl) row_load(list[wave], sv);
+                float* ra = U.dm + (long long)a * n;
+                const float* rb = U.dm + (long long)b * n;
+                float va[PER], vb[PER];
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                        const int i = tid + u * KA_UPGMA_NT, ii = i < n ? i : n - 1;
+                        va[u] = ra[ii]; vb[u] = rb[ii];
+                }
+                unsigned long long best_a = ~0ull;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                        const int i = tid + u * KA_UPGMA_NT;
+                        if (i >= n || i == b) continue;
+                        if (i == a) { ra[a] = 0.0f; continue; }
+                        const float v = (va[u] + vb[u]) * 0.5f + 0.001f;
+                        ra[i] = v;
+                        if (!aq[u]) continue;
+                        U.dm[(long long)i * n + a] = v;
+                        if (i > a) {
+                                const unsigned long long c = ka_upgma_key(v, (unsigned int)(a * n + i));
+                                best_a = c < best_a ? c : best_a;
+                        }
+                        if (listed[u]) {
+                                listv[i] = v;
+                        } else if (i < a) {
+                                const unsigned long long c = ka_upgma_key(v, (unsigned int)(i * n + a));
+                                keys[i] = c < kq[u] ? c : kq[u];
+                        }
+                }
+                best_a = ka_wave_min_u64(best_a);
+                if (lane == 0) red_a[wave] = best_a;
+                KA_LDS_BARRIER();
+                // C
+                if (wave == 0) {
+                        const unsigned long long ka = ka_wave_min_u64(red_a[lane & (nw - 1)]);
+                        if (lane == 0) keys[a] = ka;
+                }
+                for (int x = wave; x < nl; x += nw) {
+                        if (x != wave) row_load(list[x], sv);
+                        row_key(list[x], sv, a);
+                }
+                KA_LDS_BARRIER();
+        }
+}
+
+// ---- launching the n - 1 dependent merge steps, one launch per step ----
+// ~11 us each, of which the step's own work is a few.  Measured alternatives on MI355X, both bit-identical and neither
+// faster: the loop replayed as one hipGraph of n kernel nodes (12 us per node: the cost is the dependent dispatch on the
+// GPU, not the host-side launch), and one persistent kernel of 64 workgroups with a barrier in HBM between steps (21 us
+// per step).  keys: 2 * n words, active: n ones, merges: n - 1 pairs.
+// mode 0: one workgroup for all merges when n <= KA_UPGMA_ONE_WG_MAX; 1: always one launch per merge (KA_UPGMA_LAUNCHES=1)
+extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys, int2* merges, int n, int mode, hipStream_t stream)
 {
         KaUpgma U{ dm, active, { keys, keys + n }, merges, n };
+        if (mode == 0 && n <= KA_UPGMA_ONE_WG_MAX) {
+                const int lds = n * 17 + 16;                          // keys, list, listv, act
+                auto go = [&](auto kernel) {
+                        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_UPGMA_ONE_WG_MAX * 17 + 16);
+                        hipLaunchKernelGGL(kernel, dim3(1), dim3(KA_UPGMA_NT), lds, stream, U);
+                };
+                if (n <= KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<1, 8>);
+                else if (n <= 2 * KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<2, 16>);
+                else if (n <= 4 * KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<4, 32>);
+                else if (n <= 8 * KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<8, 32>);
+                else go(ka_upgma_one_wg_kernel<KA_UPGMA_ONE_WG_MAX / KA_UPGMA_NT, 32>);
+                return;
+        }
         const int blocks = n < 256 ? n : 256;
         hipLaunchKernelGGL(ka_upgma_init_kernel, dim3(blocks), dim3(256), 0, stream, U);
         for (int step = 0; step < n - 1; ++step)

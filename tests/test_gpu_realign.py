@@ -134,3 +134,25 @@ def test_tree_from_random_rows_matches_the_oracle(ctx, oracle, n, alnlen, seed):
     assert np.array_equal(dm.view(np.uint32), odm.view(np.uint32))
     assert np.array_equal(sd.view(np.uint32), osd.view(np.uint32))
     assert np.array_equal(tasks, otasks)
+
+
+@pytest.mark.parametrize("n", [300, 1100, 2100, 4200, 6200])
+def test_upgma_in_one_workgroup_and_in_per_merge_launches_agree(ctx, n):
+    """the two schedules of the device UPGMA (one workgroup for all merges, in its five sizes; one launch per merge, the
+    path above 6144 rows) give the same task list on rows with many tied distances"""
+    import os
+    rng = np.random.RandomState(n)
+    base = rng.choice(list(b"ACDE-"), size=(n // 3, 60)).astype(np.uint8)
+    rows = base[rng.randint(0, len(base), size=n)].copy()
+    flip = rng.random_sample(rows.shape) < 0.03
+    rows[flip] = rng.choice(list(b"ACDE-"), size=int(flip.sum())).astype(np.uint8)
+    rows = [bytes(r) for r in rows]
+    t1, sd1 = ctx.aln_guide_tree(rows)
+    os.environ["KA_UPGMA_LAUNCHES"] = "1"
+    try:
+        ctx.reload_env()
+        t2, sd2 = ctx.aln_guide_tree(rows)
+    finally:
+        del os.environ["KA_UPGMA_LAUNCHES"]
+        ctx.reload_env()
+    assert np.array_equal(t1, t2) and np.array_equal(sd1, sd2)
