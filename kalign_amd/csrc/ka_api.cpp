@@ -991,7 +991,6 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         if (tree_launch(c)) return KA_FAIL;
                         continue;
                 }
-                if (err == 7) return fail("consistency: a node has 65536 or more member sequences (vote counters are 16 bits wide)");
                 if (c->partial) return fail("a device arena overflowed during a partial run (ka_tree_run_tasks does not re-run)");
                 // an arena overflowed: grow it and run again (results are only trusted from a clean run)
                 if (err == 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
@@ -1751,10 +1750,6 @@ extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float we
                 }
                 std::sort(trees.begin(), trees.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a[0] < b[0]; });
         }
-        // the vote of a profile packs its `total` and `agree` counts into 16 bits each (ka_cons_votes)
-        for (auto& m : trees)
-                if (m.size() >= 65536)
-                        return fail("consistency: an alignment of 65536 or more sequences is beyond the vote counters of this build (use n_anchors = 0)");
         int K = n_anchors;
         for (auto& m : trees) if ((int)m.size() >= 3) K = std::min(K, (int)m.size());
         for (auto& m : trees)

@@ -1657,16 +1657,20 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                         continue;
                 }
                 if (LEAN) continue;                                      // lean levels hold leaf-leaf tasks only
-                if (nmem >= 65536) { if (tid == 0) atomicExch(D.error, 7); continue; }
+                // a cell's `total` and `agree` counts share one 32-bit word (16 bits each) -- below 65536 members; from there on
+                // `agree` has a word of its own (anchor_consistency.c:352-470 counts in ints)
+                const bool wide = nmem >= 65536;
+                const long long cell = wide ? 16 : 12;
                 const int* members = D.sip + D.sip_off[node];
-                int fit = (int)(lds_bytes / (12ll * dp_len));             // anchors whose tables fit into LDS together
+                int fit = (int)(lds_bytes / (cell * dp_len));             // anchors whose tables fit into LDS together
                 const bool in_lds = fit >= 1;
                 if (!in_lds) fit = nk;
                 for (int b0 = 0; b0 < nk; b0 += fit) {
                         const int nb = min(fit, nk - b0);
                         unsigned long long* key = in_lds ? (unsigned long long*)lds : (unsigned long long*)S.vote;
                         unsigned int* cnt = (unsigned int*)(key + (long long)nb * dp_len);
-                        for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; }
+                        unsigned int* agr = cnt + (long long)nb * dp_len;        // (wide only)
+                        for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; if (wide) agr[x] = 0u; }
                         __syncthreads();
                         // Two sweeps over (member, residue): [0] first-member key + total, [1] agreement with the
                         // winner.  Latency-bound gathers, so each wave pre-loads the metadata of 64 of its
@@ -1712,7 +1716,7 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                                                                                 // (HBM tables: the atomics were performed at L2; read them back past the L1)
                                                                                 const unsigned long long kk = in_lds ? key[x]
                                                                                         : __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                                                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) atomicAdd(&cnt[x], 0x10000u);
+                                                                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) { if (wide) atomicAdd(&agr[x], 1u); else atomicAdd(&cnt[x], 0x10000u); }
                                                                         }
                                                                 }
                                                         }
@@ -1724,13 +1728,14 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                         for (int x = tid; x < nb * dp_len; x += KA_NT) {
                                 const int b = x / dp_len, c = x - b * dp_len;
                                 unsigned long long kk;
-                                unsigned int cc;
-                                if (in_lds) { kk = key[x]; cc = cnt[x]; }
+                                unsigned int cc, ca = 0u;
+                                if (in_lds) { kk = key[x]; cc = cnt[x]; if (wide) ca = agr[x]; }
                                 else {
                                         kk = __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         cc = __hip_atomic_load(&cnt[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (wide) ca = __hip_atomic_load(&agr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 }
-                                const int tot = (int)(cc & 0xffffu), ag = (int)(cc >> 16);
+                                const int tot = wide ? (int)cc : (int)(cc & 0xffffu), ag = wide ? (int)ca : (int)(cc >> 16);
                                 const long long o = KS(b0 + b) * n + c;
                                 if (tot > 0 && ag > 0) { apos[o] = (int)(unsigned int)(kk & 0xffffffffull); conf[o] = (float)ag / (float)tot; }
                                 else { apos[o] = -1; conf[o] = 0.0f; }
@@ -1915,7 +1920,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
                 S.apos_c = (int*)(base + o);  o += ka_align_up(KM * n * 4, 16);
                 S.conf_c = (float*)(base + o); o += ka_align_up(KM * n * 4, 16);
                 S.invj = (int*)(base + o);    o += ka_align_up(KM * ((long long)cons_maxlen + 8) * 4, 16);
-                S.vote = base + o;            o += ka_align_up(KM * n * 12, 16);
+                S.vote = base + o;            o += ka_align_up(KM * n * 16, 16);
         }
         return o;
 }
@@ -1932,7 +1937,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
         if (g > 1) b += g * ka_private_bytes(la, lb);
         if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16 + (n * 8 + 15) / 16 * 16;
         if (rec && !refine) b += (n * 8 + 15) / 16 * 16;
-        if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 12 + 15) / 16 * 16;
+        if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 16 + 15) / 16 * 16;
         return b;
 }
 

@@ -122,3 +122,43 @@ def test_forest_in_default_mode_has_one_table_per_alignment(ctx):
         for got_row, want_row in zip(maps[s0:s0 + ns], g.maps_list()):
             for got, want in zip(got_row, want_row):
                 assert np.array_equal(got, want - 0)          # positions are within the anchor sequence: no offset
+
+
+def test_a_node_with_65536_members_votes_in_32_bits(ctx, oracle):
+    """65537 short sequences, a balanced tree over 65536 of them and the last one joining at the root: the root task's
+    profile side has 65536 members, where a cell's `total` and `agree` counts no longer fit 16 bits each
+    (anchor_consistency.c:352-470 counts in ints)"""
+    N, LEN = 65537, 8
+    rng = np.random.RandomState(5)
+    root = rng.randint(0, 20, size=LEN)
+    codes = []
+    for i in range(N):
+        s = root.copy()
+        m = rng.random_sample(LEN) < 0.15
+        s[m] = rng.randint(0, 20, size=int(m.sum()))
+        if rng.random_sample() < 0.3:
+            s = np.delete(s, rng.randint(LEN))
+        codes.append(s.astype(np.uint8))
+    nodes, tasks, nxt = list(range(N - 1)), [], N
+    while len(nodes) > 1:
+        new = []
+        for k in range(0, len(nodes) - 1, 2):
+            tasks.append((nodes[k], nodes[k + 1], nxt)); new.append(nxt); nxt += 1
+        if len(nodes) & 1:
+            new.append(nodes[-1])
+        nodes = new
+    tasks.append((nodes[0], N - 1, nxt))
+    tasks = np.array(tasks, np.int32)
+    z = np.load(os.path.join(GOLDEN, "param_tables.npz"))
+    subm, scal = z["subm_0_3"], z["scal_0_3"].copy()
+    dist = rng.uniform(0.2, 1.2, size=N).astype(np.float32)
+    recs, paths, gaps = ctx.msa_tree(codes, tasks, subm, scal, dist, n_anchors=3, weight=2.0)
+    orecs, opaths, ogaps, oids, omaps, _ = oracle.msa_tree_cons(codes, tasks, subm, scal, dist, 3, 2.0)
+    assert max(orecs[-1].nsip_a, orecs[-1].nsip_b) == 65536
+    for t in list(range(0, len(recs), 997)) + list(range(len(recs) - 40, len(recs))):
+        r, o = recs[t], orecs[t]
+        for f in ("plen", "meet", "transition", "score", "nsip_a", "nsip_b"):
+            assert getattr(r, f) == getattr(o, f), (t, f)
+        assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], opaths[o.path_off:o.path_off + o.plen + 2]), t
+    for a, b in zip(gaps[::257] + gaps[-3:], ogaps[::257] + ogaps[-3:]):
+        assert np.array_equal(a, b)
