@@ -52,11 +52,13 @@ def pmc_traffic(key):
     profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate passes for exactly this workload, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950; profiles/collect.sh).  bench.py cannot run the
     profiler on itself, so it reports the committed measurement of the named workload and null for any other."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
-            return float(json.load(fh)[key]["hbm_bytes_per_step_corrected"])
-    except Exception:
-        return None
+    for tag in ("r03", "r02"):                                   # the newest collection that has this workload
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")) as fh:
+                return float(json.load(fh)[key]["hbm_bytes_per_step_corrected"])
+        except Exception:
+            continue
+    return None
 
 
 def workload_letters(nseq, length, dna, seed):

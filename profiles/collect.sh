@@ -16,7 +16,7 @@ for WL in $WLS; do
     OUT=$ROOT/gpurun_out/prof_${TAG}_refine
     mkdir -p $OUT
     cd /tmp
-    timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/refine_time.py 1024 400 > $OUT/kt.log 2>&1
+    timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/tools/refine_time.py 1024 400 > $OUT/kt.log 2>&1
     cd $ROOT
     cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
     tail -12 $OUT/kt.log
@@ -31,11 +31,11 @@ for WL in $WLS; do
   mkdir -p $OUT
   python bench.py --steps 10 --warmup 3 --no-legs --no-cpu $ARGS > $OUT/bench.json 2> $OUT/bench.err
   cd /tmp
-  timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/bench.py --steps 10 --warmup 3 --no-legs --no-cpu $ARGS > $OUT/kt.log 2>&1
-  timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-legs --no-cpu $ARGS > $OUT/pmc_fetch.log 2>&1
-  timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-legs --no-cpu $ARGS > $OUT/pmc_write.log 2>&1
+  timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $ROOT/bench.py --steps 10 --warmup 3 --no-legs --no-cpu $ARGS > $OUT/kt.log 2>&1
+  timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 3 --warmup 1 --no-legs --no-cpu $ARGS > $OUT/pmc_fetch.log 2>&1
+  timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $ROOT/bench.py --steps 3 --warmup 1 --no-legs --no-cpu $ARGS > $OUT/pmc_write.log 2>&1
   if [ $WL = headline ]; then
-    timeout -s KILL 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-legs --no-cpu $ARGS > $OUT/pmc_sq.log 2>&1
+    timeout -s KILL 180 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-legs --no-cpu $ARGS > $OUT/pmc_sq.log 2>&1
   fi
   cd $ROOT
   python profiles/summarize.py $TAG $WL $OUT > $OUT/summary.log 2>&1
