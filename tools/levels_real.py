@@ -61,7 +61,7 @@ while node in by_c:
     node = r.a if done[r.a] >= done[r.b] else r.b
 print('%s task, per Hirschberg level: sub-problems, pass us, meetup us' % (os.environ.get('KA_PROF_TASK', 'root')))
 for l, (nsub, cp, cm) in enumerate(ctx.root_levels):
-    if nsub: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))
+    if nsub and l < 13: print('  level %2d  n=%5d  pass %7.1f  meet %6.1f' % (l, nsub, cp/GHZ/1e3, cm/GHZ/1e3))   # (slots 13.. hold the subtree statistics)
 
 # per-level times of more tasks on the critical path (KA_PROF_TASK): tree levels given as the 7th argument, e.g. 8,12,16
 if len(sys.argv) > 6:

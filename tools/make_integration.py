@@ -13,8 +13,11 @@ SEAMS = [
      ["glue_tree", "glue_collect", "create_msa_tree", "create_msa_tree_inline_refine"]),
     ("1b. `refine_alignment` (`lib/src/aln_refine.c:36-88`)", ["refine_alignment"]),
     ("1c. `anchor_consistency_build` (`lib/src/anchor_consistency.c:200-275`)", ["anchor_consistency_build"]),
-    ("1d. `build_tree_kmeans` (`lib/src/bisectingKmeans.c:177-271`)", ["build_tree_kmeans"]),
+    ("1d. `build_tree_kmeans` (`lib/src/bisectingKmeans.c:177-271`) and `build_tree_kmeans_noisy` (`:76-175`)",
+     ["glue_kmeans", "build_tree_kmeans", "build_tree_kmeans_noisy"]),
     ("1e. `finalise_alignment` (`lib/src/msa_op.c:546-576`)", ["finalise_alignment"]),
+    ("1f. `compute_aln_pairwise_dist` (`lib/src/aln_apair_dist.c:9-86`) and `build_tree_from_pairwise` (`lib/src/bisectingKmeans.c:1150-1200`)",
+     ["compute_aln_pairwise_dist", "build_tree_from_pairwise"]),
 ]
 
 
