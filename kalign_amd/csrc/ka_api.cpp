@@ -81,7 +81,7 @@ struct DevBuf {
 // context is created -- ka_debug_reload_env re-reads them for tools and tests that flip a switch on a live context.
 struct KaEnv {
         bool trace = false, no_chain = false, no_queue = false, no_half = false, no_lean = false, chain_g1 = false, no_crit = false;
-        bool no_staging = false, no_wdfs = false, no_ls0 = false, refine_serial = false;
+        bool no_staging = false, no_wdfs = false, no_ls0 = false, no_inc = false, no_ldfs = false, refine_serial = false;
         int chain_tasks = 0;           // KA_CHAIN_TASKS: the chained launch starts at the first level with at most this many tasks (0: CUs - 8)
         int max_cluster = 0;           // KA_MAX_CLUSTER: workgroups one task may use (0: the default, 16)
         int crit_top = 0;              // KA_CRIT_TOP: workgroups of the chain entry with the longest way to the root (0: default)
@@ -100,7 +100,7 @@ static void read_env(KaEnv& v)
         v.trace = getenv("KA_TRACE") != nullptr; v.no_chain = getenv("KA_NO_CHAIN") != nullptr; v.no_queue = getenv("KA_NO_QUEUE") != nullptr;
         v.no_half = getenv("KA_NO_HALF") != nullptr; v.no_lean = getenv("KA_NO_LEAN") != nullptr; v.chain_g1 = getenv("KA_CHAIN_G1") != nullptr;
         v.no_crit = getenv("KA_NO_CRIT") != nullptr; v.no_staging = getenv("KA_NO_STAGING") != nullptr;
-        v.no_wdfs = getenv("KA_NO_WDFS") != nullptr; v.no_ls0 = getenv("KA_NO_LS0") != nullptr; v.refine_serial = getenv("KA_REFINE_SERIAL") != nullptr;
+        v.no_wdfs = getenv("KA_NO_WDFS") != nullptr; v.no_ls0 = getenv("KA_NO_LS0") != nullptr; v.no_inc = getenv("KA_NO_INC") != nullptr; v.no_ldfs = getenv("KA_NO_LDFS") != nullptr; v.refine_serial = getenv("KA_REFINE_SERIAL") != nullptr;
         v.chain_tasks = env_int("KA_CHAIN_TASKS", 0); v.max_cluster = env_int("KA_MAX_CLUSTER", 0); v.crit_top = env_int("KA_CRIT_TOP", 0);
         v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", 0); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
@@ -768,7 +768,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.refine_adaptive = 0;
         D.refine_trials = 3;
         D.prof_task = -1;
-        D.wdfs = (c->env.no_wdfs ? 0 : 1) | (c->env.no_ls0 ? 0 : 2);   // measurements / tests
+        D.wdfs = (c->env.no_wdfs ? 0 : 1) | (c->env.no_ls0 ? 0 : 2) | (c->env.no_inc ? 0 : 4) | (c->env.no_ldfs ? 0 : 8);   // measurements / tests
         D.prof_task = c->env.prof_task;                                 // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));

@@ -75,6 +75,8 @@ struct KaTreeDev {
         int refine_trials;             // ... mode 3 (KALIGN_REFINE_INLINE): trials per edge (create_msa_tree_inline_refine's n_trials; 3 in kalign_run)
         int wdfs;                      // refinement: bit 0 small subtrees of the depth-first recursion run wave-locally (KA_NO_WDFS=1 in the
                                        // environment: off), bit 1 the baseline trial runs level-synchronously (KA_NO_LS0=1: off)
+                                       // bit 2 flip trials re-run only the subtrees they flip (ka_trial_incremental; KA_NO_INC=1: off)
+                                       // bit 3 the wave-local subtrees of the depth-first recursion keep everything in LDS (ka_subtree_dfs; KA_NO_LDFS=1: off)
         int prof_task;                 // KA_FLAG_TIMING: the task whose per-level times are kept (-1: the root; KA_PROF_TASK in the environment)
         int* trace;                    // host-pinned breadcrumb buffer (KA_TRACE=1) or null
         int* error;                    // 0 ok; 1 prof arena, 2 scratch, 3 path arena, 4 dbg arena overflow, 5/6 watchdogs, 7 LDS vote table

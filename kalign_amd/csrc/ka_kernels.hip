@@ -137,6 +137,9 @@ struct TaskShared {
         float* mlog;                   // refinement, adaptive budget: the margins of the trial in recursion order (first mlog_cap of them), or null
         int mlog_cap, adapt_trials;
         int2* mrec;                    // refinement, level-synchronous baseline trial: (recursion-order key, margin) of every meetup
+        char* inc;                     // refinement, incremental flip trials (KaInc): the baseline's meetups with their windows, sorted; or null
+        int inc_n, inc_nunc;           //   ... records of the baseline / the uncertain ones among them (margin < threshold)
+        int inc_j, inc_p;              //   ... walk state: sorted position of the next flip (-1: none) / first record not yet taken over
         int rec_on;                    // first pass with exact confidences (KA_FLAG_EXACT_CONFIDENCE): every meetup records (key, margin)
         float sp_value;
         int Gw, member_w;              // cluster size / member index the recursion currently works with
@@ -181,6 +184,38 @@ __device__ __forceinline__ void col_terms(const TaskShared& S, int rec, float& c
 // Meetup of one sub-problem by one wave (aln_seqseq.c:241-420 and the two profile variants),
 // then aln_continue: path writes and the two child sub-problems (aln_controller.c:194-436).
 // ------------------------------------------------------------------------------------------
+// Incremental flip trials of refinement (ka_trial_incremental): what the level-synchronous baseline trial leaves behind, carved
+// from the task's scratch behind TaskShared::inc.  n = len_a + len_b + 8 bounds the number of meetups of a trial.
+struct KaInc {
+        KaSub* win;        // [record] the sub-problem (pad = its recursion-order key)
+        int2* mx;          // [record] (width of its subtree's key range, raw path entry of its first row before its subtree ran)
+        int* msort;        // [sorted position] record
+        int* skey;         // [sorted position] key
+        float* mseq0;      // [sorted position] margin = the baseline's margins in recursion order
+        float* mseq;       // the running trial's margins in recursion order (2n)
+        int* upos;         // [u] sorted position of the u-th uncertain meetup of the baseline
+        int* ucnt;         // [sorted position] uncertain meetups in front of it (n + 1)
+        int* raw0;         // the baseline's raw path
+};
+__device__ __host__ inline long long ka_inc_bytes(long long n) { return 88 * n + 64; }
+__device__ __forceinline__ KaInc ka_inc_from(char* base, const long long n)
+{
+        KaInc I;
+        I.win = (KaSub*)base; base += 48 * n;
+        I.mx = (int2*)base; base += 8 * n;
+        I.msort = (int*)base; base += 4 * n;
+        I.skey = (int*)base; base += 4 * n;
+        I.mseq0 = (float*)base; base += 4 * n;
+        I.mseq = (float*)base; base += 8 * n;
+        I.upos = (int*)base; base += 4 * n;
+        I.ucnt = (int*)base; base += 4 * n + 16;
+        I.raw0 = (int*)base;
+        return I;
+}
+static_assert(sizeof(KaSub) == 48, "KaInc::win stride");
+
+__device__ __forceinline__ KaInc ka_inc_view(const TaskShared& S) { return ka_inc_from(S.inc, (long long)S.len_a + S.len_b + 8); }
+
 struct Best { float mx; float mx2; int key; int key2; };          // key2 (who the runner-up is) only matters to refinement trials
 
 __device__ __forceinline__ void best_consider(Best& b, float s, int key)
@@ -365,6 +400,9 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         if (rec && leader && B.mx2 > -KA_F) {
                 const int idx = atomicAdd(&S.ctl->nrec, 1);
                 S.mrec[idx] = make_int2(sb.pad, __float_as_int(B.mx - B.mx2));
+                // incremental flip trials: the sub-problem itself, the width of its subtree's key range, and what its first row
+                // holds before anything below it writes (only an ancestor can have written there; the windows of other nodes are disjoint)
+                if (REC && S.inc) { const KaInc I = ka_inc_view(S); I.win[idx] = sb; I.mx[idx] = make_int2(3 * kdig, S.raw[sb.starta]); }
         }
         if (FLIP && leader) {
                 // the reference's meetups run one after the other in DFS order: fp32 margin sum in that order, and the
@@ -805,6 +843,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
 // work lists in HBM.
 // ------------------------------------------------------------------------------------------
 #define KA_WDFS_ROWS 64                                              // subtrees of at most this many rows run wave-locally
+#define KA_LDFS_ROWS 128                                             // ... when they run in LDS (ka_subtree_dfs)
 struct KaWdfsEntry { KaSub sub; float mx, mx2; int key, key2; };
 
 // the meetup candidates of one sub-problem, scanned by GL lanes: same candidates, same order, same arithmetic as ka_meetup
@@ -1011,8 +1050,10 @@ __device__ __forceinline__ void ka_wave_dfs(TaskShared& S, const KaSub root, con
 // one the recursion enters first on top.  Subtrees of at most KA_WDFS_ROWS rows are handed to one wave (ka_wave_dfs).
 // The stack is S.q[0] (+ candidates), the sub-problems in flight are S.q[1][0..1].
 // ------------------------------------------------------------------------------------------
+// seed != nullptr: not a whole trial but the subtree below *seed (ka_trial_incremental) -- the raw path, the trial's counters
+// and its margin log are the caller's; the seed's passes run alone like the root's.
 template <int KIND, int NRES, int NB>
-__device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves, const float* tss, const bool first_trial)
+__device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves, const float* tss, const bool first_trial, const KaSub* seed = nullptr)
 {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
@@ -1020,33 +1061,36 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
         const int g = max(S.La, S.Lb) + 2;
         // candidates of the sub-problems on the stack (S.q[0]): four words each, in a work list the depth-first order never fills
         int4* const cand = (int4*)S.pack[1][0];
-        for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;               // init_alnmem / the re-initialisation of refine_edge (:206-215)
+        if (!seed) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;    // init_alnmem / the re-initialisation of refine_edge (:206-215)
         if (tid == 0) {
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
                 root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
                 root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
+                if (seed) { root = *seed; root.roff = 0; root.pad = 0; }
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.dfs_top = 0;
-                S.rf.msum = 0.0f; S.rf.mcount = 0; S.rf.counter = 0;
-                S.ctl->msum = 0.0; S.ctl->mcount = 0;
+                if (!seed) {
+                        S.rf.msum = 0.0f; S.rf.mcount = 0; S.rf.counter = 0;
+                        S.ctl->msum = 0.0; S.ctl->mcount = 0;
+                }
                 if (first_trial) { S.ctl->top_meet = -1; S.ctl->top_tr = -1; S.ctl->top_score = 0.0f; }
                 // the root's passes run alone
                 S.dfs_valid = 0;
-                if (S.La > 0 && S.Lb > 0) {
+                if (root.starta < root.enda && root.startb < root.endb) {
                         S.q[1][0] = root;
                         for (int par = 0; par < 2; ++par) {
                                 KaCtl::Lvl& L = S.ctl->lvl[par];
                                 L.nsub = 0; L.rowalloc = 0; L.nitems = 0; L.next_item = 0; L.next_job = 0; L.npack[0] = 0; L.npack[1] = 0;
                         }
                         S.ctl->lvl[0].nsub = 1;
-                        S.ctl->lvl[0].rowalloc = S.Lb + 1;
-                        ka_emit_items(ka_level_out(S, 0, false), 0, 0, S.La, S.Lb);
+                        S.ctl->lvl[0].rowalloc = root.endb - root.startb + 1;
+                        ka_emit_items(ka_level_out(S, 0, false), 0, root.starta, root.enda, root.endb - root.startb);
                         S.dfs_valid = 1;
                 }
         }
         __syncthreads();
-        bool at_root = true;
+        bool at_root = (seed == nullptr);
         while (true) {
                 // ---- the passes and candidate scans of the sub-problems in flight (S.q[1][0 .. n-1]: a decided node's children) ----
                 const int n = S.dfs_valid;
@@ -1074,7 +1118,11 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
                                 const int pos = --S.dfs_top;
                                 const KaSub cur = S.q[0][pos];
                                 const int4 cb = cand[pos];
-                                if (cur.enda - cur.starta <= KA_WDFS_ROWS && !S.dbgskip) {
+                                // (the LDS walk takes windows of up to 128 rows: the passes of the children have at most 64)
+                                const int cr = cur.enda - cur.starta, cc = cur.endb - cur.startb;
+                                const bool lds_walk = NB == 0 && (S.dbgskip & 2) == 0 && cr >= 1 && cr <= KA_LDFS_ROWS && cc >= 1 && cc < 4096 &&
+                                                      ka_sub_bytes(KIND, NRES, cr, cc) <= 7 * KA_WAVE_LDS;
+                                if ((cr <= KA_WDFS_ROWS || lds_walk) && !(S.dbgskip & 1)) {
                                         S.q[1][0] = cur; cand[pos] = cb;      // (the wave below reads them from here)
                                         S.q[1][1].pad = pos;
                                         S.dfs_valid = -2;
@@ -1107,8 +1155,16 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
                         if (wave == 0) {
                                 const int4 cb = cand[S.q[1][1].pad];
                                 const Best B = { __int_as_float(cb.x), __int_as_float(cb.y), cb.z, cb.w };
-                                ka_wave_dfs<KIND, NRES, NB>(S, S.q[1][0], B, first_trial && at_root, lane, lds_waves, 4, KA_WAVE_LDS,
-                                                            lds_waves + 7 * KA_WAVE_LDS, tss);
+                                const KaSub cur = S.q[1][0];
+                                // operands, row buffers and stack in LDS when the window fits what the idle waves leave free
+                                // (no consistency bonus there: those rows come from the task's tables in HBM)
+                                const int wr = cur.enda - cur.starta, wc = cur.endb - cur.startb;
+                                if (NB == 0 && (S.dbgskip & 2) == 0 && wr >= 1 && wr <= KA_LDFS_ROWS && wc >= 1 && wc < 4096 &&
+                                    ka_sub_bytes(KIND, NRES, wr, wc) <= 7 * KA_WAVE_LDS)
+                                        ka_subtree_dfs<KIND, NRES>(S, cur, B, first_trial && at_root, lane, lds_waves, tss);
+                                else
+                                        ka_wave_dfs<KIND, NRES, NB>(S, cur, B, first_trial && at_root, lane, lds_waves, 4, KA_WAVE_LDS,
+                                                                    lds_waves + 7 * KA_WAVE_LDS, tss);
                         }
                         __syncthreads();
                         if (tid == 0) S.dfs_valid = 0;
@@ -1116,6 +1172,129 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
                 }
                 at_root = false;
         }
+}
+
+// ------------------------------------------------------------------------------------------
+// Incremental flip trials.  A flip trial differs from the baseline trial only below the meetups it flips: a node that is not
+// flipped and has no flipped ancestor has the baseline's window, hence the baseline's candidates, margin and decision; only
+// WHETHER an uncertain node flips depends on what came before it (the running count of uncertain meetups in recursion order,
+// aln_seqseq.c:376-414).  So the trial walks the baseline's uncertain meetups in recursion order (sorted keys), counts them,
+// and where the rule says "flip" it re-runs just that node's subtree depth first (ka_hirschberg_dfs with a seed: passes and
+// candidates of the node again, this time with the runner-up, the flip, and everything below it in recursion order -- further
+// flips included, the counter runs on); the baseline's meetups inside the old subtree are skipped (a contiguous key range),
+// the raw path rows of the node's window are put back to what they held before its subtree ran.  Margins in recursion order =
+// baseline segments and re-run subtrees concatenated, added in fp32 at the end.  Bit-identical with the depth-first trial
+// (tests/test_gpu_refine.py), at the cost of the re-run subtrees instead of the whole recursion.
+// ------------------------------------------------------------------------------------------
+// after ka_margins_in_order (lds still holds the sorted (key, margin) pairs): sorted tables + the baseline's raw path
+__device__ void ka_inc_build(TaskShared& S, const char* lds)
+{
+        const int tid = threadIdx.x;
+        const int n = S.ctl->nrec;
+        const int2* buf = (const int2*)lds;
+        const KaInc I = ka_inc_view(S);
+        for (int idx = tid; idx < n; idx += KA_NT) {
+                const int key = S.mrec[idx].x;                        // keys are unique: one node, one key
+                int lo = 0, hi = n - 1;
+                while (lo < hi) { const int md = (lo + hi) >> 1; if (buf[md].x < key) lo = md + 1; else hi = md; }
+                I.msort[lo] = idx;
+        }
+        for (int pos = tid; pos < n; pos += KA_NT) { I.skey[pos] = buf[pos].x; I.mseq0[pos] = __int_as_float(buf[pos].y); }
+        const int g = max(S.La, S.Lb) + 2;
+        for (int i = tid; i < g; i += KA_NT) I.raw0[i] = S.raw[i];
+        if (tid == 0) S.inc_n = n;
+        __syncthreads();
+}
+
+// the uncertain meetups of the baseline (margin below the trials' threshold), in recursion order; wave 0
+__device__ void ka_inc_uncertain(TaskShared& S, const float thr)
+{
+        if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                const int n = S.inc_n;
+                const KaInc I = ka_inc_view(S);
+                int running = 0;
+                for (int base = 0; base < n; base += 64) {
+                        const int i = base + lane;
+                        const bool flag = i < n && thr > 0.0f && I.mseq0[i] < thr;
+                        const unsigned long long mask = __ballot(flag);
+                        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+                        if (i < n) I.ucnt[i] = running + before;
+                        if (flag) I.upos[running + before] = i;
+                        running += __popcll(mask);
+                }
+                if (lane == 0) { I.ucnt[n] = running; S.inc_nunc = running; }
+        }
+        __syncthreads();
+}
+
+template <int KIND, int NRES, int NB>
+__device__ __forceinline__ void ka_trial_incremental(TaskShared& S, char* lds_waves, const float* tss)
+{
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const KaInc I = ka_inc_view(S);
+        const int n = S.inc_n, nunc = S.inc_nunc;
+        const int g = max(S.La, S.Lb) + 2;
+        for (int i = tid; i < g; i += KA_NT) S.raw[i] = I.raw0[i];
+        if (tid == 0) {
+                S.rf.msum = 0.0f; S.rf.mcount = 0; S.rf.counter = 0; S.inc_p = 0;
+                S.mlog = I.mseq; S.mlog_cap = 2 * (S.len_a + S.len_b + 8);
+        }
+        while (true) {
+                __syncthreads();
+                if (tid == 0) {
+                        // the next flip: the uncertain meetup at which the running counter hits the trial's residue
+                        const int c = S.rf.counter, st = S.rf.stride;
+                        const int u = I.ucnt[S.inc_p];
+                        const int skip = (((S.rf.trial - 1 - c) % st) + st) % st;
+                        if (u + skip >= nunc) { S.inc_j = -1; S.rf.counter = c + (nunc - u); }
+                        else { S.inc_j = I.upos[u + skip]; S.rf.counter = c + skip; }
+                }
+                __syncthreads();
+                const int j = S.inc_j, p = S.inc_p, end = (j < 0) ? n : j, mc = S.rf.mcount;
+                for (int i = p + tid; i < end; i += KA_NT) I.mseq[mc + (i - p)] = I.mseq0[i];
+                __syncthreads();
+                if (tid == 0) S.rf.mcount = mc + (end - p);
+                if (j < 0) break;
+                const int idx = I.msort[j];
+                const KaSub X = I.win[idx];
+                const int2 xm = I.mx[idx];
+                for (int i = X.starta + tid; i <= X.enda; i += KA_NT) S.raw[i] = (i == X.starta) ? xm.y : -1;
+                __syncthreads();
+                ka_hirschberg_dfs<KIND, NRES, NB>(S, lds_waves, tss, false, &X);
+                __syncthreads();
+                // the baseline's next meetup behind the old subtree: first sorted key >= key + range (wave 0)
+                if (wave == 0) {
+                        const int bound = X.pad + xm.x;
+                        int lo = j + 1, hi = n;
+                        while (hi - lo > 64) {
+                                const int step = (hi - lo + 63) / 64;
+                                const int pos = lo + lane * step;
+                                const bool less = pos < hi && I.skey[pos] < bound;
+                                const int c = __popcll(__ballot(less));
+                                const int nlo = c > 0 ? lo + (c - 1) * step + 1 : lo;
+                                const int nhi = min(hi, lo + c * step);
+                                lo = nlo; hi = max(nhi, nlo);
+                        }
+                        const int pos = lo + lane;
+                        const bool less = pos < hi && I.skey[pos] < bound;
+                        const int c = __popcll(__ballot(less));
+                        if (lane == 0) S.inc_p = lo + c;
+                }
+        }
+        __syncthreads();
+        // the margins of the trial, added in recursion order in fp32 (the reference's running sum)
+        if (wave == 0) {
+                const int mcount = S.rf.mcount;
+                float sum = 0.0f;
+                for (int base = 0; base < mcount; base += 64) {
+                        const float v = (base + lane < mcount) ? I.mseq[base + lane] : 0.0f;
+                        const int cnt = min(64, mcount - base);
+                        for (int i = 0; i < cnt; ++i) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+                }
+                if (lane == 0) S.rf.msum = sum;
+        }
+        __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1902,13 +2081,14 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
                 S.priv.b = (KaState*)(pr + x); x += ka_align_up(n * 12, 16);
                 o += (long long)S.G * pb;
         }
-        S.best_coded = nullptr; S.best_srcA = nullptr; S.best_srcB = nullptr; S.sp_freq = nullptr; S.mrec = nullptr;
+        S.best_coded = nullptr; S.best_srcA = nullptr; S.best_srcB = nullptr; S.sp_freq = nullptr; S.mrec = nullptr; S.inc = nullptr;
         if (refine) {
                 S.best_coded = (int*)(base + o); o += ka_align_up(n * 4, 16);
                 S.best_srcA = (int*)(base + o);  o += ka_align_up(n * 4, 16);
                 S.best_srcB = (int*)(base + o);  o += ka_align_up(n * 4, 16);
                 S.sp_freq = (int*)(base + o);    o += ka_align_up(n * 24 * 4, 16);
                 S.mrec = (int2*)(base + o);      o += ka_align_up(n * 8, 16);
+                S.inc = base + o;                o += ka_align_up(ka_inc_bytes(n), 16);
         }
         if (rec && !refine) { S.mrec = (int2*)(base + o); o += ka_align_up(n * 8, 16); }
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
@@ -1935,7 +2115,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
         if (g > 1) b += g * ka_private_bytes(la, lb);
-        if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16 + (n * 8 + 15) / 16 * 16;
+        if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16 + (n * 8 + 15) / 16 * 16 + (ka_inc_bytes(n) + 15) / 16 * 16;
         if (rec && !refine) b += (n * 8 + 15) / 16 * 16;
         if (cons_maxlen > 0) b += (n * 8 * KA_NB + 15) / 16 * 16 + 4 * (((KA_NB - 1) * n * 4 + 15) / 16 * 16) + ((KA_NB - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((KA_NB - 1) * n * 16 + 15) / 16 * 16;
         return b;
@@ -2232,7 +2412,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         auto lap = [&](int k) { const long long now = __builtin_amdgcn_s_memtime(); tq[k] += now - tlast; tlast = now; };
         if (tid == 0) {
                 const int len_a = D.node_len[T.a], len_b = D.node_len[T.b];
-                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = (D.wdfs & 1) ? 0 : 1; S.prof = nullptr;   // (dbgskip: here "no wave-local subtrees")
+                S.watchdog = D.error; S.trace = D.trace; S.dbgskip = ((D.wdfs & 1) ? 0 : 1) | ((D.wdfs & 8) ? 0 : 2); S.prof = nullptr;   // (dbgskip here: bit 0 "no wave-local subtrees", bit 1 "... not in LDS")
                 S.len_a = len_a; S.len_b = len_b;
                 S.profa = D.prof_arena + D.node_prof[T.a];
                 S.profb = D.prof_arena + D.node_prof[T.b];
@@ -2307,6 +2487,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         float best_sp = -KA_F, avg_margin = 0.0f, best_msum = 0.0f;
         int best_mcount = 0, best_k = 0;
         int top_meet0 = -1, top_tr0 = -1;                            // the record carries the baseline's top-level meetup
+        bool inc_ok = false, inc_listed = false;                     // incremental flip trials: tables built / uncertain meetups listed
         float top_score0 = 0.0f;
         const int Gt = (refine_it && G > 1) ? G : 1;                 // members that share this edge's flip trials
         if (member >= Gt) return;
@@ -2323,6 +2504,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 // a fifth of the depth-first time); the margins are put back into recursion order afterwards.
                 bool done = false;
                 if (k == 0 && (D.wdfs & 2) && S.La < (1 << 17)) {
+                        inc_ok = false;
                         if (tid == 0) S.ctl->nrec = 0;
                         __syncthreads();
                         if (S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
@@ -2331,6 +2513,17 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                         else ka_hirschberg<KA_PP, 23, NB, true>(S, nullptr, lds_waves, tss, D.trace);
                         __syncthreads();
                         done = ka_margins_in_order(S, lds_waves);
+                        // the flip trials re-run only the subtrees they flip (ka_trial_incremental)
+                        inc_ok = done && (n_trials > 1 || adaptive_it) && (D.wdfs & 4) && S.inc != nullptr;
+                        if (inc_ok) ka_inc_build(S, lds_waves);
+                }
+                if (k > 0 && inc_ok) {
+                        if (!inc_listed) { ka_inc_uncertain(S, avg_margin); inc_listed = true; }
+                        if (S.kind == KA_SS) ka_trial_incremental<KA_SS, 23, NB>(S, lds_waves, tss);
+                        else if (S.kind == KA_SP) ka_trial_incremental<KA_SP, 23, NB>(S, lds_waves, tss);
+                        else if (D.nres <= 5) ka_trial_incremental<KA_PP, 5, NB>(S, lds_waves, tss);
+                        else ka_trial_incremental<KA_PP, 23, NB>(S, lds_waves, tss);
+                        done = true;
                 }
                 if (!done) {
                         if (S.kind == KA_SS) ka_hirschberg_dfs<KA_SS, 23, NB>(S, lds_waves, tss, k == 0);

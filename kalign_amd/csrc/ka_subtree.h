@@ -452,14 +452,14 @@ __device__ __forceinline__ void ka_sub_meet(TaskShared& S, const KaSubCtx& X, co
         mcount += __builtin_popcountll(__ballot(has2));
 }
 
-// The whole subtree below `root` by the calling wave.  area: the wave's LDS region (KA_WAVE_LDS bytes).
+// Context of a subtree: origin, sizes, penalties; the wave's region carved (same arithmetic as ka_sub_bytes); both operand
+// windows staged into LDS; the root in q[0][0].
 template <int KIND, int NRES>
-__device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, const int lane, char* area, const float* tss)
+__device__ __forceinline__ void ka_sub_setup(TaskShared& S, const KaSub& root, const int lane, char* area, KaSubCtx& X)
 {
         constexpr int RW = (KIND == KA_PP) ? 4 * ((NRES + 3) / 4) + 4 : (KIND == KA_SP ? 28 : 0);
         constexpr int G0 = RW - 4;
         constexpr int NV = (NRES + 3) / 4;
-        KaSubCtx X;
         X.a0 = __builtin_amdgcn_readfirstlane(root.starta); X.b0 = __builtin_amdgcn_readfirstlane(root.startb);
         X.R = __builtin_amdgcn_readfirstlane(root.enda) - X.a0; X.C = __builtin_amdgcn_readfirstlane(root.endb) - X.b0;
         X.La = __builtin_amdgcn_readfirstlane(S.La); X.Lb = __builtin_amdgcn_readfirstlane(S.Lb);
@@ -482,9 +482,6 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
         X.F = (ka_lf*)(area + o); o += rbytes;
         X.B = (ka_lf*)(area + o);
 
-        const bool tmg = S.sub_tm != 0;                               // KA_FLAG_TIMING on the profiled task: where a subtree's time goes
-        long long tq0 = 0, tq1 = 0, tpass = 0, tmeet = 0;
-        if (tmg) tq0 = __builtin_amdgcn_s_memtime();
         // ---- stage the operand windows: 16-byte chunks, four loads in flight per lane before their LDS writes ----
         const float m1 = ka_uniform_f(S.p1_mult), m2 = ka_uniform_f(S.p2_mult);
         // one record = `per` chunks: nsc chunks of 4 floats from field `src0` on, then (open, ext, text) * mult
@@ -530,6 +527,17 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
                 ka_subl_store(X.q[0], 0, e);
         }
         ka_wave_lds_sync();
+}
+
+// The whole subtree below `root` by the calling wave.  area: the wave's LDS region (KA_WAVE_LDS bytes).
+template <int KIND, int NRES>
+__device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, const int lane, char* area, const float* tss)
+{
+        KaSubCtx X;
+        const bool tmg = S.sub_tm != 0;                               // KA_FLAG_TIMING on the profiled task: where a subtree's time goes
+        long long tq0 = 0, tq1 = 0, tpass = 0, tmeet = 0;
+        if (tmg) tq0 = __builtin_amdgcn_s_memtime();
+        ka_sub_setup<KIND, NRES>(S, root, lane, area, X);
         if (tmg) tq1 = __builtin_amdgcn_s_memtime();
 
         int ncur = 1, level = 0;
@@ -570,4 +578,195 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
                 atomicAdd(&S.sub_t[6], (unsigned long long)(level * 1000000 + X.R * 1000 + min(X.C, 999)));
         }
         if (lane == 0 && mcount) { atomicAdd(&S.lctl->msum, msum); atomicAdd(&S.lctl->mcount, mcount); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same subtree DEPTH FIRST, for refinement's flip trials (aln_refine.c:93-346): a trial flips every stride-th
+// uncertain meetup in recursion order, so the decisions are sequential (ka_hirschberg_dfs) -- but the operands, the row
+// buffers, the stack and the candidates of a small subtree need not leave LDS while one wave walks it.  Per node:
+// decision (flip rule, margin log, path entries, the children's windows), the passes of BOTH children in one
+// ka_sub_pass call, their candidate scans 32 lanes apiece (runner-up key included), both on the stack with their
+// candidates -- the child the recursion enters first on top.  `root` arrives with its candidates (its passes ran with
+// its sibling's).  area: LDS the workgroup does not use while wave 0 walks (ka_sub_bytes of the window).
+// ------------------------------------------------------------------------------------------------------------------
+template <int KIND, int NRES>
+__device__ __forceinline__ void ka_subtree_dfs(TaskShared& S, const KaSub root, const Best rootB, const bool root_is_top, const int lane,
+                                               char* area, const float* tss)
+{
+        constexpr int RW = (KIND == KA_PP) ? 4 * ((NRES + 3) / 4) + 4 : (KIND == KA_SP ? 28 : 0);
+        constexpr int G0 = RW - 4;
+        KaSubCtx X;
+        ka_sub_setup<KIND, NRES>(S, root, lane, area, X);
+        ka_li* fly = X.q[0];                                          // the (up to two) sub-problems whose passes run
+        ka_li* stack = X.q[1];                                        // 8 ints per entry: KaSubL, then mx, mx2, key, key2
+        if (lane == 0) {
+                stack[0] = 0 | (X.R << 16); stack[1] = 0 | (X.C << 16); stack[2] = 0;
+                stack[4] = __float_as_int(rootB.mx); stack[5] = __float_as_int(rootB.mx2); stack[6] = rootB.key; stack[7] = rootB.key2;
+        }
+        ka_wave_lds_sync();
+        int h = 1;                                                    // stack height (wave-uniform)
+        bool top = root_is_top;
+        while (h > 0) {
+                --h;
+                // ---- the decision of the node on top of the stack (every lane computes it; lane 0 has the side effects) ----
+                const int ea_ = stack[8 * h], eb_ = stack[8 * h + 1], ec_ = stack[8 * h + 2];
+                Best B;
+                B.mx = __int_as_float(stack[8 * h + 4]); B.mx2 = __int_as_float(stack[8 * h + 5]); B.key = stack[8 * h + 6]; B.key2 = stack[8 * h + 7];
+                const int sa = ea_ & 0xffff, ea = ea_ >> 16, sb = eb_ & 0xffff, eb = eb_ >> 16;
+                const int fcode = (ec_ >> 16) & 3, bcode = (ec_ >> 18) & 3;
+                const int mid = ((ea - sa) / 2) + sa;
+                int meet = -1, tr = -1;
+                if (B.key != 0x7fffffff) { const int ord = B.key & 7; meet = sb + (B.key >> 3); tr = ord + 1 + (ord >= 3 ? 1 : 0); }
+                if (top && lane == 0) { S.ctl->top_meet = (meet >= 0) ? X.b0 + meet : -1; S.ctl->top_tr = tr; S.ctl->top_score = B.mx; }
+                top = false;
+                const bool has2 = B.mx2 > -KA_F;
+                const float margin = B.mx - B.mx2;
+                // (the trial's state: read by every lane before lane 0 changes it -- one wave, LDS in program order)
+                const float thr = S.rf.thr;
+                const int trial = S.rf.trial, stride = S.rf.stride, counter = S.rf.counter, mcount = S.rf.mcount;
+                const float msum = S.rf.msum;
+                const bool uncertain = thr > 0.0f && B.key2 != 0x7fffffff && has2 && margin < thr;     // aln_seqseq.c:376-414
+                if (uncertain && trial > 0 && counter % stride == trial - 1) {
+                        const int ord2 = B.key2 & 7;
+                        meet = sb + (B.key2 >> 3);
+                        tr = ord2 + 1 + (ord2 >= 3 ? 1 : 0);
+                }
+                if (lane == 0) {
+                        if (has2) {
+                                if (S.mlog && mcount < S.mlog_cap) S.mlog[mcount] = margin;           // aln_seqseq.c:378-380
+                                S.rf.msum = msum + margin; S.rf.mcount = mcount + 1;
+                        }
+                        if (uncertain) S.rf.counter = counter + 1;
+                }
+                // aln_continue (aln_controller.c:194-436): path entries and the two child windows
+                int c1sa = sa, c1ea = sa, c1sb = sb, c1eb = sb, c1bc = 1;
+                int c2sa = ea, c2ea = ea, c2sb = eb, c2eb = eb, c2fc = 1;
+                if (tr > 0) {
+                        int* path = S.raw;
+                        const int am = X.a0 + mid, bm = X.b0 + meet;
+                        const bool w = (lane == 0);
+                        switch (tr) {
+                        case 1:
+                                if (w) { path[am] = bm; path[am + 1] = bm + 1; }
+                                c1ea = mid - 1; c1eb = meet - 1; c1bc = 1;
+                                c2sa = mid + 1; c2sb = meet + 1; c2fc = 1;
+                                break;
+                        case 2:
+                                if (w) path[am] = bm;
+                                c1ea = mid - 1; c1eb = meet - 1; c1bc = 1;
+                                c2sa = mid; c2sb = meet + 1; c2fc = 2;
+                                break;
+                        case 3:
+                                if (w) path[am] = bm;
+                                c1ea = mid - 1; c1eb = meet - 1; c1bc = 1;
+                                c2sa = mid + 1; c2sb = meet; c2fc = 3;
+                                break;
+                        case 5:
+                                if (w) path[am + 1] = bm + 1;
+                                c1ea = mid; c1eb = meet - 1; c1bc = 2;
+                                c2sa = mid + 1; c2sb = meet + 1; c2fc = 1;
+                                break;
+                        case 6:
+                                c1ea = mid - 1; c1eb = meet; c1bc = 3;
+                                c2sa = mid + 1; c2sb = meet; c2fc = 3;
+                                break;
+                        default: /* 7 */
+                                if (w) path[am + 1] = bm + 1;
+                                c1ea = mid - 1; c1eb = meet; c1bc = 3;
+                                c2sa = mid + 1; c2sb = meet + 1; c2fc = 1;
+                                break;
+                        }
+                }
+                const bool v1 = (tr > 0) && c1sa < c1ea && c1sb < c1eb;
+                const bool v2 = (tr > 0) && c2sa < c2ea && c2sb < c2eb;
+                const int n = (v1 ? 1 : 0) + (v2 ? 1 : 0);
+                if (n == 0) { ka_wave_lds_sync(); continue; }
+                if (lane == 0) {
+                        int slot = 0, row = 0;
+                        if (v1) { fly[0] = c1sa | (c1ea << 16); fly[1] = c1sb | (c1eb << 16); fly[2] = row | (fcode << 16) | (c1bc << 18); slot = 1; row = c1eb - c1sb + 1; }
+                        if (v2) { fly[3 * slot] = c2sa | (c2ea << 16); fly[3 * slot + 1] = c2sb | (c2eb << 16); fly[3 * slot + 2] = row | (c2fc << 16) | (bcode << 18); }
+                }
+                ka_wave_lds_sync();
+                // ---- the passes of the children ----
+                {
+                        const int r1 = v1 ? (c1ea - c1sa) : 0, r2 = v2 ? (c2ea - c2sa) : 0;
+                        const int maxrows = max(r1 - r1 / 2, r2 - r2 / 2);
+                        int sshift = 0;
+                        while ((1 << sshift) < maxrows) ++sshift;
+                        const int npass = 2 * n;
+                        for (int p0 = 0; p0 < npass; p0 += 64 >> sshift) ka_sub_pass<KIND, NRES>(X, fly, npass, p0, sshift, lane, tss);
+                }
+                ka_wave_lds_sync();
+                // ---- their candidates, 32 lanes per child ----
+                {
+                        const int gidx = lane >> 5, gl = lane & 31;
+                        const bool valid = gidx < n;
+                        const KaSubL e = ka_subl_load(fly, valid ? gidx : 0);
+                        const int csa = e.a & 0xffff, cea = e.a >> 16, csb = e.b & 0xffff, ceb = e.b >> 16;
+                        const int roff = e.c & 0xffff;
+                        const int startb = X.b0 + csb, endb = X.b0 + ceb;
+                        const int cmid = ((cea - csa) / 2) + csa;
+                        const ka_lf* f = X.F + 3 * roff;
+                        const ka_lf* b = X.B + 3 * roff;
+                        const float middle = (float)(endb - startb) / 2.0f + (float)startb;
+                        float g3, g7, g6n, g6f;
+                        if (KIND == KA_SS) {
+                                g3 = -X.gpo; g7 = -X.gpo;
+                                g6n = (startb == 0) ? -X.tgpe : -X.gpe;
+                                g6f = (endb == X.Lb) ? -X.tgpe : -X.gpe;
+                        } else {
+                                const ka_lf* Rr = X.rowsL + (cmid + 1) * RW + G0;
+                                g3 = Rr[0]; g7 = Rr[-RW];
+                                g6n = (startb == 0) ? Rr[2] : Rr[1];
+                                g6f = (endb == X.Lb) ? Rr[2] : Rr[1];
+                        }
+                        Best Bt = { -KA_F, -KA_F, 0x7fffffff, 0x7fffffff };
+                        for (int i = csb + gl; valid && i <= ceb; i += 32) {
+                                const int x = i - csb;
+                                const float fa = f[3 * x], fga = f[3 * x + 1], fgb = f[3 * x + 2];
+                                const float ba = b[3 * x], bga = b[3 * x + 1], bgb = b[3 * x + 2];
+                                float sub = fabsf(middle - (float)(X.b0 + i));
+                                sub = sub / 1000.0f;
+                                const int kb = x * 8;
+                                if (i < ceb) {
+                                        float c2, c5;
+                                        if (KIND == KA_PP) { c2 = X.colsL[(i + 1) * RW + G0]; c5 = X.colsL[i * RW + G0]; }
+                                        else { c2 = X.kc_open; c5 = X.kc_open; }
+                                        best_consider(Bt, fa + ba - sub, kb + 0);
+                                        best_consider(Bt, fa + bga + c2 - sub, kb + 1);
+                                        best_consider(Bt, fa + bgb + g3 - sub, kb + 2);
+                                        best_consider(Bt, fga + ba + c5 - sub, kb + 3);
+                                        best_consider(Bt, fgb + bgb + g6n - sub, kb + 4);
+                                        best_consider(Bt, fgb + ba + g7 - sub, kb + 5);
+                                } else {
+                                        best_consider(Bt, fa + bgb + g3 - sub, kb + 2);
+                                        best_consider(Bt, fgb + bgb + g6f - sub, kb + 4);
+                                }
+                        }
+                        // reduction towards the last lane of each 32-lane group, runner-up key included
+#define KA_BEST2_STEP(ctrl_, rmask_)                                                                                          \
+                        {                                                                                                     \
+                                const float omx = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-KA_F), __float_as_int(Bt.mx), ctrl_, rmask_, 0xf, false));   \
+                                const float omx2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-KA_F), __float_as_int(Bt.mx2), ctrl_, rmask_, 0xf, false)); \
+                                const int okey = __builtin_amdgcn_update_dpp(0x7fffffff, Bt.key, ctrl_, rmask_, 0xf, false);   \
+                                const int okey2 = __builtin_amdgcn_update_dpp(0x7fffffff, Bt.key2, ctrl_, rmask_, 0xf, false); \
+                                best_merge(Bt, omx, omx2, okey, okey2);                                                       \
+                        }
+                        KA_BEST2_STEP(0x111, 0xf)
+                        KA_BEST2_STEP(0x112, 0xf)
+                        KA_BEST2_STEP(0x114, 0xf)
+                        KA_BEST2_STEP(0x118, 0xf)
+                        KA_BEST2_STEP(0x142, 0xa)                     // row_bcast:15 into rows 1 and 3: lanes 31 and 63 hold their group's answer
+#undef KA_BEST2_STEP
+                        // the child the recursion enters first (index 0) ends on top of the stack
+                        if (gl == 31 && valid) {
+                                const int pos = h + (n - 1 - gidx);
+                                stack[8 * pos] = e.a; stack[8 * pos + 1] = e.b; stack[8 * pos + 2] = e.c;
+                                stack[8 * pos + 4] = __float_as_int(Bt.mx); stack[8 * pos + 5] = __float_as_int(Bt.mx2);
+                                stack[8 * pos + 6] = Bt.key; stack[8 * pos + 7] = Bt.key2;
+                        }
+                }
+                h += n;
+                ka_wave_lds_sync();
+        }
 }

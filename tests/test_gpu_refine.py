@@ -128,6 +128,32 @@ def test_serial_trials_give_the_same_answer(ctx, name, monkeypatch):
     assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
 
 
+@pytest.mark.parametrize("switches", [{"KA_NO_INC": "1"}, {"KA_NO_LDFS": "1"}, {"KA_NO_INC": "1", "KA_NO_LDFS": "1"},
+                                      {"KA_NO_WDFS": "1"}, {"KA_NO_LS0": "1"}, {"KA_NO_INC": "1", "KA_REFINE_SERIAL": "1"},
+                                      {"KA_REFINE_SERIAL": "1"}])
+@pytest.mark.parametrize("name", refine_cases())
+def test_every_schedule_of_the_flip_trials_gives_the_reference_answer(name, switches, monkeypatch):
+    """the flip trials have four engines stacked on each other -- the incremental walk over the baseline's uncertain
+    meetups (re-running only the subtrees it flips), the depth-first recursion across the workgroup, its wave-local
+    subtrees with operands in HBM, and the same with everything in LDS -- and the baseline two (level-synchronous with
+    sorted margins, depth first): every golden again with each layer switched off in turn"""
+    import kalign_amd
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    ctx = kalign_amd.Context(0)                        # (reads the environment)
+    try:
+        g = Golden(name)
+        recs, paths, gaps = run_refine(ctx, g, first_pass=False)
+        for t, r in enumerate(recs):
+            want = g.paths[int(g.path_off[t]):int(g.path_off[t]) + r.plen + 2]
+            assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], want), (name, t, switches)
+        for got, want in zip(gaps, g.gaps_list()):
+            assert np.array_equal(got, want), (name, switches)
+        assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after), (name, switches)
+    finally:
+        ctx.close()
+
+
 def test_big_tree_parallel_and_serial_trials_agree(ctx, monkeypatch):
     """512 x 300: the lower levels have more edges than CUs (one workgroup per edge), the upper ones run their trials in
     parallel; forcing everything serial must not change a single gap"""
