@@ -216,13 +216,27 @@ def sharded_consistency(ex, n_anchors, weight, rank, world):
     table never visits the host).  ex: kalign_amd.Context after tree_upload, or anything with cons_build_part(part,
     nparts), cons_table() -> 1-D int32 torch tensor aliasing the table, cons_part_range(part, nparts)."""
     import torch.distributed as dist
-    ex.cons_build_part(n_anchors, weight, rank, world)
     if world == 1:
+        ex.cons_build_part(n_anchors, weight, rank, world)
         return
+    # a part can fail on ONE rank (e.g. a share that holds only anchors): every rank must learn of it before anybody
+    # enters a broadcast the failed rank never joins
+    import torch
+    err = None
+    try:
+        ex.cons_build_part(n_anchors, weight, rank, world)
+    except Exception as e:                                        # noqa: BLE001 -- re-raised below, on every rank
+        err = e
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    bad = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+    if int(bad.item()):
+        if err is not None:
+            raise err
+        raise RuntimeError("sharded consistency: the part of another rank could not be built")
     table = ex.cons_table()
     if table is None:                                             # the job declined (no distances / fewer than 3 sequences)
         return
-    import torch
     # RCCL moves the ranges HBM to HBM in place.  Any other backend (gloo: the one-GPU tests) goes through host tensors:
     # gloo would write into the device table from the CPU side, past the GPU's caches.
     direct = (not table.is_cuda) or dist.get_backend() == "nccl"

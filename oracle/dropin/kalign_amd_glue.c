@@ -69,6 +69,29 @@ static void glue_report(void)
 static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
 static const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
 static int glue_job_numseq = 0;
+static uint64_t glue_job_stamp = 0;            /* FNV-1a over the lengths and gap arrays the device job left in that msa */
+
+/* The device job is recognised by more than the msa's address: an msa freed without finalise_alignment leaves a stale
+   pointer that a later allocation can reuse, and the host may edit gaps[] between the seams.  The stamp covers what the
+   device state stands for -- every sequence's length and gaps[] as glue_collect wrote them. */
+static uint64_t glue_stamp(const struct msa* msa)
+{
+        uint64_t h = 1469598103934665603ULL;
+        int i, j;
+        for(i = 0; i < msa->numseq; i++){
+                const struct msa_seq* s = msa->sequences[i];
+                h = (h ^ (uint64_t)(uint32_t)s->len) * 1099511628211ULL;
+                for(j = 0; j <= s->len; j++){
+                        h = (h ^ (uint64_t)(uint32_t)s->gaps[j]) * 1099511628211ULL;
+                }
+        }
+        return h;
+}
+
+static int glue_same_job(const struct msa* msa)
+{
+        return msa == glue_job_msa && msa->numseq == glue_job_numseq && glue_stamp(msa) == glue_job_stamp;
+}
 
 static int glue_context(void)
 {
@@ -302,6 +325,7 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         glue_counts[inline_refine ? GLUE_INLINE : GLUE_TREE]++;
         glue_job_msa = msa;
         glue_job_numseq = n;
+        glue_job_stamp = glue_stamp(msa);
         MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
         return OK;
 ERROR:
@@ -394,7 +418,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         if(refine_mode == 0){                            /* KALIGN_REFINE_NONE */
                 return OK;
         }
-        if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx || (refine_mode != 1 && refine_mode != 2)){
+        if(!glue_same_job(msa) || !glue_ctx || (refine_mode != 1 && refine_mode != 2)){
                 glue_job_msa = NULL;                     /* the host state moves on without the device */
                 glue_counts[GLUE_REFINE_REF]++;
                 return kalign_ref_refine_alignment(msa, ap, t, refine_mode);
@@ -409,10 +433,12 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         RUN(glue_collect(msa, t, lens, total));
+        glue_job_stamp = glue_stamp(msa);                /* the refined gaps are what the device holds now */
         glue_counts[GLUE_REFINE]++;
         MFREE(lens);
         return OK;
 ERROR:
+        glue_job_msa = NULL;                             /* (whatever the device holds is no longer this msa's state) */
         if(lens) MFREE(lens);
         return FAIL;
 }
@@ -624,7 +650,7 @@ int finalise_alignment(struct msa* msa)
         long long o = 0;
         int width = 0;
         int i;
-        if(msa != glue_job_msa || n != glue_job_numseq || !glue_ctx){
+        if(!glue_same_job(msa) || !glue_ctx){
                 glue_counts[GLUE_FINALISE_REF]++;
                 glue_rows_msa = NULL;
                 return kalign_ref_finalise_alignment(msa);
