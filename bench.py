@@ -745,6 +745,21 @@ def multi_gpu_main(args, rank, world, local_rank):
         dist.barrier()
         torch.cuda.synchronize()
 
+    # the first step of the C layer is guarded: a rank on which it fails says so, and ALL ranks continue on the
+    # torch.distributed path (an error, not a hang: every RCCL call of the layer is matched rank by rank in one global order)
+    if cd is not None:
+        failed = 0.0
+        try:
+            step()
+        except Exception as e:                                     # pragma: no cover
+            sys.stderr.write("rank %d: C multi-GPU layer failed in its first step (%s): torch.distributed path\n" % (rank, e))
+            failed = 1.0
+        if kd.reduce_scalar(failed, "sum", device=coll_dev) > 0.5:
+            try:
+                cd.close()
+            except Exception:                                      # pragma: no cover
+                pass
+            cd, dist_layer = None, "python (kalign_amd/dist.py over torch.distributed; the C layer failed in its first step)"
     for _ in range(max(args.warmup, 1)):
         recs, paths = step()
     barrier()
