@@ -87,6 +87,9 @@ struct KaTreeDev {
         int lean4;                     // leaf levels (seq-seq tasks only) on 4-wave workgroups, four per CU (KA_LEAN4)
         int q1_mode;                   // 64-row strips (one DP row per lane): 0 never, 1 for tasks whose cluster has a SIMD per top-level strip,
                                        // 2 also at two strips per SIMD, 3 always (experiments; KA_Q1 in the environment)
+        int ho_mode;                   // neighbouring strips of a pass hand over through LDS rings (ka_strip<.., HO>): 0 off, 1 on,
+                                       // 2 on with four strips per workgroup (KA_HO in the environment)
+        int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
         int cons_K;                    // anchors
         int cons_maxlen;               // longest sequence: bounds every anchor position
         float cons_paw;                // weight / (float)K  (per_anchor_weight, anchor_consistency.c:487)

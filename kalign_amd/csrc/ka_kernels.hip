@@ -123,6 +123,7 @@ struct TaskShared {
         int sub_tm;                    // KA_FLAG_TIMING, the profiled task: subtree phase times are accumulated in sub_t
         unsigned long long sub_t[7];   //   subtrees, staging / pass / meetup / total cycles (sums over the workgroup's subtrees), longest one, sum of level*1e6 + R*1e3 + C
         int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
+        int ho_ok;                     // neighbouring strips of this task hand over through LDS rings (ka_strip<.., HO>; KaTreeDev::ho_mode, profile-profile tasks of the 8-wave kernel)
         // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
         // over the workgroups, agent-scope hand-over, two cluster barriers per level).  As soon as a level has at least
         // G sub-problems (or single-strip passes) the cluster SPLITS: every workgroup takes its share of the
@@ -577,7 +578,8 @@ __device__ void ka_cluster_sync(TaskShared& S)
 
 // The passes of one recursion level: its work items (strips, packed jobs) dealt to / pulled by the waves of the team.
 // Q1: the kernel also carries the one-row-per-lane strip (TaskShared::srows == 64 selects it per task)
-template <int KIND, int NRES, int NB, bool Q1 = false>
+// HO: strips dealt to neighbouring waves of a workgroup hand over through LDS rings (ka_strip<.., HO>; TaskShared::ho_ok)
+template <int KIND, int NRES, int NB, bool Q1 = false, bool HO = false>
 __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cur, const int level, const KaSub* qc, char* lds_waves,
                                              const float* tss, long long* pslot)
 {
@@ -669,14 +671,23 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const bool st_me = it < nstatic;
                                 const bool prod_local = k > 0 && st_me && (it - 1) / per == member_w;
                                 const bool cons_local = k + 1 < ns && st_me && it + 1 < nstatic && (it + 1) / per == member_w;
+                                // LDS hand-over: only on levels where every wave has at most ONE item (nothing is pulled after a strip, so
+                                // a producer's LDS region stays as it is until the level's barrier); the neighbour strip runs on the
+                                // neighbour wave by the static dealing above (item it +- 1 <-> wave +- 1 of this workgroup)
+                                const bool ho_lvl = HO && ntotal <= nslots && __builtin_amdgcn_readfirstlane(S.ho_ok) != 0;
+                                const bool in_lds = ho_lvl && prod_local && wave > 0;
+                                const bool out_lds = ho_lvl && cons_local && wave + 1 < KA_NW;
+                                int* const ho_ctl_w = (int*)(lds_waves - KA_LDS_HO_BACK) + wave;
                                 if (Q1 && srows == KA_STRIP1_ROWS)
-                                        ka_strip<KIND, NRES, NB, 1>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                        ka_strip<KIND, NRES, NB, 1, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                              (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
-                                                             lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
+                                                             lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
+                                                             in_lds, out_lds, ho_ctl_w);
                                 else
-                                        ka_strip<KIND, NRES, NB, 2>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                        ka_strip<KIND, NRES, NB, 2, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                              (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
-                                                             lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot);
+                                                             lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
+                                                             in_lds, out_lds, ho_ctl_w);
                         }
         }
 }
@@ -685,7 +696,7 @@ __device__ const int ka_pow3[20] = { 1, 3, 9, 27, 81, 243, 729, 2187, 6561, 1968
                                      43046721, 129140163, 387420489, 1162261467 };
 #define KA_REC_DEPTH 19                                              // recursion levels the keys of ka_meetup<.., REC> can tell apart
 
-template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false>
+template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false, bool HO = false>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
@@ -693,6 +704,18 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         const int wave = tid >> 6;
         const int g = max(S.La, S.Lb) + 2;
         const bool lead = (S.member == 0);
+        // HO: every wave zeroes the tags of its hand-over ring and its consumed-columns word while no strip runs (before the
+        // first level and at the start of every meetup phase); the barrier that follows orders it before the next strips
+        auto ho_clear = [&]() {
+                if (HO && S.ho_ok) {
+                        float4v* r = (float4v*)(lds_waves + wave * KA_WAVE_LDS + KA_HO_RING);
+                        const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int i = 0; i < KA_HO_SLOTS / 64; ++i) r[lane + 64 * i] = z;
+                        if (lane == 0) ((int*)(lds_waves - KA_LDS_HO_BACK))[wave] = 0;
+                }
+        };
+        ho_clear();
         if (lead) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
         if (tid == 0) { S.lctl = S.ctl; S.Gw = S.G; S.member_w = S.member; S.split = 0; }
         if (lead && tid == 0) {
@@ -770,13 +793,14 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 const long long tp0 = __builtin_amdgcn_s_memtime();
                 long long* pslot = nullptr;
 #ifdef KA_PROF
-                if (S.prof && lead && level < 8) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; } }
+                if (S.prof && lead && level < 4) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; pslot[6] = 0; pslot[7] = 0; if (level < 4) for (int x = 0; x < 8; ++x) pslot[256 + x] = 0; } }
 #endif
-                ka_run_items<KIND, NRES, NB, Q1>(S, cur, level, qc, lds_waves, tss, pslot);
+                ka_run_items<KIND, NRES, NB, Q1, HO>(S, cur, level, qc, lds_waves, tss, pslot);
 #ifdef KA_PROF
                 if (pslot && lane == 0) pslot[3] = __builtin_amdgcn_s_memtime();
 #endif
                 ka_cluster_sync(S);
+                ho_clear();
 #ifdef KA_PROF
                 if (pslot && lane == 0) pslot[4] = __builtin_amdgcn_s_memtime();
 #endif
@@ -2010,6 +2034,7 @@ __device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskD
 #define KA_LDS_DBG 1400
 #define KA_LDS_TSS 1408
 #define KA_LDS_WAVES 4096                                           // per-wave regions: 2048-B aligned (ring addressing ORs the column offset in)
+static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES - KA_LDS_HO_BACK, "score table overlaps the hand-over control words");
 static_assert(KA_LDS_TSS + 23 * KA_T_STRIDE * 4 <= KA_LDS_WAVES, "score table overlaps the wave regions");
 #define KA_LDS_TOTAL (KA_LDS_WAVES + KA_WAVES * KA_WAVE_LDS)
 #define KA_HALF_BLOCK 256
@@ -2233,6 +2258,18 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         const int g1 = (s1 + 3) / 4;
                         if (g1 <= g_launch || (D.q1_mode >= 2 && (s1 + 7) / 8 <= g_launch) || D.q1_mode >= 3) { srows = KA_STRIP1_ROWS; g_eff = g1; }
                 }
+                // LDS hand-over between neighbouring strips (ka_strip<.., HO>): profile-profile tasks of the 8-wave kernel, fast mode.
+                // ho_mode >= 2: four strips per workgroup (one per SIMD) instead of three -- fewer hand-overs cross workgroups.
+                S.ho_ok = (Q1 && NB == 0 && D.ho_mode && kind == KA_PP) ? 1 : 0;
+                if (S.ho_ok && D.ho_mode >= 2) {
+                        const int s2 = ka_strips_of(S.La / 2, srows) + ka_strips_of(S.La - S.La / 2, srows);
+                        g_eff = max((s2 + 3) / 4, 1);
+                }
+                // experiments (KA_PER): strips per workgroup at the task's top level -> workgroups used
+                if (Q1 && D.per_target > 0 && kind == KA_PP) {
+                        const int s2 = ka_strips_of(S.La / 2, srows) + ka_strips_of(S.La - S.La / 2, srows);
+                        g_eff = max((s2 + D.per_target - 1) / D.per_target, 1);
+                }
                 if (g_eff > g_launch) g_eff = g_launch;
                 S.srows = srows;
                 // wave-local subtrees (ka_subtree.h): every kernel shape has a region per wave behind the workgroup's scratch
@@ -2297,11 +2334,11 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         // P2
         if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1, Q1 && NB == 0>(S, s_dbg, lds_waves, tss, D.trace);
         // no B / Z / X in the job (the usual case): every profile's counts [20..22] are zero and the reference skips
         // zero counts (aln_profileprofile.c:70-77) -- 20 terms per cell instead of 23
-        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
-        else ka_hirschberg<KA_PP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1, Q1 && NB == 0>(S, s_dbg, lds_waves, tss, D.trace);
+        else ka_hirschberg<KA_PP, 23, NB, false, Q1, Q1 && NB == 0>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         // exact confidence: the cluster's last barrier (inside ka_hirschberg) has published every member's records
         bool conf_exact = false;

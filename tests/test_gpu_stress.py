@@ -1,6 +1,6 @@
 """Schedule stress: every tree / consistency golden of the real reference again and again under randomised launch plans
 -- cluster sizes, with and without the queued launch, the chained launch, the half kernel, the 4-wave leaf kernel, the
-wave-local subtrees, the multi-wave meetup scan, 64-row strips -- and the answer must be the reference's bit for bit
+wave-local subtrees, the multi-wave meetup scan, 64-row strips, the LDS hand-over between strips -- and the answer must be the reference's bit for bit
 every time (paths, meetups, scores, top-level f / b rows, gap arrays).  What varies is only WHO computes WHEN: a missing
 barrier or an LDS region reused too early shows up here as a run that differs (round 2's multi-wave meetup experiment
 failed one golden deterministically; this is the net that was missing).  KA_STRESS_REPS raises the repetitions."""
@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 EXACT = ["plen", "kind", "swapped", "meet", "transition", "score", "fhash", "bhash"]
 SWITCHES = {"KA_MAX_CLUSTER": ["1", "2", "4", "8", "16", None], "KA_NO_HALF": ["1", None], "KA_NO_QUEUE": ["1", None],
             "KA_NO_CHAIN": ["1", None, None], "KA_NO_LEAN": ["1", None, None], "KA_LEAN4": ["0", None], "KA_SUBTREE": ["0", None, None],
-            "KA_MW": ["0", None, None], "KA_Q1": ["1", "2", "3", None], "KA_CHAIN_G1": ["1", None], "KA_NO_CRIT": ["1", None]}
+            "KA_MW": ["0", None, None], "KA_Q1": ["1", "2", "3", None], "KA_CHAIN_G1": ["1", None], "KA_NO_CRIT": ["1", None],
+            "KA_HO": ["0", "1", "2", None]}
 
 
 @pytest.mark.parametrize("name", tree_cases() + cons_cases())

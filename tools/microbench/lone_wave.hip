@@ -68,6 +68,28 @@ KERNEL(k_salu20, asm volatile(".rept 20\n s_add_u32 s20, s20, 1\n .endr" ::: "s2
 // 14: v_pk_mul (independent) x20
 KERNEL(k_pkmul20, asm volatile(".rept 10\n v_pk_mul_f32 %0, %2, %3\n v_pk_mul_f32 %1, %2, %3\n .endr" : "=v"(p2), "=v"(q2) : "v"(a2), "v"(b2));)
 
+// 15..18: the steady step of ka_strip<KA_PP, 20, 0, 2> as an instruction mix (round 3, second session): wait, 3 v_mul, 2 x (2 v_add + v_max3),
+// 20 x (v_pk_mul, dependent v_pk_add), 3 address VALU + 7 ds_read_b128, 9 DPP wave shifts, 4 x (2 v_add + v_max) -- 80 instructions.
+// Variants leave out the LDS reads / the DPP moves / both: which part of the step costs more than its issue slots?
+#define MIX_HEAD "s_waitcnt lgkmcnt(0)\n v_mul_f32 v60, %3, v45\n v_mul_f32 v61, %3, v46\n v_mul_f32 v62, %3, v47\n" \
+                 "v_add_f32 v63, %0, v60\n v_add_f32 v64, %0, v61\n v_max3_f32 v40, %0, v63, v64\n v_add_f32 v63, %0, v60\n v_add_f32 v64, %0, v61\n v_max3_f32 v41, %0, v63, v64\n"
+#define MIX_CHAIN ".rept 10\n v_pk_mul_f32 v[50:51], %1, v[20:21]\n v_pk_add_f32 v[40:41], v[40:41], v[52:53]\n v_pk_mul_f32 v[52:53], %1, v[24:25]\n v_pk_add_f32 v[40:41], v[40:41], v[50:51]\n .endr\n"
+#define MIX_LDS "v_sub_u32 v65, %4, %4\n v_lshl_add_u32 v65, v65, 4, 16\n v_and_or_b32 v65, v65, 63, %4\n" \
+                "ds_read_b128 v[20:23], v65\n ds_read_b128 v[24:27], v65 offset:2048\n ds_read_b128 v[28:31], v65 offset:4096\n ds_read_b128 v[32:35], v65 offset:6144\n" \
+                "ds_read_b128 v[36:39], v65 offset:8192\n ds_read_b128 v[42:45], v65 offset:10240\n ds_read_b128 v[46:49], v65 offset:12288\n"
+#define MIX_DPP "s_nop 1\n v_mov_b32_dpp v66, v40 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v67, v41 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v68, v60 wave_shr:1 row_mask:0xf bank_mask:0xf\n" \
+                "v_mov_b32_dpp v69, v61 wave_rol:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp v70, v62 wave_rol:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp v71, v63 wave_rol:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+                "v_mov_b32_dpp v72, v40 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v73, v41 wave_shl:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp v74, v64 wave_shl:1 row_mask:0xf bank_mask:0xf\n"
+#define MIX_GAP ".rept 4\n v_add_f32 v63, %0, v60\n v_add_f32 v64, v40, v61\n v_max_f32 %0, v63, v64\n .endr\n"
+#define MIX_CLOB "v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49", \
+                 "v50","v51","v52","v53","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","memory"
+KERNEL(k_mix_full, asm volatile(MIX_HEAD MIX_CHAIN MIX_LDS MIX_DPP MIX_GAP : "+v"(acc) : "v"(a2), "v"(b2), "v"(x), "v"(addr) : MIX_CLOB);)
+KERNEL(k_mix_nolds, asm volatile(MIX_HEAD MIX_CHAIN MIX_DPP MIX_GAP : "+v"(acc) : "v"(a2), "v"(b2), "v"(x), "v"(addr) : MIX_CLOB);)
+KERNEL(k_mix_nodpp, asm volatile(MIX_HEAD MIX_CHAIN MIX_LDS MIX_GAP : "+v"(acc) : "v"(a2), "v"(b2), "v"(x), "v"(addr) : MIX_CLOB);)
+KERNEL(k_mix_chain, asm volatile(MIX_HEAD MIX_CHAIN MIX_GAP : "+v"(acc) : "v"(a2), "v"(b2), "v"(x), "v"(addr) : MIX_CLOB);)
+// the LDS reads FIRST (right behind the wait), the chain behind them: do returning reads slow the VALU down?
+KERNEL(k_mix_ldsfirst, asm volatile(MIX_HEAD MIX_LDS MIX_CHAIN MIX_DPP MIX_GAP : "+v"(acc) : "v"(a2), "v"(b2), "v"(x), "v"(addr) : MIX_CLOB);)
+
 __global__ void k_clock(long long* cyc)
 {
         const long long w0 = wall_clock64(), t0 = __builtin_amdgcn_s_memtime(), c0 = clock64();
@@ -90,7 +112,10 @@ int main()
                    {"10 v_pk_mul + 20 dependent v_add (one-row dot)", k_q1dot, 30}, {"20 independent v_mul_f32", k_indep20, 20},
                    {"9 v_add + 9 DPP wave_shr + 3 s_nop", k_dpp9, 21}, {"7 ds_read_b128, 40 v_add, wait", k_lds7_40, 48},
                    {"7 ds_read_b128, 15 v_add, wait", k_lds7_15, 23}, {"7 ds_read_b128, wait", k_lds7_0, 9}, {"1 ds_read_b128, wait", k_lds1_0, 3},
-                   {"10 x (v_add, v_max) dependent", k_addmax, 20}, {"20 s_add_u32", k_salu20, 20}, {"20 independent v_pk_mul_f32", k_pkmul20, 20} };
+                   {"10 x (v_add, v_max) dependent", k_addmax, 20}, {"20 independent v_pk_mul_f32", k_pkmul20, 20},
+                   {"step mix: head + chain + 7 LDS + 9 DPP + gap", k_mix_full, 82}, {"step mix without the LDS reads", k_mix_nolds, 72},
+                   {"step mix without the DPP moves", k_mix_nodpp, 72}, {"step mix: head + chain + gap only", k_mix_chain, 62},
+                   {"step mix with the LDS reads ahead of the chain", k_mix_ldsfirst, 82} };
         for (int waves = 1; waves <= 8; waves *= 2) {
                 // waves per workgroup: 1 (lone wave), 2, 4 (one per SIMD), 8 (two per SIMD)
                 printf("---- %d wave(s) in the workgroup ----\n", waves);
