@@ -90,7 +90,7 @@ struct KaEnv {
         int lean4 = 1;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU (1.60 -> 1.28 ms on the 4096 x 400 leaf level)
         int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
         int per = 0;                   // KA_PER: strips per workgroup (KaTreeDev::per_target; experiments)
-        int ho = 0;                    // KA_HO: LDS hand-over between neighbouring strips (KaTreeDev::ho_mode)
+        int ho = -1;                   // KA_HO: hand-over between neighbouring strips through LDS (KaTreeDev::ho_mode); -1: on (1)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
         bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
@@ -108,7 +108,7 @@ static void read_env(KaEnv& v)
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
         v.mw = env_int("KA_MW", 1);
-        v.ho = env_int("KA_HO", 0);
+        v.ho = env_int("KA_HO", -1);
         v.per = env_int("KA_PER", 0);
         v.upgma_launches = getenv("KA_UPGMA_LAUNCHES") != nullptr;
 }
@@ -777,7 +777,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
         D.q1_mode = c->env.q1;
-        D.ho_mode = c->env.ho;
+        D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;

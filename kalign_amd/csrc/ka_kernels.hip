@@ -704,16 +704,10 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         const int wave = tid >> 6;
         const int g = max(S.La, S.Lb) + 2;
         const bool lead = (S.member == 0);
-        // HO: every wave zeroes the tags of its hand-over ring and its consumed-columns word while no strip runs (before the
-        // first level and at the start of every meetup phase); the barrier that follows orders it before the next strips
+        // HO: the waves' hand-over control words (columns written / columns read, ka_strip) go back to zero while no strip runs:
+        // before the first level and at the start of every meetup phase; the barrier that follows orders it before the next strips
         auto ho_clear = [&]() {
-                if (HO && S.ho_ok) {
-                        float4v* r = (float4v*)(lds_waves + wave * KA_WAVE_LDS + KA_HO_RING);
-                        const float4v z = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int i = 0; i < KA_HO_SLOTS / 64; ++i) r[lane + 64 * i] = z;
-                        if (lane == 0) ((int*)(lds_waves - KA_LDS_HO_BACK))[wave] = 0;
-                }
+                if (HO && S.ho_ok && tid < 16) ((int*)(lds_waves - KA_LDS_HO_BACK))[tid] = 0;
         };
         ho_clear();
         if (lead) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
@@ -2261,9 +2255,12 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // LDS hand-over between neighbouring strips (ka_strip<.., HO>): profile-profile tasks of the 8-wave kernel, fast mode.
                 // ho_mode >= 2: four strips per workgroup (one per SIMD) instead of three -- fewer hand-overs cross workgroups.
                 S.ho_ok = (Q1 && NB == 0 && D.ho_mode && kind == KA_PP) ? 1 : 0;
-                if (S.ho_ok && D.ho_mode >= 2) {
+                if (Q1 && kind == KA_PP) {
+                        // Tasks with more top-level strips than the table's workgroups have SIMDs (rows beyond ~4000: nucleotide
+                        // jobs) take a workgroup per four strips, up to what the launch gave them: 4096 x 2000 nt 104 -> 93 ms.
+                        // (ho_mode 2, experiments: four strips per workgroup whatever the table says -- costs protein 7 %.)
                         const int s2 = ka_strips_of(S.La / 2, srows) + ka_strips_of(S.La - S.La / 2, srows);
-                        g_eff = max((s2 + 3) / 4, 1);
+                        g_eff = (S.ho_ok && D.ho_mode >= 2) ? max((s2 + 3) / 4, 1) : max(g_eff, (s2 + 3) / 4);
                 }
                 // experiments (KA_PER): strips per workgroup at the task's top level -> workgroups used
                 if (Q1 && D.per_target > 0 && kind == KA_PP) {

@@ -138,25 +138,24 @@ struct KaBonus {
 // twice the waves.  The profile-profile dot product then packs two RESIDUES per v_pk_mul_f32 (the counts of residues
 // 2i, 2i+1 against the matching half of the column record's float4) and adds the two products one after the other.
 //
-// HO (round 3, second attempt at the event-free hand-over): two strips of one pass that were dealt to NEIGHBOURING waves of one
-// workgroup (wave w-1 -> wave w) hand the boundary row over column by column through a 256-slot ring in the producer's LDS
-// region (KA_HO_RING) instead of 64-column batches through the HBM row buffer:
-//   * producer (OUT): the owner of its last row (lane 63 of a full strip) stores (a, ga, gb, column + 1) of every column it
-//     finishes -- the column number is the slot's validity tag; slots are zeroed between the levels (ka_hirschberg), so a
-//     tag can only be this pass's;
-//   * consumer (IN): reads ONE slot per step, a step ahead (same untracked ds_read_b128 + the step's one s_waitcnt as the
-//     column ring), and compares the tag with the column it expects: one v_readfirstlane + one scalar branch per step; a
-//     mismatch (the producer is not there yet) spins on the slot.  It starts KA_HO_SLACK columns behind the earliest
-//     possible step so that it does not ride the producer's edge;
-//   * flow control: every 32 steps the consumer publishes the columns it has consumed (ho_ctl word of its wave), the
-//     producer makes sure the next 32 columns do not overwrite unread slots -- in steady state from a cached value.
-// No fences, no HBM traffic, no 64-step events on either side; a strip starts 63 + KA_HO_SLACK columns behind the one
-// above instead of 63 + 64.  Only for levels whose items are all dealt statically (one item per wave: the region of a
-// producer stays untouched until the level's barrier).
+// HO (round 3): two strips of one pass that were dealt to NEIGHBOURING waves of one workgroup (wave w-1 -> wave w) hand the
+// boundary row over through LDS instead of the HBM row buffer -- the same 64-column batches at the same steps, but a batch
+// is three ds_write / ds_read and a progress word in LDS instead of global stores behind a release fence (which waits
+// for the stores to be acknowledged: ~1700 cycles per event in a strip that waits for nobody, ~2900 in one that does,
+// three events per 64 steps; profiles/r03b_strip_phases.log) and global loads behind a flag in HBM.  The step itself is
+// the same code either way: the choice is a wave-uniform branch inside the event steps.
+//   * producer: its 256-slot ring (16 B per column) sits in its own LDS region behind the column ring (KA_HO_RING); after the
+//     batch it raises `columns written` in its control word;
+//   * consumer: waits for that word, reads its 64 columns, then raises `columns read` in ITS control word -- the producer
+//     checks it before it re-uses a slot (256 columns later; never waits in practice);
+//   * the words and nothing else are reset between the levels (ka_hirschberg), while no strip runs.
+// Only for levels whose items are all dealt statically (one item per wave: a producer's LDS region stays untouched
+// until the level's barrier).  (A first version handed over column by column behind a tag per slot -- no batches, a strip
+// started 63 + 4 instead of 63 + 64 columns behind the one above -- and cost 16 instructions per step on the two sides:
+// 13 % fewer steps at 17 % more per step on the root task, profiles/r03b_variants_ho_per_column.log.)
 #define KA_HO_RING KA_RING_BYTES                                // 256 slots x 16 B behind the column ring: [14336, 18432) of the wave's region
 #define KA_HO_SLOTS 256
-#define KA_HO_SLACK 4
-#define KA_LDS_HO_BACK 64                                       // the waves' consumed-columns words: 8 ints, this many bytes below the wave regions
+#define KA_LDS_HO_BACK 64                                       // control words, this many bytes below the wave regions: [wave] columns written, [8 + wave] columns read
 static_assert(KA_HO_RING + KA_HO_SLOTS * 16 <= KA_WAVE_LDS, "hand-over ring outgrew the wave's LDS region");
 
 template <int KIND, int NRES, int NB, int Q = 2, bool HO = false>
@@ -382,25 +381,9 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                              : "memory");
         };
 
-        // ---- HO: the LDS hand-over ring (see the head of ka_strip) ----
-        float4v bq[2];                                                // boundary state of this step's / the next step's column (the same in every lane)
-        int cp_seen = 0;                                              // producer: what the consumer had consumed when last looked at
-        const unsigned ho_out_u = wlds_u + KA_HO_RING;                // my ring (I produce)
-        const unsigned ho_in_u = wlds_u - KA_WAVE_LDS + KA_HO_RING;   // the ring of the wave before me (I consume)
-        const unsigned ho_my_u = (unsigned)(unsigned long long)ho_ctl_w;        // columns I have consumed; the word after it: my consumer's
-        auto ring_wait_b = [&](float4v* qq, float4v& b) {
-                if (NRES <= 8) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]), "+v"(b) : : "memory");
-                        return;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]), "+v"(b)
-                             :
-                             : "memory");
-        };
-        // KA_RING_EARLY: the next step's column record (and boundary slot) is requested at the TOP of a step, before this step's
-        // record is waited for -- LDS returns in order, so `s_waitcnt lgkmcnt(<reads just issued>)` is exactly "this step's
-        // record has landed" and the fresh reads have the whole step to arrive instead of its last ~20 instructions.
+        // KA_RING_EARLY (experiment, off: slower): the next step's column record is requested at the TOP of a step, before this
+        // step's record is waited for -- LDS returns in order, so `s_waitcnt lgkmcnt(<reads just issued>)` is exactly "this
+        // step's record has landed".
         auto ring_read_early = [&](float4v* dstq, int vcol) {
                 const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
                 if (NRES <= 8) {
@@ -424,55 +407,33 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                              : "v"(a)
                              : "memory");
         };
-        auto bnd_read_early = [&](float4v& dst, const int c) {
-                const unsigned a = ho_in_u + (((unsigned)c & (KA_HO_SLOTS - 1)) << 4);
-                asm volatile("ds_read_b128 %0, %1" : "=&v"(dst) : "v"(a) : "memory");
-        };
-        // wait until at most N LDS reads are outstanding (N = the reads issued after this step's own); B: the boundary slot too
 #define KA_RING_WAIT_N(N_)                                                                                                          \
         do {                                                                                                                        \
-                if (NRES <= 8) {                                                                                                    \
-                        if (wb) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]), "+v"(*wb) : : "memory"); \
-                        else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");          \
-                } else {                                                                                                            \
-                        if (wb) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]), "+v"(*wb) : : "memory"); \
-                        else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory"); \
-                }                                                                                                                   \
+                if (NRES <= 8) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");          \
+                else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory"); \
         } while (0)
-        auto ring_wait_n = [&](float4v* qq, float4v* wb, auto n_tag) {
+        auto ring_wait_n = [&](float4v* qq, auto n_tag) {
                 constexpr int N = decltype(n_tag)::value;
-                static_assert(N == 4 || N == 5 || N == 7 || N == 8, "outstanding-read count");
-                if (N == 4) KA_RING_WAIT_N(4); else if (N == 5) KA_RING_WAIT_N(5); else if (N == 7) KA_RING_WAIT_N(7); else KA_RING_WAIT_N(8);
+                static_assert(N == 4 || N == 7, "outstanding-read count");
+                if (N == 4) KA_RING_WAIT_N(4); else KA_RING_WAIT_N(7);
         };
 #undef KA_RING_WAIT_N
-        auto bnd_read = [&](float4v& dst, const int c, auto& dep) {
-                const unsigned a = ho_in_u + (((unsigned)c & (KA_HO_SLOTS - 1)) << 4);
-                asm volatile("ds_read_b128 %0, %2" : "=&v"(dst), "+v"(dep) : "v"(a) : "memory");
-        };
-        // the slot of column c, read until its tag says so (bounded: a stuck producer surfaces as error 5)
-        auto bnd_fetch = [&](const int c) -> float4v {
-                const unsigned a = ho_in_u + (((unsigned)c & (KA_HO_SLOTS - 1)) << 4);
-                float4v x;
-                int spins = 0;
-                while (true) {
-                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(a) : "memory");
-                        if (__builtin_amdgcn_readfirstlane(__float_as_int(x.w)) == c + 1) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
-                }
-                return x;
-        };
-        auto ho_write = [&](const int c, const float a_, const float ga_, const float gb_) {
-                const unsigned ad = ho_out_u + (((unsigned)c & (KA_HO_SLOTS - 1)) << 4);
-                const int tag = c + 1;
-                // (a, ga) first, (gb, tag) second: LDS executes one wave's instructions in order, a reader that sees the tag sees the rest
-                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3"
-                             : : "v"(ad), "v"(a_), "v"(ga_), "v"(gb_), "v"(tag) : "memory");
-        };
+
+        // ---- HO: batches through LDS (see the head of ka_strip) ----
+        const unsigned ho_out_u = wlds_u + KA_HO_RING;                // my ring (I produce)
+        const unsigned ho_in_u = wlds_u - KA_WAVE_LDS + KA_HO_RING;   // the ring of the wave before me (I consume)
+        const unsigned ho_my_u = (unsigned)(unsigned long long)ho_ctl_w;        // [0] columns I have written; [+32 B] columns I have read
         auto lds_word = [&](const unsigned addr) -> int {
                 int x;
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(addr) : "memory");
                 return __builtin_amdgcn_readfirstlane(x);
+        };
+        auto lds_wait_for = [&](const unsigned addr, const int need) {
+                int spins = 0;
+                while (lds_word(addr) < need) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
+                }
         };
 
         if (KIND == KA_PP) {
@@ -497,16 +458,17 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         //   P    : which half of q[] holds this step's column record (the other half receives the next)
         //   EV   : this step may carry a periodic event (ring batch hand-over, boundary / residue batch
         //          reload, flush of the output batch); EV = false steps are branch-free
-        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag, auto ev_tag, auto first_tag, auto in_tag, auto out_tag, auto lb_tag) {
+        auto step = [&](const int t, auto st_tag, auto full_tag, auto par_tag, auto ev_tag, auto first_tag, auto lb_tag) {
                 constexpr bool LASTB = decltype(lb_tag)::value;                // partial strips: the last row is its lane's row B (always so in full strips)
                 constexpr bool FIRST = decltype(first_tag)::value;             // strip 0 of its pass: the row above is the pass's generated row -1
-                constexpr bool IN = decltype(in_tag)::value;                   // the row above arrives through the LDS ring of the wave before this one
-                constexpr bool OUT = decltype(out_tag)::value;                 // this strip's last row goes to its LDS ring (full strips only)
                 constexpr bool ST = decltype(st_tag)::value;
                 constexpr bool FULL = decltype(full_tag)::value;
                 constexpr int P = decltype(par_tag)::value;
                 constexpr bool EV = decltype(ev_tag)::value;
                 const int v = t - lane;
+#ifdef KA_PROF
+                const long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
@@ -519,18 +481,11 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 }
                                 constexpr int NRD = (NRES <= 8) ? 4 : 7;
                                 ring_read_early(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols));
-                                if (IN) {
-                                        if (ST || t + 1 <= ncols) {
-                                                bnd_read_early(bq[1 - P], t + 1);
-                                                ring_wait_n(q[P], &bq[P], std::integral_constant<int, NRD + 1>());
-                                        } else {
-                                                ring_wait_n(q[P], &bq[P], std::integral_constant<int, NRD>());
-                                        }
-                                } else {
-                                        ring_wait_n(q[P], (float4v*)nullptr, std::integral_constant<int, NRD>());
-                                }
-                        } else if (IN) ring_wait_b(q[P], bq[P]);      // ... and this step's boundary slot
-                        else ring_wait(q[P]);                         // this step's column record (issued one step ago)
+                                ring_wait_n(q[P], std::integral_constant<int, NRD>());
+                        } else ring_wait(q[P]);                       // this step's column record (issued one step ago)
+#ifdef KA_PROF
+                        if (EV && ST && pslot && lane == 0) pslot[256 + 0] += __builtin_amdgcn_s_memtime() - tq0;      // (head slot reused: top-of-step wait)
+#endif
                         copen = q[P][5].w * m2; cext = q[P][6].x * m2; ctext = q[P][6].y * m2;
                 } else {
                         copen = kc_open; cext = kc_ext; ctext = kc_text;
@@ -563,14 +518,23 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 inia = -KA_F; iniga = -KA_F; inigb = -KA_F;
                         }
                         bta = inia; btga = iniga; btgb = inigb;
-                } else if (IN) {
-                        // the slot read a step ago must carry this column's tag; if the producer is not there yet, wait for it
-                        if (ST || t <= ncols) {
-                                if (__builtin_expect(__builtin_amdgcn_readfirstlane(__float_as_int(bq[P].w)) != t + 1, 0)) bq[P] = bnd_fetch(t);
-                        }
                 } else {
                         if (EV && (t & CBM) == 0) {
-                                if (t <= ncols) {
+                                if (HO && in_lds) {
+                                        if (t <= ncols) {
+                                                // the strip above runs on the wave before this one: its batch sits in its LDS ring
+                                                const int need = min(t + CBM + 1, ncols + 1);
+                                                lds_wait_for(ho_my_u - 4, need);
+                                                const unsigned a = ho_in_u + (((unsigned)min(t + lane, ncols) & (KA_HO_SLOTS - 1)) << 4);
+                                                float2v x01;
+                                                float x2;
+                                                asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                                                             : "=&v"(x01), "=&v"(x2) : "v"(a) : "memory");
+                                                bta = x01.x; btga = x01.y; btgb = x2;
+                                                // ... and it may re-use the slots of everything below `need`
+                                                if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(ho_my_u + 32), "v"(need) : "memory");
+                                        }
+                                } else if (t <= ncols) {
                                         // the previous strip must have published columns t .. t+CBM
                                         const int need = min(t + CBM + 1, ncols + 1);
                                         if (lane == 0) {
@@ -604,9 +568,6 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 const float lra = (Q == 2) ? cBa : cAa, lrga = (Q == 2) ? cBga : cAga, lrgb = (Q == 2) ? cBgb : cAgb;
                 if (FIRST) {
                         upa = wave_shr1_old(bta, lra); upga = wave_shr1_old(btga, lrga); upgb = wave_shr1_old(btgb, lrgb);
-                } else if (IN) {
-                        // (the slot's registers die in the DPP that splices lane 0 in: no copy)
-                        upa = wave_shr1_old(bq[P].x, lra); upga = wave_shr1_old(bq[P].y, lrga); upgb = wave_shr1_old(bq[P].z, lrgb);
                 } else {
                         const float nbta = wave_rol1(bta), nbtga = wave_rol1(btga), nbtgb = wave_rol1(btgb);
                         upa = wave_shr1_old(bta, lra); upga = wave_shr1_old(btga, lrga); upgb = wave_shr1_old(btgb, lrgb);
@@ -653,12 +614,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 if (!KA_RING_EARLY) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 const int tn = t + 1;
-                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
-                                        __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
-                                        ring_issue((tn >> 5) + 1);
-                                }
+#ifdef KA_PROF
+                                const long long tq2 = __builtin_amdgcn_s_memtime();
+#endif
+                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed; the next one is issued at the end of the step
+#ifdef KA_PROF
+                                if (EV && ST && pslot && lane == 0) { const long long tq3 = __builtin_amdgcn_s_memtime(); pslot[256 + 1] += tq3 - tq2; pslot[256 + 4] += tq2 - tq0; }   // (tail slot: vmcnt wait; singles slot: start .. after the chain)
+#endif
                                 ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
-                                if (IN && (ST || t + 1 <= ncols)) bnd_read(bq[1 - P], t + 1, acc);      // next step's boundary slot
                                 __builtin_amdgcn_sched_barrier(0);
                                 }
                         }
@@ -722,12 +685,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 if (!KA_RING_EARLY) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 const int tn = t + 1;
-                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
-                                        __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
-                                        ring_issue((tn >> 5) + 1);
-                                }
+                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
                                 ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), a1);
-                                if (IN && (ST || t + 1 <= ncols)) bnd_read(bq[1 - P], t + 1, a1);       // next step's boundary slot
                                 __builtin_amdgcn_sched_barrier(0);
                                 }
                         }
@@ -749,31 +708,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         copen_prev = copen;
                 }
 
-                // ---- HO consumer: every 32 steps the strip above learns how far this one has read (columns <= t are in registers) ----
-                if (IN && EV && ((t + 1) & 31) == 0) {
-                        if (lane == 0) { const int cp = t + 1; asm volatile("ds_write_b32 %0, %1" : : "v"(ho_my_u), "v"(cp) : "memory"); }
-                }
-                // ---- collect the strip's last row and hand it on (64 columns at a time through the row buffer, or slot by slot) ----
+                // ---- collect the strip's last row and hand it on 64 columns at a time (through the row buffer, or through LDS) ----
                 const int vL = t - lastl;
-                if (OUT) {
-                        // (full strips only: lane 63 owns the last row) one slot per finished column
-                        if (ST || (vL >= 0 && vL <= ncols)) {
-                                if (lane == 63) ho_write(vL, Q == 2 ? cBa : cAa, Q == 2 ? cBga : cAga, Q == 2 ? cBgb : cAgb);
-                        }
-                        if (EV && ((t + 1) & 31) == 0) {
-                                // steps t+1 .. t+32 store columns up to t - 31: their slots' previous columns (256 lower) must have been consumed
-                                const int need = t - 31 - (KA_HO_SLOTS - 1);
-                                if (__builtin_expect(need > cp_seen, 0)) {
-                                        int spins = 0;
-                                        cp_seen = lds_word(ho_my_u + 4);
-                                        while (cp_seen < need) {
-                                                __builtin_amdgcn_s_sleep(2);
-                                                if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
-                                                cp_seen = lds_word(ho_my_u + 4);
-                                        }
-                                }
-                        }
-                } else if (ST || (vL >= 0 && vL <= ncols)) {
+#ifdef KA_PROF
+                const long long tfl0_outer = __builtin_amdgcn_s_memtime();
+#endif
+                if (ST || (vL >= 0 && vL <= ncols)) {
                         if (FULL) {
                                 // shift register: lane 63 (the last row's owner) feeds its fresh state in
                                 oba = wave_shl1_old(Q == 2 ? cBa : cAa, oba); obga = wave_shl1_old(Q == 2 ? cBga : cAga, obga); obgb = wave_shl1_old(Q == 2 ? cBgb : cAgb, obgb);
@@ -798,6 +738,17 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 // FULL: lane i holds column vL - 63 + i; partial: lane i holds column vL - ((i - lastl) mod 64)
                                 const int c0 = (vL == 0) ? 0 : (((vL - 1) & ~PBM) + 1);
                                 const int col = FULL ? (vL - 63 + lane) : (vL - ((lane - lastl) & 63));
+                                if (HO && out_lds) {
+                                        // the strip below runs on the next wave: the batch goes to my LDS ring.  Its slots held the
+                                        // columns 256 lower: the consumer must be through with them (it is, by ~190 columns).
+                                        if (vL >= KA_HO_SLOTS) lds_wait_for(ho_my_u + 32 + 4, vL - (KA_HO_SLOTS - 1));
+                                        if (col >= c0 && col <= vL) {
+                                                const unsigned a = ho_out_u + (((unsigned)col & (KA_HO_SLOTS - 1)) << 4);
+                                                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write_b32 %0, %3 offset:8" : : "v"(a), "v"(oba), "v"(obga), "v"(obgb) : "memory");
+                                        }
+                                        // (LDS executes a wave's instructions in order: who sees the count sees the batch)
+                                        if (lane == 0) { const int pp = vL + 1; asm volatile("ds_write_b32 %0, %1" : : "v"(ho_my_u), "v"(pp) : "memory"); }
+                                } else {
                                 if (col >= c0 && col <= vL) {
                                         ka_gfloat* w = grows + 3 * IDX(col);
                                         w[0] = oba; w[1] = obga; w[2] = obgb;
@@ -814,24 +765,37 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                         if (lane == 0) __hip_atomic_store(prog + k, vL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 }
+                                }
                         }
                 }
+#ifdef KA_PROF
+                if (EV && ST && pslot && lane == 0) pslot[256 + 7] += __builtin_amdgcn_s_memtime() - tfl0_outer;
+#endif
+                // the column ring's next batch goes out LAST: a release fence of the flush above waits for everything outstanding,
+                // and these loads take a microsecond
+#ifdef KA_PROF
+                const long long tri0 = __builtin_amdgcn_s_memtime();
+#endif
+                if (KIND == KA_PP && !KA_RING_EARLY && EV && ((t + 1) & (KA_RING_BATCH - 1)) == 0) ring_issue(((t + 1) >> 5) + 1);
+#ifdef KA_PROF
+                if (EV && ST && pslot && lane == 0) pslot[256 + 6] += __builtin_amdgcn_s_memtime() - tri0;
+#endif
         };
 
-        // q[t & 1] (and bq[t & 1]) hold step t's column record: a step's parity is its t's, so a single step between two
+        // q[t & 1] holds step t's column record: a step's parity is its t's, so a single step between two
         // pairs needs no copy of the 28 record registers (round 2 started every phase on half 0 and copied after odd steps
         // and after every event step: four copies, each behind an exposed LDS wait, per 64 steps)
-        auto run = [&](int& t, const int tend, auto st_tag, auto full_tag, auto first_tag, auto in_tag, auto out_tag, auto lb_tag) {
+        auto run = [&](int& t, const int tend, auto st_tag, auto full_tag, auto first_tag, auto lb_tag) {
                 if ((t & 1) && t < tend) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, in_tag, out_tag, lb_tag);
+                        step(t, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, lb_tag);
                         ++t;
                 }
                 for (; t + 1 < tend; t += 2) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, in_tag, out_tag, lb_tag);
-                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, in_tag, out_tag, lb_tag);
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, lb_tag);
+                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, lb_tag);
                 }
                 if (t < tend) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, in_tag, out_tag, lb_tag);
+                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, lb_tag);
                         ++t;
                 }
         };
@@ -839,17 +803,17 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // output flush, at t = lastl mod 64 --, batch reloads at t = 0 mod 64); everything between two event steps runs
         // as branch-free step pairs.  (HO: a strip that takes its boundary from an LDS ring has no batch reloads, one that
         // hands on through its LDS ring no flushes -- the 32-step ring event carries the flow control.)
-        auto run_steady = [&](int& t, const int tend, auto full_tag, auto first_tag, auto in_tag, auto out_tag, auto lb_tag) {
-                constexpr bool IN = decltype(in_tag)::value;
-                constexpr bool OUT = decltype(out_tag)::value;
+        auto run_steady = [&](int& t, const int tend, auto full_tag, auto first_tag, auto lb_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 while (t < tend) {
                         const int e1 = t | 31;
-                        const int e2 = IN ? 0x7fffffff : ((t + CBM) & ~CBM);
-                        const int e3 = OUT ? 0x7fffffff : (t + ((lastl - t) & PBM));
+                        // (profile columns, first strip of the pass: nothing is reloaded every 64 steps -- no event)
+                        const int e2 = (KIND == KA_PP && FIRST) ? 0x7fffffff : ((t + CBM) & ~CBM);
+                        const int e3 = t + ((lastl - t) & PBM);
                         const int ev = min(e1, min(e2, e3));
                         const int fend = min(ev, tend);
                         if ((t & 1) && t < fend) {
-                                step(t, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag, in_tag, out_tag, lb_tag);
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag, lb_tag);
                                 ++t;
                         }
 #ifdef KA_PROF
@@ -857,29 +821,27 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         const int t_in = t;
 #endif
                         for (; t + 1 < fend; t += 2) {
-                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag, in_tag, out_tag, lb_tag);
-                                step(t + 1, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag, in_tag, out_tag, lb_tag);
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag, lb_tag);
+                                step(t + 1, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag, lb_tag);
                         }
 #ifdef KA_PROF
                         // cycles inside the branch-free step pairs / steps taken there (the rest of the strip: events, single steps, edges)
                         if (pslot && lane == 0) { pslot[6] += __builtin_amdgcn_s_memtime() - tpair0; pslot[7] += t - t_in; }
 #endif
-#ifdef KA_PROF
-                        const long long tsg0 = __builtin_amdgcn_s_memtime();
-                        const int sg_in = t;
-#endif
                         if (t < fend) {
-                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag, in_tag, out_tag, lb_tag);
+                                step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag, lb_tag);
                                 ++t;
                         }
 #ifdef KA_PROF
+                        // KA_PROF builds, slots [256 ..] of the wave's profile record (tools/strip_phases.py): per event step of the
+                        // steady phase -- [2] cycles, [3] count, [0] wait for the column record, [4] start .. end of the dot products,
+                        // [1] wait for the ring batch, [7] collection + flush, [6] issue of the next ring batch
                         const long long tev0 = __builtin_amdgcn_s_memtime();
-                        if (pslot && lane == 0) { pslot[256 + 4] += tev0 - tsg0; pslot[256 + 5] += t - sg_in; }
                         const int ev_in = t;
 #endif
                         if (t < tend && t == ev) {
-                                if (t & 1) step(t, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, in_tag, out_tag, lb_tag);
-                                else step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, in_tag, out_tag, lb_tag);
+                                if (t & 1) step(t, std::true_type(), full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, lb_tag);
+                                else step(t, std::true_type(), full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, lb_tag);
                                 ++t;
                         }
 #ifdef KA_PROF
@@ -891,51 +853,17 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const int nsteps = ncols + nl;                                // t = 0 .. ncols + nl - 1
         const int t_steady0 = min(nl, nsteps);                        // first step with every active lane at v >= 1
         const int t_steady1 = ncols;                                  // one past the last step with every lane at v <= ncols-1
-        auto phases = [&](auto full_tag, auto first_tag, auto in_tag, auto out_tag, auto lb_tag) {
-                constexpr bool IN = decltype(in_tag)::value;
-                if (IN) {
-                        // start a few columns behind the producer's edge, then take column 0
-                        (void)bnd_fetch(min(KA_HO_SLACK, ncols));
-                        bq[0] = bnd_fetch(0);
-                }
+        auto phases = [&](auto full_tag, auto first_tag, auto lb_tag) {
                 int t = 0;
-#ifdef KA_PROF
-                const long long th0 = __builtin_amdgcn_s_memtime();
-#endif
-                run(t, t_steady0, std::false_type(), full_tag, first_tag, in_tag, out_tag, lb_tag);
-#ifdef KA_PROF
-                if (pslot && lane == 0) pslot[256 + 0] += __builtin_amdgcn_s_memtime() - th0;
-#endif
-                run_steady(t, t_steady1, full_tag, first_tag, in_tag, out_tag, lb_tag);
-#ifdef KA_PROF
-                const long long tt0 = __builtin_amdgcn_s_memtime();
-#endif
-                run(t, nsteps, std::false_type(), full_tag, first_tag, in_tag, out_tag, lb_tag);
-#ifdef KA_PROF
-                if (pslot && lane == 0) pslot[256 + 1] += __builtin_amdgcn_s_memtime() - tt0;
-#endif
-        };
-        // HO: IN needs a producer (never the first strip), OUT a full strip (only the last strip of a pass can be partial)
-        auto go2 = [&](auto full_tag, auto first_tag, auto lb_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
-                constexpr bool FIRST = decltype(first_tag)::value;
-                if constexpr (HO && KIND == KA_PP) {
-                        if constexpr (!FIRST) {
-                                if (in_lds) {
-                                        if constexpr (FULL) { if (out_lds) { phases(full_tag, first_tag, std::true_type(), std::true_type(), lb_tag); return; } }
-                                        phases(full_tag, first_tag, std::true_type(), std::false_type(), lb_tag);
-                                        return;
-                                }
-                        }
-                        if constexpr (FULL) { if (out_lds) { phases(full_tag, first_tag, std::false_type(), std::true_type(), lb_tag); return; } }
-                }
-                phases(full_tag, first_tag, std::false_type(), std::false_type(), lb_tag);
+                run(t, t_steady0, std::false_type(), full_tag, first_tag, lb_tag);
+                run_steady(t, t_steady1, full_tag, first_tag, lb_tag);
+                run(t, nsteps, std::false_type(), full_tag, first_tag, lb_tag);
         };
         // (which row of its lane a partial strip's last row is: two instances, so that the step does not select)
         auto go = [&](auto full_tag, auto first_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                if constexpr (FULL || Q == 1) go2(full_tag, first_tag, std::integral_constant<bool, Q == 2>());
-                else { if (last_is_b) go2(full_tag, first_tag, std::true_type()); else go2(full_tag, first_tag, std::false_type()); }
+                if constexpr (FULL || Q == 1) phases(full_tag, first_tag, std::integral_constant<bool, Q == 2>());
+                else { if (last_is_b) phases(full_tag, first_tag, std::true_type()); else phases(full_tag, first_tag, std::false_type()); }
         };
         if (nr == SROWS) {
                 if (first) go(std::true_type(), std::true_type());

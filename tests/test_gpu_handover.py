@@ -1,9 +1,10 @@
-"""LDS hand-over between neighbouring strips (ka_strip<.., HO>; KA_HO in the environment): strips of one pass that run on
-neighbouring waves of a workgroup pass the boundary row through an LDS ring, column by column, instead of 64-column batches
-through the HBM row buffer.  Only WHEN a strip learns its boundary changes -- every meetup, path and gap array must stay the
-reference's bit for bit.  The cases have tasks with several 128-row (and, with KA_Q1, 64-row) strips per pass, one workgroup
-and clusters, protein (20 / 23 residue classes) and nucleotide profiles, and passes longer than the ring (256 slots: the
-flow control is exercised by the ~2000-column DNA tasks)."""
+"""Hand-over between neighbouring strips through LDS (ka_strip<.., HO>; KA_HO in the environment, on by default): strips of one
+pass that run on neighbouring waves of a workgroup pass the boundary row -- the same 64-column batches -- through a ring in LDS
+with progress words in LDS, instead of the HBM row buffer behind release / acquire fences.  Only HOW a strip learns its boundary
+changes: every meetup, path and gap array must stay the reference's bit for bit, with the hand-over on (1), with four strips per
+workgroup (2) and off (0).  The cases have tasks with several 128-row (and, with KA_Q1, 64-row) strips per pass, one workgroup
+and clusters, protein (20 / 23 residue classes) and nucleotide profiles, and passes longer than the ring (256 slots: the slot
+re-use check is exercised by the ~2000-column DNA tasks)."""
 import os
 import sys
 
@@ -14,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
-MODES = [{"KA_HO": "1"}, {"KA_HO": "2"}, {"KA_HO": "1", "KA_Q1": "3"}, {"KA_HO": "2", "KA_Q1": "1"},
+MODES = [{"KA_HO": "1"}, {"KA_HO": "2"}, {"KA_HO": "0"}, {"KA_HO": "1", "KA_Q1": "3"}, {"KA_HO": "2", "KA_Q1": "1"},
          {"KA_HO": "1", "KA_MAX_CLUSTER": "1"}, {"KA_HO": "1", "KA_NO_CHAIN": "1"}]
 
 
@@ -70,7 +71,7 @@ def test_lds_handover_with_b_z_x_residues(monkeypatch):
     ctx = kalign_amd.Context(0)
     try:
         ctx.tree_upload(codes, tasks, subm, scal, dist)
-        for mode in MODES[:3]:
+        for mode in MODES[:4]:
             for k, v in mode.items():
                 monkeypatch.setenv(k, v)
             ctx.reload_env()

@@ -1,3 +1,7 @@
+"""Where a strip spends its time (KA_PROF build of unit 0: hipcc ... -DKA_UNIT=0 -DKA_PROF, linked as libkalign_amd_prof.so and copied
+over libkalign_amd.so on the GPU box): per wave of the leading workgroup of a synthetic profile-profile task -- loop start / end,
+steps and cycles inside the branch-free step pairs, the event steps of the steady phase and what they spend where.
+KA_MAX_CLUSTER=1 puts all strips of both passes on the eight waves of one workgroup.  Run on the GPU box from the repo root."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench, kalign_amd, torch
@@ -24,6 +28,6 @@ for rows, cols in [(1000, 3000), (500, 500)]:
             print("  L%d wave %d: loop start at %.1f us, end at %.1f us (barrier done %.1f) | loop %.1f us: pair loops %d steps at %.0f cyc/step; everything else %d cycles" % (
                 lvl, w, (p[2] - p[0]) / 2.4e3, (p[3] - p[0]) / 2.4e3, (p[4] - p[0]) / 2.4e3, total / 2.4e3, p[7], p[6] / max(p[7], 1), total - p[6]))
             x = ctx.prof[lvl + 4][w]
-            print("      head %d cycles, tail %d cycles; steady: %d event steps at %.0f cycles each, %d single steps at %.0f each" % (
-                x[0], x[1], x[3], x[2] / max(x[3], 1), x[5], x[4] / max(x[5], 1)))
+            print("      steady phase: %d event steps at %.0f cycles each" % (x[3], x[2] / max(x[3], 1)))
+            print("      in the event steps: ring issue %.0f cycles per event, collection + flush %.0f per event; top wait %.0f, start..chain end %.0f, vmcnt wait %.0f" % (x[6] / max(x[3], 1), x[7] / max(x[3], 1), x[0] / max(x[3], 1), x[4] / max(x[3], 1), x[1] / max(x[3], 1)))
 ctx.close()
