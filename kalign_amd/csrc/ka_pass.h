@@ -17,8 +17,8 @@
 //     (global_load_lds_dwordx4), 32 columns per batch, chunk-major so the per-lane reads are
 //     conflict-free ds_read_b128, issued one step ahead; sequence operands flow lane to lane
 //     through one more DPP shift;
-//   * the strip's last row is collected in registers (one column per lane) and written to the
-//     row buffer 64 columns at a time (coalesced), then published.
+//   * the strip's last row is collected in registers (one column per lane) and handed on 64 columns at a time: to the
+//     row buffer (coalesced, then published), or -- neighbouring waves of one workgroup -- through a ring in LDS (HO, below).
 //
 // All arithmetic is binary32 in the reference's order, no contraction (see ka_kernels.hip).
 #pragma once
