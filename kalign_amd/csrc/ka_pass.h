@@ -506,7 +506,9 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 
                 // ---- state of the row above A: lane l-1's row B, lane 0 takes the boundary ----
                 if (FIRST) {
-                        if (t == 0) {
+                        // (!ST: a steady step is never step 0 -- without the hint the test, two selects and their operand moves
+                        // sat in every step of every first strip, the strip that sets its pass's pace)
+                        if (!ST && t == 0) {
                                 inia = inj_a; iniga = inj_ga; inigb = inj_gb;
                         } else if (ST || t < ncols) {
                                 // max(x, y) + c == max(x + c, y + c) bit for bit (rounding is monotonic): one select-free form
