@@ -787,18 +787,38 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         // q[t & 1] holds step t's column record: a step's parity is its t's, so a single step between two
         // pairs needs no copy of the 28 record registers (round 2 started every phase on half 0 and copied after odd steps
         // and after every event step: four copies, each behind an exposed LDS wait, per 64 steps)
+        // The head (lanes still entering at column 0) and the tail (lanes leaving at the last column) of a strip: the edge form of
+        // the step (selects for the first / last column, clamped column indices).  Its periodic events fall on the same known
+        // steps as in the steady phase, plus the strip's last step (the final flush) -- everything else runs WITHOUT the event
+        // tests (round 2 ran all 128 edge steps of a strip as event steps, ~900 cycles each; the head of a strip is what its
+        // consumer's start waits for, at every hand-over of every pass).
         auto run = [&](int& t, const int tend, auto st_tag, auto full_tag, auto first_tag, auto lb_tag) {
-                if ((t & 1) && t < tend) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, lb_tag);
-                        ++t;
-                }
-                for (; t + 1 < tend; t += 2) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, lb_tag);
-                        step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, lb_tag);
-                }
-                if (t < tend) {
-                        step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, lb_tag);
-                        ++t;
+                constexpr bool FIRST = decltype(first_tag)::value;
+                const int e4 = ncols + lastl;                                 // the last step: vL == ncols
+                while (t < tend) {
+                        const int e1 = t | 31;
+                        const int e2 = (KIND == KA_PP && FIRST) ? 0x7fffffff : ((t + CBM) & ~CBM);
+                        const int e3 = t + ((lastl - t) & PBM);
+                        const int e5 = (t <= e4) ? e4 : 0x7fffffff;
+                        const int ev = min(min(e1, e2), min(e3, e5));
+                        const int fend = min(ev, tend);
+                        if ((t & 1) && t < fend) {
+                                step(t, st_tag, full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag, lb_tag);
+                                ++t;
+                        }
+                        for (; t + 1 < fend; t += 2) {
+                                step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag, lb_tag);
+                                step(t + 1, st_tag, full_tag, std::integral_constant<int, 1>(), std::false_type(), first_tag, lb_tag);
+                        }
+                        if (t < fend) {
+                                step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::false_type(), first_tag, lb_tag);
+                                ++t;
+                        }
+                        if (t < tend && t == ev) {
+                                if (t & 1) step(t, st_tag, full_tag, std::integral_constant<int, 1>(), std::true_type(), first_tag, lb_tag);
+                                else step(t, st_tag, full_tag, std::integral_constant<int, 0>(), std::true_type(), first_tag, lb_tag);
+                                ++t;
+                        }
                 }
         };
         // steady state: the periodic events fall on known steps (ring hand-over at t = 31 mod 32 -- in full strips also the
