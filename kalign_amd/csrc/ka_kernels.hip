@@ -44,6 +44,17 @@ __device__ __forceinline__ float ka_uniform_f(float x)
         return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
 
+// a wave-uniform pointer that came out of LDS (a VGPR pair as far as the compiler knows) as an SGPR pair: the strip's event code
+// kept such pointers in scratch memory and reloaded them -- a memory round trip each -- several times per event step
+template <typename T>
+__device__ __forceinline__ T* ka_uniform_ptr(T* p)
+{
+        const unsigned long long x = (unsigned long long)p;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32));
+        return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 // Bounded spin: gives up when the limit is reached, reporting `code` unless an error is already set.
 // other_tasks: the wait depends on ANOTHER task (a join point of the chained launch): also give up, checked
 // every 256 iterations, as soon as any workgroup has reported an error -- a failed task (arena overflow)
@@ -680,12 +691,12 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 int* const ho_ctl_w = (int*)(lds_waves - KA_LDS_HO_BACK) + wave;
                                 if (Q1 && srows == KA_STRIP1_ROWS)
                                         ka_strip<KIND, NRES, NB, 1, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
-                                                             (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
+                                                             ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
                                                              lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
                                                              in_lds, out_lds, ho_ctl_w);
                                 else
                                         ka_strip<KIND, NRES, NB, 2, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
-                                                             (dir == KA_FWD ? S.fbuf : S.bbuf) + roff, prog + (it - k), lane,
+                                                             ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
                                                              lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
                                                              in_lds, out_lds, ho_ctl_w);
                         }

@@ -202,6 +202,10 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 return;
         }
 
+        // (the operand pointers the event code needs, as SGPR pairs: see ka_uniform_ptr)
+        const float* const p2u = (KIND == KA_PP) ? ka_uniform_ptr(S.p2) : nullptr;
+        const uint8_t* const s2u = (KIND != KA_PP) ? ka_uniform_ptr(S.s2) : nullptr;
+        int* const wdu = ka_uniform_ptr(S.watchdog);
         float* const sp_tbl = (float*)wlds;                           // seq-profile: this lane's two score rows
         const float m1 = ka_uniform_f(S.p1_mult), m2 = ka_uniform_f(S.p2_mult);
         ka_gfloat* const grows = (ka_gfloat*)rows;
@@ -240,7 +244,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // start the global->LDS copy of column batch nb (32 columns x 7 chunks)
                 if (lane < KA_RING_BATCH && nb * KA_RING_BATCH <= ncols) {
                         const int vv = min(nb * KA_RING_BATCH + lane, ncols);
-                        const float* g = S.p2 + ((long long)REC(vv) << 6) + 32;
+                        const float* g = p2u + ((long long)REC(vv) << 6) + 32;
                         // ring layout: chunk-major, 128 columns per chunk row (2048 B): column v of chunk ch at
                         // ch * 2048 + (v & 127) * 16 -- the read address is one AND + one shift-OR
                         char* dst = wlds + (nb & (KA_RING_SLOTS - 1)) * (KA_RING_BATCH * 16);
@@ -432,7 +436,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 int spins = 0;
                 while (lds_word(addr) < need) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
+                        if (ka_spin_expired(wdu, ++spins, 1 << 22, 5)) break;
                 }
         };
 
@@ -444,7 +448,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // step t+1 are prepared (the LDS latency of the look-up and, every 64 steps, the L2 latency
                 // of the residue batch would otherwise sit in every step of a lone wave).  resn = batch of
                 // columns 64m+1+lane, fetched 64 steps before it is rotated in.
-                resn = ((ka_gbytec*)S.s2)[REC(min(1 + lane, ncols)) - 1];
+                resn = ((ka_gbytec*)s2u)[REC(min(1 + lane, ncols)) - 1];
                 if (KIND == KA_SS) { scA = tss[res1A]; if (Q == 2) scB = tss[res1B]; }        // step 0: no lane is at a real column yet
                 else { scA = sp_tbl[(Q * lane) * KA_SP_STRIDE]; if (Q == 2) scB = sp_tbl[(2 * lane + 1) * KA_SP_STRIDE]; }
         }
@@ -495,7 +499,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         // prepare step t+1: lane 0 takes column t+1 from the batch, lanes > 0 their upper neighbour's residue
                         if (EV && (t & 63) == 0) {
                                 resb = resn;
-                                resn = ((ka_gbytec*)S.s2)[REC(min(t + 65 + lane, ncols)) - 1];
+                                resn = ((ka_gbytec*)s2u)[REC(min(t + 65 + lane, ncols)) - 1];
                         } else {
                                 resb = __builtin_amdgcn_update_dpp(resb, resb, 0x134, 0xf, 0xf, false);   // wave_rol:1
                         }
@@ -545,12 +549,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                                 if (acq_agent) {
                                                         while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                                                                 __builtin_amdgcn_s_sleep(4);
-                                                                if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
+                                                                if (ka_spin_expired(wdu, ++spins, 1 << 22, 5)) break;
                                                         }
                                                 } else {
                                                         while (__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
                                                                 __builtin_amdgcn_s_sleep(2);
-                                                                if (ka_spin_expired(S.watchdog, ++spins, 1 << 22, 5)) break;
+                                                                if (ka_spin_expired(wdu, ++spins, 1 << 22, 5)) break;
                                                         }
                                                 }
                                         }
