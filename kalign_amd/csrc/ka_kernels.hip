@@ -2848,7 +2848,7 @@ __device__ __forceinline__ void ka_task_queue_entry(const KaTreeDev& D, const in
 //   unit 0: ka_task_kernel            unit 1: ka_task_kernel_cons
 //   unit 2: the two half kernels      unit 3: the two lean kernels + ka_pair_kernel
 #ifndef KA_UNIT
-#error "compile with -DKA_UNIT=0..4 (see csrc/Makefile)"
+#error "compile with -DKA_UNIT=0..5 (see csrc/Makefile)"
 #endif
 
 // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
@@ -2878,27 +2878,35 @@ extern "C" int ka_max_g_host(void) { return KA_MAX_G; }
 #endif
 
 #if KA_UNIT == 4
-// refinement pass (unit 4): one workgroup per edge, per-level launches
+// refinement pass (units 4 and 5: one kernel each -- they are the longest compiles of the library, side by side they halve the
+// build's critical path): one workgroup per edge, per-level launches
+extern "C" void ka_unit5_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
 __global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
 {
         const int2 blk = blocks[blockIdx.x];
         if (blk.x >= 0) ka_task_body_refine<0>(D, blk.x, blk.y & 0xff, blk.y >> 8);
 }
+extern "C" void ka_unit4_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
+{
+        static bool done0 = false;
+        if (cons) { ka_unit5_launch(D, blocks_dev, nblocks, stream); return; }
+        if (ka_optin(ka_refine_kernel, KA_LDS_TOTAL, &done0) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_refine_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
+}
+#endif
+
+#if KA_UNIT == 5
+// the refinement pass with the anchor-consistency bonus
 __global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel_cons(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
 {
         const int2 blk = blocks[blockIdx.x];
         if (blk.x >= 0) ka_task_body_refine<KA_NB>(D, blk.x, blk.y & 0xff, blk.y >> 8);
 }
-extern "C" void ka_unit4_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream)
+extern "C" void ka_unit5_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream)
 {
-        static bool done0 = false, done1 = false;
-        if (cons) {
-                if (ka_optin(ka_refine_kernel_cons, KA_LDS_TOTAL, &done1) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_refine_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
-        } else {
-                if (ka_optin(ka_refine_kernel, KA_LDS_TOTAL, &done0) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_refine_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
-        }
+        static bool done1 = false;
+        if (ka_optin(ka_refine_kernel_cons, KA_LDS_TOTAL, &done1) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_refine_kernel_cons, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
 }
 #endif
 
