@@ -827,8 +827,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         };
         // steady state: the periodic events fall on known steps (ring hand-over at t = 31 mod 32 -- in full strips also the
         // output flush, at t = lastl mod 64 --, batch reloads at t = 0 mod 64); everything between two event steps runs
-        // as branch-free step pairs.  (HO: a strip that takes its boundary from an LDS ring has no batch reloads, one that
-        // hands on through its LDS ring no flushes -- the 32-step ring event carries the flow control.)
+        // as branch-free step pairs.  (HO changes what a reload and a flush DO -- LDS instead of HBM -- not when they happen.)
         auto run_steady = [&](int& t, const int tend, auto full_tag, auto first_tag, auto lb_tag) {
                 constexpr bool FIRST = decltype(first_tag)::value;
                 while (t < tend) {
