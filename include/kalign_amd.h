@@ -367,6 +367,10 @@ int ka_dist_tree_run(ka_dist* d);
 long long ka_dist_paths_size(ka_dist* d);
 int ka_dist_download(ka_dist* d, ka_task_rec* recs, int* paths, long long paths_cap, long long* used);
 double ka_dist_last_ms(ka_dist* d);
+/* Steps ka_dist_tree_run repeated because a device arena overflowed on SOME rank: the ranks agree on the outcome of their parts
+   (all-reduce of a status word) before the gather's collectives, the ranks that overflowed grow their arenas and every rank
+   runs the step again -- no rank fails, or waits in a collective, alone. */
+int ka_dist_retries(ka_dist* d);
 /* Tests: the ranks as threads of ONE process, each with its own context on the same GPU (RCCL refuses two ranks on one
    device): an in-process stand-in for the communicator with the same call sequence, host-synchronous. */
 void* ka_dist_loopback_new(int world);

@@ -49,7 +49,7 @@ EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_
            "ka_tree_aligned_rows", "ka_guide_tree", "ka_guide_tree_from",
            "ka_aln_guide_tree", "ka_run_encoded", "ka_run_encoded_refine", "ka_tree_plan_tasks", "ka_tree_run_planned",
            "ka_dist_unique_id", "ka_dist_create", "ka_dist_destroy", "ka_dist_plan_subtrees", "ka_dist_plan", "ka_dist_get_plan",
-           "ka_dist_consistency", "ka_dist_tree_run", "ka_dist_paths_size", "ka_dist_download", "ka_dist_last_ms",
+           "ka_dist_consistency", "ka_dist_tree_run", "ka_dist_paths_size", "ka_dist_download", "ka_dist_last_ms", "ka_dist_retries",
            "ka_dist_loopback_new", "ka_dist_loopback_free", "ka_dist_create_loopback"]
 
 
@@ -120,6 +120,7 @@ def load_library():
     L.ka_dist_download.argtypes = [vp, vp, vp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.ka_dist_last_ms.argtypes = [vp]
     L.ka_dist_last_ms.restype = C.c_double
+    L.ka_dist_retries.argtypes = [vp]
     L.ka_dist_loopback_new.argtypes = [C.c_int]
     L.ka_dist_loopback_new.restype = vp
     L.ka_dist_loopback_free.argtypes = [vp]
@@ -680,6 +681,9 @@ class Dist:
 
     def last_ms(self):
         return float(self.L.ka_dist_last_ms(self.h))
+
+    def retries(self):
+        return int(self.L.ka_dist_retries(self.h))
 
     def close(self):
         if self.h:

@@ -91,6 +91,7 @@ struct KaEnv {
         int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
         int per = 0;                   // KA_PER: strips per workgroup (KaTreeDev::per_target; experiments)
         int ho = -1;                   // KA_HO: hand-over between neighbouring strips through LDS (KaTreeDev::ho_mode); -1: on (1)
+        int hw = 1;                    // KA_HW: profile-profile strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
         bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
@@ -110,6 +111,7 @@ static void read_env(KaEnv& v)
         v.mw = env_int("KA_MW", 1);
         v.ho = env_int("KA_HO", -1);
         v.per = env_int("KA_PER", 0);
+        v.hw = env_int("KA_HW", 1);
         v.upgma_launches = getenv("KA_UPGMA_LAUNCHES") != nullptr;
 }
 
@@ -486,7 +488,8 @@ static int plan_launches(ka_ctx* c)
                         int top_g = 4;
                         if (c->env.crit_top > 0) top_g = std::min(c->max_cluster, c->env.crit_top);   // experiments
                         for (size_t i = 0; i < by_up.size() && spare > 0; i++) {
-                                const int want = std::min(spare, std::max(0, (i == 0 ? top_g : 2 * G0) - G0));
+                                // (never beyond the cluster limit: surplus workgroups would only spin at a join and leave)
+                                const int want = std::min(spare, std::max(0, std::min(c->max_cluster, i == 0 ? top_g : 2 * G0) - G0));
                                 extra[by_up[i]] = want; spare -= want;
                         }
                 }
@@ -779,6 +782,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1;
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
+        D.hw_mode = c->env.hw;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
         D.mw_mode = c->env.mw;
@@ -893,6 +897,7 @@ extern "C" int ka_tree_run(ka_ctx* c)
 // counter walks them in recursion order), so an edge gets ONE workgroup per trial in flight: on a level that leaves CUs
 // idle the flip trials of a refined edge run side by side on 2 or 4 workgroups (ka_task_body_refine), otherwise one
 // workgroup runs them one after the other.
+#define KA_REFINE_MAX_G 4
 static int refine_blocks(ka_ctx* c, int mode)
 {
         std::vector<int2> tbl;
@@ -906,7 +911,9 @@ static int refine_blocks(ka_ctx* c, int mode)
                 for (int t : L) nref += (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? 1 : 0;
                 int G = 1;
                 if (!c->shared_gpu && !c->env.refine_serial)
-                        while (G * 2 <= flips && (long long)nref * G * 2 + ((long long)L.size() - nref) <= c->n_cus) G *= 2;
+                        // (at most KA_REFINE_MAX_G members: the member report of ka_task_body_refine has that many slots in the
+                        // task's control block -- n_trials beyond 9 would otherwise ask for 8 or more and overrun it)
+                        while (G * 2 <= std::min(flips, KA_REFINE_MAX_G) && (long long)nref * G * 2 + ((long long)L.size() - nref) <= c->n_cus) G *= 2;
                 for (int t : L) {
                         const int g = (flips > 0 && (base_mode != 2 || c->descs[t].refine)) ? G : 1;
                         // tests: one member of the first multi-workgroup edge never starts -- its member barrier starves, the
@@ -2074,7 +2081,9 @@ struct ka_dist {
         std::vector<KaMove> moves;                       // in the order the top tasks need them
         std::vector<std::vector<int>> top_moves;         // per top task: indices into moves
         std::vector<DevBuf<int2>> top_blocks;            // per top task this rank runs: its workgroup table
-        DevBuf<char> d_mine; DevBuf<int> d_counts, d_gpaths, d_colbuf; DevBuf<long long> d_goff;
+        DevBuf<char> d_mine; DevBuf<int> d_counts, d_gpaths, d_colbuf, d_hdr, d_status; DevBuf<long long> d_goff;
+        DevBuf<float> d_sink;                            // an incoming profile the arena has no room for (the step is then repeated)
+        int retries = 0;                                 // steps repeated after an arena overflow on some rank
         std::vector<char> mine;
         std::vector<ka_task_rec> h_recs;
         std::vector<int> h_paths;
@@ -2385,19 +2394,24 @@ extern "C" int ka_dist_consistency(ka_dist* d, int n_anchors, float weight)
         return KA_OK;
 }
 
-// One step of the sharded tree: from the leaves to every rank holding every record and coded path.
-extern "C" int ka_dist_tree_run(ka_dist* d)
+// One attempt at a step of the sharded tree, up to the point where this rank knows how ITS part went.  Conditions a repeat can
+// cure -- a device arena overflowed in one of this rank's kernels, the profile arena has no room for an incoming profile, a
+// profile this rank should send was never made because an earlier task failed -- do NOT leave the protocol: the rank keeps
+// matching every send / receive of the walk (an unusable profile travels as a header of zero and nothing else; a profile
+// without room lands in a sink buffer), stops launching, and reports through *status (0 clean, 1 repeat after growing, 2 fatal).
+// Only HIP / RCCL API failures return KA_FAIL from inside (nothing sensible can be agreed on a broken device).
+static int dist_tree_attempt(ka_dist* d, int* status, int* grow)
 {
-        if (!d || !d->planned) return fail("ka_dist_tree_run: plan first");
         ka_ctx* c = d->c;
-        HIPCHK(hipSetDevice(c->device));
-        const auto t_begin = std::chrono::steady_clock::now();
         const int n_tasks = c->n_tasks;
+        *status = 0; *grow = 0;
         if (c->plan_active.empty()) return fail("ka_dist_tree_run: the context's plan was replaced by a whole-tree run; call ka_dist_plan again");
         c->ran = false; c->synced = false;
         if (tree_reset(c)) return KA_FAIL;                          // (keeps the consistency table; residue -> column tables back to the leaves)
         if (tree_launch(c, false)) return KA_FAIL;                  // this rank's subtrees
         const KaTreeDev D = tree_dev(c);
+        if (d->d_hdr.alloc(4)) return fail("hipMalloc failed");
+        bool stop = false;                                           // something went wrong on this rank: no more launches
         for (size_t i = 0; i < d->top.size(); i++) {
                 const int t = d->top[i], dst = d->run_rank[t];
                 for (int mi : d->top_moves[i]) {
@@ -2408,31 +2422,47 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
                                 // header (plen) straight from the node table, the records from where they lie in the arena
                                 HIPCHK(hipMemcpyAsync(d->h_head, c->d_node_len.p + m.child, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                                 HIPCHK(hipMemcpyAsync(d->h_head + 2, c->d_node_prof.p + m.child, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+                                HIPCHK(hipMemcpyAsync(d->h_head + 8, c->d_error.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                                 HIPCHK(hipStreamSynchronize(c->stream));
-                                const int plen = d->h_head[0];
+                                int plen = d->h_head[0];
                                 long long po; memcpy(&po, d->h_head + 2, sizeof(po));
-                                if (plen < 1 || po < 0) return fail("ka_dist_tree_run: a subtree root has no profile");
-                                if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_node_len.p, m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 0, c->stream);
+                                if (stop || d->h_head[8] != 0 || plen < 1 || po < 0) { plen = 0; stop = true; }   // (its status comes from the device error word below)
+                                d->h_head[12] = plen;
+                                HIPCHK(hipMemcpyAsync(d->d_hdr.p, d->h_head + 12, sizeof(int), hipMemcpyHostToDevice, c->stream));
                                 // (plain stream-ordered point-to-point operations, matched in order with the receiver's: every rank
                                 // walks the hand-overs in the same order, so no two ranks ever wait for each other crosswise)
-                                if (d->send(c->d_node_len.p + m.child, sizeof(int), m.dst)) return KA_FAIL;
-                                if (d->send(c->d_prof_arena.p + po, sizeof(float) * (size_t)(plen + 2) * KA_REC, m.dst)) return KA_FAIL;
-                                if (cols && d->send(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.dst)) return KA_FAIL;
+                                if (d->send(d->d_hdr.p, sizeof(int), m.dst)) return KA_FAIL;
+                                if (plen > 0) {
+                                        if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_node_len.p, m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 0, c->stream);
+                                        if (d->send(c->d_prof_arena.p + po, sizeof(float) * (size_t)(plen + 2) * KA_REC, m.dst)) return KA_FAIL;
+                                        if (cols && d->send(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.dst)) return KA_FAIL;
+                                }
+                                HIPCHK(hipStreamSynchronize(c->stream));          // (h_head and d_hdr are reused by the next hand-over)
                         } else {
                                 // the header first: it sizes the room the records get in this rank's arena
-                                if (d->recv(c->d_node_len.p + m.child, sizeof(int), m.src)) return KA_FAIL;
-                                HIPCHK(hipMemcpyAsync(d->h_head, c->d_node_len.p + m.child, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                                if (d->recv(d->d_hdr.p, sizeof(int), m.src)) return KA_FAIL;
+                                HIPCHK(hipMemcpyAsync(d->h_head, d->d_hdr.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                                 HIPCHK(hipMemcpyAsync(d->h_head + 2, c->d_counters.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
                                 HIPCHK(hipStreamSynchronize(c->stream));
                                 const int plen = d->h_head[0];
+                                if (plen < 1) { stop = true; if (*status < 1) *status = 1; continue; }   // the sender has nothing to send: its own status says why
                                 unsigned long long top_; memcpy(&top_, d->h_head + 2, sizeof(top_));
                                 const unsigned long long need = (unsigned long long)(plen + 2) * KA_REC;
-                                if (plen < 1 || (long long)(top_ + need) > c->prof_cap) return fail("ka_dist_tree_run: profile arena too small for an incoming profile");
+                                if ((long long)(top_ + need) > c->prof_cap) {
+                                        // no room: take the payload off the wire all the same, then ask for a repeat with a bigger arena
+                                        if (d->d_sink.alloc((size_t)need)) return fail("hipMalloc failed");
+                                        if (d->recv(d->d_sink.p, sizeof(float) * (size_t)need, m.src)) return KA_FAIL;
+                                        if (cols && d->recv(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.src)) return KA_FAIL;
+                                        HIPCHK(hipStreamSynchronize(c->stream));
+                                        stop = true; *status = std::max(*status, 1); *grow |= 1;
+                                        continue;
+                                }
                                 const long long po = (long long)top_;
                                 top_ += need;
                                 memcpy(d->h_head + 4, &top_, sizeof(top_)); memcpy(d->h_head + 6, &po, sizeof(po));
                                 HIPCHK(hipMemcpyAsync(c->d_counters.p, d->h_head + 4, sizeof(top_), hipMemcpyHostToDevice, c->stream));
                                 HIPCHK(hipMemcpyAsync(c->d_node_prof.p + m.child, d->h_head + 6, sizeof(po), hipMemcpyHostToDevice, c->stream));
+                                HIPCHK(hipMemcpyAsync(c->d_node_len.p + m.child, d->h_head, sizeof(int), hipMemcpyHostToDevice, c->stream));
                                 if (d->recv(c->d_prof_arena.p + po, sizeof(float) * (size_t)need, m.src)) return KA_FAIL;
                                 if (cols && d->recv(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.src)) return KA_FAIL;
                                 if (cols) ka_launch_cols_pack(c->d_colof.p, c->d_seq_off.p, c->d_node_len.p, m.d_members.p, m.d_moff.p, m.nmem, d->d_colbuf.p, 1, c->stream);
@@ -2440,7 +2470,7 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
                                 c->injected.push_back(m.child);
                         }
                 }
-                if (dst == d->rank) {
+                if (dst == d->rank && !stop) {
                         HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
                         ka_launch_task_level(&D, d->top_blocks[i].p, (int)d->top_blocks[i].n, 0, 0, c->stream);
                         c->n_launches++;
@@ -2450,8 +2480,53 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         c->ran = true; c->partial = true;
+        // how this rank's kernels went (ka_tree_sync would turn an overflow of a partial run into a failure of this rank alone)
+        int err = 0;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(&err, c->d_error.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (err >= 1 && err <= 4) { *status = std::max(*status, 1); *grow |= (err == 1) ? 1 : (err == 2 ? 2 : (err == 3 ? 4 : 8)); }
+        else if (err != 0) { *status = 2; fail(err == 5 ? "device watchdog: a strip pipeline stopped making progress" : "device watchdog: a wait between workgroups never completed"); }
+        (void)n_tasks;
+        return KA_OK;
+}
+
+// One step of the sharded tree: from the leaves to every rank holding every record and coded path.  Every rank learns how
+// every other rank's part went BEFORE the collectives of the gather (all-reduce of the status: a rank that failed alone would
+// leave the others waiting in RCCL); an arena overflow anywhere makes every rank repeat the step, the ranks that overflowed
+// with bigger arenas -- what ka_tree_sync does for a single GPU.
+extern "C" int ka_dist_tree_run(ka_dist* d)
+{
+        if (!d || !d->planned) return fail("ka_dist_tree_run: plan first");
+        ka_ctx* c = d->c;
+        HIPCHK(hipSetDevice(c->device));
+        const auto t_begin = std::chrono::steady_clock::now();
+        const int n_tasks = c->n_tasks;
+        if (d->d_status.alloc(1)) return fail("hipMalloc failed");
+        for (int attempt = 0; ; attempt++) {
+                int status = 0, grow = 0;
+                if (dist_tree_attempt(d, &status, &grow)) return KA_FAIL;
+                const std::string why = g_err;
+                int agreed = status;
+                if (d->world > 1 || d->comm) {
+                        HIPCHK(hipMemcpyAsync(d->d_status.p, &status, sizeof(int), hipMemcpyHostToDevice, c->stream));
+                        if (d->all_reduce_i32(d->d_status.p, 1, true)) return KA_FAIL;
+                        HIPCHK(hipMemcpyAsync(&agreed, d->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(hipStreamSynchronize(c->stream));
+                }
+                if (agreed == 0) break;
+                if (agreed >= 2) return fail(status >= 2 ? why : std::string("ka_dist_tree_run: another rank's part of the step failed"));
+                if (attempt >= 24) return fail("ka_dist_tree_run: device arenas kept overflowing");
+                d->retries++;
+                if (grow & 1) { c->prof_cap *= 2; c->path_cap *= 2; c->d_prof_arena.release(); c->d_path_arena.release(); }
+                if (grow & 2) { c->scratch_cap *= 2; c->d_scratch.release(); }
+                if (grow & 4) { c->path_cap *= 2; c->d_path_arena.release(); }
+                if (grow & 8) { c->dbg_cap *= 2; c->d_dbg_arena.release(); }
+                if (c->d_prof_arena.alloc((size_t)c->prof_cap) || c->d_path_arena.alloc((size_t)c->path_cap) ||
+                    c->d_scratch.alloc((size_t)c->scratch_cap) || c->d_dbg_arena.alloc((size_t)std::max<long long>(c->dbg_cap, 1)))
+                        return fail("hipMalloc failed while growing an arena");
+        }
         // ---- every rank ends with every record and every coded path ----
-        if (ka_tree_sync(c)) return KA_FAIL;                        // (arena overflow, watchdogs: partial runs do not re-run)
+        if (ka_tree_sync(c)) return KA_FAIL;                        // (clean on every rank: reads the counters)
         ka_launch_path_counts(c->d_recs.p, d->d_mine.p, n_tasks, d->d_counts.p, c->stream);
         if (d->all_reduce_i32(d->d_counts.p, (size_t)n_tasks, false)) return KA_FAIL;
         std::vector<int> counts(n_tasks);
@@ -2478,6 +2553,9 @@ extern "C" int ka_dist_tree_run(ka_dist* d)
         d->last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         return KA_OK;
 }
+
+// How many times ka_dist_tree_run repeated a step on this rank because an arena overflowed somewhere (tests, reports)
+extern "C" int ka_dist_retries(ka_dist* d) { return d ? d->retries : -1; }
 
 // Records (task order, path_off into paths) and coded paths of the last ka_dist_tree_run; *used = ints written.
 extern "C" int ka_dist_download(ka_dist* d, ka_task_rec* recs, int* paths, long long paths_cap, long long* used)

@@ -89,6 +89,7 @@ struct KaTreeDev {
                                        // 2 also at two strips per SIMD, 3 always (experiments; KA_Q1 in the environment)
         int ho_mode;                   // neighbouring strips of a pass hand over through LDS rings (ka_strip<.., HO>): 0 off, 1 on,
                                        // 2 on with four strips per workgroup (KA_HO in the environment)
+        int hw_mode;                   // strips with helper waves (ka_wstrip.h) on levels with at most four items per workgroup: 0 off, 1 on (KA_HW in the environment)
         int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
         int cons_K;                    // anchors
         int cons_maxlen;               // longest sequence: bounds every anchor position

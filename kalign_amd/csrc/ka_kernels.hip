@@ -135,6 +135,7 @@ struct TaskShared {
         unsigned long long sub_t[7];   //   subtrees, staging / pass / meetup / total cycles (sums over the workgroup's subtrees), longest one, sum of level*1e6 + R*1e3 + C
         int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
         int ho_ok;                     // neighbouring strips of this task hand over through LDS rings (ka_strip<.., HO>; KaTreeDev::ho_mode, profile-profile tasks of the 8-wave kernel)
+        int hw_ok;                     // levels with at most four items per workgroup run their strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode, profile-profile tasks of the 8-wave kernel)
         // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
         // over the workgroups, agent-scope hand-over, two cluster barriers per level).  As soon as a level has at least
         // G sub-problems (or single-strip passes) the cluster SPLITS: every workgroup takes its share of the
@@ -254,6 +255,7 @@ __device__ __forceinline__ void best_merge(Best& x, float omx, float omx2, int o
 }
 
 #include "ka_subtree.h"
+#include "ka_wstrip.h"
 
 // Queue the two passes of sub-problem `slot` for the next recursion level.  A pass with more
 // than 32 rows becomes strip items (its strips are contiguous and ascending, so strip k-1 is
@@ -590,7 +592,7 @@ __device__ void ka_cluster_sync(TaskShared& S)
 // The passes of one recursion level: its work items (strips, packed jobs) dealt to / pulled by the waves of the team.
 // Q1: the kernel also carries the one-row-per-lane strip (TaskShared::srows == 64 selects it per task)
 // HO: strips dealt to neighbouring waves of a workgroup hand over through LDS rings (ka_strip<.., HO>; TaskShared::ho_ok)
-template <int KIND, int NRES, int NB, bool Q1 = false, bool HO = false>
+template <int KIND, int NRES, int NB, bool Q1 = false, bool HO = false, bool HW = false>
 __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cur, const int level, const KaSub* qc, char* lds_waves,
                                              const float* tss, long long* pslot)
 {
@@ -631,6 +633,43 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                         const int per = max((nstatic + Gw - 1) / Gw, 1);
                         int it = __builtin_amdgcn_readfirstlane((wave < per && member_w * per + wave < nstatic) ? member_w * per + wave : ntotal);
                         bool dealt = true;
+                        // Helper mode (ka_wstrip.h): every item of the level is dealt statically, at most four per workgroup
+                        // (waves 0..3, one per SIMD) -- wave w + 4 serves the strip of wave w.  The same for every workgroup of the
+                        // cluster (ntotal, Gw and per are), so both ends of a hand-over between workgroups speak the same protocol.
+                        const bool wmode = HW && KIND == KA_PP && KA_NW == 8 && ntotal <= nslots && per <= KA_NW / 2
+                                           && __builtin_amdgcn_readfirstlane(S.hw_ok) != 0 && __builtin_amdgcn_readfirstlane(S.srows) == KA_STRIP_ROWS;
+                        if (HW && KIND == KA_PP && wmode && wave >= KA_NW / 2) {
+                                const int sw = wave - KA_NW / 2;                       // the strip wave this one helps
+                                const int hit = __builtin_amdgcn_readfirstlane((sw < per && member_w * per + sw < nstatic) ? member_w * per + sw : ntotal);
+                                if (hit < nitems) {
+                                        const int2 item = items[hit];
+                                        const int subi = __builtin_amdgcn_readfirstlane(item.x);
+                                        const int dk = __builtin_amdgcn_readfirstlane(item.y);
+                                        const KaSub* sp = qc + subi;
+                                        const int dir = dk >> 16, k = dk & 0xffff;
+                                        if (dir != KA_ITEM_SUBTREE) {
+                                                const int sa = __builtin_amdgcn_readfirstlane(sp->starta);
+                                                const int ea = __builtin_amdgcn_readfirstlane(sp->enda);
+                                                const int sbb = __builtin_amdgcn_readfirstlane(sp->startb);
+                                                const int eb = __builtin_amdgcn_readfirstlane(sp->endb);
+                                                const int roff = __builtin_amdgcn_readfirstlane(sp->roff);
+                                                const float ja = ka_uniform_f(dir == KA_FWD ? sp->fin.a : sp->bin.a);
+                                                const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
+                                                const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
+                                                const int mid_ = ((ea - sa) / 2) + sa;
+                                                const int nrows_ = (dir == KA_FWD) ? mid_ - sa : ea - mid_;
+                                                const int ns = ka_strips_of(nrows_, KA_STRIP_ROWS);
+                                                const bool prod_local = k > 0 && (hit - 1) / per == member_w;
+                                                const bool cons_local = k + 1 < ns && hit + 1 < nstatic && (hit + 1) / per == member_w;
+                                                if (nrows_ > 0)
+                                                        ka_whelper<NRES>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k, ns,
+                                                                         ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (hit - k)), lane,
+                                                                         lds_waves + sw * KA_WAVE_LDS, lds_waves + wave * KA_WAVE_LDS, (int*)(lds_waves - KA_LDS_HO_BACK), sw,
+                                                                         k == 0 ? 0 : (prod_local ? 1 : 2), cons_local);
+                                        }
+                                }
+                                return;
+                        }
                         while (true) {
                                 // One lane takes the next item, then it is broadcast.  The puller lane is
                                 // compared through an opaque copy: with a plain `lane == 0` the optimiser
@@ -689,6 +728,18 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const bool in_lds = ho_lvl && prod_local && wave > 0;
                                 const bool out_lds = ho_lvl && cons_local && wave + 1 < KA_NW;
                                 int* const ho_ctl_w = (int*)(lds_waves - KA_LDS_HO_BACK) + wave;
+                                if constexpr (HW && KIND == KA_PP) {
+                                        if (wmode && (dir == KA_FWD ? mid_ - sa : ea - mid_) > 0) {
+                                                const unsigned ctl_u = (unsigned)(unsigned long long)(lds_waves - KA_LDS_HO_BACK);
+                                                // the row above: the out ring and step count of the wave before this one, or the in ring my helper fills
+                                                const unsigned in_ring_u = prod_local ? (unsigned)(unsigned long long)(lds_waves + (wave - 1) * KA_WAVE_LDS + KA_HO_RING)
+                                                                                      : (unsigned)(unsigned long long)(lds_waves + (wave + KA_NW / 2) * KA_WAVE_LDS + KA_W_INRING);
+                                                const unsigned in_word_u = ctl_u + 4 * (prod_local ? KA_W_TPUB(wave - 1) : KA_W_IN(wave));
+                                                ka_wstrip<NRES, NB>(S, sa, ea, sbb, eb, dir, k, lane, lds_waves + wave * KA_WAVE_LDS,
+                                                                    in_ring_u, in_word_u, prod_local ? 63 : 0, ctl_u, wave, pslot);
+                                                continue;
+                                        }
+                                }
                                 if (Q1 && srows == KA_STRIP1_ROWS)
                                         ka_strip<KIND, NRES, NB, 1, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                              ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
@@ -707,7 +758,7 @@ __device__ const int ka_pow3[20] = { 1, 3, 9, 27, 81, 243, 729, 2187, 6561, 1968
                                      43046721, 129140163, 387420489, 1162261467 };
 #define KA_REC_DEPTH 19                                              // recursion levels the keys of ka_meetup<.., REC> can tell apart
 
-template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false, bool HO = false>
+template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false, bool HO = false, bool HW = false>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
@@ -718,7 +769,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         // HO: the waves' hand-over control words (columns written / columns read, ka_strip) go back to zero while no strip runs:
         // before the first level and at the start of every meetup phase; the barrier that follows orders it before the next strips
         auto ho_clear = [&]() {
-                if (HO && S.ho_ok && tid < 16) ((int*)(lds_waves - KA_LDS_HO_BACK))[tid] = 0;
+                if (((HO && S.ho_ok) || (HW && S.hw_ok)) && tid < 16) ((int*)(lds_waves - KA_LDS_HO_BACK))[tid] = 0;
         };
         ho_clear();
         if (lead) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
@@ -800,7 +851,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
 #ifdef KA_PROF
                 if (S.prof && lead && level < 4) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; pslot[6] = 0; pslot[7] = 0; if (level < 4) for (int x = 0; x < 8; ++x) pslot[256 + x] = 0; } }
 #endif
-                ka_run_items<KIND, NRES, NB, Q1, HO>(S, cur, level, qc, lds_waves, tss, pslot);
+                ka_run_items<KIND, NRES, NB, Q1, HO, HW>(S, cur, level, qc, lds_waves, tss, pslot);
 #ifdef KA_PROF
                 if (pslot && lane == 0) pslot[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -2266,6 +2317,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // LDS hand-over between neighbouring strips (ka_strip<.., HO>): profile-profile tasks of the 8-wave kernel, fast mode.
                 // ho_mode >= 2: four strips per workgroup (one per SIMD) instead of three -- fewer hand-overs cross workgroups.
                 S.ho_ok = (Q1 && NB == 0 && D.ho_mode && kind == KA_PP) ? 1 : 0;
+                S.hw_ok = (Q1 && D.hw_mode && kind == KA_PP) ? 1 : 0;
                 if (Q1 && kind == KA_PP) {
                         // Tasks with more top-level strips than the table's workgroups have SIMDs (rows beyond ~4000: nucleotide
                         // jobs) take a workgroup per four strips, up to what the launch gave them: 4096 x 2000 nt 104 -> 93 ms.
@@ -2342,11 +2394,11 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         // P2
         if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1, Q1 && NB == 0>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1, Q1 && NB == 0, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         // no B / Z / X in the job (the usual case): every profile's counts [20..22] are zero and the reference skips
         // zero counts (aln_profileprofile.c:70-77) -- 20 terms per cell instead of 23
-        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1, Q1 && NB == 0>(S, s_dbg, lds_waves, tss, D.trace);
-        else ka_hirschberg<KA_PP, 23, NB, false, Q1, Q1 && NB == 0>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1, Q1 && NB == 0, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else ka_hirschberg<KA_PP, 23, NB, false, Q1, Q1 && NB == 0, Q1>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         // exact confidence: the cluster's last barrier (inside ka_hirschberg) has published every member's records
         bool conf_exact = false;

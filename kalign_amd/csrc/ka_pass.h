@@ -645,11 +645,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 const bool term = (at0 && near_t) || (atN && far_t);
                                 nAa = at0 ? -KA_F : acc.x;
                                 nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
-                                nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
+                                // (the terminal case `max(gb, a) + t` as the inner case with both penalties replaced by t:
+                                // max(x, y) + c == max(x + c, y + c) bit for bit, and two selects on the operands instead of
+                                // the exec-masked regions the compiler made of `term ? .. : ..` over the results; round 4)
+                                nAgb = kmax(upgb + (term ? tA : eA), upa + (term ? tA : oA));
                                 // B: the row above is A's fresh state
                                 nBa = at0 ? -KA_F : acc.y;
                                 nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
-                                nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
+                                nBgb = kmax(nAgb + (term ? tB : eB), nAa + (term ? tB : oB));
                         }
                         // No predication on "this lane is inside its row/column range": state only flows DOWN the lanes
                         // (lane l -> l+1) and a lane's first real column (v = 0) rebuilds all six states from the lane above,
@@ -707,7 +710,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 const bool term = (at0 && near_t) || (atN && far_t);
                                 nAa = at0 ? -KA_F : a1;
                                 nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
-                                nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
+                                nAgb = kmax(upgb + (term ? tA : eA), upa + (term ? tA : oA));
                         }
                         cAa = nAa; cAga = nAga; cAgb = nAgb;
                         dga = upa; dgga = upga; dggb = upgb;
@@ -1111,10 +1114,11 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 const bool term = (at0 && near_t) || (atN && far_t);
                 const float nAa = at0 ? -KA_F : acc.x;
                 const float nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
-                const float nAgb = term ? kmax(upgb, upa) + tA : kmax(upgb + eA, upa + oA);
+                // (selects on the penalties, not on the results: see ka_strip)
+                const float nAgb = kmax(upgb + (term ? tA : eA), upa + (term ? tA : oA));
                 const float nBa = at0 ? -KA_F : acc.y;
                 const float nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
-                const float nBgb = term ? kmax(nAgb, nAa) + tB : kmax(nAgb + eB, nAa + oB);
+                const float nBgb = kmax(nAgb + (term ? tB : eB), nAa + (term ? tB : oB));
                 // (no range predication, as in ka_strip: state flows down the lanes of a slot only, lane 0 of every
                 // slot takes the generated row, and v == 0 rebuilds all six states)
                 cAa = nAa; cAga = nAga; cAgb = nAgb;

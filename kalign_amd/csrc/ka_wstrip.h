@@ -1,0 +1,526 @@
+// ka_wstrip.h -- profile-profile strips with a HELPER WAVE (round 4).
+//
+// ka_strip (ka_pass.h) does everything itself: every 32 steps it issues the global->LDS copy of the next column batch, every
+// 64 steps it flushes its last row behind a release fence and reloads its boundary batch behind an acquire.  Those "event
+// steps" cost 1700-3500 cycles against ~404 for a plain step (profiles/r03b_strip_phases.log): 20-30 % of every pass, and
+// their code (and its spills) sits inside the strip's loop.  A lone wave issues one instruction per ~4.4 cycles of ANY kind,
+// while its SIMD could issue a scalar, an LDS and a memory instruction of ANOTHER wave in the same cycles -- and at the
+// levels that matter for latency (at most four work items per 8-wave workgroup: one strip per SIMD) waves 4..7 of the
+// workgroup have nothing to do.
+//
+// So here the strip wave only computes.  Everything it touches is in LDS:
+//   * its column ring (same layout as ka_strip's: chunk-major, 128 columns), filled by its helper (wave + 4), which also
+//     applies set_gap_penalties_n's multiplier to the three gap fields (three multiplies per COLUMN instead of per step);
+//   * its boundary row ("the row above"): the out ring of the strip above when that runs on the wave before it, else an in
+//     ring in the helper's region that the helper fills -- for the first strip of a pass with the pass's generated row -1
+//     (aln_seqseq.c:40-58: a serial chain along the columns, which ka_strip's first strips carried in every step), for a
+//     strip whose upper neighbour runs in another workgroup with that strip's last row, fetched from the HBM row buffer
+//     behind its progress flag;
+//   * its out ring: the strip's last row, one ds_write per step by the lane that owns it (no shift register, no
+//     rotate-and-insert for partial strips, no flush).  The strip below reads it in place, or the helper copies it to the
+//     HBM row buffer (and publishes it to a strip in another workgroup: release fence + flag -- in the helper).
+// Steps run in OCTETS: eight unrolled steps (immediate LDS offsets for boundary and out ring), then the strip publishes its
+// step count (one ds_write) and compares two LDS words read one step earlier with what the next octet needs ("columns
+// loaded / out slots free" from the helper, "boundary columns available" from the producer): ~8 instructions per 8 steps,
+// no branch taken unless it must wait.  A strip therefore starts 63 + ~8 columns behind the strip above it, not 63 + 64.
+//
+// Same arithmetic as ka_strip, statement for statement (binary32, the reference's order, no contraction).
+#pragma once
+
+#define KA_W_CH 8                                               // steps per octet
+#define KA_W_BIG (1 << 30)
+typedef float float3v __attribute__((ext_vector_type(3)));
+
+// control words of helper mode: 16 ints at lds_waves - KA_LDS_HO_BACK (the words ka_strip<.., HO> uses in ITS mode; a level
+// runs in one mode or the other, ka_hirschberg zeroes them between levels):
+//   [w]      steps strip wave w has completed (its t_pub)
+//   [4 + w]  GO: columns strip w may read / steps it may take, from its helper (see ka_whelper)
+//   [8 + w]  boundary columns in strip w's helper-fed in ring
+#define KA_W_TPUB(w_) (w_)
+#define KA_W_GO(w_) (4 + (w_))
+#define KA_W_IN(w_) (8 + (w_))
+#define KA_W_INRING 0                                           // the in ring: first 4 KB of the HELPER wave's region (256 slots x 16 B)
+
+template <int NRES, int NB>
+__device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
+                                          const int dir, const int k, const int lane, char* wlds,
+                                          const unsigned in_ring_u, const unsigned in_word_u, const int in_bias,
+                                          const unsigned ctl_u, const int w, long long* pslot = nullptr)
+{
+        // the strip wave goes first on its SIMD: its helper (same SIMD, priority 0) takes the issue slots it leaves
+        __builtin_amdgcn_s_setprio(3);
+        const int ncols = endb - startb;
+        const int mid = ((enda - starta) / 2) + starta;
+        const int r0 = (dir == KA_FWD) ? starta : mid;
+        const int r1 = (dir == KA_FWD) ? mid : enda;
+        const int nrows = r1 - r0;                                    // > 0 (the caller keeps empty passes on ka_strip)
+        const int Lb = __builtin_amdgcn_readfirstlane(S.Lb);
+        const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == Lb);
+        const bool far_t = (dir == KA_FWD) ? (endb == Lb) : (startb == 0);
+        int* const wdu = ka_uniform_ptr(S.watchdog);
+        const float m1 = ka_uniform_f(S.p1_mult);
+
+        const int u0 = k * KA_STRIP_ROWS;
+        const int nr = min(KA_STRIP_ROWS, nrows - u0);
+        const int nl = (nr + 1) >> 1;
+        const int lastl = nl - 1;
+        const bool last_is_b = (nr & 1) == 0;
+        const bool actB = 2 * lane + 1 < nr;
+        const int uA = u0 + min(2 * lane, nr - 1);
+        const int uB = u0 + min(2 * lane + 1, nr - 1);
+        const int iA = (dir == KA_FWD) ? (r0 + uA) : (r1 - 1 - uA);
+        const int iB = (dir == KA_FWD) ? (r0 + uB) : (r1 - 1 - uB);
+        const int recA = iA + 1, recB = iB + 1;
+        const int prevA = (dir == KA_FWD) ? recA - 1 : recA + 1;
+        const int prevB = (dir == KA_FWD) ? recB - 1 : recB + 1;
+
+        const unsigned wlds_u = (unsigned)(unsigned long long)wlds;
+        const unsigned out_u = wlds_u + KA_HO_RING;
+        const unsigned tpub_u = ctl_u + 4 * KA_W_TPUB(w), go_u = ctl_u + 4 * KA_W_GO(w);
+        const unsigned long long own_mask = 1ull << lastl;            // the lane that owns the strip's last row
+
+        // ---- stationary row operand (as in ka_strip) ----
+        float oA, eA, tA, oB, eB, tB, orpA, orpB;
+        float2v p1v[NRES];
+        {
+                const float* pA = S.p1 + ((long long)recA << 6);
+                const float* pB = S.p1 + ((long long)recB << 6);
+                oA = pA[55] * m1; eA = pA[56] * m1; tA = pA[57] * m1;
+                oB = pB[55] * m1; eB = pB[56] * m1; tB = pB[57] * m1;
+                orpA = S.p1[((long long)prevA << 6) + 55] * m1;
+                orpB = S.p1[((long long)prevB << 6) + 55] * m1;
+                constexpr int NV = (NRES + 3) / 4;
+                float4v va[NV], vb[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
+#pragma unroll
+                for (int c = 0; c < NRES; ++c) {
+                        p1v[c].x = va[c >> 2][c & 3];
+                        p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
+                }
+        }
+        KaBonus<NB> bonA, bonB;
+        if (NB) { bonA.load(S.ent, iA); bonB.load(S.ent, iB); }
+
+        float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
+        float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
+        float dga = -KA_F, dgga = -KA_F, dggb = -KA_F;
+        float copen_prev = 0.0f;
+        float4v q[2][KA_REC_CHUNKS];                                  // column record: this step / next step
+        float4v bq[2];                                                // boundary state of column t: this step / next step
+        int gv = 0, iv = 0;                                           // the two control words, read one step before they are tested
+        unsigned in_oct = 0, out_oct = 0;                             // bases of an octet's immediate-offset LDS accesses
+
+        auto ring_read = [&](float4v* dstq, int vcol, auto& dep) {
+                const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
+                if (NRES <= 8) {
+                        asm volatile("ds_read_b128 %0, %5\n\t"
+                                     "ds_read_b128 %1, %5 offset:2048\n\t"
+                                     "ds_read_b128 %2, %5 offset:10240\n\t"
+                                     "ds_read_b128 %3, %5 offset:12288"
+                                     : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[5]), "=&v"(dstq[6]), "+v"(dep)
+                                     : "v"(a)
+                                     : "memory");
+                        return;
+                }
+                asm volatile("ds_read_b128 %0, %8\n\t"
+                             "ds_read_b128 %1, %8 offset:2048\n\t"
+                             "ds_read_b128 %2, %8 offset:4096\n\t"
+                             "ds_read_b128 %3, %8 offset:6144\n\t"
+                             "ds_read_b128 %4, %8 offset:8192\n\t"
+                             "ds_read_b128 %5, %8 offset:10240\n\t"
+                             "ds_read_b128 %6, %8 offset:12288"
+                             : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "=&v"(dstq[3]), "=&v"(dstq[4]), "=&v"(dstq[5]), "=&v"(dstq[6]),
+                               "+v"(dep)
+                             : "v"(a)
+                             : "memory");
+        };
+        // everything read from LDS one step ago has landed (the control words ride along: no use can move above the wait)
+        auto ring_wait = [&](float4v* qq, float4v& bb) {
+                if (NRES <= 8) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]), "+v"(bb), "+v"(gv), "+v"(iv) : : "memory");
+                        return;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]), "+v"(bb), "+v"(gv), "+v"(iv)
+                             :
+                             : "memory");
+        };
+        auto lds_word = [&](const unsigned addr) -> int {
+                int x;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(addr) : "memory");
+                return __builtin_amdgcn_readfirstlane(x);
+        };
+        // Before steps t0 .. t0+CH-1: they read column records and boundary states of columns <= t0 + CH and write out slots
+        // of steps <= t0 + CH - 1.  Columns clamp at ncols, steps end at nsteps.
+        const int nsteps = ncols + nl;
+        auto wait_for = [&](const int t0) {
+                const int needg = min(t0 + KA_W_CH + 1, nsteps + 1);
+                const int needi = min(t0 + KA_W_CH + 1, ncols + 1);
+                int g = __builtin_amdgcn_readfirstlane(gv), i = __builtin_amdgcn_readfirstlane(iv) - in_bias;
+                if (g >= needg && i >= needi) return;
+#ifdef KA_PROF
+                const long long tw0 = __builtin_amdgcn_s_memtime();
+                const bool for_in = (g >= needg);
+#endif
+                int spins = 0;
+                while (g < needg || i < needi) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (ka_spin_expired(wdu, ++spins, 1 << 22, 5)) break;
+                        g = lds_word(go_u); i = lds_word(in_word_u) - in_bias;
+                }
+#ifdef KA_PROF
+                // KA_PROF builds (tools/strip_phases.py): [256+0] cycles waited, [256+3] waits, [256+1] of them for the boundary row only
+                if (pslot && lane == 0) { pslot[256 + 0] += __builtin_amdgcn_s_memtime() - tw0; pslot[256 + 3] += 1; pslot[256 + 1] += for_in ? 1 : 0; }
+#endif
+        };
+        auto prefetch_words = [&]() {
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(gv), "=&v"(iv) : "v"(go_u), "v"(in_word_u) : "memory");
+        };
+        auto publish = [&](const int tdone) {
+                asm volatile("ds_write_b32 %0, %1" : : "v"(tpub_u), "v"(tdone) : "memory");
+        };
+
+        // One wavefront step.  ST: steady state (no edge cases); P: the half of q / bq that holds this step's operands;
+        // I: position in an octet (0 .. CH-1; immediate LDS offsets, the octet's checks are compile-time) or -1 (single step)
+        auto step = [&](const int t, auto st_tag, auto par_tag, auto i_tag, auto lb_tag) {
+                constexpr bool LASTB = decltype(lb_tag)::value;
+                constexpr bool ST = decltype(st_tag)::value;
+                constexpr int P = decltype(par_tag)::value;
+                constexpr int I = decltype(i_tag)::value;
+                const int v = t - lane;
+
+                ring_wait(q[P], bq[P]);
+                // The strip's last row as the PREVIOUS step left it: its owner writes column t - 1 - lastl into out slot (t - 1) & 255.
+                // (Here and not at the end of the step that computed it: a ds_write right in front of the next step's
+                // s_waitcnt lgkmcnt(0) would be waited for; here the whole dot product lies between it and the next wait.)
+                {
+                        const int vLp = t - 1 - lastl;
+                        if (ST || (vLp >= 0 && vLp <= ncols)) {
+                                float3v o;
+                                o.x = LASTB ? cBa : cAa; o.y = LASTB ? cBga : cAga; o.z = LASTB ? cBgb : cAgb;
+                                unsigned long long sv;
+                                if constexpr (I >= 1) {
+                                        asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b96 %1, %2 offset:%4\n\ts_mov_b64 exec, %0"
+                                                     : "=&s"(sv) : "v"(out_oct), "v"(o), "s"(own_mask), "n"((I - 1) * 16) : "memory", "scc");
+                                } else {
+                                        const unsigned oa = out_u + ((((unsigned)t - 1u) & 255u) << 4);
+                                        asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
+                                                     : "=&s"(sv) : "v"(oa), "v"(o), "s"(own_mask) : "memory", "scc");
+                                }
+                        }
+                }
+                // steps < t are computed and written: say so, then make sure the next CH steps have their operands
+                if (I == 0 || (I < 0 && (t & (KA_W_CH - 1)) == 0)) { publish(t); wait_for(t); }
+                const float copen = q[P][5].w, cext = q[P][6].x;                    // (the helper has applied the multiplier; ctext only feeds row -1)
+
+                // the row above A: lane l-1's row B, lane 0 takes the boundary state of column t
+                const float upa = wave_shr1_old(bq[P].x, cBa), upga = wave_shr1_old(bq[P].y, cBga), upgb = wave_shr1_old(bq[P].z, cBgb);
+
+                float2v acc;
+                acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
+                acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
+                {
+                        float2v prod;
+                        prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
+#pragma unroll
+                        for (int c = NRES - 1; c >= 1; --c) {
+                                float2v nprod;
+                                switch ((c - 1) & 3) {
+                                case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                case 1: nprod = ka_mul_bcast<1>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                case 2: nprod = ka_mul_bcast<2>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                default: nprod = ka_mul_bcast<3>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                }
+                                acc = acc + prod;
+                                prod = nprod;
+                        }
+                        acc = acc + prod;
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
+                        // next step's operands: after the chain (see ka_strip)
+                        __builtin_amdgcn_sched_barrier(0);
+                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
+                        if constexpr (I >= 0) {
+                                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[1 - P]) : "v"(in_oct), "n"(I * 16) : "memory");
+                        } else {
+                                const unsigned ia = in_ring_u + ((((unsigned)t + 64u) & 255u) << 4);
+                                asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[1 - P]) : "v"(ia) : "memory");
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                }
+                float nAa, nAga, nAgb, nBa, nBga, nBgb;
+                if (ST) {
+                        nAa = acc.x;
+                        nAga = kmax(cAga + cext, cAa + copen);
+                        nAgb = kmax(upgb + eA, upa + oA);
+                        nBa = acc.y;
+                        nBga = kmax(cBga + cext, cBa + copen);
+                        nBgb = kmax(nAgb + eB, nAa + oB);
+                } else {
+                        // (selects on the OPERANDS, no branches: max(x, y) + c == max(x + c, y + c) bit for bit -- rounding is monotonic --
+                        // so the terminal case `max(gb, a) + t` is the inner case with both penalties replaced by t; written as
+                        // `term ? .. : ..` over the two results the compiler made four exec-masked regions per step of it)
+                        const bool at0 = (v == 0), atN = (v == ncols);
+                        const bool edge = at0 || atN;
+                        const bool term = (at0 && near_t) || (atN && far_t);
+                        const float xeA = term ? tA : eA, xoA = term ? tA : oA, xeB = term ? tB : eB, xoB = term ? tB : oB;
+                        nAa = at0 ? -KA_F : acc.x;
+                        nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
+                        nAgb = kmax(upgb + xeA, upa + xoA);
+                        nBa = at0 ? -KA_F : acc.y;
+                        nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
+                        nBgb = kmax(nAgb + xeB, nAa + xoB);
+                }
+                cAa = nAa; cAga = nAga; cAgb = nAgb;
+                cBa = nBa; cBga = nBga; cBgb = nBgb;
+                dga = upa; dgga = upga; dggb = upgb;
+                copen_prev = copen;
+
+                if (I == KA_W_CH - 1 || (I < 0 && ((t + 1) & (KA_W_CH - 1)) == 0)) prefetch_words();
+        };
+
+        auto single = [&](const int t, auto st_tag, auto lb_tag) {
+                if (t & 1) step(t, st_tag, std::integral_constant<int, 1>(), std::integral_constant<int, -1>(), lb_tag);
+                else step(t, st_tag, std::integral_constant<int, 0>(), std::integral_constant<int, -1>(), lb_tag);
+        };
+        // eight steps with compile-time parities and immediate LDS offsets; t0 is a multiple of 8
+        auto octet = [&](const int t0, auto st_tag, auto lb_tag) {
+                in_oct = in_ring_u + ((((unsigned)t0 + 64u) & 255u) << 4);
+                out_oct = out_u + (((unsigned)t0 & 255u) << 4);
+                step(t0 + 0, st_tag, std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), lb_tag);
+                step(t0 + 1, st_tag, std::integral_constant<int, 1>(), std::integral_constant<int, 1>(), lb_tag);
+                step(t0 + 2, st_tag, std::integral_constant<int, 0>(), std::integral_constant<int, 2>(), lb_tag);
+                step(t0 + 3, st_tag, std::integral_constant<int, 1>(), std::integral_constant<int, 3>(), lb_tag);
+                step(t0 + 4, st_tag, std::integral_constant<int, 0>(), std::integral_constant<int, 4>(), lb_tag);
+                step(t0 + 5, st_tag, std::integral_constant<int, 1>(), std::integral_constant<int, 5>(), lb_tag);
+                step(t0 + 6, st_tag, std::integral_constant<int, 0>(), std::integral_constant<int, 6>(), lb_tag);
+                step(t0 + 7, st_tag, std::integral_constant<int, 1>(), std::integral_constant<int, 7>(), lb_tag);
+        };
+        // a phase: single steps up to the next multiple of 8, octets, single steps for the rest.  The head of a strip (its lanes
+        // entering at column 0: what the strip below waits for before it can start) and its tail run the edge form of the step
+        // in octets too -- as single steps with run-time parity they cost 2.3 steady steps each (profiles/r04_strip_phases_v1.log).
+        auto run = [&](int& t, const int tend, auto st_tag, auto lb_tag) {
+                for (; t < tend && (t & (KA_W_CH - 1)); ++t) single(t, st_tag, lb_tag);
+                for (; t + KA_W_CH <= tend; t += KA_W_CH) octet(t, st_tag, lb_tag);
+                for (; t < tend; ++t) single(t, st_tag, lb_tag);
+        };
+        auto phases = [&](auto lb_tag) {
+                const int t_steady0 = min(nl, nsteps);
+                const int t_steady1 = ncols;
+                int t = 0;
+                run(t, t_steady0, std::false_type(), lb_tag);
+#ifdef KA_PROF
+                if (pslot && lane == 0) pslot[256 + 2] += __builtin_amdgcn_s_memtime() - pslot[2];      // the head
+                const long long toct0 = __builtin_amdgcn_s_memtime();
+                const int t_in = t;
+#endif
+                run(t, t_steady1, std::true_type(), lb_tag);
+#ifdef KA_PROF
+                // cycles in the steady phase (its waits included) / its steps
+                if (pslot && lane == 0) { pslot[6] += __builtin_amdgcn_s_memtime() - toct0; pslot[7] += t - t_in; }
+                const long long ttail0 = __builtin_amdgcn_s_memtime();
+#endif
+                run(t, nsteps, std::false_type(), lb_tag);
+#ifdef KA_PROF
+                if (pslot && lane == 0) pslot[256 + 4] += __builtin_amdgcn_s_memtime() - ttail0;             // the tail
+#endif
+        };
+        static_assert(KA_W_CH == 8, "the octet is written out for eight steps");
+
+        // the operands of step 0: column 0 (every lane: v <= 0 clamps to it) and the boundary state of column 0
+        {
+                int spins = 0;
+                while (true) {
+                        gv = lds_word(go_u); iv = lds_word(in_word_u);
+                        if (gv >= min(KA_W_CH + 1, nsteps + 1) && iv - in_bias >= min(KA_W_CH + 1, ncols + 1)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (ka_spin_expired(wdu, ++spins, 1 << 22, 5)) break;
+                }
+#ifdef KA_PROF
+                if (pslot && lane == 0 && pslot[2] == 0) pslot[2] = __builtin_amdgcn_s_memtime();
+#endif
+                float2v nodep = {0.0f, 0.0f};
+                ring_read(q[0], 0, nodep);
+                const unsigned ia = in_ring_u + ((63u & 255u) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[0]) : "v"(ia) : "memory");
+        }
+        if (last_is_b) phases(std::true_type()); else phases(std::false_type());
+        // the last step's column (vL = ncols), then done: everything the strip wrote to its out ring is in LDS before the count
+        // says so (LDS runs a wave's instructions in order)
+        {
+                float3v o;
+                o.x = last_is_b ? cBa : cAa; o.y = last_is_b ? cBga : cAga; o.z = last_is_b ? cBgb : cAgb;
+                unsigned long long sv;
+                const unsigned oa = out_u + ((((unsigned)nsteps - 1u) & 255u) << 4);
+                asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
+                             : "=&s"(sv) : "v"(oa), "v"(o), "s"(own_mask) : "memory", "scc");
+        }
+        publish(nsteps);
+        __builtin_amdgcn_s_setprio(0);
+}
+
+// ------------------------------------------------------------------------------------------
+// The helper of strip wave w (wave w + 4 of the workgroup): feeds the strip's rings and drains its out ring.
+//   in_mode   0: the strip is the first of its pass -- generate row -1 into the in ring, column batch by column batch
+//             1: the strip above runs on wave w - 1: nothing to do (the strip reads that wave's out ring and step count)
+//             2: the strip above runs in another workgroup: copy its last row from the HBM row buffer behind its flag
+//   out_local the strip below runs on wave w + 1 (reads my strip's out ring in place); else copy the out ring to the HBM
+//             row buffer -- and, when a strip below exists (in another workgroup), publish it: release fence + flag
+// GO word: min(columns loaded (BIG once all are), out slots free expressed as a step bound + 1), see ka_wstrip::wait_for.
+// ------------------------------------------------------------------------------------------
+template <int NRES>
+__device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
+                                           const float inj_a, const float inj_ga, const float inj_gb,
+                                           const int dir, const int k, const int ns, KaState* rows, int* prog, const int lane,
+                                           char* slds, char* hlds, int* ctl, const int w, const int in_mode, const bool out_local)
+{
+        const int ncols = endb - startb;
+        const int mid = ((enda - starta) / 2) + starta;
+        const int r0 = (dir == KA_FWD) ? starta : mid;
+        const int r1 = (dir == KA_FWD) ? mid : enda;
+        const int nrows = r1 - r0;
+        const int Lb = __builtin_amdgcn_readfirstlane(S.Lb);
+        const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == Lb);
+        const int u0 = k * KA_STRIP_ROWS;
+        const int nr = min(KA_STRIP_ROWS, nrows - u0);
+        const int nl = (nr + 1) >> 1;
+        const int lastl = nl - 1;
+        const int nsteps = ncols + nl;
+        const bool last_strip = (k + 1 == ns);
+        const float m2 = ka_uniform_f(S.p2_mult);
+        const float* const p2 = ka_uniform_ptr(S.p2);
+        int* const wdu = ka_uniform_ptr(S.watchdog);
+        ka_gfloat* const grows = (ka_gfloat*)rows;
+
+#define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
+#define IDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
+        const int j = lane & 31, half = lane >> 5;                    // column within a 32-column batch / which half of its chunks
+        int Lc = 0;                                                   // columns loaded into the strip's ring
+        int Li = 0;                                                   // boundary columns in the in ring (in_mode 0, 2)
+        int To = 0;                                                   // out columns copied to HBM (!out_local)
+        float ca = -KA_F, cg = -KA_F;                                 // in_mode 0: (a, ga) of the last generated column
+        int lastG = -1, lastI = -1;
+        int idle = 0;
+
+        while (true) {
+                bool progress = false;
+                // (the control words as scalars: the helper's bookkeeping runs on the scalar unit, next to the strip's vector work)
+                const int tp = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[KA_W_TPUB(w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const bool done = tp >= nsteps;
+
+                // ---- the column ring: 32 columns per batch.  Column c overwrites column c - 128, last read in step c - 66 ----
+                if (Lc <= ncols && Lc + 31 <= tp + 65) {
+                        const int c = Lc + j;
+                        float4v r[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r[i] = (float4v){0.0f, 0.0f, 0.0f, 0.0f};
+                        if (c <= ncols) {
+                                ka_gfloat4c* g = (ka_gfloat4c*)(p2 + ((long long)REC(c) << 6) + 32);
+                                if (half == 0) {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) if (ka_chunk_used<NRES>(i)) r[i] = g[i];
+                                } else {
+#pragma unroll
+                                        for (int i = 0; i < 3; ++i) if (ka_chunk_used<NRES>(4 + i)) r[i] = g[4 + i];
+                                }
+                        }
+                        // set_gap_penalties_n (aln_setup.c:101-119): fields 55..57 times the other side's nsip -- chunk 5 .w, chunk 6 .x .y
+                        if (half == 1) { r[1].w = r[1].w * m2; r[2].x = r[2].x * m2; r[2].y = r[2].y * m2; }
+                        if (c <= ncols) {
+                                char* dst = slds + ((c & 127) << 4);
+                                if (half == 0) {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) if (ka_chunk_used<NRES>(i)) *(float4v*)(dst + i * 2048) = r[i];
+                                } else {
+#pragma unroll
+                                        for (int i = 0; i < 3; ++i) if (ka_chunk_used<NRES>(4 + i)) *(float4v*)(dst + (4 + i) * 2048) = r[i];
+                                }
+                        }
+                        if (in_mode == 0) {
+                                // row -1 of the pass (aln_seqseq.c:40-58; ka_strip's FIRST steps): column 0 is the injected state, columns
+                                // 1 .. ncols-1 the serial chain g = max(g + gx, a + gy), column ncols -FLT_MAX.  The gap terms of column
+                                // Lc + jj sit in lane 32 + jj.
+                                const float gx_l = near_t ? r[2].y : r[2].x;
+                                const float gy_l = near_t ? r[2].y : r[1].w;
+                                float ma = -KA_F, mg = -KA_F, mb = -KA_F;
+#pragma unroll
+                                for (int jj = 0; jj < 32; ++jj) {
+                                        const int cc = Lc + jj;
+                                        float na, ng, nb;
+                                        if (cc == 0) { na = inj_a; ng = inj_ga; nb = inj_gb; }
+                                        else if (cc < ncols) {
+                                                const float gx = lane_bcast(gx_l, 32 + jj), gy = lane_bcast(gy_l, 32 + jj);
+                                                ng = kmax(cg + gx, ca + gy); na = -KA_F; nb = -KA_F;
+                                        } else { na = -KA_F; ng = -KA_F; nb = -KA_F; }
+                                        if (lane == jj) { ma = na; mg = ng; mb = nb; }
+                                        ca = na; cg = ng;
+                                }
+                                if (lane < 32 && c <= ncols)
+                                        *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){ma, mg, mb, 0.0f};
+                                Li = min(Lc + 32, ncols + 1);
+                        }
+                        Lc += 32;
+                        progress = true;
+                }
+
+                // ---- boundary row from another workgroup: in column c overwrites column c - 256, read in step c - 257 ----
+                if (in_mode == 2 && Li <= ncols) {
+                        const int avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        const int n = min(min(avail - Li, 64), tp + 256 - Li);
+                        if (n > 0) {
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                if (lane < n) {
+                                        const int c = Li + lane;
+                                        const ka_gfloat* r = grows + 3 * IDX(c);
+                                        const float x0 = r[0], x1 = r[1], x2 = r[2];
+                                        *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){x0, x1, x2, 0.0f};
+                                }
+                                Li += n;
+                                progress = true;
+                        }
+                }
+
+                // ---- the out ring to the HBM row buffer (16 columns or more at a time; the rest when the strip is done) ----
+                if (!out_local) {
+                        const int outc = done ? (ncols + 1) : min(max(tp - lastl, 0), ncols + 1);
+                        const int n = min(outc - To, 64);
+                        if (n >= 16 || (done && n > 0)) {
+                                if (lane < n) {
+                                        const int c = To + lane;
+                                        const float4v x = *(const float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
+                                        ka_gfloat* wr = grows + 3 * IDX(c);
+                                        wr[0] = x.x; wr[1] = x.y; wr[2] = x.z;
+                                }
+                                To += n;
+                                if (!last_strip) {
+                                        // the strip below runs in another workgroup of the cluster
+                                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                        if (lane == 0) __hip_atomic_store(prog + k, To, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                progress = true;
+                        }
+                }
+
+                // ---- what the strip may do next ----
+                const int taken = out_local ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[KA_W_TPUB(w + 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : To;
+                const int G = min(Lc > ncols ? KA_W_BIG : Lc, taken + 257 + lastl);
+                if (G != lastG || Li != lastI) {
+                        // (ring contents first, then the counts: LDS keeps a wave's order; the fence keeps the compiler's)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                                if (Li != lastI) __hip_atomic_store(&ctl[KA_W_IN(w)], Li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (G != lastG) __hip_atomic_store(&ctl[KA_W_GO(w)], G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        lastG = G; lastI = Li;
+                }
+                if (done && (out_local || To > ncols)) break;
+                if (!progress) {
+                        __builtin_amdgcn_s_sleep(8);                  // ~500 cycles: the strip publishes every ~3000
+                        if (ka_spin_expired(wdu, ++idle, 1 << 22, 5)) break;
+                } else idle = 0;
+        }
+#undef REC
+#undef IDX
+}

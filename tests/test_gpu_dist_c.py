@@ -121,3 +121,46 @@ def test_ranks_as_threads_over_the_loopback(world, anchors):
     assert all(o is not None for o in out)
     for recs, paths in out:
         _same(recs, paths, want)
+
+
+@pytest.mark.parametrize("anchors", [0, 5])
+def test_an_overflow_on_one_rank_repeats_the_step_on_all(anchors):
+    """rank 1 alone starts with device arenas that are certainly too small (KA_DEBUG_SMALL_ARENAS): its part of the step
+    overflows.  The ranks agree on the outcome before the gather's collectives, rank 1 grows its arenas, EVERY rank runs the
+    step again, and the result is the whole tree's -- no rank fails, or hangs in a collective, alone."""
+    import kalign_amd
+    from kalign_amd import api
+    world = 2
+    ctx0, codes, tasks, sd, subm, scal = _job(128, 160, seed=9)
+    want = _whole(ctx0, codes, tasks, sd, subm, scal, anchors)
+    ctx0.close()
+    L = api.load_library()
+    loop = L.ka_dist_loopback_new(world)
+    out, errs, retries = [None] * world, [], [0] * world
+
+    def rank_main(r):
+        try:
+            ctx = kalign_amd.Context(0, shared=True)
+            if r == 1:
+                ctx.debug_set_hooks(1)                      # KA_DEBUG_SMALL_ARENAS
+            ctx.tree_upload(codes, tasks, subm, scal, sd)
+            d = api.Dist(ctx, r, world, loopback=loop)
+            d.plan()
+            if anchors:
+                d.consistency(anchors, 2.0)
+            d.tree_run()
+            retries[r] = d.retries()
+            out[r] = d.download()
+            d.close()
+            ctx.close()
+        except Exception as e:                              # noqa
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    L.ka_dist_loopback_free(loop)
+    assert not errs, errs
+    assert retries[0] >= 1 and retries[0] == retries[1], retries
+    for recs, paths in out:
+        _same(recs, paths, want)

@@ -15,8 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
+# (KA_HW: strips with helper waves, ka_wstrip.h -- on by default; the LDS hand-over of ka_strip is what runs with KA_HW=0 and on
+# levels with more than four items per workgroup)
 MODES = [{"KA_HO": "1"}, {"KA_HO": "2"}, {"KA_HO": "0"}, {"KA_HO": "1", "KA_Q1": "3"}, {"KA_HO": "2", "KA_Q1": "1"},
-         {"KA_HO": "1", "KA_MAX_CLUSTER": "1"}, {"KA_HO": "1", "KA_NO_CHAIN": "1"}]
+         {"KA_HO": "1", "KA_MAX_CLUSTER": "1"}, {"KA_HO": "1", "KA_NO_CHAIN": "1"},
+         {"KA_HW": "0"}, {"KA_HW": "0", "KA_HO": "2"}, {"KA_HW": "0", "KA_HO": "0"}, {"KA_HW": "0", "KA_MAX_CLUSTER": "1"},
+         {"KA_HW": "1", "KA_MAX_CLUSTER": "2"}, {"KA_HW": "1", "KA_MAX_CLUSTER": "4"}]
 
 
 def reference_gaps(codes, tasks, dist, dna):

@@ -10,24 +10,37 @@ from kalign_amd import api
 subm, scal = bench.scoring(False)
 ctx = kalign_amd.Context(0)
 rng = np.random.RandomState(3)
+JOBS = []
 for rows, cols in [(1000, 3000), (500, 500)]:
     base_r = rng.randint(0, 20, rows).astype(np.uint8); base_c = rng.randint(0, 20, cols).astype(np.uint8)
     def mutate(b):
         x = b.copy(); m = rng.rand(len(x)) < 0.2; x[m] = rng.randint(0, 20, m.sum()); return x
-    codes = [mutate(base_r), mutate(base_r), mutate(base_c), mutate(base_c)]
-    tasks = np.array([[0, 1, 4], [2, 3, 5], [4, 5, 6]], np.int32)
-    ctx.tree_upload(codes, tasks, subm, scal, np.full(4, 0.5, np.float32), flags=api.FLAG_TIMING)
-    for _ in range(3): ctx.tree_run(); ctx.tree_sync()
-    ctx.tree_timing()
-    print("%d x %d: level 0 pass %.0f us" % (rows, cols, ctx.root_levels[0][1] / 2.4e3))
-    for lvl in range(1):
-        for w in range(8):
-            p = ctx.prof[lvl][w]
-            if p[5] == 0: continue
-            total = p[3] - p[2]
-            print("  L%d wave %d: loop start at %.1f us, end at %.1f us (barrier done %.1f) | loop %.1f us: pair loops %d steps at %.0f cyc/step; everything else %d cycles" % (
-                lvl, w, (p[2] - p[0]) / 2.4e3, (p[3] - p[0]) / 2.4e3, (p[4] - p[0]) / 2.4e3, total / 2.4e3, p[7], p[6] / max(p[7], 1), total - p[6]))
-            x = ctx.prof[lvl + 4][w]
-            print("      steady phase: %d event steps at %.0f cycles each" % (x[3], x[2] / max(x[3], 1)))
-            print("      in the event steps: ring issue %.0f cycles per event, collection + flush %.0f per event; top wait %.0f, start..chain end %.0f, vmcnt wait %.0f" % (x[6] / max(x[3], 1), x[7] / max(x[3], 1), x[0] / max(x[3], 1), x[4] / max(x[3], 1), x[1] / max(x[3], 1)))
+    JOBS.append((rows, cols, [mutate(base_r), mutate(base_r), mutate(base_c), mutate(base_c)]))
+tasks = np.array([[0, 1, 4], [2, 3, 5], [4, 5, 6]], np.int32)
+# KA_HW=1 (default): strips with helper waves (ka_wstrip.h) -- their counters: cycles in the octets (waits included), waits and
+# cycles waited for operands, head and tail; KA_HW=0: ka_strip and its event steps
+for hw in os.environ.get("PHASES_HW", "1,0").split(","):
+    os.environ["KA_HW"] = hw
+    ctx.reload_env()
+    print("== KA_HW=%s%s" % (hw, " KA_MAX_CLUSTER=" + os.environ["KA_MAX_CLUSTER"] if "KA_MAX_CLUSTER" in os.environ else ""))
+    for rows, cols, codes in JOBS:
+        ctx.tree_upload(codes, tasks, subm, scal, np.full(4, 0.5, np.float32), flags=api.FLAG_TIMING)
+        for _ in range(3): ctx.tree_run(); ctx.tree_sync()
+        ctx.tree_timing()
+        print("%d x %d: level 0 pass %.0f us, level 1 %.0f us, level 2 %.0f us" % (rows, cols, ctx.root_levels[0][1] / 2.4e3, ctx.root_levels[1][1] / 2.4e3, ctx.root_levels[2][1] / 2.4e3))
+        for lvl in range(1):
+            for w in range(8):
+                p = ctx.prof[lvl][w]
+                if p[5] == 0: continue
+                total = p[3] - p[2]
+                x = ctx.prof[lvl + 4][w]
+                if hw != "0":
+                    print("  L%d wave %d: loop start at %.1f us, end at %.1f us (barrier done %.1f) | loop %.1f us: octets %d steps at %.0f cyc/step (%d waits, %d of them for the row above, %.0f cycles each); head %d cycles, tail %d, rest %d" % (
+                        lvl, w, (p[2] - p[0]) / 2.4e3, (p[3] - p[0]) / 2.4e3, (p[4] - p[0]) / 2.4e3, total / 2.4e3, p[7], p[6] / max(p[7], 1),
+                        x[3], x[1], x[0] / max(x[3], 1), x[2], x[4], total - p[6] - x[2] - x[4]))
+                    continue
+                print("  L%d wave %d: loop start at %.1f us, end at %.1f us (barrier done %.1f) | loop %.1f us: pair loops %d steps at %.0f cyc/step; everything else %d cycles" % (
+                    lvl, w, (p[2] - p[0]) / 2.4e3, (p[3] - p[0]) / 2.4e3, (p[4] - p[0]) / 2.4e3, total / 2.4e3, p[7], p[6] / max(p[7], 1), total - p[6]))
+                print("      steady phase: %d event steps at %.0f cycles each" % (x[3], x[2] / max(x[3], 1)))
+                print("      in the event steps: ring issue %.0f cycles per event, collection + flush %.0f per event; top wait %.0f, start..chain end %.0f, vmcnt wait %.0f" % (x[6] / max(x[3], 1), x[7] / max(x[3], 1), x[0] / max(x[3], 1), x[4] / max(x[3], 1), x[1] / max(x[3], 1)))
 ctx.close()
