@@ -92,6 +92,7 @@ struct KaEnv {
         int per = 0;                   // KA_PER: strips per workgroup (KaTreeDev::per_target; experiments)
         int ho = -1;                   // KA_HO: hand-over between neighbouring strips through LDS (KaTreeDev::ho_mode); -1: on (1)
         int hw = 1;                    // KA_HW: profile-profile strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode)
+        int hw_prio = 3;               // KA_HW_PRIO: s_setprio of a strip wave that has a helper (experiments)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
         bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
@@ -112,6 +113,7 @@ static void read_env(KaEnv& v)
         v.ho = env_int("KA_HO", -1);
         v.per = env_int("KA_PER", 0);
         v.hw = env_int("KA_HW", 1);
+        v.hw_prio = std::max(0, std::min(3, env_int("KA_HW_PRIO", 3)));
         v.upgma_launches = getenv("KA_UPGMA_LAUNCHES") != nullptr;
 }
 
@@ -782,7 +784,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1;
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
-        D.hw_mode = c->env.hw;
+        D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
         D.mw_mode = c->env.mw;

@@ -2317,7 +2317,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // LDS hand-over between neighbouring strips (ka_strip<.., HO>): profile-profile tasks of the 8-wave kernel, fast mode.
                 // ho_mode >= 2: four strips per workgroup (one per SIMD) instead of three -- fewer hand-overs cross workgroups.
                 S.ho_ok = (Q1 && NB == 0 && D.ho_mode && kind == KA_PP) ? 1 : 0;
-                S.hw_ok = (Q1 && D.hw_mode && kind == KA_PP) ? 1 : 0;
+                S.hw_ok = (Q1 && D.hw_mode && kind == KA_PP) ? D.hw_mode : 0;
                 if (Q1 && kind == KA_PP) {
                         // Tasks with more top-level strips than the table's workgroups have SIMDs (rows beyond ~4000: nucleotide
                         // jobs) take a workgroup per four strips, up to what the launch gave them: 4096 x 2000 nt 104 -> 93 ms.

@@ -641,8 +641,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 nBgb = kmax(nAgb + eB, nAa + oB);
                         } else {
                                 const bool at0 = (v == 0), atN = (v == ncols);
-                                const bool edge = at0 || atN;
-                                const bool term = (at0 && near_t) || (atN && far_t);
+                                const bool edge = at0 | atN;
+                                const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
                                 nAa = at0 ? -KA_F : acc.x;
                                 nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
                                 // (the terminal case `max(gb, a) + t` as the inner case with both penalties replaced by t:
@@ -706,8 +706,8 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 nAgb = kmax(upgb + eA, upa + oA);
                         } else {
                                 const bool at0 = (v == 0), atN = (v == ncols);
-                                const bool edge = at0 || atN;
-                                const bool term = (at0 && near_t) || (atN && far_t);
+                                const bool edge = at0 | atN;
+                                const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
                                 nAa = at0 ? -KA_F : a1;
                                 nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
                                 nAgb = kmax(upgb + (term ? tA : eA), upa + (term ? tA : oA));
@@ -1110,8 +1110,8 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 }
                 if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<true>(jb); acc.y += bonB.template at<true>(jb); }
                 const bool at0 = (v == 0), atN = (v == ncols);
-                const bool edge = at0 || atN;
-                const bool term = (at0 && near_t) || (atN && far_t);
+                const bool edge = at0 | atN;
+                const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
                 const float nAa = at0 ? -KA_F : acc.x;
                 const float nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
                 // (selects on the penalties, not on the results: see ka_strip)

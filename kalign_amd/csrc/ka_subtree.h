@@ -284,8 +284,8 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                         __builtin_amdgcn_sched_barrier(0);
                 }
                 const bool at0 = (v == 0), atN = (v == ncols);
-                const bool edge = at0 || atN;
-                const bool term = (at0 && near_t) || (atN && far_t);
+                const bool edge = at0 | atN;
+                const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
                 // selects only (a branchy cell costs more than the arithmetic it skips); max(x, y) + c == max(x + c, y + c) bit
                 // for bit (rounding is monotonic), so the terminal and the inner form of the gb state share one expression
                 const float nAa = at0 ? -KA_F : a1;

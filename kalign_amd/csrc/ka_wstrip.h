@@ -28,6 +28,9 @@
 #pragma once
 
 #define KA_W_CH 8                                               // steps per octet
+#ifndef KA_W_EARLY
+#define KA_W_EARLY 1                                            // next step's LDS reads right behind this step's wait (0: after the dot products, as in ka_strip)
+#endif
 #define KA_W_BIG (1 << 30)
 typedef float float3v __attribute__((ext_vector_type(3)));
 
@@ -48,7 +51,11 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                                           const unsigned ctl_u, const int w, long long* pslot = nullptr)
 {
         // the strip wave goes first on its SIMD: its helper (same SIMD, priority 0) takes the issue slots it leaves
-        __builtin_amdgcn_s_setprio(3);
+        // (KA_HW_PRIO in the environment, experiments: 0 .. 3, default 3; TaskShared::hw_ok carries it in bits 4..5)
+        {
+                const int prio = (__builtin_amdgcn_readfirstlane(S.hw_ok) >> 4) & 3;
+                if (prio == 3) __builtin_amdgcn_s_setprio(3); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        }
         const int ncols = endb - startb;
         const int mid = ((enda - starta) / 2) + starta;
         const int r0 = (dir == KA_FWD) ? starta : mid;
@@ -217,9 +224,45 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                 // the row above A: lane l-1's row B, lane 0 takes the boundary state of column t
                 const float upa = wave_shr1_old(bq[P].x, cBa), upga = wave_shr1_old(bq[P].y, cBga), upgb = wave_shr1_old(bq[P].z, cBgb);
 
+                // The gap states that do not wait for the dot products come FIRST in the source: the scheduler then has them to put
+                // into the wait states at the end of the dependent v_pk_add chain (six s_nop per step before; round 4).
+                const bool at0 = (v == 0), atN = (v == ncols);
+                const bool edge = at0 | atN;
+                const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
+                float nAga, nAgb, nBga;
+                // (edge form: selects on the OPERANDS, no branches: max(x, y) + c == max(x + c, y + c) bit for bit -- rounding is
+                // monotonic -- so the terminal case `max(gb, a) + t` is the inner case with both penalties replaced by t; written as
+                // `term ? .. : ..` over the two results the compiler made four exec-masked regions per step of it)
+                const float xeB = (!ST && term) ? tB : eB, xoB = (!ST && term) ? tB : oB;
+                if (ST) {
+                        nAga = kmax(cAga + cext, cAa + copen);
+                        nAgb = kmax(upgb + eA, upa + oA);
+                        nBga = kmax(cBga + cext, cBa + copen);
+                } else {
+                        const float xeA = term ? tA : eA, xoA = term ? tA : oA;
+                        nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
+                        nAgb = kmax(upgb + xeA, upa + xoA);
+                        nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
+                }
                 float2v acc;
                 acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
                 acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
+                // Next step's operands into the other half of q / bq.  ka_strip reads them AFTER the dot products (its waits were
+                // once the compiler's, and those waited for fresh loads too); here the step's one wait is the manual lgkmcnt(0) at
+                // its top, so the reads can go out right behind it and have the whole dot product to land: with four strips
+                // reading 8 KB per step each the LDS pipe is half busy and a read issued late was still in flight at the next wait.
+                auto next_reads = [&](auto& dep) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), dep);
+                        if constexpr (I >= 0) {
+                                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[1 - P]) : "v"(in_oct), "n"(I * 16) : "memory");
+                        } else {
+                                const unsigned ia = in_ring_u + ((((unsigned)t + 64u) & 255u) << 4);
+                                asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[1 - P]) : "v"(ia) : "memory");
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                };
+                if (KA_W_EARLY) next_reads(acc);
                 {
                         float2v prod;
                         prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
@@ -237,40 +280,11 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                         }
                         acc = acc + prod;
                         if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
-                        // next step's operands: after the chain (see ka_strip)
-                        __builtin_amdgcn_sched_barrier(0);
-                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), acc);
-                        if constexpr (I >= 0) {
-                                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[1 - P]) : "v"(in_oct), "n"(I * 16) : "memory");
-                        } else {
-                                const unsigned ia = in_ring_u + ((((unsigned)t + 64u) & 255u) << 4);
-                                asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[1 - P]) : "v"(ia) : "memory");
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (!KA_W_EARLY) next_reads(acc);
                 }
-                float nAa, nAga, nAgb, nBa, nBga, nBgb;
-                if (ST) {
-                        nAa = acc.x;
-                        nAga = kmax(cAga + cext, cAa + copen);
-                        nAgb = kmax(upgb + eA, upa + oA);
-                        nBa = acc.y;
-                        nBga = kmax(cBga + cext, cBa + copen);
-                        nBgb = kmax(nAgb + eB, nAa + oB);
-                } else {
-                        // (selects on the OPERANDS, no branches: max(x, y) + c == max(x + c, y + c) bit for bit -- rounding is monotonic --
-                        // so the terminal case `max(gb, a) + t` is the inner case with both penalties replaced by t; written as
-                        // `term ? .. : ..` over the two results the compiler made four exec-masked regions per step of it)
-                        const bool at0 = (v == 0), atN = (v == ncols);
-                        const bool edge = at0 || atN;
-                        const bool term = (at0 && near_t) || (atN && far_t);
-                        const float xeA = term ? tA : eA, xoA = term ? tA : oA, xeB = term ? tB : eB, xoB = term ? tB : oB;
-                        nAa = at0 ? -KA_F : acc.x;
-                        nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
-                        nAgb = kmax(upgb + xeA, upa + xoA);
-                        nBa = at0 ? -KA_F : acc.y;
-                        nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
-                        nBgb = kmax(nAgb + xeB, nAa + xoB);
-                }
+                const float nAa = (!ST && at0) ? -KA_F : acc.x;
+                const float nBa = (!ST && at0) ? -KA_F : acc.y;
+                const float nBgb = kmax(nAgb + xeB, nAa + xoB);           // B: the row above is A's fresh state
                 cAa = nAa; cAga = nAga; cAgb = nAgb;
                 cBa = nBa; cBga = nBga; cBgb = nBgb;
                 dga = upa; dgga = upga; dggb = upgb;
@@ -394,11 +408,11 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
 
 #define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
 #define IDX(v_) ((dir == KA_FWD) ? (v_) : (ncols - (v_)))
-        const int j = lane & 31, half = lane >> 5;                    // column within a 32-column batch / which half of its chunks
+        const int j = lane & 15, part = lane >> 4;                    // column within a 16-column batch / which chunks of it: part p loads chunks p and p + 4
         int Lc = 0;                                                   // columns loaded into the strip's ring
         int Li = 0;                                                   // boundary columns in the in ring (in_mode 0, 2)
         int To = 0;                                                   // out columns copied to HBM (!out_local)
-        float ca = -KA_F, cg = -KA_F;                                 // in_mode 0: (a, ga) of the last generated column
+        float cg = -KA_F;                                             // in_mode 0: ga of the last generated column
         int lastG = -1, lastI = -1;
         int idle = 0;
 
@@ -409,58 +423,52 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const bool done = tp >= nsteps;
 
-                // ---- the column ring: 32 columns per batch.  Column c overwrites column c - 128, last read in step c - 66 ----
-                if (Lc <= ncols && Lc + 31 <= tp + 65) {
+                // ---- the column ring: 16 columns per batch, up to two batches per round.  Column c overwrites column c - 128, last
+                // read in step c - 66: batch [Lc, Lc + 15] may go out once the strip has published step Lc - 50, and is needed by its
+                // check at step Lc - 8 ----
+                for (int rep = 0; rep < 2 && Lc <= ncols && Lc + 15 <= tp + 65; ++rep) {
                         const int c = Lc + j;
-                        float4v r[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) r[i] = (float4v){0.0f, 0.0f, 0.0f, 0.0f};
+                        float4v r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                        const bool use0 = (part == 0 && ka_chunk_used<NRES>(0)) || (part == 1 && ka_chunk_used<NRES>(1)) ||
+                                          (part == 2 && ka_chunk_used<NRES>(2)) || (part == 3 && ka_chunk_used<NRES>(3));
+                        const bool use1 = (part == 0 && ka_chunk_used<NRES>(4)) || (part == 1) || (part == 2);    // chunks 5 and 6: every alphabet
                         if (c <= ncols) {
                                 ka_gfloat4c* g = (ka_gfloat4c*)(p2 + ((long long)REC(c) << 6) + 32);
-                                if (half == 0) {
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) if (ka_chunk_used<NRES>(i)) r[i] = g[i];
-                                } else {
-#pragma unroll
-                                        for (int i = 0; i < 3; ++i) if (ka_chunk_used<NRES>(4 + i)) r[i] = g[4 + i];
-                                }
+                                if (use0) r0 = g[part];
+                                if (use1) r1 = g[part + 4];
                         }
-                        // set_gap_penalties_n (aln_setup.c:101-119): fields 55..57 times the other side's nsip -- chunk 5 .w, chunk 6 .x .y
-                        if (half == 1) { r[1].w = r[1].w * m2; r[2].x = r[2].x * m2; r[2].y = r[2].y * m2; }
+                        // set_gap_penalties_n (aln_setup.c:101-119): fields 55..57 times the other side's nsip -- chunk 5 .w (part 1), chunk 6 .x .y (part 2)
+                        if (part == 1) r1.w = r1.w * m2;
+                        if (part == 2) { r1.x = r1.x * m2; r1.y = r1.y * m2; }
                         if (c <= ncols) {
                                 char* dst = slds + ((c & 127) << 4);
-                                if (half == 0) {
-#pragma unroll
-                                        for (int i = 0; i < 4; ++i) if (ka_chunk_used<NRES>(i)) *(float4v*)(dst + i * 2048) = r[i];
-                                } else {
-#pragma unroll
-                                        for (int i = 0; i < 3; ++i) if (ka_chunk_used<NRES>(4 + i)) *(float4v*)(dst + (4 + i) * 2048) = r[i];
-                                }
+                                if (use0) *(float4v*)(dst + part * 2048) = r0;
+                                if (use1) *(float4v*)(dst + (part + 4) * 2048) = r1;
                         }
                         if (in_mode == 0) {
-                                // row -1 of the pass (aln_seqseq.c:40-58; ka_strip's FIRST steps): column 0 is the injected state, columns
-                                // 1 .. ncols-1 the serial chain g = max(g + gx, a + gy), column ncols -FLT_MAX.  The gap terms of column
-                                // Lc + jj sit in lane 32 + jj.
-                                const float gx_l = near_t ? r[2].y : r[2].x;
-                                const float gy_l = near_t ? r[2].y : r[1].w;
-                                float ma = -KA_F, mg = -KA_F, mb = -KA_F;
+                                // Row -1 of the pass (aln_seqseq.c:40-58; ka_strip's FIRST steps): column 0 is the injected state; columns
+                                // 1 .. ncols-1 carry (-FLT_MAX, g, -FLT_MAX) with the serial chain g = max(g' + gx, a' + gy) over the column
+                                // before (a' = the injected a for column 1, -FLT_MAX after it: a' + gy does not depend on the chain); column
+                                // ncols is all -FLT_MAX.  The chain as 16 rounds of "every lane recomputes from its left neighbour": lane l is
+                                // final after round l and recomputing a final lane from a final neighbour changes nothing -- two instructions
+                                // per column and no selects (a column that is NOT on the chain -- 0, ncols -- gets gx = -FLT_MAX and its fixed
+                                // value as the other operand of the max).  The gap terms of column Lc + l: copen in lane 16 + l, cext / ctext in
+                                // lane 32 + l.
+                                const float copen_c = __shfl(r1.w, (lane & 15) + 16, 64), cext_c = __shfl(r1.x, (lane & 15) + 32, 64), ctext_c = __shfl(r1.y, (lane & 15) + 32, 64);
+                                float gx = near_t ? ctext_c : cext_c;
+                                const float gy = near_t ? ctext_c : copen_c;
+                                float fix = ((c == 1) ? inj_a : -KA_F) + gy;
+                                if (c >= ncols) { gx = -KA_F; fix = -KA_F; }
+                                if (c == 0) { gx = -KA_F; fix = inj_ga; }
+                                float g = -KA_F;
 #pragma unroll
-                                for (int jj = 0; jj < 32; ++jj) {
-                                        const int cc = Lc + jj;
-                                        float na, ng, nb;
-                                        if (cc == 0) { na = inj_a; ng = inj_ga; nb = inj_gb; }
-                                        else if (cc < ncols) {
-                                                const float gx = lane_bcast(gx_l, 32 + jj), gy = lane_bcast(gy_l, 32 + jj);
-                                                ng = kmax(cg + gx, ca + gy); na = -KA_F; nb = -KA_F;
-                                        } else { na = -KA_F; ng = -KA_F; nb = -KA_F; }
-                                        if (lane == jj) { ma = na; mg = ng; mb = nb; }
-                                        ca = na; cg = ng;
-                                }
-                                if (lane < 32 && c <= ncols)
-                                        *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){ma, mg, mb, 0.0f};
-                                Li = min(Lc + 32, ncols + 1);
+                                for (int round = 0; round < 16; ++round) g = kmax(wave_shr1_old(cg, g) + gx, fix);
+                                cg = lane_bcast(g, 15);
+                                if (lane < 16 && c <= ncols)
+                                        *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){c == 0 ? inj_a : -KA_F, g, c == 0 ? inj_gb : -KA_F, 0.0f};
+                                Li = min(Lc + 16, ncols + 1);
                         }
-                        Lc += 32;
+                        Lc += 16;
                         progress = true;
                 }
 
@@ -469,11 +477,14 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                         const int avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog + (k - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         const int n = min(min(avail - Li, 64), tp + 256 - Li);
                         if (n > 0) {
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                // (agent-scope loads that go past L1 and L2, matching the producer's write-through stores: no
+                                // cache invalidate -- an acquire fence at agent scope drops the whole L1 and the L2's clean lines)
                                 if (lane < n) {
                                         const int c = Li + lane;
-                                        const ka_gfloat* r = grows + 3 * IDX(c);
-                                        const float x0 = r[0], x1 = r[1], x2 = r[2];
+                                        float* r = (float*)rows + 3 * IDX(c);
+                                        const float x0 = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        const float x1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        const float x2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){x0, x1, x2, 0.0f};
                                 }
                                 Li += n;
@@ -485,17 +496,30 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                 if (!out_local) {
                         const int outc = done ? (ncols + 1) : min(max(tp - lastl, 0), ncols + 1);
                         const int n = min(outc - To, 64);
-                        if (n >= 16 || (done && n > 0)) {
-                                if (lane < n) {
-                                        const int c = To + lane;
-                                        const float4v x = *(const float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
-                                        ka_gfloat* wr = grows + 3 * IDX(c);
-                                        wr[0] = x.x; wr[1] = x.y; wr[2] = x.z;
-                                }
-                                To += n;
-                                if (!last_strip) {
-                                        // the strip below runs in another workgroup of the cluster
-                                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        if (n >= (last_strip ? 64 : 8) || (done && n > 0)) {
+                                if (last_strip) {
+                                        // nobody reads the pass's last row before the level's barrier: plain stores
+                                        if (lane < n) {
+                                                const int c = To + lane;
+                                                const float4v x = *(const float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
+                                                ka_gfloat* wr = grows + 3 * IDX(c);
+                                                wr[0] = x.x; wr[1] = x.y; wr[2] = x.z;
+                                        }
+                                        To += n;
+                                } else {
+                                        // The strip below runs in another workgroup of the cluster.  Agent-scope WRITE-THROUGH stores, a wait for
+                                        // their acknowledgements, then the flag -- not a release fence: at agent scope that is a write-back
+                                        // of the XCD's whole L2 (ka_strip pays it once per 64 columns; "gets slower the more the other CUs
+                                        // have written"), and this hand-over wants to publish every 8 columns.
+                                        if (lane < n) {
+                                                const int c = To + lane;
+                                                const float4v x = *(const float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
+                                                float* wr = (float*)rows + 3 * IDX(c);
+                                                __hip_atomic_store(wr + 0, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                __hip_atomic_store(wr + 1, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                __hip_atomic_store(wr + 2, x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        }
+                                        To += n;
                                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                                         if (lane == 0) __hip_atomic_store(prog + k, To, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 }

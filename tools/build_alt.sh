@@ -1,0 +1,12 @@
+#!/bin/bash
+# A variant of unit 0 (the 8-wave fast-mode task kernel) with extra -D flags, linked with the regular objects as
+# kalign_amd/libkalign_amd_alt.so: A/B runs of compile-time switches (tools/r4_ab.sh copies it over the library on the GPU box).
+# usage: tools/build_alt.sh -DKA_W_EARLY=0
+set -e
+cd "$(dirname "$0")/../kalign_amd/csrc"
+mkdir -p build/alt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-function \
+    -DKA_UNIT=0 "$@" -c -o build/alt/ka_kernels_u0.o ka_kernels.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libkalign_amd_alt.so build/alt/ka_kernels_u0.o \
+    $(ls build/*.o | grep -v ka_kernels_u0.o)
+echo built kalign_amd/libkalign_amd_alt.so

@@ -17,6 +17,10 @@ for rows, cols in [(1000, 3000), (500, 500)]:
         x = b.copy(); m = rng.rand(len(x)) < 0.2; x[m] = rng.randint(0, 20, m.sum()); return x
     JOBS.append((rows, cols, [mutate(base_r), mutate(base_r), mutate(base_c), mutate(base_c)]))
 tasks = np.array([[0, 1, 4], [2, 3, 5], [4, 5, 6]], np.int32)
+if os.environ.get("PHASES_REAL"):
+    # the root task of the headline tree (4096 x 400, the reference's guide tree): the strips of its leading workgroup
+    rj = bench.make_job(ctx, 4096, 400, False, seed=1)
+    JOBS = [(0, 0, None)]
 # KA_HW=1 (default): strips with helper waves (ka_wstrip.h) -- their counters: cycles in the octets (waits included), waits and
 # cycles waited for operands, head and tail; KA_HW=0: ka_strip and its event steps
 for hw in os.environ.get("PHASES_HW", "1,0").split(","):
@@ -24,11 +28,14 @@ for hw in os.environ.get("PHASES_HW", "1,0").split(","):
     ctx.reload_env()
     print("== KA_HW=%s%s" % (hw, " KA_MAX_CLUSTER=" + os.environ["KA_MAX_CLUSTER"] if "KA_MAX_CLUSTER" in os.environ else ""))
     for rows, cols, codes in JOBS:
-        ctx.tree_upload(codes, tasks, subm, scal, np.full(4, 0.5, np.float32), flags=api.FLAG_TIMING)
+        if codes is None:
+            ctx.tree_upload(rj["codes"], rj["tasks"], subm, scal, rj["seq_distances"], flags=api.FLAG_TIMING)
+        else:
+            ctx.tree_upload(codes, tasks, subm, scal, np.full(4, 0.5, np.float32), flags=api.FLAG_TIMING)
         for _ in range(3): ctx.tree_run(); ctx.tree_sync()
         ctx.tree_timing()
         print("%d x %d: level 0 pass %.0f us, level 1 %.0f us, level 2 %.0f us" % (rows, cols, ctx.root_levels[0][1] / 2.4e3, ctx.root_levels[1][1] / 2.4e3, ctx.root_levels[2][1] / 2.4e3))
-        for lvl in range(1):
+        for lvl in range(int(os.environ.get("PHASES_LEVELS", "1"))):
             for w in range(8):
                 p = ctx.prof[lvl][w]
                 if p[5] == 0: continue
