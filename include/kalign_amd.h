@@ -233,6 +233,7 @@ int ka_tree_launch_ms(ka_ctx* ctx, float* ms, int cap);
  * In a forest job every alignment gets its own table (its own anchors among its own sequences).
  * ka_tree_upload drops the table again.
  */
+#define KA_CONS_MAX_ANCHORS 5   /* anchors ka_tree_build_consistency takes (a DP row carries that many bonus entries + the wrap-around one) */
 int ka_tree_build_consistency(ka_ctx* ctx, int n_anchors, float weight);
 /* The N x K batch sharded over `nparts` GPUs: every rank uploads the same job and calls this with its
  * own `part`; it selects the same anchors, aligns only its contiguous share of the sequences (balanced by length) and
@@ -376,6 +377,35 @@ int ka_dist_retries(ka_dist* d);
 void* ka_dist_loopback_new(int world);
 void ka_dist_loopback_free(void* loopback);
 int ka_dist_create_loopback(ka_ctx* ctx, int rank, int world, void* loopback, ka_dist** out);
+
+
+/* ---- the GPUs of one node under ONE caller (ka_multi.cpp) ----------------------------------------------------------------
+ * ka_dist_* wants one caller per rank; a single-process C program (kalign_run behind the drop-in glue) has
+ * one.  ka_multi_* runs the ranks as threads of the caller, one context + one ka_dist per device, behind calls shaped like
+ * ka_tree_build_consistency / ka_tree_upload + run + download; results are the single-GPU results bit for bit
+ * (lib/src/aln_run.c:95-109).  devices == NULL: devices 0 .. world-1; loopback != 0: every rank on ONE device over the
+ * in-process transport (tests on one-GPU boxes).  Errors: ka_multi_last_error().
+ *   ka_multi_consistency  anchor_consistency_build (anchor_consistency.c:200-275) sharded; returns the number of anchors (0: the
+ *                         job declines, like the reference), < 0 on error; anchor_ids_out / maps_out as ka_tree_get_consistency
+ *   ka_multi_tree_run     create_msa_tree (aln_run.c:43-78): ka_tree_upload's arguments; n_anchors > 0 = default mode (the table
+ *                         is built unless flags carry KA_FLAG_KEEP_CONSISTENCY and ka_multi_consistency left it on the ranks)
+ *   ka_multi_download     rank 0's records and coded paths, gaps woven on the host (gaps_out may be NULL)
+ */
+typedef struct ka_multi ka_multi;
+int ka_device_count(void);                       /* visible GPUs (hipGetDeviceCount; 0 when there is none or no driver) */
+int ka_multi_create(int world, const int* devices, int loopback, ka_multi** out);
+void ka_multi_destroy(ka_multi* m);
+int ka_multi_world(ka_multi* m);
+long long ka_multi_runs(ka_multi* m);
+const char* ka_multi_last_error(void);
+int ka_multi_consistency(ka_multi* m, int numseq, const uint8_t* codes, const int* off, const int* lens, const float* seq_distances,
+                         int n_tasks, const int* tasks_abc, const float* subm, const float* scal, int flags,
+                         int n_anchors, float weight, int* anchor_ids_out, int* maps_out);
+int ka_multi_tree_run(ka_multi* m, int numseq, const uint8_t* codes, const int* off, const int* lens, const float* seq_distances,
+                      int n_tasks, const int* tasks_abc, const float* subm, const float* scal, int flags,
+                      int n_anchors, float weight);
+long long ka_multi_paths_size(ka_multi* m);
+int ka_multi_download(ka_multi* m, int numseq, const int* lens, int n_tasks, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
 
 #ifdef __cplusplus
 }

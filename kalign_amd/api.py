@@ -50,7 +50,9 @@ EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_
            "ka_aln_guide_tree", "ka_run_encoded", "ka_run_encoded_refine", "ka_tree_plan_tasks", "ka_tree_run_planned",
            "ka_dist_unique_id", "ka_dist_create", "ka_dist_destroy", "ka_dist_plan_subtrees", "ka_dist_plan", "ka_dist_get_plan",
            "ka_dist_consistency", "ka_dist_tree_run", "ka_dist_paths_size", "ka_dist_download", "ka_dist_last_ms", "ka_dist_retries",
-           "ka_dist_loopback_new", "ka_dist_loopback_free", "ka_dist_create_loopback"]
+           "ka_dist_loopback_new", "ka_dist_loopback_free", "ka_dist_create_loopback",
+           "ka_device_count", "ka_multi_create", "ka_multi_destroy", "ka_multi_world", "ka_multi_runs", "ka_multi_last_error",
+           "ka_multi_consistency", "ka_multi_tree_run", "ka_multi_paths_size", "ka_multi_download"]
 
 
 def lib_path():
@@ -121,6 +123,20 @@ def load_library():
     L.ka_dist_last_ms.argtypes = [vp]
     L.ka_dist_last_ms.restype = C.c_double
     L.ka_dist_retries.argtypes = [vp]
+    L.ka_device_count.argtypes = []
+    L.ka_multi_create.argtypes = [C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.ka_multi_destroy.argtypes = [vp]
+    L.ka_multi_destroy.restype = None
+    L.ka_multi_world.argtypes = [vp]
+    L.ka_multi_runs.argtypes = [vp]
+    L.ka_multi_runs.restype = C.c_longlong
+    L.ka_multi_last_error.argtypes = []
+    L.ka_multi_last_error.restype = C.c_char_p
+    L.ka_multi_consistency.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
+    L.ka_multi_tree_run.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float]
+    L.ka_multi_paths_size.argtypes = [vp]
+    L.ka_multi_paths_size.restype = C.c_longlong
+    L.ka_multi_download.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_longlong, vp]
     L.ka_dist_loopback_new.argtypes = [C.c_int]
     L.ka_dist_loopback_new.restype = vp
     L.ka_dist_loopback_free.argtypes = [vp]
@@ -688,4 +704,66 @@ class Dist:
     def close(self):
         if self.h:
             self.L.ka_dist_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Multi:
+    """ka_multi_*: the GPUs of one node under one caller -- one context and one rank of the sharded path per device, the ranks
+    as threads inside the library.  loopback=True: every rank on device 0 over the in-process transport (one-GPU boxes)."""
+
+    def __init__(self, world, loopback=False, devices=None):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        if self.L.ka_multi_create(int(world), _ptr(dev) if dev is not None else None, 1 if loopback else 0, C.byref(self.h)):
+            raise RuntimeError(self.L.ka_multi_last_error().decode())
+        self._job = None
+
+    def _chk(self, rc):
+        if rc:
+            raise RuntimeError(self.L.ka_multi_last_error().decode())
+
+    def _args(self, codes, tasks, subm, scal, seq_distances):
+        flat, off, lens = _flatten(codes)
+        tasks = np.ascontiguousarray(tasks, np.int32)
+        sd = np.ascontiguousarray(seq_distances, np.float32)
+        sub = np.ascontiguousarray(subm, np.float32).reshape(-1)
+        sc = np.ascontiguousarray(scal, np.float32)
+        self._job = {"lens": lens, "ntasks": len(tasks), "keep": (flat, off, lens, tasks, sd, sub, sc)}
+        return flat, off, lens, tasks, sd, sub, sc
+
+    def consistency(self, codes, tasks, subm, scal, seq_distances, n_anchors, weight):
+        flat, off, lens, tasks, sd, sub, sc = self._args(codes, tasks, subm, scal, seq_distances)
+        ids = np.zeros(max(n_anchors, 1), np.int32)
+        maps = np.zeros(int(lens.sum()) * max(n_anchors, 1) + 1, np.int32)
+        k = self.L.ka_multi_consistency(self.h, len(lens), _ptr(flat), _ptr(off), _ptr(lens), _ptr(sd), len(tasks), _ptr(tasks),
+                                        _ptr(sub), _ptr(sc), 0, int(n_anchors), float(weight), _ptr(ids), _ptr(maps))
+        if k < 0:
+            raise RuntimeError(self.L.ka_multi_last_error().decode())
+        return ids[:k], maps[:int(lens.sum()) * k]
+
+    def tree_run(self, codes, tasks, subm, scal, seq_distances, n_anchors=0, weight=0.0, keep_consistency=False):
+        flat, off, lens, tasks, sd, sub, sc = self._args(codes, tasks, subm, scal, seq_distances)
+        self._chk(self.L.ka_multi_tree_run(self.h, len(lens), _ptr(flat), _ptr(off), _ptr(lens), _ptr(sd), len(tasks), _ptr(tasks),
+                                           _ptr(sub), _ptr(sc), FLAG_KEEP_CONSISTENCY if keep_consistency else 0, int(n_anchors), float(weight)))
+
+    def download(self):
+        lens, n = self._job["lens"], self._job["ntasks"]
+        recs = (TaskRec * n)()
+        cap = int(self.L.ka_multi_paths_size(self.h))
+        paths = np.zeros(max(cap, 1), np.int32)
+        gaps = np.zeros(int(lens.sum()) + len(lens), np.int32)
+        self._chk(self.L.ka_multi_download(self.h, len(lens), _ptr(lens), n, recs, _ptr(paths), cap, _ptr(gaps)))
+        out, g = [], 0
+        for ln in lens:
+            out.append(gaps[g:g + int(ln) + 1].copy())
+            g += int(ln) + 1
+        return list(recs), paths, out
+
+    def runs(self):
+        return int(self.L.ka_multi_runs(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.ka_multi_destroy(self.h)
             self.h = C.c_void_p()

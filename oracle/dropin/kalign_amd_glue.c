@@ -48,9 +48,11 @@ extern int kalign_ref_anchor_consistency_build(struct msa* msa, struct aln_param
 
 /* how often each seam ran on the device / fell back to the reference (tests/test_gpu_dropin.py reads them) */
 enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF,
-       GLUE_CONS, GLUE_CONS_REF, GLUE_KMEANS, GLUE_KMEANS_NOISY, GLUE_ALNDIST, GLUE_ALNDIST_REF, GLUE_ALNTREE, GLUE_ALNTREE_REF, GLUE_INLINE_REF, GLUE_N };
+       GLUE_CONS, GLUE_CONS_REF, GLUE_KMEANS, GLUE_KMEANS_NOISY, GLUE_ALNDIST, GLUE_ALNDIST_REF, GLUE_ALNTREE, GLUE_ALNTREE_REF, GLUE_INLINE_REF,
+       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_N };
 static const char* glue_names[GLUE_N] = { "tree", "inline", "refine", "refine_ref", "finalise", "finalise_ref",
-                                          "cons", "cons_ref", "kmeans", "kmeans_noisy", "alndist", "alndist_ref", "alntree", "alntree_ref", "inline_ref" };
+                                          "cons", "cons_ref", "kmeans", "kmeans_noisy", "alndist", "alndist_ref", "alntree", "alntree_ref", "inline_ref",
+                                          "tree_multi", "cons_multi" };
 static int glue_counts[GLUE_N];
 int kalign_amd_glue_count(int which)
 {
@@ -91,6 +93,42 @@ static uint64_t glue_stamp(const struct msa* msa)
 static int glue_same_job(const struct msa* msa)
 {
         return msa == glue_job_msa && msa->numseq == glue_job_numseq && glue_stamp(msa) == glue_job_stamp;
+}
+
+/*
+ * More than one GPU (north_star: "tasks ... sharded across the 8 GPUs of one node"; lib/src/aln_run.c:95-109: subtrees are
+ * independent): create_msa_tree and anchor_consistency_build go through ka_multi_* -- one context and one rank of the sharded
+ * path (ka_dist_*: subtree cut, RCCL hand-overs above the cut, gathered records and paths) per device, the ranks as threads
+ * of this process.  KALIGN_AMD_DEVICES=n limits / forces the number of devices (1: this path off); KALIGN_AMD_GLUE_WORLD=n
+ * runs n ranks on device 0 over the library's in-process transport (tests on one-GPU boxes).  The result does not depend on
+ * the number of ranks.  The seams that work on a job resident on ONE device (refinement, finalise, the realignment
+ * distances) then take the reference's own functions: after a sharded run no single GPU holds the whole alignment.
+ */
+static ka_multi* glue_multi = NULL;
+static int glue_multi_tried = 0;
+static ka_multi* glue_multi_context(void)
+{
+        if(!glue_multi_tried){
+                const char* w = getenv("KALIGN_AMD_GLUE_WORLD");
+                const char* d = getenv("KALIGN_AMD_DEVICES");
+                int world = 0;
+                int loopback = 0;
+                glue_multi_tried = 1;
+                if(w && atoi(w) > 1){
+                        world = atoi(w);
+                        loopback = 1;
+                }else{
+                        world = d ? atoi(d) : ka_device_count();
+                        if(world > ka_device_count()){
+                                world = ka_device_count();
+                        }
+                }
+                if(world > 1 && ka_multi_create(world, NULL, loopback, &glue_multi)){
+                        WARNING_MSG("kalign_amd: %d devices could not be opened together (%s): one GPU", world, ka_multi_last_error());
+                        glue_multi = NULL;
+                }
+        }
+        return glue_multi;
 }
 
 static int glue_context(void)
@@ -190,6 +228,7 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         int* lens = NULL;
         int* abc = NULL;
         int* maps = NULL;
+        int* ids_multi = NULL;
         float subm[23 * 23];
         float scal[6];
         long long total = 0;
@@ -211,6 +250,15 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         glue_params(ap, subm, scal);
         glue_job_msa = NULL;
         glue_ct_resident = NULL;
+        if(K <= KA_CONS_MAX_ANCHORS && glue_multi_context()){
+                /* the N x K batch sharded over the devices, every rank's share of the maps broadcast in place (ka_dist_consistency) */
+                MMALLOC(ids_multi, sizeof(int) * K);
+                MMALLOC(maps, sizeof(int) * (total * K + 1));
+                if(ka_multi_consistency(glue_multi, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0, K, weight, ids_multi, maps) != K){
+                        ERROR_MSG("kalign_amd: %s", ka_multi_last_error());
+                }
+                glue_counts[GLUE_CONS_MULTI]++;
+        }else
         if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0) ||
            ka_tree_build_consistency(glue_ctx, K, weight)){
                 /* a request the library does not take (more than 5 anchors ...): the reference's own function, like every
@@ -219,7 +267,9 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
                 glue_counts[GLUE_CONS_REF]++;
                 return kalign_ref_anchor_consistency_build(msa, ap, n_anchors, weight, ct_out);
         }
-        glue_counts[GLUE_CONS]++;
+        if(!ids_multi){
+                glue_counts[GLUE_CONS]++;
+        }
         MMALLOC(ct, sizeof(struct consistency_table));
         ct->pos_maps = NULL;
         ct->map_lengths = NULL;
@@ -234,9 +284,13 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
                 ct->pos_maps[i] = NULL;
                 ct->map_lengths[i] = 0;
         }
-        MMALLOC(maps, sizeof(int) * (total * K + 1));
-        if(ka_tree_get_consistency(glue_ctx, ct->anchor_ids, maps) != K){
-                ERROR_MSG("kalign_amd: the device declined to build the consistency table");
+        if(ids_multi){
+                memcpy(ct->anchor_ids, ids_multi, sizeof(int) * K);
+        }else{
+                MMALLOC(maps, sizeof(int) * (total * K + 1));
+                if(ka_tree_get_consistency(glue_ctx, ct->anchor_ids, maps) != K){
+                        ERROR_MSG("kalign_amd: the device declined to build the consistency table");
+                }
         }
         for(i = 0; i < n; i++){
                 for(k = 0; k < K; k++){
@@ -253,6 +307,7 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         glue_ct_resident = ct;
         *ct_out = ct;
         MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc); MFREE(maps);
+        if(ids_multi) MFREE(ids_multi);
         return OK;
 ERROR:
         if(codes) MFREE(codes);
@@ -260,6 +315,7 @@ ERROR:
         if(lens) MFREE(lens);
         if(abc) MFREE(abc);
         if(maps) MFREE(maps);
+        if(ids_multi) MFREE(ids_multi);
         if(ct){
                 anchor_consistency_free(ct);
         }
@@ -271,7 +327,7 @@ ERROR:
  * seq_distances, the task list; leaves sequences[i]->gaps[], nsip[], sip[][], plen[], task confidence -- exactly
  * the state the reference's dispatcher leaves.  Merged profiles stay in HBM.
  */
-static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total);
+static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total, int multi);
 
 /* inline_refine: 0 = create_msa_tree, n > 0 = create_msa_tree_inline_refine with n trials per edge */
 static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int inline_refine)
@@ -302,6 +358,20 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         }
         glue_params(ap, subm, scal);
 
+        if(!inline_refine && (!ct || ct->n_anchors <= KA_CONS_MAX_ANCHORS) && glue_multi_context()){
+                /* the whole node: every rank uploads the job, runs its subtrees and its share of the tasks above the cut; records
+                   and coded paths come back gathered, the gap arrays are woven on the host.  The table the ranks hold from
+                   anchor_consistency_build is kept when it is this msa's. */
+                int mflags = (ct && ct == glue_ct_resident) ? KA_FLAG_KEEP_CONSISTENCY : 0;
+                if(ka_multi_tree_run(glue_multi, n, codes, off, lens, msa->seq_distances, nt, abc, subm, scal, mflags, ct ? ct->n_anchors : 0, ct ? ct->weight : 0.0f)){
+                        ERROR_MSG("kalign_amd: %s", ka_multi_last_error());
+                }
+                glue_ct_resident = ct;
+                RUN(glue_collect(msa, t, lens, total, 1));
+                glue_counts[GLUE_TREE_MULTI]++;
+                MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
+                return OK;                                /* (glue_job_msa stays NULL: no single device holds this alignment) */
+        }
         /* the table anchor_consistency_build left in HBM for these sequences is kept across the upload (also by the
            realignment passes of kalign_run_realign, aln_wrap.c:449-504: same sequences, new tree); if another job has
            used the device since, it is built again (same anchors, same maps) */
@@ -321,7 +391,7 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         if((inline_refine ? ka_tree_refine(glue_ctx, 3 | KA_REFINE_TRIALS(inline_refine), NULL) : ka_tree_run(glue_ctx)) || ka_tree_sync(glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
-        RUN(glue_collect(msa, t, lens, total));
+        RUN(glue_collect(msa, t, lens, total, 0));
         glue_counts[inline_refine ? GLUE_INLINE : GLUE_TREE]++;
         glue_job_msa = msa;
         glue_job_numseq = n;
@@ -337,7 +407,7 @@ ERROR:
 }
 
 /* leave exactly the state do_align leaves (aln_run.c:391-436): gaps[], plen[], nsip[], sip[][], task confidence */
-static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total)
+static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total, int multi)
 {
         int n = msa->numseq;
         int nt = t->n_tasks;
@@ -346,10 +416,15 @@ static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, l
         ka_task_rec* recs = NULL;
         long long cap;
         int i, j, g;
-        cap = ka_tree_paths_size(glue_ctx);
+        cap = multi ? ka_multi_paths_size(glue_multi) : ka_tree_paths_size(glue_ctx);
         MMALLOC(recs, sizeof(ka_task_rec) * nt);
         MMALLOC(gaps, sizeof(int) * (total + n));
         MMALLOC(paths, sizeof(int) * (cap + 1));
+        if(multi){
+                if(ka_multi_download(glue_multi, n, lens, nt, recs, paths, cap, gaps)){
+                        ERROR_MSG("kalign_amd: %s", ka_multi_last_error());
+                }
+        }else
         if(ka_tree_download(glue_ctx, recs, paths, cap, gaps)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
@@ -432,7 +507,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         if(ka_tree_refine(glue_ctx, refine_mode | (ap->adaptive_budget ? KA_REFINE_ADAPTIVE : 0), NULL) || ka_tree_sync(glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
-        RUN(glue_collect(msa, t, lens, total));
+        RUN(glue_collect(msa, t, lens, total, 0));
         glue_job_stamp = glue_stamp(msa);                /* the refined gaps are what the device holds now */
         glue_counts[GLUE_REFINE]++;
         MFREE(lens);

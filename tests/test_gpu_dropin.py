@@ -29,10 +29,11 @@ def _need(name):
     return p
 
 
-def _cli(binary, infile, outfile, *flags, counters=None):
+def _cli(binary, infile, outfile, *flags, counters=None, env_extra=None):
     """counters: a dict that receives the seam counters the drop-in prints at exit (KALIGN_AMD_GLUE_REPORT=1): how often
     every seam ran on the device and how often it handed the call to the reference's own function"""
     env = dict(os.environ, OMP_NUM_THREADS="8", KALIGN_AMD_GLUE_REPORT="1")
+    env.update(env_extra or {})
     r = subprocess.run([_need(binary), "-i", infile, "-o", outfile, "-n", "8"] + list(flags), env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -184,3 +185,41 @@ def test_library_kalign_run_with_refinement(tmp_path, refine):
     # which seams ran on the device: (tree, inline tree, refine, refine by the reference, finalise, finalise by the reference)
     delta = [L.kalign_amd_glue_count(k) - b for k, b in enumerate(before)]
     assert delta == ([0, 1, 0, 0, 1, 0] if refine == 3 else [1, 0, 1, 0, 1, 0])
+
+
+# ---- several GPUs under the drop-in (kalign_amd_glue.c: glue_multi_context; ka_multi_* in the library) ----
+# KALIGN_AMD_GLUE_WORLD=n: n ranks of the sharded path as threads of the kalign process, all on the box's one GPU over the
+# library's in-process transport -- on a node with several GPUs the same code runs one rank per device over RCCL
+# (KALIGN_AMD_DEVICES).  create_msa_tree and anchor_consistency_build must have gone through the sharded path (tree_multi /
+# cons_multi counters), the single-device forms of those seams must NOT have run, and the FASTA must be the reference's.
+MULTI_CASES = [("BB11001.tfa", []), ("BB11001.tfa", ["--fast"]), ("BB30014.tfa", []), ("BB30014.tfa", ["--fast"]),
+               ("BB12006.tfa", []), ("BB12006.tfa", ["--fast", "--realign", "2"]), ("BB11001.tfa", ["--ensemble=3"]),
+               ("BB30014.tfa", ["--refine", "all"])]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name,flags", MULTI_CASES, ids=["%s%s" % (n.split(".")[0], "_".join([""] + f).replace("--", "").replace("__", "_")) for n, f in MULTI_CASES])
+def test_cli_with_several_ranks_under_the_dropin(tmp_path, name, flags, world):
+    inp = os.path.join(DATA, name)
+    c = {}
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags, counters=c, env_extra={"KALIGN_AMD_GLUE_WORLD": str(world)})
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), *flags)
+    assert len(want) > 100 and got == want
+    realign = int(flags[flags.index("--realign") + 1]) if "--realign" in flags else 0
+    ens = [f for f in flags if f.startswith("--ensemble=")]
+    members = int(ens[0].split("=")[1]) if ens else 1
+    assert c["tree_multi"] >= members * (1 + realign) and c["tree"] == 0, c
+    if "--fast" not in flags and members == 1:
+        assert c["cons_multi"] >= 1 and c["cons"] == 0 and c["cons_ref"] == 0, c
+
+
+@pytest.mark.parametrize("flags", [[], ["--fast"]], ids=["default", "fast"])
+def test_cli_with_several_ranks_on_a_dssim_set(tmp_path, flags):
+    from kalign_amd import synth
+    inp = str(tmp_path / "in.fa")
+    _write_fasta(inp, synth.dssim(200, 150, seed=1))
+    c = {}
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), *flags, counters=c, env_extra={"KALIGN_AMD_GLUE_WORLD": "3"})
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), *flags)
+    assert got == want
+    assert c["tree_multi"] >= 1 and c["tree"] == 0, c
