@@ -391,6 +391,13 @@ int ka_dist_create_loopback(ka_ctx* ctx, int rank, int world, void* loopback, ka
  *                         is built unless flags carry KA_FLAG_KEEP_CONSISTENCY and ka_multi_consistency left it on the ranks)
  *   ka_multi_download     rank 0's records and coded paths, gaps woven on the host (gaps_out may be NULL)
  */
+/* build_tree_kmeans' 2-means bisection (bisectingKmeans.c:273-402, split2 :766-971) runs on the device inside ka_guide_tree from
+   2048 sequences up (ka_kmeans.hip: all of a set's up to 40 seeds side by side, every set of a recursion level in one launch,
+   the order-dependent fp32 sums as chains in the reference's sample order -- the same tree, bit for bit); KA_KMEANS=0 / 1 in
+   the environment forces the host / the device.  Wall time of the bisection inside the last ka_guide_tree of this process and
+   where it ran (measurements). */
+double ka_guide_last_bisect_ms(int* on_device);
+
 typedef struct ka_multi ka_multi;
 int ka_device_count(void);                       /* visible GPUs (hipGetDeviceCount; 0 when there is none or no driver) */
 int ka_multi_create(int world, const int* devices, int loopback, ka_multi** out);

@@ -51,7 +51,7 @@ EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_
            "ka_dist_unique_id", "ka_dist_create", "ka_dist_destroy", "ka_dist_plan_subtrees", "ka_dist_plan", "ka_dist_get_plan",
            "ka_dist_consistency", "ka_dist_tree_run", "ka_dist_paths_size", "ka_dist_download", "ka_dist_last_ms", "ka_dist_retries",
            "ka_dist_loopback_new", "ka_dist_loopback_free", "ka_dist_create_loopback",
-           "ka_device_count", "ka_multi_create", "ka_multi_destroy", "ka_multi_world", "ka_multi_runs", "ka_multi_last_error",
+           "ka_guide_last_bisect_ms", "ka_device_count", "ka_multi_create", "ka_multi_destroy", "ka_multi_world", "ka_multi_runs", "ka_multi_last_error",
            "ka_multi_consistency", "ka_multi_tree_run", "ka_multi_paths_size", "ka_multi_download"]
 
 
@@ -124,6 +124,8 @@ def load_library():
     L.ka_dist_last_ms.restype = C.c_double
     L.ka_dist_retries.argtypes = [vp]
     L.ka_device_count.argtypes = []
+    L.ka_guide_last_bisect_ms.argtypes = [vp]
+    L.ka_guide_last_bisect_ms.restype = C.c_double
     L.ka_multi_create.argtypes = [C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.ka_multi_destroy.argtypes = [vp]
     L.ka_multi_destroy.restype = None
@@ -594,6 +596,14 @@ def guide_tree_from(lens, dist, n_threads=1, dm_scale=None):
     if L.ka_guide_tree_from(len(lens), _ptr(lens), DIST_FN(cb), None, int(n_threads), _ptr(sc), _ptr(tasks), _ptr(sd)):
         raise KalignAmdError(L.ka_last_error().decode())
     return tasks, sd
+
+
+def guide_last_bisect():
+    """(milliseconds, ran on the device) of the 2-means bisection inside the last ka_guide_tree of this process"""
+    L = load_library()
+    on = C.c_int(0)
+    ms = float(L.ka_guide_last_bisect_ms(C.byref(on)))
+    return ms, bool(on.value)
 
 
 def weave_gaps(lens, recs, paths):

@@ -219,6 +219,8 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
 static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi);
 
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
+struct ka_ctx;
+int ka_ctx_device_stream(ka_ctx* c, int* device, hipStream_t* stream);    // (library-internal: ka_guide.cpp)
 extern "C" int ka_abi_version(void) { return 7; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
@@ -249,6 +251,13 @@ extern "C" int ka_ctx_create(int device, ka_ctx** out)
 }
 
 // Tests only: fault injection that used to hide behind environment variables.
+__attribute__((visibility("hidden"))) int ka_ctx_device_stream(ka_ctx* c, int* device, hipStream_t* stream)
+{
+        if (!c) return 1;
+        *device = c->device; *stream = c->stream;
+        return 0;
+}
+
 extern "C" int ka_debug_set_hooks(ka_ctx* c, int hooks)
 {
         if (!c) return fail("null ctx");

@@ -7,6 +7,7 @@
 // reference's fp32 evaluation order so that the tree is the same tree, bit for bit.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "kalign_amd.h"
+#include "ka_kmeans.h"
 
 namespace {
 
@@ -289,6 +291,22 @@ static int dist_failed()
 static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
                            const float* dm_scale, int* tasks_abc, float* seq_distances);
 
+// The 2-means bisection on the device (ka_kmeans.hip) for the callers that have one: ka_guide_tree sets the device and stream
+// of its context here for the duration of the call.  KA_KMEANS in the environment: "0" host, "1" device whatever the size;
+// default: the device from 2048 sequences (below that the host's 40 x 2-means take less than the launches).
+namespace {
+struct KmDevice { bool on = false; int device = 0; hipStream_t stream = nullptr; };
+thread_local KmDevice g_km;
+double g_last_bisect_ms = 0.0;
+int g_last_bisect_device = 0;
+}
+int ka_ctx_device_stream(ka_ctx* c, int* device, hipStream_t* stream);    // ka_api.cpp
+extern "C" double ka_guide_last_bisect_ms(int* on_device)
+{
+        if (on_device) *on_device = g_last_bisect_device;
+        return g_last_bisect_ms;
+}
+
 extern "C" int ka_guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* user, int n_threads,
                                   const float* dm_scale, int* tasks_abc, float* seq_distances)
 {
@@ -328,9 +346,29 @@ static int guide_tree_from(int numseq, const int* lens, ka_dist_fn dist, void* u
         // ---- bisecting k-means down to clusters of < 50 sequences ----
         Builder B;
         B.numseq = numseq; B.num_anchors = A; B.padded = padded; B.dm = dm.data(); B.n_threads = std::max(1, n_threads);
-        std::vector<int> all(numseq);
-        for (int i = 0; i < numseq; i++) all[i] = i;
-        std::unique_ptr<Sub> root = bisect(B, std::move(all), 0);
+        std::unique_ptr<Sub> root;
+        const auto t_bisect = std::chrono::steady_clock::now();
+        const char* km_env = getenv("KA_KMEANS");
+        const bool km_dev = g_km.on && A == 32 && padded == 32 && (km_env ? atoi(km_env) != 0 : numseq >= 2048);
+        g_last_bisect_device = km_dev ? 1 : 0;
+        if (km_dev) {
+                std::vector<KaKmNode> kn;
+                std::string why;
+                if (ka_kmeans_device(g_km.device, g_km.stream, dm.data(), numseq, kn, why)) return ka_fail_message(("ka_guide_tree: " + why).c_str());
+                // the device's node table as the builder's tree (iteratively: lopsided splits make it deep)
+                std::vector<std::unique_ptr<Sub>> made(kn.size());
+                for (size_t k = kn.size(); k--;) {                  // children have larger indices than their parent
+                        made[k].reset(new Sub());
+                        if (kn[k].left < 0) made[k]->cluster = std::move(kn[k].cluster);
+                        else { made[k]->l = std::move(made[kn[k].left]); made[k]->r = std::move(made[kn[k].right]); }
+                }
+                root = std::move(made[0]);
+        } else {
+                std::vector<int> all(numseq);
+                for (int i = 0; i < numseq; i++) all[i] = i;
+                root = bisect(B, std::move(all), 0);
+        }
+        g_last_bisect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_bisect).count();
 
         // ---- all pairs inside every leaf cluster in one batch (d_estimation with pair = 1): the value the reference
         //      keeps for i < j is the one it computes last, calc_distance(seq[samples[j]], seq[samples[i]]) ----
@@ -432,5 +470,9 @@ extern "C" int ka_guide_tree(ka_ctx* ctx, int numseq, const uint8_t* codes, cons
 {
         if (!ctx || !codes || !off) return ka_fail_message("ka_guide_tree: bad arguments");
         DeviceDist D{ ctx, codes, off, lens, numseq };
-        return ka_guide_tree_from(numseq, lens, device_dist, &D, n_threads, dm_scale, tasks_abc, seq_distances);
+        g_km = KmDevice();
+        g_km.on = ka_ctx_device_stream(ctx, &g_km.device, &g_km.stream) == 0;
+        const int rc = ka_guide_tree_from(numseq, lens, device_dist, &D, n_threads, dm_scale, tasks_abc, seq_distances);
+        g_km = KmDevice();
+        return rc;
 }

@@ -24,6 +24,40 @@ def test_device_guide_tree_matches_reference(ctx, name):
     assert np.array_equal(sd.view(np.uint32), g.seq_distances.view(np.uint32))
 
 
+@pytest.mark.parametrize("name", guide_cases())
+def test_device_bisection_matches_reference(ctx, name, monkeypatch):
+    """the 2-means bisection on the device (ka_kmeans.hip; KA_KMEANS=1 forces it below its size threshold): the goldens of the
+    real reference, task list and seq_distances bit for bit"""
+    from kalign_amd import api
+    g = Golden(name)
+    if len(g.tree_seqs) < 64:
+        pytest.skip("fewer than 32 anchors / nothing to bisect")
+    monkeypatch.setenv("KA_KMEANS", "1")
+    tasks, sd = ctx.guide_tree(g.tree_seqs, n_threads=4, dm_scale=g.dm_scale if hasattr(g, "dm_scale") else None)
+    assert api.guide_last_bisect()[1]
+    assert np.array_equal(tasks, g.tasks)
+    assert np.array_equal(sd.view(np.uint32), g.seq_distances.view(np.uint32))
+
+
+@pytest.mark.parametrize("nseq,length,dna", [(300, 120, False), (2500, 150, False), (1500, 200, True), (6000, 100, False)])
+def test_device_bisection_equals_the_host_one(ctx, nseq, length, dna, monkeypatch):
+    """the same tree from the device's candidates-side-by-side bisection as from the host's restatement of the reference
+    (which the guide goldens pin to the real build_tree_kmeans): levels with hundreds of sets, lopsided splits, sets that
+    stop at the 50-sequence threshold at different depths"""
+    from kalign_amd import api, guide, synth
+    seqs = synth.dssim(nseq, length, dna=dna, seed=3) if nseq <= 4096 else synth.dssim_fast(nseq, length, dna=dna, seed=3)
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))
+    tcodes = guide.encode_tree([seqs[i] for i in order], dna=dna)
+    monkeypatch.setenv("KA_KMEANS", "0")
+    t0, sd0 = ctx.guide_tree(tcodes, n_threads=8)
+    assert not api.guide_last_bisect()[1]
+    monkeypatch.setenv("KA_KMEANS", "1")
+    t1, sd1 = ctx.guide_tree(tcodes, n_threads=8)
+    assert api.guide_last_bisect()[1]
+    assert np.array_equal(t0, t1)
+    assert np.array_equal(sd0.view(np.uint32), sd1.view(np.uint32))
+
+
 @pytest.mark.parametrize("name", tree_cases() + cons_cases())
 def test_sequences_to_rows(ctx, name):
     """kalign_run's alignment phase end to end on the device: guide tree, (consistency,) task tree, final rows"""
