@@ -86,7 +86,7 @@ struct KaEnv {
         int max_cluster = 0;           // KA_MAX_CLUSTER: workgroups one task may use (0: the default, 16)
         int crit_top = 0;              // KA_CRIT_TOP: workgroups of the chain entry with the longest way to the root (0: default)
         int prof_task = -1;            // KA_PROF_TASK: the task whose per-level times KA_FLAG_TIMING keeps (-1: the root)
-        int q1 = 0;                    // KA_Q1: 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
+        int q1 = -1;                   // KA_Q1 (-1: the default, 0; 4 = experiment: per recursion level where every strip still gets a helper wave -- 2 % on the headline, but the debug rows of some goldens then differ: DESIGN 4f): 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
         int lean4 = 1;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU (1.60 -> 1.28 ms on the 4096 x 400 leaf level)
         int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
         int per = 0;                   // KA_PER: strips per workgroup (KaTreeDev::per_target; experiments)
@@ -106,7 +106,7 @@ static void read_env(KaEnv& v)
         v.no_crit = getenv("KA_NO_CRIT") != nullptr; v.no_staging = getenv("KA_NO_STAGING") != nullptr;
         v.no_wdfs = getenv("KA_NO_WDFS") != nullptr; v.no_ls0 = getenv("KA_NO_LS0") != nullptr; v.no_inc = getenv("KA_NO_INC") != nullptr; v.no_ldfs = getenv("KA_NO_LDFS") != nullptr; v.refine_serial = getenv("KA_REFINE_SERIAL") != nullptr;
         v.chain_tasks = env_int("KA_CHAIN_TASKS", 0); v.max_cluster = env_int("KA_MAX_CLUSTER", 0); v.crit_top = env_int("KA_CRIT_TOP", 0);
-        v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", 0); v.lean4 = env_int("KA_LEAN4", 1);
+        v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", -1); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
         v.mw = env_int("KA_MW", 1);
@@ -790,7 +790,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.prof_task = c->env.prof_task;                                 // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
-        D.q1_mode = c->env.q1;
+        D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : 0;
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
@@ -1136,6 +1136,9 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
                                 for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ULL; }
                                 return h;
                         };
+                        if (const char* dump = getenv("KA_DUMP_ROWS")) {   // debugging aid: the rows of every task appended to a file (task, n, 2n floats)
+                                if (FILE* fh = fopen(dump, "ab")) { const long long hd[2] = { t, (long long)n }; fwrite(hd, sizeof(hd), 1, fh); fwrite(rows.data(), sizeof(float), 2 * n, fh); fclose(fh); }
+                        }
                         r.fhash = fnv(rows.data(), sizeof(float) * n);
                         r.bhash = fnv(rows.data() + n, sizeof(float) * n);
                 }

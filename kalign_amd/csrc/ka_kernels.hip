@@ -134,6 +134,8 @@ struct TaskShared {
         int sub_tm;                    // KA_FLAG_TIMING, the profiled task: subtree phase times are accumulated in sub_t
         unsigned long long sub_t[7];   //   subtrees, staging / pass / meetup / total cycles (sums over the workgroup's subtrees), longest one, sum of level*1e6 + R*1e3 + C
         int srows;                     // rows per strip of this task: 128 (two DP rows per lane) or 64 (one; ka_strip<.., Q = 1>)
+        int lvl_srows[2];              // ... of the recursion level with this parity (== srows unless q1_lvl)
+        int q1_lvl;                    // KaTreeDev::q1_mode 4: every recursion level takes 64-row strips when the cluster has a SIMD for each of them (ka_level_srows)
         int ho_ok;                     // neighbouring strips of this task hand over through LDS rings (ka_strip<.., HO>; KaTreeDev::ho_mode, profile-profile tasks of the 8-wave kernel)
         int hw_ok;                     // levels with at most four items per workgroup run their strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode, profile-profile tasks of the 8-wave kernel)
         // The recursion of a cluster: levels whose passes need more than one CU run cluster-wide (Gw = G: strips spread
@@ -302,6 +304,20 @@ __device__ __forceinline__ void ka_emit_items(const KaLevelOut& o, int slot, int
         ka_emit_pass(o, slot, KA_BWD, enda - mid, ncols);
 }
 
+// Rows per strip of recursion level `level` (q1_mode 4): one DP row per lane costs 0.72 of a two-row step (ka_wstrip<.., Q = 1>:
+// 290 against 400 cycles) at twice the strips, so a level takes 64-row strips exactly when all of them still get a strip
+// wave with a helper -- four per workgroup of the cluster.  From the task's shape and the level alone (an upper bound on the
+// level's strips: 2^(level+1) passes of ceil(La / 2^(level+1)) rows): every workgroup and every emitting wave derives the
+// same answer without talking.  Once the cluster has split, workgroups work alone on small sub-problems: 128.
+__device__ __forceinline__ int ka_level_srows(const TaskShared& S, int level)
+{
+        if (!S.q1_lvl) return S.srows;
+        if (S.split || level > 12) return KA_STRIP_ROWS;
+        const int pr = (S.La + (2 << level) - 1) >> (level + 1);
+        const long long strips = (long long)(2 << level) * ((pr + KA_STRIP1_ROWS - 1) / KA_STRIP1_ROWS);
+        return strips <= 4ll * S.G ? KA_STRIP1_ROWS : KA_STRIP_ROWS;
+}
+
 __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bool next)
 {
         KaLevelOut o;
@@ -313,7 +329,7 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
         o.n4 = &S.lctl->lvl[parity].npack[1];
         o.nsub = &S.lctl->lvl[parity].nsub;
         o.rowalloc = &S.lctl->lvl[parity].rowalloc;
-        o.srows = S.srows;
+        o.srows = S.lvl_srows[parity];
         o.sub_ok = S.sub_ok; o.kind = S.kind; o.nres = S.nres_t; o.sub_bytes = S.sub_stride;
         return o;
 }
@@ -637,7 +653,10 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                         // (waves 0..3, one per SIMD) -- wave w + 4 serves the strip of wave w.  The same for every workgroup of the
                         // cluster (ntotal, Gw and per are), so both ends of a hand-over between workgroups speak the same protocol.
                         const bool wmode = HW && KIND == KA_PP && KA_NW == 8 && ntotal <= nslots && per <= KA_NW / 2
-                                           && __builtin_amdgcn_readfirstlane(S.hw_ok) != 0 && __builtin_amdgcn_readfirstlane(S.srows) == KA_STRIP_ROWS;
+                                           && __builtin_amdgcn_readfirstlane(S.hw_ok) != 0
+                                           && (__builtin_amdgcn_readfirstlane(S.lvl_srows[level & 1]) == KA_STRIP_ROWS || __builtin_amdgcn_readfirstlane(S.q1_lvl) != 0);
+                        // (64-row strips with helper waves only in the per-level experiment, KaTreeDev::q1_mode 4)
+                        const int wsrows = __builtin_amdgcn_readfirstlane(S.lvl_srows[level & 1]);
                         if (HW && KIND == KA_PP && wmode && wave >= KA_NW / 2) {
                                 const int sw = wave - KA_NW / 2;                       // the strip wave this one helps
                                 const int hit = __builtin_amdgcn_readfirstlane((sw < per && member_w * per + sw < nstatic) ? member_w * per + sw : ntotal);
@@ -658,14 +677,20 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                                 const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
                                                 const int mid_ = ((ea - sa) / 2) + sa;
                                                 const int nrows_ = (dir == KA_FWD) ? mid_ - sa : ea - mid_;
-                                                const int ns = ka_strips_of(nrows_, KA_STRIP_ROWS);
+                                                const int ns = ka_strips_of(nrows_, wsrows);
                                                 const bool prod_local = k > 0 && (hit - 1) / per == member_w;
                                                 const bool cons_local = k + 1 < ns && hit + 1 < nstatic && (hit + 1) / per == member_w;
-                                                if (nrows_ > 0)
-                                                        ka_whelper<NRES>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k, ns,
-                                                                         ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (hit - k)), lane,
-                                                                         lds_waves + sw * KA_WAVE_LDS, lds_waves + wave * KA_WAVE_LDS, (int*)(lds_waves - KA_LDS_HO_BACK), sw,
-                                                                         k == 0 ? 0 : (prod_local ? 1 : 2), cons_local);
+                                                if (nrows_ > 0) {
+                                                        KaWHelperArgs ha;
+                                                        ha.p2 = S.p2; ha.rows = (dir == KA_FWD ? S.fbuf : S.bbuf) + roff; ha.prog = prog + (hit - k); ha.watchdog = S.watchdog;
+                                                        ha.m2 = S.p2_mult; ha.inj_a = ja; ha.inj_ga = jga; ha.inj_gb = jgb; ha.Lb = S.Lb;
+                                                        ha.starta = sa; ha.enda = ea; ha.startb = sbb; ha.endb = eb; ha.dir = dir; ha.k = k; ha.ns = ns;
+                                                        ha.slds_u = (unsigned)(unsigned long long)(lds_waves + sw * KA_WAVE_LDS);
+                                                        ha.hlds_u = (unsigned)(unsigned long long)(lds_waves + wave * KA_WAVE_LDS);
+                                                        ha.ctl_u = (unsigned)(unsigned long long)(lds_waves - KA_LDS_HO_BACK);
+                                                        ha.w = sw; ha.in_mode = k == 0 ? 0 : (prod_local ? 1 : 2); ha.out_local = cons_local ? 1 : 0;
+                                                        if (Q1 && wsrows == KA_STRIP1_ROWS) ka_whelper<NRES, 1>(ha); else ka_whelper<NRES, 2>(ha);
+                                                }
                                         }
                                 }
                                 return;
@@ -716,7 +741,7 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const float jga = ka_uniform_f(dir == KA_FWD ? sp->fin.ga : sp->bin.ga);
                                 const float jgb = ka_uniform_f(dir == KA_FWD ? sp->fin.gb : sp->bin.gb);
                                 const int mid_ = ((ea - sa) / 2) + sa;
-                                const int srows = __builtin_amdgcn_readfirstlane(S.srows);
+                                const int srows = wsrows;
                                 const int ns = ka_strips_of(dir == KA_FWD ? mid_ - sa : ea - mid_, srows);
                                 const bool st_me = it < nstatic;
                                 const bool prod_local = k > 0 && st_me && (it - 1) / per == member_w;
@@ -735,8 +760,12 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                                 const unsigned in_ring_u = prod_local ? (unsigned)(unsigned long long)(lds_waves + (wave - 1) * KA_WAVE_LDS + KA_HO_RING)
                                                                                       : (unsigned)(unsigned long long)(lds_waves + (wave + KA_NW / 2) * KA_WAVE_LDS + KA_W_INRING);
                                                 const unsigned in_word_u = ctl_u + 4 * (prod_local ? KA_W_TPUB(wave - 1) : KA_W_IN(wave));
-                                                ka_wstrip<NRES, NB>(S, sa, ea, sbb, eb, dir, k, lane, lds_waves + wave * KA_WAVE_LDS,
-                                                                    in_ring_u, in_word_u, prod_local ? 63 : 0, ctl_u, wave, pslot);
+                                                KaWStripArgs wa;
+                                                wa.p1 = S.p1; wa.ent = S.ent; wa.watchdog = S.watchdog; wa.pslot = pslot; wa.m1 = S.p1_mult; wa.Lb = S.Lb; wa.prio = (S.hw_ok >> 4) & 3;
+                                                wa.starta = sa; wa.enda = ea; wa.startb = sbb; wa.endb = eb; wa.dir = dir; wa.k = k;
+                                                wa.wlds_u = (unsigned)(unsigned long long)(lds_waves + wave * KA_WAVE_LDS);
+                                                wa.in_ring_u = in_ring_u; wa.in_word_u = in_word_u; wa.in_bias = prod_local ? 63 : 0; wa.ctl_u = ctl_u; wa.w = wave;
+                                                if (Q1 && srows == KA_STRIP1_ROWS) ka_wstrip<NRES, NB, 1>(wa); else ka_wstrip<NRES, NB, 2>(wa);
                                                 continue;
                                         }
                                 }
@@ -773,7 +802,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
         };
         ho_clear();
         if (lead) for (int i = tid; i < g; i += KA_NT) S.raw[i] = -1;  // init_alnmem, aln_setup.c:33-36
-        if (tid == 0) { S.lctl = S.ctl; S.Gw = S.G; S.member_w = S.member; S.split = 0; }
+        if (tid == 0) { S.lctl = S.ctl; S.Gw = S.G; S.member_w = S.member; S.split = 0; S.lvl_srows[0] = ka_level_srows(S, 0); S.lvl_srows[1] = ka_level_srows(S, 1); }
         if (lead && tid == 0) {
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
@@ -818,7 +847,8 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                         }
                                         S.ctl_lds.msum = 0.0; S.ctl_lds.mcount = 0;
                                         KaCtl::Lvl& L = S.ctl_lds.lvl[level & 1];
-                                        const KaLevelOut lo = ka_level_out(S, level & 1, false);
+                                        KaLevelOut lo = ka_level_out(S, level & 1, false);
+                                        lo.srows = S.srows;                      // (what ka_level_srows says once S.split is set, below)
                                         // this member's share: every G-th sub-problem of the level (they are independent
                                         // subtrees of the recursion; their order in the queue is arbitrary)
                                         for (int k = S.member; k < nshared; k += S.G) {
@@ -830,11 +860,13 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                                 L.nsub += 1;
                                         }
                                         S.Gw = 1; S.member_w = 0; S.split = 1;
+                                        S.lvl_srows[0] = ka_level_srows(S, level); S.lvl_srows[1] = S.lvl_srows[0];     // (split: the task's own strip shape from here on)
                                 }
                                 __syncthreads();
                         }
                 }
                 const bool lead_w = (S.member_w == 0);
+                if (tid == 0) S.lvl_srows[(level + 1) & 1] = ka_level_srows(S, level + 1);    // (read by this level's meetups, behind the barrier that ends its passes)
                 KaCtl::Lvl* const cur = &S.lctl->lvl[level & 1];
                 const int ncur = cur->nsub;
                 if (ncur == 0) break;
@@ -2309,11 +2341,22 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // cluster has a SIMD for every strip of the two top-level passes -- the number of strips in flight stays
                 // about the same down the recursion (rows halve, passes double) -- else 128-row strips.
                 int srows = KA_STRIP_ROWS;
-                if (Q1 && D.q1_mode) {
+                int q1_lvl = 0;
+                if (Q1 && D.q1_mode == 4) {
+                        // per level (ka_level_srows): profile-profile tasks with helper waves; the cluster as wide as the top level's
+                        // 64-row strips want it, if the launch gave that many workgroups
+                        if (D.hw_mode && kind == KA_PP) {
+                                const int s1 = ka_strips_of(S.La / 2, KA_STRIP1_ROWS) + ka_strips_of(S.La - S.La / 2, KA_STRIP1_ROWS);
+                                q1_lvl = 1;
+                                g_eff = max(g_eff, min(g_launch, (s1 + 3) / 4));
+                        }
+                } else if (Q1 && D.q1_mode) {
                         const int s1 = ka_strips_of(S.La / 2, KA_STRIP1_ROWS) + ka_strips_of(S.La - S.La / 2, KA_STRIP1_ROWS);
                         const int g1 = (s1 + 3) / 4;
                         if (g1 <= g_launch || (D.q1_mode >= 2 && (s1 + 7) / 8 <= g_launch) || D.q1_mode >= 3) { srows = KA_STRIP1_ROWS; g_eff = g1; }
                 }
+                S.q1_lvl = q1_lvl;
+                S.lvl_srows[0] = srows; S.lvl_srows[1] = srows;
                 // LDS hand-over between neighbouring strips (ka_strip<.., HO>): profile-profile tasks of the 8-wave kernel, fast mode.
                 // ho_mode >= 2: four strips per workgroup (one per SIMD) instead of three -- fewer hand-overs cross workgroups.
                 S.ho_ok = (Q1 && NB == 0 && D.ho_mode && kind == KA_PP) ? 1 : 0;
@@ -2540,7 +2583,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.p2_mult = swapped ? (float)T.nsip_b : (float)T.nsip_a;
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
-                S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS;
+                S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS; S.q1_lvl = 0; S.lvl_srows[0] = KA_STRIP_ROWS; S.lvl_srows[1] = KA_STRIP_ROWS;
                 S.sub_ok = 0; S.rec_on = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
@@ -3052,7 +3095,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int i = P.ia[k], j = P.ib[k];
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
-                S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS;
+                S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS; S.q1_lvl = 0; S.lvl_srows[0] = KA_STRIP_ROWS; S.lvl_srows[1] = KA_STRIP_ROWS;
                 S.sub_ok = 1; S.rec_on = 0; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0; S.mw_ok = 1;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;

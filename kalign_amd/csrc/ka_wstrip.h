@@ -44,16 +44,74 @@ typedef float float3v __attribute__((ext_vector_type(3)));
 #define KA_W_IN(w_) (8 + (w_))
 #define KA_W_INRING 0                                           // the in ring: first 4 KB of the HELPER wave's region (256 slots x 16 B)
 
-template <int NRES, int NB>
-__device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
-                                          const int dir, const int k, const int lane, char* wlds,
-                                          const unsigned in_ring_u, const unsigned in_word_u, const int in_bias,
-                                          const unsigned ctl_u, const int w, long long* pslot = nullptr)
+// Q: DP rows per lane.  Q = 2: 128-row strips, ~83 instructions per step.  Q = 1: 64-row strips, ~57 instructions per step (the
+// products pack two RESIDUES per v_pk_mul_f32, the sums of the one row stay scalar) and twice the strips per pass: a pass of K
+// 128-row strips costs (C + 64 + (K - 1) * D) steps either way in STEPS (D ~ 80: the lane skew plus the hand-over) with 2K
+// strips in place of K, but a step is 0.63 of the two-row step -- with ka_strip's 127-column hand-over delay the narrow strips
+// were a wash (round 3), with this one they win wherever the cluster has a SIMD per strip (TaskShared::srows says which).
+//
+// ka_wstrip and ka_whelper take their arguments as a struct by value so that they can be built as REAL functions: inlined into
+// the task kernel -- one __global__ with three DP kinds, the recursion, meetups, path coding and the profile merge inlined
+// into it -- the strip's loop shares the kernel's register allocation with everything that is live across it and sits at the
+// edge of 256 VGPRs (a version with eight more live values tipped over: 700 VGPR spills, 80 scratch accesses per STEP, and
+// wrong results on top).  tools/check_hot_loops.py disassembles the built object and counts scratch accesses per strip step.
+// KA_W_NOINLINE=1 (experiment, -D at build time): as real functions with an allocation of their own.  Measured (r04_ab5): the
+// strip's octets then carry no scratch access at all (inlined, the head and tail forms keep up to five per step), but every
+// OTHER path of the kernel pays for the calls in its loop -- ka_strip's levels +10 %, the 1024 x 2000 nucleotide tree 37.8 ->
+// 42.4 ms, the protein headline unchanged -- so the default stays inlined.
+#ifndef KA_W_NOINLINE
+#define KA_W_NOINLINE 0
+#endif
+#if KA_W_NOINLINE
+#define KA_W_CALL __attribute__((noinline))
+#else
+#define KA_W_CALL __forceinline__
+#endif
+// The HELPER alone as a real function (KA_WH_NOINLINE, default 1): its call sits where waves 4..7 have nothing else live (they
+// return to the level's barrier right behind it).
+#ifndef KA_WH_NOINLINE
+#define KA_WH_NOINLINE 1
+#endif
+#if KA_WH_NOINLINE
+#define KA_WH_CALL __attribute__((noinline))
+#else
+#define KA_WH_CALL __forceinline__
+#endif
+typedef __attribute__((address_space(3))) char ka_lchar;
+typedef __attribute__((address_space(3))) int ka_lint;
+
+struct KaWStripArgs {
+        const float* p1;                 // row profile
+        const int2* ent;                 // consistency bonus entries (NB > 0)
+        int* watchdog;
+        long long* pslot;                // KA_PROF builds
+        float m1;                        // TaskShared::p1_mult
+        int Lb, prio;
+        int starta, enda, startb, endb, dir, k;
+        unsigned wlds_u;                 // LDS offset of the strip wave's region
+        unsigned in_ring_u, in_word_u;   // the row above: ring base and the word that counts its columns
+        int in_bias;
+        unsigned ctl_u;                  // control words of helper mode
+        int w;                           // strip wave index in the workgroup
+};
+
+__device__ __forceinline__ int ka_u(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned ka_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+
+template <int NRES, int NB, int Q = 2>
+__device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
 {
+        // (everything in `a` is wave-uniform, but arrives in vector registers: back to scalars)
+        const int lane = threadIdx.x & 63;
+        const int starta = ka_u(a.starta), enda = ka_u(a.enda), startb = ka_u(a.startb), endb = ka_u(a.endb), dir = ka_u(a.dir), k = ka_u(a.k);
+        const unsigned in_ring_u = ka_u(a.in_ring_u), in_word_u = ka_u(a.in_word_u), ctl_u = ka_u(a.ctl_u);
+        const int in_bias = ka_u(a.in_bias), w = ka_u(a.w);
+        const float* const p1 = ka_uniform_ptr(a.p1);
+        long long* const pslot = ka_uniform_ptr(a.pslot);
         // the strip wave goes first on its SIMD: its helper (same SIMD, priority 0) takes the issue slots it leaves
-        // (KA_HW_PRIO in the environment, experiments: 0 .. 3, default 3; TaskShared::hw_ok carries it in bits 4..5)
+        // (KA_HW_PRIO in the environment, experiments: 0 .. 3, default 3)
         {
-                const int prio = (__builtin_amdgcn_readfirstlane(S.hw_ok) >> 4) & 3;
+                const int prio = ka_u(a.prio);
                 if (prio == 3) __builtin_amdgcn_s_setprio(3); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 1) __builtin_amdgcn_s_setprio(1);
         }
         const int ncols = endb - startb;
@@ -61,53 +119,68 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
         const int r0 = (dir == KA_FWD) ? starta : mid;
         const int r1 = (dir == KA_FWD) ? mid : enda;
         const int nrows = r1 - r0;                                    // > 0 (the caller keeps empty passes on ka_strip)
-        const int Lb = __builtin_amdgcn_readfirstlane(S.Lb);
+        const int Lb = ka_u(a.Lb);
         const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == Lb);
         const bool far_t = (dir == KA_FWD) ? (endb == Lb) : (startb == 0);
-        int* const wdu = ka_uniform_ptr(S.watchdog);
-        const float m1 = ka_uniform_f(S.p1_mult);
+        int* const wdu = ka_uniform_ptr(a.watchdog);
+        const float m1 = ka_uniform_f(a.m1);
 
-        const int u0 = k * KA_STRIP_ROWS;
-        const int nr = min(KA_STRIP_ROWS, nrows - u0);
-        const int nl = (nr + 1) >> 1;
+        constexpr int SROWS = 64 * Q;
+        const int u0 = k * SROWS;
+        const int nr = min(SROWS, nrows - u0);
+        const int nl = (Q == 2) ? ((nr + 1) >> 1) : nr;
         const int lastl = nl - 1;
-        const bool last_is_b = (nr & 1) == 0;
-        const bool actB = 2 * lane + 1 < nr;
-        const int uA = u0 + min(2 * lane, nr - 1);
-        const int uB = u0 + min(2 * lane + 1, nr - 1);
+        const bool last_is_b = (Q == 2) && (nr & 1) == 0;
+        const bool actB = (Q == 2) && 2 * lane + 1 < nr;
+        const int uA = u0 + min(Q * lane, nr - 1);
+        const int uB = u0 + min(Q * lane + 1, nr - 1);              // (Q = 1: row B does not exist; its operand loads are dead code)
         const int iA = (dir == KA_FWD) ? (r0 + uA) : (r1 - 1 - uA);
         const int iB = (dir == KA_FWD) ? (r0 + uB) : (r1 - 1 - uB);
         const int recA = iA + 1, recB = iB + 1;
         const int prevA = (dir == KA_FWD) ? recA - 1 : recA + 1;
         const int prevB = (dir == KA_FWD) ? recB - 1 : recB + 1;
 
-        const unsigned wlds_u = (unsigned)(unsigned long long)wlds;
+        const unsigned wlds_u = ka_u(a.wlds_u);
         const unsigned out_u = wlds_u + KA_HO_RING;
         const unsigned tpub_u = ctl_u + 4 * KA_W_TPUB(w), go_u = ctl_u + 4 * KA_W_GO(w);
-        const unsigned long long own_mask = 1ull << lastl;            // the lane that owns the strip's last row
+        // the lane that owns the strip's last row writes it: exec narrowed to that lane around the ds_write (v_cmpx on two VGPRs --
+        // an exec mask handed to the inline asm as a 64-bit "s" operand arrived in a VGPR pair once the kernel ran short of SGPRs)
+        const int lastl_v = lastl;
 
         // ---- stationary row operand (as in ka_strip) ----
         float oA, eA, tA, oB, eB, tB, orpA, orpB;
-        float2v p1v[NRES];
+        float2v p1v[Q == 2 ? NRES : 1];                               // Q = 2: the counts of residue c in rows (A, B)
+        constexpr int NPAIR = NRES / 2;
+        float2v p1p[Q == 1 ? (NPAIR > 0 ? NPAIR : 1) : 1];            // Q = 1: the counts of residues (2i, 2i+1) in row A
+        float p1last = 0.0f;                                          // Q = 1, odd alphabets: the count of residue NRES-1
         {
-                const float* pA = S.p1 + ((long long)recA << 6);
-                const float* pB = S.p1 + ((long long)recB << 6);
+                const float* pA = p1 + ((long long)recA << 6);
+                const float* pB = p1 + ((long long)recB << 6);
                 oA = pA[55] * m1; eA = pA[56] * m1; tA = pA[57] * m1;
                 oB = pB[55] * m1; eB = pB[56] * m1; tB = pB[57] * m1;
-                orpA = S.p1[((long long)prevA << 6) + 55] * m1;
-                orpB = S.p1[((long long)prevB << 6) + 55] * m1;
+                orpA = p1[((long long)prevA << 6) + 55] * m1;
+                orpB = p1[((long long)prevB << 6) + 55] * m1;
                 constexpr int NV = (NRES + 3) / 4;
-                float4v va[NV], vb[NV];
+                if constexpr (Q == 2) {
+                        float4v va[NV], vb[NV];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
+                        for (int i = 0; i < NV; ++i) { va[i] = ((const float4v*)pA)[i]; vb[i] = ((const float4v*)pB)[i]; }
 #pragma unroll
-                for (int c = 0; c < NRES; ++c) {
-                        p1v[c].x = va[c >> 2][c & 3];
-                        p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
+                        for (int c = 0; c < NRES; ++c) {
+                                p1v[c].x = va[c >> 2][c & 3];
+                                p1v[c].y = actB ? vb[c >> 2][c & 3] : 0.0f;
+                        }
+                } else {
+                        float4v va[NV];
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) va[i] = ((const float4v*)pA)[i];
+#pragma unroll
+                        for (int i = 0; i < NPAIR; ++i) { p1p[i].x = va[(2 * i) >> 2][(2 * i) & 3]; p1p[i].y = va[(2 * i + 1) >> 2][(2 * i + 1) & 3]; }
+                        if (NRES & 1) p1last = va[(NRES - 1) >> 2][(NRES - 1) & 3];
                 }
         }
         KaBonus<NB> bonA, bonB;
-        if (NB) { bonA.load(S.ent, iA); bonB.load(S.ent, iB); }
+        if (NB) { bonA.load(a.ent, iA); if (Q == 2) bonB.load(a.ent, iB); }
 
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
         float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;
@@ -190,9 +263,15 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
 
         // One wavefront step.  ST: steady state (no edge cases); P: the half of q / bq that holds this step's operands;
         // I: position in an octet (0 .. CH-1; immediate LDS offsets, the octet's checks are compile-time) or -1 (single step)
+        // FORM: 0 steady state (every active lane strictly inside the column range); 1 head (lanes still entering: the lane at
+        // column 0 is the only special one -- ncols >= nl, so nobody is at the last column yet); 2 tail (lanes leaving: the lane at
+        // the last column is the special one); 3 both at once (passes with fewer columns than the strip has lanes).  Lanes outside
+        // the column range compute on whatever their ring slot holds: state only flows DOWN the lanes, so nothing of it reaches a
+        // lane inside the range (see ka_strip), and forms 1 and 2 do without the clamped column index of form 3.
         auto step = [&](const int t, auto st_tag, auto par_tag, auto i_tag, auto lb_tag) {
                 constexpr bool LASTB = decltype(lb_tag)::value;
-                constexpr bool ST = decltype(st_tag)::value;
+                constexpr int FORM = decltype(st_tag)::value;
+                constexpr bool ST = FORM == 0;
                 constexpr int P = decltype(par_tag)::value;
                 constexpr int I = decltype(i_tag)::value;
                 const int v = t - lane;
@@ -203,17 +282,18 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                 // s_waitcnt lgkmcnt(0) would be waited for; here the whole dot product lies between it and the next wait.)
                 {
                         const int vLp = t - 1 - lastl;
-                        if (ST || (vLp >= 0 && vLp <= ncols)) {
+                        // (head: the last row's owner has not reached column 0 yet; steady state and tail: always inside the range)
+                        if (FORM != 1 && (FORM != 3 || (vLp >= 0 && vLp <= ncols))) {
                                 float3v o;
-                                o.x = LASTB ? cBa : cAa; o.y = LASTB ? cBga : cAga; o.z = LASTB ? cBgb : cAgb;
+                                o.x = (Q == 2 && LASTB) ? cBa : cAa; o.y = (Q == 2 && LASTB) ? cBga : cAga; o.z = (Q == 2 && LASTB) ? cBgb : cAgb;
                                 unsigned long long sv;
                                 if constexpr (I >= 1) {
-                                        asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b96 %1, %2 offset:%4\n\ts_mov_b64 exec, %0"
-                                                     : "=&s"(sv) : "v"(out_oct), "v"(o), "s"(own_mask), "n"((I - 1) * 16) : "memory", "scc");
+                                        asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_eq_u32_e32 %3, %4\n\tds_write_b96 %1, %2 offset:%5\n\ts_mov_b64 exec, %0"
+                                                     : "=&s"(sv) : "v"(out_oct), "v"(o), "v"(lastl_v), "v"(lane), "n"((I - 1) * 16) : "memory", "vcc");
                                 } else {
                                         const unsigned oa = out_u + ((((unsigned)t - 1u) & 255u) << 4);
-                                        asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
-                                                     : "=&s"(sv) : "v"(oa), "v"(o), "s"(own_mask) : "memory", "scc");
+                                        asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_eq_u32_e32 %3, %4\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
+                                                     : "=&s"(sv) : "v"(oa), "v"(o), "v"(lastl_v), "v"(lane) : "memory", "vcc");
                                 }
                         }
                 }
@@ -222,38 +302,46 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                 const float copen = q[P][5].w, cext = q[P][6].x;                    // (the helper has applied the multiplier; ctext only feeds row -1)
 
                 // the row above A: lane l-1's row B, lane 0 takes the boundary state of column t
-                const float upa = wave_shr1_old(bq[P].x, cBa), upga = wave_shr1_old(bq[P].y, cBga), upgb = wave_shr1_old(bq[P].z, cBgb);
+                // (the lane's last row: B, or A when a lane owns one row)
+                const float lra = (Q == 2) ? cBa : cAa, lrga = (Q == 2) ? cBga : cAga, lrgb = (Q == 2) ? cBgb : cAgb;
+                const float upa = wave_shr1_old(bq[P].x, lra), upga = wave_shr1_old(bq[P].y, lrga), upgb = wave_shr1_old(bq[P].z, lrgb);
 
                 // The gap states that do not wait for the dot products come FIRST in the source: the scheduler then has them to put
                 // into the wait states at the end of the dependent v_pk_add chain (six s_nop per step before; round 4).
-                const bool at0 = (v == 0), atN = (v == ncols);
+                const bool at0 = (FORM == 1 || FORM == 3) && (v == 0), atN = (FORM == 2 || FORM == 3) && (v == ncols);
                 const bool edge = at0 | atN;
-                const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
-                float nAga, nAgb, nBga;
-                // (edge form: selects on the OPERANDS, no branches: max(x, y) + c == max(x + c, y + c) bit for bit -- rounding is
+                float nAga, nAgb, nBga = -KA_F;
+                // (edge forms: selects on the OPERANDS, no branches: max(x, y) + c == max(x + c, y + c) bit for bit -- rounding is
                 // monotonic -- so the terminal case `max(gb, a) + t` is the inner case with both penalties replaced by t; written as
-                // `term ? .. : ..` over the two results the compiler made four exec-masked regions per step of it)
-                const float xeB = (!ST && term) ? tB : eB, xoB = (!ST && term) ? tB : oB;
+                // `term ? .. : ..` over the two results the compiler made four exec-masked regions per step of it.  The penalties of
+                // a lane at the first / last column are t where that column is a terminal one, else the inner ones.)
+                // (near_t / far_t are wave-uniform: `uniform ? t : e` is one select on a scalar condition, made here in the edge steps
+                // rather than kept in eight more registers across the steady loop -- the kernel has none to spare)
+                float xeA = eA, xoA = oA, xeB = eB, xoB = oB;
+                if (FORM == 1 || FORM == 3) {
+                        xeA = at0 ? (near_t ? tA : eA) : xeA; xoA = at0 ? (near_t ? tA : oA) : xoA;
+                        if (Q == 2) { xeB = at0 ? (near_t ? tB : eB) : xeB; xoB = at0 ? (near_t ? tB : oB) : xoB; }
+                }
+                if (FORM == 2 || FORM == 3) {
+                        xeA = atN ? (far_t ? tA : eA) : xeA; xoA = atN ? (far_t ? tA : oA) : xoA;
+                        if (Q == 2) { xeB = atN ? (far_t ? tB : eB) : xeB; xoB = atN ? (far_t ? tB : oB) : xoB; }
+                }
                 if (ST) {
                         nAga = kmax(cAga + cext, cAa + copen);
                         nAgb = kmax(upgb + eA, upa + oA);
-                        nBga = kmax(cBga + cext, cBa + copen);
+                        if (Q == 2) nBga = kmax(cBga + cext, cBa + copen);
                 } else {
-                        const float xeA = term ? tA : eA, xoA = term ? tA : oA;
                         nAga = edge ? -KA_F : kmax(cAga + cext, cAa + copen);
                         nAgb = kmax(upgb + xeA, upa + xoA);
-                        nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
+                        if (Q == 2) nBga = edge ? -KA_F : kmax(cBga + cext, cBa + copen);
                 }
-                float2v acc;
-                acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
-                acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
                 // Next step's operands into the other half of q / bq.  ka_strip reads them AFTER the dot products (its waits were
                 // once the compiler's, and those waited for fresh loads too); here the step's one wait is the manual lgkmcnt(0) at
                 // its top, so the reads can go out right behind it and have the whole dot product to land: with four strips
                 // reading 8 KB per step each the LDS pipe is half busy and a read issued late was still in flight at the next wait.
                 auto next_reads = [&](auto& dep) {
                         __builtin_amdgcn_sched_barrier(0);
-                        ring_read(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols), dep);
+                        ring_read(q[1 - P], FORM != 3 ? (v + 1) : min(max(v + 1, 0), ncols), dep);
                         if constexpr (I >= 0) {
                                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[1 - P]) : "v"(in_oct), "n"(I * 16) : "memory");
                         } else {
@@ -262,31 +350,63 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                         }
                         __builtin_amdgcn_sched_barrier(0);
                 };
-                if (KA_W_EARLY) next_reads(acc);
-                {
-                        float2v prod;
-                        prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
+                if constexpr (Q == 2) {
+                        float2v acc;
+                        acc.x = kmax3(dga, dgga + copen_prev, dggb + orpA);
+                        acc.y = kmax3(cAa, cAga + copen_prev, cAgb + orpB);
+                        if (KA_W_EARLY) next_reads(acc);
+                        {
+                                float2v prod;
+                                prod = ka_mul_bcast<(NRES - 1) & 3>(p1v[NRES - 1], q[P][(NRES - 1) >> 2]);
 #pragma unroll
-                        for (int c = NRES - 1; c >= 1; --c) {
-                                float2v nprod;
-                                switch ((c - 1) & 3) {
-                                case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
-                                case 1: nprod = ka_mul_bcast<1>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
-                                case 2: nprod = ka_mul_bcast<2>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
-                                default: nprod = ka_mul_bcast<3>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                for (int c = NRES - 1; c >= 1; --c) {
+                                        float2v nprod;
+                                        switch ((c - 1) & 3) {
+                                        case 0: nprod = ka_mul_bcast<0>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        case 1: nprod = ka_mul_bcast<1>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        case 2: nprod = ka_mul_bcast<2>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        default: nprod = ka_mul_bcast<3>(p1v[c - 1], q[P][(c - 1) >> 2]); break;
+                                        }
+                                        acc = acc + prod;
+                                        prod = nprod;
                                 }
                                 acc = acc + prod;
-                                prod = nprod;
+                                if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<(FORM >= 2)>(jb); acc.y += bonB.template at<(FORM >= 2)>(jb); }
+                                if (!KA_W_EARLY) next_reads(acc);
                         }
-                        acc = acc + prod;
-                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); acc.x += bonA.template at<!ST>(jb); acc.y += bonB.template at<!ST>(jb); }
-                        if (!KA_W_EARLY) next_reads(acc);
+                        const float nAa = at0 ? -KA_F : acc.x;
+                        const float nBa = at0 ? -KA_F : acc.y;
+                        const float nBgb = kmax(nAgb + xeB, nAa + xoB);           // B: the row above is A's fresh state
+                        cAa = nAa; cAga = nAga; cAgb = nAgb;
+                        cBa = nBa; cBga = nBga; cBgb = nBgb;
+                } else {
+                        // ---- the one cell of this lane: residue NRES-1 first (aln_profileprofile.c:99-107 walks the non-zero counts
+                        // downwards); a pair of residues per v_pk_mul_f32, products one pair ahead of the (dependent) sums ----
+                        float a1 = kmax3(dga, dgga + copen_prev, dggb + orpA);
+                        if (KA_W_EARLY) next_reads(a1);
+                        if (NRES & 1) a1 += p1last * q[P][(NRES - 1) >> 2][(NRES - 1) & 3];
+                        if (NPAIR > 0) {
+                                auto qpair = [&](int i) -> float2v {
+                                        const float4v& w4 = q[P][(2 * i) >> 2];
+                                        return ((2 * i) & 3) ? __builtin_shufflevector(w4, w4, 2, 3) : __builtin_shufflevector(w4, w4, 0, 1);
+                                };
+                                float2v prod = p1p[NPAIR - 1] * qpair(NPAIR - 1);
+#pragma unroll
+                                for (int i = NPAIR - 1; i >= 1; --i) {
+                                        const float2v nprod = p1p[i - 1] * qpair(i - 1);
+                                        a1 += prod.y;
+                                        a1 += prod.x;
+                                        prod = nprod;
+                                }
+                                a1 += prod.y;
+                                a1 += prod.x;
+                        }
+                        if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); a1 += bonA.template at<(FORM >= 2)>(jb); }
+                        if (!KA_W_EARLY) next_reads(a1);
+                        const float nAa = at0 ? -KA_F : a1;
+                        cAa = nAa; cAga = nAga; cAgb = nAgb;
+                        (void)xeB; (void)xoB; (void)nBga;
                 }
-                const float nAa = (!ST && at0) ? -KA_F : acc.x;
-                const float nBa = (!ST && at0) ? -KA_F : acc.y;
-                const float nBgb = kmax(nAgb + xeB, nAa + xoB);           // B: the row above is A's fresh state
-                cAa = nAa; cAga = nAga; cAgb = nAgb;
-                cBa = nBa; cBga = nBga; cBgb = nBgb;
                 dga = upa; dgga = upga; dggb = upgb;
                 copen_prev = copen;
 
@@ -318,26 +438,35 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                 for (; t + KA_W_CH <= tend; t += KA_W_CH) octet(t, st_tag, lb_tag);
                 for (; t < tend; ++t) single(t, st_tag, lb_tag);
         };
+        auto singles = [&](int& t, const int tend, auto st_tag, auto lb_tag) {
+                for (; t < tend; ++t) single(t, st_tag, lb_tag);
+        };
         auto phases = [&](auto lb_tag) {
                 const int t_steady0 = min(nl, nsteps);
                 const int t_steady1 = ncols;
                 int t = 0;
-                run(t, t_steady0, std::false_type(), lb_tag);
+                if (ncols >= nl) {
+                        run(t, t_steady0, std::integral_constant<int, 1>(), lb_tag);
 #ifdef KA_PROF
-                if (pslot && lane == 0) pslot[256 + 2] += __builtin_amdgcn_s_memtime() - pslot[2];      // the head
-                const long long toct0 = __builtin_amdgcn_s_memtime();
-                const int t_in = t;
+                        if (pslot && lane == 0) pslot[256 + 2] += __builtin_amdgcn_s_memtime() - pslot[2];      // the head
+                        const long long toct0 = __builtin_amdgcn_s_memtime();
+                        const int t_in = t;
 #endif
-                run(t, t_steady1, std::true_type(), lb_tag);
+                        run(t, t_steady1, std::integral_constant<int, 0>(), lb_tag);
 #ifdef KA_PROF
-                // cycles in the steady phase (its waits included) / its steps
-                if (pslot && lane == 0) { pslot[6] += __builtin_amdgcn_s_memtime() - toct0; pslot[7] += t - t_in; }
-                const long long ttail0 = __builtin_amdgcn_s_memtime();
+                        // cycles in the steady phase (its waits included) / its steps
+                        if (pslot && lane == 0) { pslot[6] += __builtin_amdgcn_s_memtime() - toct0; pslot[7] += t - t_in; }
+                        const long long ttail0 = __builtin_amdgcn_s_memtime();
 #endif
-                run(t, nsteps, std::false_type(), lb_tag);
+                        run(t, nsteps, std::integral_constant<int, 2>(), lb_tag);
 #ifdef KA_PROF
-                if (pslot && lane == 0) pslot[256 + 4] += __builtin_amdgcn_s_memtime() - ttail0;             // the tail
+                        if (pslot && lane == 0) pslot[256 + 4] += __builtin_amdgcn_s_memtime() - ttail0;             // the tail
 #endif
+                } else {
+                        // fewer columns than lanes: some lane is at column 0 while another is at the last one -- the general edge form,
+                        // step by step (short passes: deep recursion levels)
+                        singles(t, nsteps, std::integral_constant<int, 3>(), lb_tag);
+                }
         };
         static_assert(KA_W_CH == 8, "the octet is written out for eight steps");
 
@@ -358,16 +487,17 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
                 const unsigned ia = in_ring_u + ((63u & 255u) << 4);
                 asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[0]) : "v"(ia) : "memory");
         }
-        if (last_is_b) phases(std::true_type()); else phases(std::false_type());
+        if constexpr (Q == 2) { if (last_is_b) phases(std::true_type()); else phases(std::false_type()); }
+        else phases(std::false_type());
         // the last step's column (vL = ncols), then done: everything the strip wrote to its out ring is in LDS before the count
         // says so (LDS runs a wave's instructions in order)
         {
                 float3v o;
-                o.x = last_is_b ? cBa : cAa; o.y = last_is_b ? cBga : cAga; o.z = last_is_b ? cBgb : cAgb;
+                o.x = (Q == 2 && last_is_b) ? cBa : cAa; o.y = (Q == 2 && last_is_b) ? cBga : cAga; o.z = (Q == 2 && last_is_b) ? cBgb : cAgb;
                 unsigned long long sv;
                 const unsigned oa = out_u + ((((unsigned)nsteps - 1u) & 255u) << 4);
-                asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
-                             : "=&s"(sv) : "v"(oa), "v"(o), "s"(own_mask) : "memory", "scc");
+                asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_eq_u32_e32 %3, %4\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
+                             : "=&s"(sv) : "v"(oa), "v"(o), "v"(lastl_v), "v"(lane) : "memory", "vcc");
         }
         publish(nsteps);
         __builtin_amdgcn_s_setprio(0);
@@ -382,28 +512,48 @@ __device__ __forceinline__ void ka_wstrip(const TaskShared& S, const int starta,
 //             row buffer -- and, when a strip below exists (in another workgroup), publish it: release fence + flag
 // GO word: min(columns loaded (BIG once all are), out slots free expressed as a step bound + 1), see ka_wstrip::wait_for.
 // ------------------------------------------------------------------------------------------
-template <int NRES>
-__device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
-                                           const float inj_a, const float inj_ga, const float inj_gb,
-                                           const int dir, const int k, const int ns, KaState* rows, int* prog, const int lane,
-                                           char* slds, char* hlds, int* ctl, const int w, const int in_mode, const bool out_local)
+struct KaWHelperArgs {
+        const float* p2;                 // column profile
+        KaState* rows;                   // the sub-problem's row buffer (HBM)
+        int* prog;                       // progress flags of the pass's strips (HBM)
+        int* watchdog;
+        float m2;                        // TaskShared::p2_mult
+        float inj_a, inj_ga, inj_gb;     // the pass's injected boundary state
+        int Lb;
+        int starta, enda, startb, endb, dir, k, ns;
+        unsigned slds_u, hlds_u, ctl_u;  // LDS offsets: the strip wave's region, this (helper) wave's region, the control words
+        int w, in_mode, out_local;
+};
+
+template <int NRES, int Q = 2>
+__device__ KA_WH_CALL void ka_whelper(const KaWHelperArgs a)
 {
+        const int lane = threadIdx.x & 63;
+        const int starta = ka_u(a.starta), enda = ka_u(a.enda), startb = ka_u(a.startb), endb = ka_u(a.endb), dir = ka_u(a.dir), k = ka_u(a.k), ns = ka_u(a.ns);
+        const int w = ka_u(a.w), in_mode = ka_u(a.in_mode);
+        const bool out_local = ka_u(a.out_local) != 0;
+        const float inj_a = ka_uniform_f(a.inj_a), inj_ga = ka_uniform_f(a.inj_ga), inj_gb = ka_uniform_f(a.inj_gb);
+        KaState* const rows = ka_uniform_ptr(a.rows);
+        int* const prog = ka_uniform_ptr(a.prog);
+        ka_lchar* const slds = (ka_lchar*)(unsigned long)ka_u(a.slds_u);
+        ka_lchar* const hlds = (ka_lchar*)(unsigned long)ka_u(a.hlds_u);
+        ka_lint* const ctl = (ka_lint*)(unsigned long)ka_u(a.ctl_u);
         const int ncols = endb - startb;
         const int mid = ((enda - starta) / 2) + starta;
         const int r0 = (dir == KA_FWD) ? starta : mid;
         const int r1 = (dir == KA_FWD) ? mid : enda;
         const int nrows = r1 - r0;
-        const int Lb = __builtin_amdgcn_readfirstlane(S.Lb);
+        const int Lb = ka_u(a.Lb);
         const bool near_t = (dir == KA_FWD) ? (startb == 0) : (endb == Lb);
-        const int u0 = k * KA_STRIP_ROWS;
-        const int nr = min(KA_STRIP_ROWS, nrows - u0);
-        const int nl = (nr + 1) >> 1;
+        const int u0 = k * (64 * Q);
+        const int nr = min(64 * Q, nrows - u0);
+        const int nl = (Q == 2) ? ((nr + 1) >> 1) : nr;
         const int lastl = nl - 1;
         const int nsteps = ncols + nl;
         const bool last_strip = (k + 1 == ns);
-        const float m2 = ka_uniform_f(S.p2_mult);
-        const float* const p2 = ka_uniform_ptr(S.p2);
-        int* const wdu = ka_uniform_ptr(S.watchdog);
+        const float m2 = ka_uniform_f(a.m2);
+        const float* const p2 = ka_uniform_ptr(a.p2);
+        int* const wdu = ka_uniform_ptr(a.watchdog);
         ka_gfloat* const grows = (ka_gfloat*)rows;
 
 #define REC(v_) ((dir == KA_FWD) ? (startb + (v_)) : (endb + 1 - (v_)))
@@ -441,9 +591,9 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                         if (part == 1) r1.w = r1.w * m2;
                         if (part == 2) { r1.x = r1.x * m2; r1.y = r1.y * m2; }
                         if (c <= ncols) {
-                                char* dst = slds + ((c & 127) << 4);
-                                if (use0) *(float4v*)(dst + part * 2048) = r0;
-                                if (use1) *(float4v*)(dst + (part + 4) * 2048) = r1;
+                                ka_lchar* dst = slds + ((c & 127) << 4);
+                                if (use0) *(__attribute__((address_space(3))) float4v*)(dst + part * 2048) = r0;
+                                if (use1) *(__attribute__((address_space(3))) float4v*)(dst + (part + 4) * 2048) = r1;
                         }
                         if (in_mode == 0) {
                                 // Row -1 of the pass (aln_seqseq.c:40-58; ka_strip's FIRST steps): column 0 is the injected state; columns
@@ -465,7 +615,7 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                                 for (int round = 0; round < 16; ++round) g = kmax(wave_shr1_old(cg, g) + gx, fix);
                                 cg = lane_bcast(g, 15);
                                 if (lane < 16 && c <= ncols)
-                                        *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){c == 0 ? inj_a : -KA_F, g, c == 0 ? inj_gb : -KA_F, 0.0f};
+                                        *(__attribute__((address_space(3))) float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){c == 0 ? inj_a : -KA_F, g, c == 0 ? inj_gb : -KA_F, 0.0f};
                                 Li = min(Lc + 16, ncols + 1);
                         }
                         Lc += 16;
@@ -485,7 +635,7 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                                         const float x0 = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         const float x1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         const float x2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        *(float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){x0, x1, x2, 0.0f};
+                                        *(__attribute__((address_space(3))) float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){x0, x1, x2, 0.0f};
                                 }
                                 Li += n;
                                 progress = true;
@@ -501,7 +651,7 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                                         // nobody reads the pass's last row before the level's barrier: plain stores
                                         if (lane < n) {
                                                 const int c = To + lane;
-                                                const float4v x = *(const float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
+                                                const float4v x = *(const __attribute__((address_space(3))) float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
                                                 ka_gfloat* wr = grows + 3 * IDX(c);
                                                 wr[0] = x.x; wr[1] = x.y; wr[2] = x.z;
                                         }
@@ -513,7 +663,7 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                                         // have written"), and this hand-over wants to publish every 8 columns.
                                         if (lane < n) {
                                                 const int c = To + lane;
-                                                const float4v x = *(const float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
+                                                const float4v x = *(const __attribute__((address_space(3))) float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
                                                 float* wr = (float*)rows + 3 * IDX(c);
                                                 __hip_atomic_store(wr + 0, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                                 __hip_atomic_store(wr + 1, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -539,7 +689,12 @@ __device__ __forceinline__ void ka_whelper(const TaskShared& S, const int starta
                         }
                         lastG = G; lastI = Li;
                 }
-                if (done && (out_local || To > ncols)) break;
+                if (done && (out_local || To > ncols)) {
+                        // (the rows this wave stored are read behind the level's barrier, whose release is ONE thread's fence: an L2
+                        // write-back that does not wait for other waves' stores in flight -- so this wave's are acknowledged first)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        break;
+                }
                 if (!progress) {
                         __builtin_amdgcn_s_sleep(8);                  // ~500 cycles: the strip publishes every ~3000
                         if (ka_spin_expired(wdu, ++idle, 1 << 22, 5)) break;

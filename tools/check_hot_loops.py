@@ -1,0 +1,38 @@
+"""Build-time check (no GPU): disassemble a task-kernel object and report, for every run of strip steps (consecutive ds_write_b96 --
+the out-ring write of ka_wstrip's step), instructions and scratch accesses per step, plus the kernel's register / spill metadata.
+A steady-state octet must have NO scratch access.  usage: check_hot_loops.py [kalign_amd/csrc/build/ka_kernels_u0.o]"""
+import os, subprocess, sys, tempfile
+LLVM = "/opt/rocm/lib/llvm/bin/"
+obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kalign_amd/csrc/build/ka_kernels_u0.o")
+with tempfile.TemporaryDirectory() as d:
+    fat, co = os.path.join(d, "x.fat"), os.path.join(d, "x.co")
+    subprocess.check_call([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj])
+    subprocess.check_call([LLVM + "clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
+    notes = subprocess.check_output([LLVM + "llvm-readelf", "--notes", co]).decode()
+    for ln in notes.split("\n"):
+        if any(k in ln for k in (".name:", "private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count", ".vgpr_count")) and ".kd" not in ln:
+            print(ln.strip())
+    dis = subprocess.check_output([LLVM + "llvm-objdump", "-d", co]).decode().split("\n")
+idx = [i for i, l in enumerate(dis) if "ds_write_b96" in l]
+def count(a, b, pat=None):
+    n = 0
+    for l in dis[a + 1:b + 1]:
+        t = l.strip()
+        if not t or t.startswith(";") or t.endswith(":"): continue
+        if pat is None or pat in t: n += 1
+    return n
+runs, cur = [], []
+for a, b in zip(idx, idx[1:]):
+    if b - a < 260: cur.append((count(a, b), count(a, b, "scratch_")))
+    else:
+        if len(cur) >= 6: runs.append(cur)
+        cur = []
+if len(cur) >= 6: runs.append(cur)
+bad = 0
+for r in runs:
+    n = sorted(x[0] for x in r)[len(r) // 2]
+    sc = max(x[1] for x in r[1:-1]) if len(r) > 2 else max(x[1] for x in r)
+    print("octet: %d steps, median %d instructions per step, scratch accesses per step (inner steps) <= %d" % (len(r) + 1, n, sc))
+    bad += sc > 0
+print("octets with scratch traffic: %d of %d" % (bad, len(runs)))
+sys.exit(1 if bad else 0)
