@@ -108,6 +108,8 @@ struct TaskShared {
         float p1_mult, p2_mult;        // (float)nsip of the OTHER operand: set_gap_penalties_n folded into the loads
         KaState* fbuf;
         KaState* bbuf;
+        KaState* xfbuf;                // hand-over rows between strips of one pass that run in DIFFERENT workgroups with helper waves (ka_whelper):
+        KaState* xbbuf;                //   written and read past the caches (agent-scope atomics) -- kept apart from fbuf / bbuf, which plain loads read
         KaSub* q[2];
         int* raw;
         int* raw2;
@@ -682,7 +684,8 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                                 const bool cons_local = k + 1 < ns && hit + 1 < nstatic && (hit + 1) / per == member_w;
                                                 if (nrows_ > 0) {
                                                         KaWHelperArgs ha;
-                                                        ha.p2 = S.p2; ha.rows = (dir == KA_FWD ? S.fbuf : S.bbuf) + roff; ha.prog = prog + (hit - k); ha.watchdog = S.watchdog;
+                                                        ha.p2 = S.p2; ha.rows = (dir == KA_FWD ? S.fbuf : S.bbuf) + roff; ha.xrows = (dir == KA_FWD ? S.xfbuf : S.xbbuf) + roff;
+                                                        ha.prog = prog + (hit - k); ha.watchdog = S.watchdog;
                                                         ha.m2 = S.p2_mult; ha.inj_a = ja; ha.inj_ga = jga; ha.inj_gb = jgb; ha.Lb = S.Lb;
                                                         ha.starta = sa; ha.enda = ea; ha.startb = sbb; ha.endb = eb; ha.dir = dir; ha.k = k; ha.ns = ns;
                                                         ha.slds_u = (unsigned)(unsigned long long)(lds_waves + sw * KA_WAVE_LDS);
@@ -899,7 +902,11 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                         const int n = 3 * (S.Lb + 1);
                         const float* f = (const float*)S.fbuf;
                         const float* b = (const float*)S.bbuf;
+#ifdef KA_DBG_SC1
+                        for (int i = tid; i < n; i += KA_NT) { dbg_rows[i] = __hip_atomic_load((float*)f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dbg_rows[n + i] = __hip_atomic_load((float*)b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
                         for (int i = tid; i < n; i += KA_NT) { dbg_rows[i] = f[i]; dbg_rows[n + i] = b[i]; }
+#endif
                 }
                 {
                         const KaLevelOut lout = ka_level_out(S, (level + 1) & 1, true);
@@ -2167,6 +2174,8 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         S.srcB = (int*)(base + o);  o += ka_align_up(n * 4, 16);
         S.fbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
         S.bbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+        S.xfbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+        S.xbbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
         const long long nq = (long long)(la < lb ? la : lb) + 20;
         S.q[0] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
         S.q[1] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
@@ -2223,7 +2232,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 20;
         const long long ni = 2 * nq + 2 * (n / KA_STRIP1_ROWS + 2);
-        long long b = 5 * ((n * 4 + 15) / 16 * 16) + 2 * ((n * 12 + 15) / 16 * 16)
+        long long b = 5 * ((n * 4 + 15) / 16 * 16) + 4 * ((n * 12 + 15) / 16 * 16)
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;

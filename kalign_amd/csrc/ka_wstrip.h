@@ -514,7 +514,8 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
 // ------------------------------------------------------------------------------------------
 struct KaWHelperArgs {
         const float* p2;                 // column profile
-        KaState* rows;                   // the sub-problem's row buffer (HBM)
+        KaState* rows;                   // the sub-problem's row buffer (HBM): the pass's LAST row, read by the meetups
+        KaState* xrows;                  // ... and its twin for rows handed from workgroup to workgroup (same offsets; see TaskShared::xfbuf)
         int* prog;                       // progress flags of the pass's strips (HBM)
         int* watchdog;
         float m2;                        // TaskShared::p2_mult
@@ -534,6 +535,7 @@ __device__ KA_WH_CALL void ka_whelper(const KaWHelperArgs a)
         const bool out_local = ka_u(a.out_local) != 0;
         const float inj_a = ka_uniform_f(a.inj_a), inj_ga = ka_uniform_f(a.inj_ga), inj_gb = ka_uniform_f(a.inj_gb);
         KaState* const rows = ka_uniform_ptr(a.rows);
+        KaState* const xrows = ka_uniform_ptr(a.xrows);
         int* const prog = ka_uniform_ptr(a.prog);
         ka_lchar* const slds = (ka_lchar*)(unsigned long)ka_u(a.slds_u);
         ka_lchar* const hlds = (ka_lchar*)(unsigned long)ka_u(a.hlds_u);
@@ -631,7 +633,7 @@ __device__ KA_WH_CALL void ka_whelper(const KaWHelperArgs a)
                                 // cache invalidate -- an acquire fence at agent scope drops the whole L1 and the L2's clean lines)
                                 if (lane < n) {
                                         const int c = Li + lane;
-                                        float* r = (float*)rows + 3 * IDX(c);
+                                        float* r = (float*)xrows + 3 * IDX(c);
                                         const float x0 = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         const float x1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         const float x2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,7 +666,7 @@ __device__ KA_WH_CALL void ka_whelper(const KaWHelperArgs a)
                                         if (lane < n) {
                                                 const int c = To + lane;
                                                 const float4v x = *(const __attribute__((address_space(3))) float4v*)(slds + KA_HO_RING + (((c + lastl) & 255) << 4));
-                                                float* wr = (float*)rows + 3 * IDX(c);
+                                                float* wr = (float*)xrows + 3 * IDX(c);
                                                 __hip_atomic_store(wr + 0, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                                 __hip_atomic_store(wr + 1, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                                 __hip_atomic_store(wr + 2, x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
