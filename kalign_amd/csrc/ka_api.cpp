@@ -86,7 +86,7 @@ struct KaEnv {
         int max_cluster = 0;           // KA_MAX_CLUSTER: workgroups one task may use (0: the default, 16)
         int crit_top = 0;              // KA_CRIT_TOP: workgroups of the chain entry with the longest way to the root (0: default)
         int prof_task = -1;            // KA_PROF_TASK: the task whose per-level times KA_FLAG_TIMING keeps (-1: the root)
-        int q1 = -1;                   // KA_Q1 (-1: the default, 0; 4 = experiment: per recursion level where every strip still gets a helper wave -- 2 % on the headline, but the debug rows of some goldens then differ: DESIGN 4f): 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
+        int q1 = -1;                   // KA_Q1 (-1: the default -- 4 for protein jobs: 64-row strips per recursion level where every strip still gets a helper wave, 0 for nucleotides): 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
         int lean4 = 1;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU (1.60 -> 1.28 ms on the 4096 x 400 leaf level)
         int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
         int per = 0;                   // KA_PER: strips per workgroup (KaTreeDev::per_target; experiments)
@@ -790,7 +790,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.prof_task = c->env.prof_task;                                 // measurements only (tools/levels_real.py)
         D.timing = (c->flags & KA_FLAG_TIMING) ? c->d_timing.p : nullptr;
         D.max_g = std::max(1, std::min(c->max_cluster, ka_max_g_host()));
-        D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : 0;
+        D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : (c->nres > 5 ? 4 : 0);     // (nucleotides: five residues -- a one-row step is 0.85 of a two-row one: not worth twice the strips)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;

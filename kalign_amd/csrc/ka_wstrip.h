@@ -28,6 +28,17 @@
 #pragma once
 
 #define KA_W_CH 8                                               // steps per octet
+#ifndef KA_W_TAG
+#define KA_W_TAG 0                                              // debugging: every ring slot of a boundary row carries its column; a strip that reads another column reports error 9
+#endif
+#if KA_W_TAG
+#define KA_W_DSW "ds_write_b128"
+#else
+#define KA_W_DSW "ds_write_b96"
+#endif
+#ifndef KA_W_FORMS
+#define KA_W_FORMS 1                                            // head / tail forms of the step (0, experiment: the general edge form)
+#endif
 #ifndef KA_W_EARLY
 #define KA_W_EARLY 1                                            // next step's LDS reads right behind this step's wait (0: after the dot products, as in ka_strip)
 #endif
@@ -143,9 +154,12 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
         const unsigned wlds_u = ka_u(a.wlds_u);
         const unsigned out_u = wlds_u + KA_HO_RING;
         const unsigned tpub_u = ctl_u + 4 * KA_W_TPUB(w), go_u = ctl_u + 4 * KA_W_GO(w);
-        // the lane that owns the strip's last row writes it: exec narrowed to that lane around the ds_write (v_cmpx on two VGPRs --
-        // an exec mask handed to the inline asm as a 64-bit "s" operand arrived in a VGPR pair once the kernel ran short of SGPRs)
-        const int lastl_v = lastl;
+        // The lane that owns the strip's last row writes it: exec narrowed to that lane around the ds_write, with SCALAR instructions
+        // (1 << lastl built inside the asm from a 32-bit scalar: a 64-bit mask handed in as an "s" operand arrived in a VGPR pair once
+        // the kernel ran short of SGPRs).  NOT v_cmpx: a vector compare writing exec right in front of the ds_write inside one asm
+        // block -- where the compiler's hazard recognizer does not look -- left the write with the OLD exec every now and then: all 64
+        // lanes stored, lane 63 won, and a PARTIAL strip (owner below lane 63) handed on garbage (caught by the schedule stress
+        // test as a top-level row hash that differed in one run of three).
 
         // ---- stationary row operand (as in ka_strip) ----
         float oA, eA, tA, oB, eB, tB, orpA, orpB;
@@ -277,6 +291,11 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                 const int v = t - lane;
 
                 ring_wait(q[P], bq[P]);
+#if KA_W_TAG
+                if (t <= ncols && __builtin_amdgcn_readfirstlane(__float_as_int(bq[P].w)) != t) {
+                        if (lane == 0) { atomicCAS(wdu, 0, 9); }
+                }
+#endif
                 // The strip's last row as the PREVIOUS step left it: its owner writes column t - 1 - lastl into out slot (t - 1) & 255.
                 // (Here and not at the end of the step that computed it: a ds_write right in front of the next step's
                 // s_waitcnt lgkmcnt(0) would be waited for; here the whole dot product lies between it and the next wait.)
@@ -284,16 +303,21 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                         const int vLp = t - 1 - lastl;
                         // (head: the last row's owner has not reached column 0 yet; steady state and tail: always inside the range)
                         if (FORM != 1 && (FORM != 3 || (vLp >= 0 && vLp <= ncols))) {
+#if KA_W_TAG
+                                float4v o;
+                                o.w = __int_as_float(vLp);
+#else
                                 float3v o;
+#endif
                                 o.x = (Q == 2 && LASTB) ? cBa : cAa; o.y = (Q == 2 && LASTB) ? cBga : cAga; o.z = (Q == 2 && LASTB) ? cBgb : cAgb;
-                                unsigned long long sv;
+                                unsigned long long sv, sm;
                                 if constexpr (I >= 1) {
-                                        asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_eq_u32_e32 %3, %4\n\tds_write_b96 %1, %2 offset:%5\n\ts_mov_b64 exec, %0"
-                                                     : "=&s"(sv) : "v"(out_oct), "v"(o), "v"(lastl_v), "v"(lane), "n"((I - 1) * 16) : "memory", "vcc");
+                                        asm volatile("s_lshl_b64 %1, 1, %4\n\ts_and_saveexec_b64 %0, %1\n\t" KA_W_DSW " %2, %3 offset:%5\n\ts_mov_b64 exec, %0"
+                                                     : "=&s"(sv), "=&s"(sm) : "v"(out_oct), "v"(o), "s"(__builtin_amdgcn_readfirstlane(lastl)), "n"((I - 1) * 16) : "memory", "scc");
                                 } else {
                                         const unsigned oa = out_u + ((((unsigned)t - 1u) & 255u) << 4);
-                                        asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_eq_u32_e32 %3, %4\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
-                                                     : "=&s"(sv) : "v"(oa), "v"(o), "v"(lastl_v), "v"(lane) : "memory", "vcc");
+                                        asm volatile("s_lshl_b64 %1, 1, %4\n\ts_and_saveexec_b64 %0, %1\n\t" KA_W_DSW " %2, %3\n\ts_mov_b64 exec, %0"
+                                                     : "=&s"(sv), "=&s"(sm) : "v"(oa), "v"(o), "s"(__builtin_amdgcn_readfirstlane(lastl)) : "memory", "scc");
                                 }
                         }
                 }
@@ -339,16 +363,26 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                 // once the compiler's, and those waited for fresh loads too); here the step's one wait is the manual lgkmcnt(0) at
                 // its top, so the reads can go out right behind it and have the whole dot product to land: with four strips
                 // reading 8 KB per step each the LDS pipe is half busy and a read issued late was still in flight at the next wait.
+                // UNTRACKED reads (inline asm: the compiler believes the registers are written when the asm ends, the data lands later,
+                // ring_wait at the top of the next step is the matching wait) only where the registers cannot be touched in between:
+                // the steady-state octets, which tools/check_hot_loops.py shows free of scratch traffic.  Everywhere else -- edge
+                // forms, single steps -- plain loads the compiler tracks: a version that read untracked in the head and tail octets
+                // too, where the allocator spills, had its in-flight registers SPILLED AND RELOADED now and then: stale column
+                // records in the first steps of a strip, a wrong prefix of its last row (schedule stress test, 1 run in 8).
                 auto next_reads = [&](auto& dep) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        ring_read(q[1 - P], FORM != 3 ? (v + 1) : min(max(v + 1, 0), ncols), dep);
-                        if constexpr (I >= 0) {
+                        const int vcol = FORM != 3 ? (v + 1) : min(max(v + 1, 0), ncols);
+                        if constexpr (FORM == 0 && I >= 0) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                ring_read(q[1 - P], vcol, dep);
                                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[1 - P]) : "v"(in_oct), "n"(I * 16) : "memory");
+                                __builtin_amdgcn_sched_barrier(0);
                         } else {
-                                const unsigned ia = in_ring_u + ((((unsigned)t + 64u) & 255u) << 4);
-                                asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[1 - P]) : "v"(ia) : "memory");
+                                typedef const __attribute__((address_space(3))) float4v ka_l4;
+                                ka_l4* const cr = (ka_l4*)(unsigned long)(wlds_u | (((unsigned)vcol & 127u) << 4));
+#pragma unroll
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) q[1 - P][ch] = cr[ch * 128];
+                                bq[1 - P] = *(ka_l4*)(unsigned long)(in_ring_u + ((((unsigned)t + 64u) & 255u) << 4));
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                 };
                 if constexpr (Q == 2) {
                         float2v acc;
@@ -436,6 +470,8 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
         auto run = [&](int& t, const int tend, auto st_tag, auto lb_tag) {
                 for (; t < tend && (t & (KA_W_CH - 1)); ++t) single(t, st_tag, lb_tag);
                 for (; t + KA_W_CH <= tend; t += KA_W_CH) octet(t, st_tag, lb_tag);
+                // (the last octet's untracked reads have landed before anything but an octet step may touch their registers)
+                if (decltype(st_tag)::value == 0) { ring_wait(q[0], bq[0]); ring_wait(q[1], bq[1]); }
                 for (; t < tend; ++t) single(t, st_tag, lb_tag);
         };
         auto singles = [&](int& t, const int tend, auto st_tag, auto lb_tag) {
@@ -445,7 +481,7 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                 const int t_steady0 = min(nl, nsteps);
                 const int t_steady1 = ncols;
                 int t = 0;
-                if (ncols >= nl) {
+                if (KA_W_FORMS && ncols >= nl) {
                         run(t, t_steady0, std::integral_constant<int, 1>(), lb_tag);
 #ifdef KA_PROF
                         if (pslot && lane == 0) pslot[256 + 2] += __builtin_amdgcn_s_memtime() - pslot[2];      // the head
@@ -462,6 +498,11 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
 #ifdef KA_PROF
                         if (pslot && lane == 0) pslot[256 + 4] += __builtin_amdgcn_s_memtime() - ttail0;             // the tail
 #endif
+                } else if (!KA_W_FORMS && ncols >= nl) {
+                        // (experiment: the general edge form for head and tail)
+                        singles(t, t_steady0, std::integral_constant<int, 3>(), lb_tag);
+                        run(t, t_steady1, std::integral_constant<int, 0>(), lb_tag);
+                        singles(t, nsteps, std::integral_constant<int, 3>(), lb_tag);
                 } else {
                         // fewer columns than lanes: some lane is at column 0 while another is at the last one -- the general edge form,
                         // step by step (short passes: deep recursion levels)
@@ -482,22 +523,29 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
 #ifdef KA_PROF
                 if (pslot && lane == 0 && pslot[2] == 0) pslot[2] = __builtin_amdgcn_s_memtime();
 #endif
-                float2v nodep = {0.0f, 0.0f};
-                ring_read(q[0], 0, nodep);
-                const unsigned ia = in_ring_u + ((63u & 255u) << 4);
-                asm volatile("ds_read_b128 %0, %1" : "=&v"(bq[0]) : "v"(ia) : "memory");
+                // (plain loads: see next_reads)
+                typedef const __attribute__((address_space(3))) float4v ka_l4;
+                ka_l4* const cr = (ka_l4*)(unsigned long)wlds_u;
+#pragma unroll
+                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) q[0][ch] = cr[ch * 128];
+                bq[0] = *(ka_l4*)(unsigned long)(in_ring_u + ((63u & 255u) << 4));
         }
         if constexpr (Q == 2) { if (last_is_b) phases(std::true_type()); else phases(std::false_type()); }
         else phases(std::false_type());
         // the last step's column (vL = ncols), then done: everything the strip wrote to its out ring is in LDS before the count
         // says so (LDS runs a wave's instructions in order)
         {
+#if KA_W_TAG
+                float4v o;
+                o.w = __int_as_float(ncols);
+#else
                 float3v o;
+#endif
                 o.x = (Q == 2 && last_is_b) ? cBa : cAa; o.y = (Q == 2 && last_is_b) ? cBga : cAga; o.z = (Q == 2 && last_is_b) ? cBgb : cAgb;
-                unsigned long long sv;
+                unsigned long long sv, sm;
                 const unsigned oa = out_u + ((((unsigned)nsteps - 1u) & 255u) << 4);
-                asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_eq_u32_e32 %3, %4\n\tds_write_b96 %1, %2\n\ts_mov_b64 exec, %0"
-                             : "=&s"(sv) : "v"(oa), "v"(o), "v"(lastl_v), "v"(lane) : "memory", "vcc");
+                asm volatile("s_lshl_b64 %1, 1, %4\n\ts_and_saveexec_b64 %0, %1\n\t" KA_W_DSW " %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(sv), "=&s"(sm) : "v"(oa), "v"(o), "s"(__builtin_amdgcn_readfirstlane(lastl)) : "memory", "scc");
         }
         publish(nsteps);
         __builtin_amdgcn_s_setprio(0);
@@ -617,7 +665,7 @@ __device__ KA_WH_CALL void ka_whelper(const KaWHelperArgs a)
                                 for (int round = 0; round < 16; ++round) g = kmax(wave_shr1_old(cg, g) + gx, fix);
                                 cg = lane_bcast(g, 15);
                                 if (lane < 16 && c <= ncols)
-                                        *(__attribute__((address_space(3))) float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){c == 0 ? inj_a : -KA_F, g, c == 0 ? inj_gb : -KA_F, 0.0f};
+                                        *(__attribute__((address_space(3))) float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){c == 0 ? inj_a : -KA_F, g, c == 0 ? inj_gb : -KA_F, __int_as_float(c)};
                                 Li = min(Lc + 16, ncols + 1);
                         }
                         Lc += 16;
@@ -637,7 +685,7 @@ __device__ KA_WH_CALL void ka_whelper(const KaWHelperArgs a)
                                         const float x0 = __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         const float x1 = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         const float x2 = __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        *(__attribute__((address_space(3))) float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){x0, x1, x2, 0.0f};
+                                        *(__attribute__((address_space(3))) float4v*)(hlds + KA_W_INRING + (((c + 63) & 255) << 4)) = (float4v){x0, x1, x2, __int_as_float(c)};
                                 }
                                 Li += n;
                                 progress = true;
