@@ -47,17 +47,27 @@ def algorithmic_bytes(recs):
     return total
 
 
-def pmc_traffic(key):
+def pmc_traffic(key, workload=None, kernel_ms=None):
     """HBM bytes per STEP (all launches of one ka_tree_run) from the rocprofv3 PMC passes committed under
     profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate passes for exactly this workload, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950; profiles/collect.sh).  bench.py cannot run the
-    profiler on itself, so it reports the committed measurement of the named workload and null for any other."""
-    for tag in ("r03", "r02"):                                   # the newest collection that has this workload
+    profiler on itself, so it reports the committed measurement -- but only of THIS workload on THIS build: the
+    committed record names its workload and the kernel time per step it was collected at; another workload string,
+    or a live kernel time more than 5 % away, gives null (a stale profile is not this run's traffic)."""
+    for tag in ("r04", "r03", "r02"):                            # the newest collection that has this workload
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")) as fh:
-                return float(json.load(fh)[key]["hbm_bytes_per_step_corrected"])
+                rec = json.load(fh)[key]
         except Exception:
             continue
+        if workload is not None and rec.get("workload") != workload:
+            return None
+        ref_ms = rec.get("kernel_ms_per_step")
+        if kernel_ms is not None and ref_ms and abs(kernel_ms - ref_ms) > 0.05 * ref_ms:
+            return None
+        if kernel_ms is not None and not ref_ms:
+            return None                                          # (records without a kernel time cannot be matched to a build)
+        return float(rec["hbm_bytes_per_step_corrected"])
     return None
 
 
@@ -143,10 +153,10 @@ def timed_tree(ctx, job, subm, scal, steps, warmup, barrier=None):
             "cells": float(sum(r.len_a * r.len_b for r in recs))}
 
 
-def roofline_of(res, key):
+def roofline_of(res, key, workload=None):
     abytes = algorithmic_bytes(res["recs"])
     achieved = abytes / (res["kern_ms"] * 1e-3) / 1e9
-    traffic = pmc_traffic(key)
+    traffic = pmc_traffic(key, workload, res["kern_ms"])
     return {"bound": "hbm", "kernel": "ka_task_kernel (all launches of one step)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "HBM bytes per step (FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
@@ -159,6 +169,46 @@ def workload_name(job, res):
     return ("%d %s seqs x ~%d (DSSim), --fast mode, the reference's k-means guide tree; whole tree per step: %d seq-seq + %d "
             "seq-profile + %d profile-profile DP tasks (Hirschberg), profile merge, path coding"
             % (job["nseq"], "DNA" if job["dna"] else "protein", job["len"], kinds[0], kinds[1], kinds[2]))
+
+
+def pp_rate_leg(ctx, job, subm, scal):
+    """What north_star's target is quoted on: the rate of the profile-profile DP itself.  One more run of the same job
+    with per-task phase timers (KA_FLAG_TIMING; outside the timed steps -- the timers cost a few per cent): every
+    task's wall time on its cluster.  `per_task`: profile-profile cells / the summed run times of the profile-profile
+    tasks (the rate at which ONE such task proceeds on its workgroups, tasks counted one after the other);
+    `critical_path`: the same over the profile-profile tasks on the dependency-driven critical path; `root`: the root
+    task alone.  Cells are the useful ones (len_a * len_b); Hirschberg executes ~2.06 x as many."""
+    from kalign_amd import api
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"], flags=api.FLAG_TIMING)
+    for _ in range(2):
+        ctx.tree_run()
+        ctx.tree_sync()
+    recs, _, _ = ctx.tree_download(want_gaps=False)
+    tm = ctx.tree_timing()
+    ghz = 2.4                                                    # shader clock of the s_memtime counter
+    tot = tm[:, :4].sum(1) / ghz / 1e3                           # us per task
+    cells = np.array([float(r.len_a) * r.len_b for r in recs])
+    pp = np.array([r.kind == 2 for r in recs])
+    done, crit_parent = {}, {}
+    for r, t in zip(recs, tot):
+        a, b = done.get(r.a, 0.0), done.get(r.b, 0.0)
+        done[r.c] = max(a, b) + t
+        crit_parent[r.c] = r.a if a >= b else r.b
+    by_c = {r.c: i for i, r in enumerate(recs)}
+    node, crit = recs[-1].c, []
+    while node in by_c:
+        crit.append(by_c[node])
+        node = crit_parent[node]
+    crit = np.array(crit)
+    cpp = crit[pp[crit]]
+    out = {"gcups_per_task": float(cells[pp].sum() / max(tot[pp].sum(), 1e-9) / 1e3),
+           "gcups_critical_path_tasks": float(cells[cpp].sum() / max(tot[cpp].sum(), 1e-9) / 1e3),
+           "gcups_root_task": float(cells[-1] / max(tot[-1], 1e-9) / 1e3),
+           "critical_path_ms": float(done[recs[-1].c] / 1e3), "critical_path_tasks": int(len(crit)),
+           "profile_profile_tasks": int(pp.sum()), "root_task_ms": float(tot[-1] / 1e3),
+           "note": "per-task wall times from KA_FLAG_TIMING (one extra run with timers); useful cells"}
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])   # (back to the untimed job)
+    return out
 
 
 def pp_share(res):
@@ -510,7 +560,7 @@ def secondary_tree_leg(ctx, name, nseq, length, dna, args, steps=3, warmup=1):
     out = {"workload": workload_name(job, res), "value": res["cells"] * steps / res["elapsed"] / 1e9, "unit": "GCUPS",
            "ms_per_step": res["elapsed"] / steps * 1e3, "steps": steps, "useful_cells_per_step": res["cells"],
            "profile_profile_share_of_cells": pp_share(res), "guide_tree_ms": job["guide_tree_ms"],
-           "roofline": roofline_of(res, name)}
+           "roofline": roofline_of(res, name, workload_name(job, res))}
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(job["codes"], job["tasks"], job["seq_distances"], dna, res["cells"], budget_s=12.0, gpu_gaps=res["gaps"])
         out["gaps_identical_to_reference"] = out["cpu_baseline"]["gaps_identical_to_reference"]
@@ -555,11 +605,18 @@ def c4_single_gpu_leg(ctx, steps=3):
     lens = np.array([len(c) for c in job["codes"]], np.int64)
     ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
 
+    split = [0.0, 0.0]
+
     def step():
+        t0 = time.perf_counter()
         ctx.tree_build_consistency(5, 2.0)
+        t1 = time.perf_counter()
         ctx.tree_run()
         ctx.tree_sync()
+        split[0] += t1 - t0
+        split[1] += time.perf_counter() - t1
     step()
+    split[:] = [0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -568,9 +625,79 @@ def c4_single_gpu_leg(ctx, steps=3):
     cells = float(sum(r.len_a * r.len_b for r in recs))
     ids, _ = ctx.tree_consistency()
     pair_cells = float(sum(int(lens[i]) * int(lens[a]) for i in range(len(lens)) for a in ids if a != i))
-    return {"workload": "16384 protein seqs x ~500 (DSSim), default mode (5 anchors), the reference's guide tree, one GPU",
-            "value": (cells + pair_cells) / dt / 1e9, "unit": "GCUPS", "ms_per_step": dt * 1e3, "steps": steps,
-            "useful_cells_tree": cells, "useful_cells_consistency_batch": pair_cells, "guide_tree_ms": job["guide_tree_ms"]}
+    cons_ms, tree_ms = split[0] / steps * 1e3, split[1] / steps * 1e3
+    out = {"workload": "16384 protein seqs x ~500 (DSSim), default mode (5 anchors), the reference's guide tree, one GPU",
+           "value": (cells + pair_cells) / dt / 1e9, "unit": "GCUPS", "ms_per_step": dt * 1e3, "steps": steps,
+           "consistency_ms": cons_ms, "tree_ms": tree_ms,
+           "useful_cells_tree": cells, "useful_cells_consistency_batch": pair_cells, "guide_tree_ms": job["guide_tree_ms"]}
+    try:
+        out["guide_tree_bisection_ms"], out["guide_tree_bisection_on_device"] = api_bisect()
+    except Exception:                                              # pragma: no cover
+        pass
+    out["sharding_projection"] = sharding_projection(ctx, job, subm, scal, lens, cons_ms)
+    return out
+
+
+def api_bisect():
+    from kalign_amd import api
+    return api.guide_last_bisect()
+
+
+def sharding_projection(ctx, job, subm, scal, lens, cons_ms, worlds=(2, 4, 8)):
+    """What `bench.py --gpus N` should show for this job, from the N = 1 measurements alone (no multi-GPU box in the pool):
+    the consistency batch divides by N (plus the broadcast of the 164 MB table at ~100 GB/s of xGMI ring bandwidth); the
+    tree is cut exactly as ka_dist_plan cuts it (api.dist_plan_subtrees); a rank's subtrees take the larger of (its share
+    of the summed task times of the one-GPU run / the concurrency that run had) and its own dependency chain; the tasks
+    above the cut run one after the other on their owners, each after its children, with the smaller child's profile
+    moved at 50 GB/s.  Per-task times: one default-mode run with KA_FLAG_TIMING.  A projection, labelled as one."""
+    from kalign_amd import api
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"], flags=api.FLAG_TIMING)
+    ctx.tree_build_consistency(5, 2.0)
+    for _ in range(2):
+        ctx.tree_run()
+        ctx.tree_sync()
+    recs, _, _ = ctx.tree_download(want_gaps=False)
+    tm = ctx.tree_timing()
+    kern_ms, _ = ctx.tree_kernel_ms()
+    tot = tm[:, :4].sum(1) / 2.4 / 1e6                           # ms per task
+    concurrency = max(float(tot.sum()) / max(kern_ms, 1e-9), 1.0)
+    n = len(lens)
+    idx = {r.c: i for i, r in enumerate(recs)}
+    table_mb = float(lens.sum()) * 5 * 4 / 1e6
+    out = {"one_gpu": {"consistency_ms": cons_ms, "tree_kernel_ms": kern_ms, "mean_tasks_in_flight": concurrency},
+           "note": "projection from the one-GPU run, not a measurement"}
+    for w in worlds:
+        run_rank, top = api.dist_plan_subtrees([int(x) for x in lens], job["tasks"], w)
+        top = set(int(t) for t in top)
+        work = np.zeros(w)
+        chain = {}                                               # node -> dependency chain (ms) inside its rank's subtrees
+        for i, r in enumerate(recs):
+            if i in top:
+                continue
+            work[run_rank[i]] += tot[i]
+            chain[r.c] = max(chain.get(r.a, 0.0), chain.get(r.b, 0.0)) + tot[i]
+        sub = np.zeros(w)
+        for i, r in enumerate(recs):
+            if i not in top:
+                sub[run_rank[i]] = max(sub[run_rank[i]], chain[r.c])
+        sub = np.maximum(sub, work / concurrency)
+        done = {}
+        for i, r in enumerate(recs):                             # (task order = dependency order)
+            if i not in top:
+                done[r.c] = sub[run_rank[i]]
+                continue
+            ta, tb = done.get(r.a, 0.0), done.get(r.b, 0.0)
+            smaller = min(r.len_a, r.len_b) if r.a in idx and r.b in idx else 0
+            move_ms = (smaller + 2) * 256 / 50e9 * 1e3 + 0.05
+            done[r.c] = max(ta, tb) + move_ms + tot[i]
+        tree_ms = done[recs[-1].c]
+        cons = cons_ms / w + table_mb / 1e3 / 100.0 * 1e3 * (w - 1) / w
+        gather_ms = 0.3
+        out["n%d" % w] = {"consistency_ms": cons, "subtree_ms": float(sub.max()), "top_ms": float(tree_ms - sub.max()), "gather_ms": gather_ms,
+                          "ms_per_step": cons + tree_ms + gather_ms,
+                          "speedup_vs_one_gpu": (cons_ms + kern_ms) / (cons + tree_ms + gather_ms)}
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+    return out
 
 
 def main():
@@ -636,8 +763,9 @@ def main():
             "profile_profile_share_of_cells": pp_share(res),
             "gcups_profile_profile_lower_bound": pp_share(res) * cells * args.steps / elapsed / 1e9,
         },
-        "roofline": roofline_of(res, key),
+        "roofline": roofline_of(res, key, workload_name(job, res)),
     }
+    out["config"]["gcups_profile_profile"] = pp_rate_leg(ctx, job, subm, scal)
     if not args.no_legs:
         # SURVEY.md 8(d)'s t_DP bracket (H2D of sequences and tasks + run + D2H of records and paths).  The bench contract
         # keeps `value` on inputs resident in HBM ("the PCIe-inclusive rate ... is never `value`"); the bracket the survey
