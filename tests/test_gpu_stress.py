@@ -54,3 +54,85 @@ def test_randomised_schedules_give_the_reference_answer(name, monkeypatch):
         for k in SWITCHES:
             monkeypatch.delenv(k, raising=False)
         ctx.close()
+
+
+# ---- the big-shape schedule paths: clusters of 8-16 workgroups, hand-overs between workgroups (helper
+# waves: write-through stores + flags; ka_strip: release fences), the multi-wave meetup scan over thousands of columns, four
+# strips per workgroup, tasks beyond 4000 rows -- none of which the goldens (<= 64 sequences, <= 300 columns) reach.  Live
+# reference (oracle/_ref: the real create_msa_tree), the same randomised switches, gap arrays bit for bit every time.
+BIG_SWITCHES = dict(SWITCHES, KA_MAX_CLUSTER=["2", "8", "16", None, None], KA_HO=["0", "1", "2", None], KA_HW=["0", "1", None, None],
+                    KA_Q1=["0", "4", None, None], KA_MW=["0", None, None])
+
+
+def _caterpillar(n):
+    """a guide tree that adds one sequence at a time: its last tasks align one long profile to a sequence / small profile --
+    with 2000-column sequences and gaps the root passes 4000 rows"""
+    tasks, cur, nxt = [], 0, n
+    for i in range(1, n):
+        tasks.append((cur, i, nxt))
+        cur, nxt = nxt, nxt + 1
+    return np.array(tasks, np.int32)
+
+
+def _big_jobs():
+    import bench
+    jobs = []
+    codes, tasks, dist = bench.make_workload(768, 400, False, 3)
+    jobs.append(("768x400 aa", codes, tasks, dist, False))
+    codes, tasks, dist = bench.make_workload(256, 2000, True, 5)
+    jobs.append(("256x2000 nt", codes, tasks, dist, True))
+    # pairs first (profiles), then a caterpillar over the pair profiles' roots: profile-profile tasks that grow past 4000 rows
+    from kalign_amd import synth, guide
+    seqs = synth.dssim(96, 2400, dna=True, seed=7)
+    codes = guide.encode(seqs, dna=True)
+    n = len(codes)
+    t, nxt, roots = [], n, []
+    for i in range(0, n, 2):
+        t.append((i, i + 1, nxt)); roots.append(nxt); nxt += 1
+    cur = roots[0]
+    for r in roots[1:]:
+        t.append((cur, r, nxt)); cur = nxt; nxt += 1
+    jobs.append(("96x2400 nt caterpillar of pair profiles", codes, np.array(t, np.int32), np.random.RandomState(7).uniform(0.3, 0.9, n).astype(np.float32), True))
+    return jobs
+
+
+@pytest.mark.parametrize("which", [0, 1, 2], ids=["768x400aa", "256x2000nt", "caterpillar_gt4000_rows"])
+def test_randomised_schedules_on_big_shapes(which, monkeypatch):
+    import bench
+    import kalign_amd
+    from oracle import refdrv
+    if not refdrv.available():
+        pytest.skip("oracle/_ref not built")
+    label, codes, tasks, dist, dna = _big_jobs()[which]
+    job = refdrv.EncodedJob(codes, tasks, dist, biotype=1 if dna else 0, type_=0 if dna else -1, n_threads=min(16, os.cpu_count() or 1))
+    want, _ = job.run_tree()
+    job.close()
+    subm, scal = bench.scoring(dna)
+    reps = int(os.environ.get("KA_STRESS_REPS_BIG", "10"))
+    rng = np.random.RandomState(100 + which)
+    ctx = kalign_amd.Context(0)
+    try:
+        ctx.tree_upload(codes, tasks, subm, scal, dist)
+        longest = 0
+        for rep in range(reps):
+            chosen = {}
+            for k, vals in BIG_SWITCHES.items():
+                v = vals[rng.randint(len(vals))]
+                if v is None:
+                    monkeypatch.delenv(k, raising=False)
+                else:
+                    monkeypatch.setenv(k, v)
+                    chosen[k] = v
+            ctx.reload_env()
+            ctx.tree_run()
+            recs, paths, gaps = ctx.tree_download()
+            longest = max(longest, max(max(r.len_a, r.len_b) for r in recs))
+            for i, (got, w) in enumerate(zip(gaps, want)):
+                assert np.array_equal(got, w), (label, rep, chosen, i)
+            assert ctx.fallback_runs() == 0, (label, rep, chosen)
+        if which == 2:
+            assert longest > 4000, longest                       # (the "workgroup per four strips" rule of long tasks was reached)
+    finally:
+        for k in BIG_SWITCHES:
+            monkeypatch.delenv(k, raising=False)
+        ctx.close()
