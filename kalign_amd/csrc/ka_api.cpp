@@ -2006,7 +2006,19 @@ extern "C" int ka_bpm_batch(ka_ctx* c, const uint8_t* codes, const int* off, con
 #include <deque>
 #include <map>
 #include <mutex>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// (hosts without the RCCL development headers: the few names of NCCL's public, stable ABI this file uses -- the library
+// itself is only ever looked for at run time, rccl_load)
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclInt32 = 2 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
+}
+#endif
 
 extern "C" void ka_launch_cols_pack(int* colof, const int* seq_off, const int* seq_len, const int* members, const long long* moff, int nmem,
                                     int* buf, int unpack, hipStream_t stream);

@@ -457,16 +457,22 @@ extern "C" void ka_launch_upgma(float* dm, int* active, unsigned long long* keys
         KaUpgma U{ dm, active, { keys, keys + n }, merges, n };
         if (mode == 0 && n <= KA_UPGMA_ONE_WG_MAX) {
                 const int lds = n * 17 + 16;                          // keys, list, listv, act
-                auto go = [&](auto kernel) {
-                        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_UPGMA_ONE_WG_MAX * 17 + 16);
+                // (the opt-in to more than 64 KB of LDS can fail -- another GPU, a smaller limit: then the per-merge launches below)
+                auto go = [&](auto kernel) -> bool {
+                        if (lds > 65536 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KA_UPGMA_ONE_WG_MAX * 17 + 16) != hipSuccess) {
+                                (void)hipGetLastError();
+                                return false;
+                        }
                         hipLaunchKernelGGL(kernel, dim3(1), dim3(KA_UPGMA_NT), lds, stream, U);
+                        return true;
                 };
-                if (n <= KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<1, 8>);
-                else if (n <= 2 * KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<2, 16>);
-                else if (n <= 4 * KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<4, 32>);
-                else if (n <= 8 * KA_UPGMA_NT) go(ka_upgma_one_wg_kernel<8, 32>);
-                else go(ka_upgma_one_wg_kernel<KA_UPGMA_ONE_WG_MAX / KA_UPGMA_NT, 32>);
-                return;
+                bool ok;
+                if (n <= KA_UPGMA_NT) ok = go(ka_upgma_one_wg_kernel<1, 8>);
+                else if (n <= 2 * KA_UPGMA_NT) ok = go(ka_upgma_one_wg_kernel<2, 16>);
+                else if (n <= 4 * KA_UPGMA_NT) ok = go(ka_upgma_one_wg_kernel<4, 32>);
+                else if (n <= 8 * KA_UPGMA_NT) ok = go(ka_upgma_one_wg_kernel<8, 32>);
+                else ok = go(ka_upgma_one_wg_kernel<KA_UPGMA_ONE_WG_MAX / KA_UPGMA_NT, 32>);
+                if (ok) return;
         }
         const int blocks = n < 256 ? n : 256;
         hipLaunchKernelGGL(ka_upgma_init_kernel, dim3(blocks), dim3(256), 0, stream, U);

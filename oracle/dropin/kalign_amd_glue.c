@@ -71,6 +71,7 @@ static void glue_report(void)
 static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
 static const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
 static int glue_job_numseq = 0;
+static const struct msa* glue_rows_msa;        /* (defined with the realignment seams below) */
 static uint64_t glue_job_stamp = 0;            /* FNV-1a over the lengths and gap arrays the device job left in that msa */
 
 /* The device job is recognised by more than the msa's address: an msa freed without finalise_alignment leaves a stale
@@ -249,6 +250,7 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         glue_pairing_tasks(n, abc);
         glue_params(ap, subm, scal);
         glue_job_msa = NULL;
+        glue_rows_msa = NULL;                            /* (a new job: the rows of the last one leave HBM) */
         glue_ct_resident = NULL;
         if(K <= KA_CONS_MAX_ANCHORS && glue_multi_context()){
                 /* the N x K batch sharded over the devices, every rank's share of the maps broadcast in place (ka_dist_consistency) */
@@ -348,6 +350,7 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         RUN(sort_tasks(t, TASK_ORDER_TREE));             /* as the reference does, aln_run.c:48 */
         RUN(glue_context());
         glue_job_msa = NULL;
+        glue_rows_msa = NULL;                            /* (a new job: the rows of the last one leave HBM) */
 
         RUN(glue_flatten(msa, &codes, &off, &lens, &total));
         MMALLOC(abc, sizeof(int) * 3 * nt);
@@ -620,6 +623,39 @@ static int* glue_dm_abc = NULL;
 static float* glue_dm_sd = NULL;
 static int glue_dm_n = 0;
 static const struct msa* glue_rows_msa = NULL;   /* the msa whose finalised rows the device holds */
+static int glue_rows_numseq = 0;
+static int glue_rows_alnlen = 0;
+static uint64_t glue_rows_stamp_v = 0;
+
+/* The rows in HBM are recognised by more than the msa's address (as glue_same_job does for the job): a freed msa's address
+   can come back with an alignment read from a file.  numseq, alnlen and FNV-1a over up to 64 evenly spaced rows. */
+static uint64_t glue_rows_stamp(const struct msa* msa)
+{
+        uint64_t h = 1469598103934665603ULL;
+        int n = msa->numseq;
+        int step = n > 64 ? n / 64 : 1;
+        int i, j;
+        for(i = 0; i < n; i += step){
+                const char* r = msa->sequences[i]->seq;
+                for(j = 0; j < msa->alnlen && r[j]; j++){
+                        h = (h ^ (uint64_t)(uint8_t)r[j]) * 1099511628211ULL;
+                }
+                h = (h ^ (uint64_t)(uint32_t)j) * 1099511628211ULL;
+        }
+        return h;
+}
+
+static int glue_same_rows(const struct msa* msa)
+{
+        return msa == glue_rows_msa && msa->numseq == glue_rows_numseq && msa->alnlen == glue_rows_alnlen
+               && glue_rows_stamp(msa) == glue_rows_stamp_v;
+}
+
+static void glue_dm_free(void)
+{
+        if(glue_dm_abc){ MFREE(glue_dm_abc); glue_dm_abc = NULL; }
+        if(glue_dm_sd){ MFREE(glue_dm_sd); glue_dm_sd = NULL; }
+}
 
 int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
 {
@@ -632,13 +668,16 @@ int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
                 glue_counts[GLUE_ALNDIST_REF]++;
                 return kalign_ref_compute_aln_pairwise_dist(msa, dm_ptr);
         }
-        if(glue_dm_abc){ MFREE(glue_dm_abc); glue_dm_abc = NULL; }
-        if(glue_dm_sd){ MFREE(glue_dm_sd); glue_dm_sd = NULL; }
+        {
+                static int registered = 0;
+                if(!registered){ registered = 1; atexit(glue_dm_free); }
+        }
+        glue_dm_free();
         glue_dm = NULL;
         MMALLOC(flat, sizeof(float) * (size_t)n * n);
         MMALLOC(glue_dm_abc, sizeof(int) * 3 * (n - 1));
         MMALLOC(glue_dm_sd, sizeof(float) * n);
-        if(msa == glue_rows_msa){
+        if(glue_same_rows(msa)){
                 /* the rows are where ka_tree_aligned_rows left them */
                 if(ka_aln_guide_tree(glue_ctx, n, NULL, 0, 0, '-', glue_dm_abc, glue_dm_sd, flat)){
                         ERROR_MSG("kalign_amd: %s", ka_last_error());
@@ -764,6 +803,7 @@ int finalise_alignment(struct msa* msa)
         }
         msa->alnlen = alnlen[0];
         msa->aligned = ALN_STATUS_FINAL;
+        glue_rows_numseq = n; glue_rows_alnlen = msa->alnlen; glue_rows_stamp_v = glue_rows_stamp(msa);
         MFREE(letters); MFREE(alnlen); MFREE(rows);
         return OK;
 ERROR:
