@@ -2006,7 +2006,7 @@ extern "C" int ka_bpm_batch(ka_ctx* c, const uint8_t* codes, const int* off, con
 #include <deque>
 #include <map>
 #include <mutex>
-#if __has_include(<rccl/rccl.h>)
+#if __has_include(<rccl/rccl.h>) && !defined(KA_NO_RCCL_HEADERS)
 #include <rccl/rccl.h>
 #else
 // (hosts without the RCCL development headers: the few names of NCCL's public, stable ABI this file uses -- the library

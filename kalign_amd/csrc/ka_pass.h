@@ -40,8 +40,17 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 #define KA_SP_STRIDE 25                                         // floats per row in the seq-profile score table
 #define KA_T_STRIDE 24                                          // floats per row in the seq-seq score table
 
-#ifndef KA_RING_EARLY
-#define KA_RING_EARLY 0                                         // ka_strip: column-ring reads at the top of the step, partial lgkmcnt wait (0: after the chain, lgkmcnt(0))
+// Column-record reads of the DP steps (ka_strip, ka_sub_pass; ka_wstrip outside its steady octets): plain loads the compiler
+// tracks (0, the default), or inline-asm ds_read_b128 it does not, waited for by a hand-placed s_waitcnt one step later (1).
+// The untracked form was round 3's: between the asm that issues the reads and the asm that waits, the compiler believes the
+// destination registers written -- and where a loop exit or a join wants the record in other registers it COPIES them
+// (v_mov_b64 of all 28) while the data may still be on its way; tools/check_lds_hazards.py finds those copies in the built
+// objects (2387 uses of in-flight registers in the round-3 form of the fast-mode kernel).  They only bite when LDS is slow
+// enough (four waves streaming 7 KB per step each) -- the intermittent wrong rows round 4 chased in ka_wstrip.  The tracked
+// form keeps the reads where they were (sched_barrier) and marks the old wait's place with an empty asm that USES the
+// registers: the compiler puts the s_waitcnt it needs in front of it, and in front of any copy it makes before.
+#ifndef KA_UNTRACKED_READS
+#define KA_UNTRACKED_READS 0
 #endif
 #define KA_WAIT_VM0 0x0F70                                      // s_waitcnt vmcnt(0) only (gfx9 encoding)
 
@@ -352,6 +361,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         auto ring_read = [&](float4v* dstq, int vcol, auto& dep) {
                 // (the wave's LDS region is 2048-B aligned: OR instead of ADD)
                 const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
+                if (!KA_UNTRACKED_READS) {
+                        typedef const __attribute__((address_space(3))) float4v ka_l4;
+                        ka_l4* const cr = (ka_l4*)(unsigned long)a;
+                        asm volatile("" : "+v"(dep) : : "memory");      // (the loads stay behind `dep`, as the asm form's operand made them)
+#pragma unroll
+                        for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) dstq[ch] = cr[ch * 128];
+                        return;
+                }
                 if (NRES <= 8) {
                         asm volatile("ds_read_b128 %0, %5\n\t"
                                      "ds_read_b128 %1, %5 offset:2048\n\t"
@@ -375,6 +392,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                              : "memory");
         };
         auto ring_wait = [&](float4v* qq) {
+                if (!KA_UNTRACKED_READS) {
+                        // (a use of the record: the compiler's own wait lands here at the latest)
+                        if (NRES <= 8) asm volatile("" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");
+                        else asm volatile("" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");
+                        return;
+                }
                 if (NRES <= 8) {
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");
                         return;
@@ -384,44 +407,6 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                              :
                              : "memory");
         };
-
-        // KA_RING_EARLY (experiment, off: slower): the next step's column record is requested at the TOP of a step, before this
-        // step's record is waited for -- LDS returns in order, so `s_waitcnt lgkmcnt(<reads just issued>)` is exactly "this
-        // step's record has landed".
-        auto ring_read_early = [&](float4v* dstq, int vcol) {
-                const unsigned a = wlds_u | (((unsigned)vcol & 127u) << 4);
-                if (NRES <= 8) {
-                        asm volatile("ds_read_b128 %0, %4\n\t"
-                                     "ds_read_b128 %1, %4 offset:2048\n\t"
-                                     "ds_read_b128 %2, %4 offset:10240\n\t"
-                                     "ds_read_b128 %3, %4 offset:12288"
-                                     : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[5]), "=&v"(dstq[6])
-                                     : "v"(a)
-                                     : "memory");
-                        return;
-                }
-                asm volatile("ds_read_b128 %0, %7\n\t"
-                             "ds_read_b128 %1, %7 offset:2048\n\t"
-                             "ds_read_b128 %2, %7 offset:4096\n\t"
-                             "ds_read_b128 %3, %7 offset:6144\n\t"
-                             "ds_read_b128 %4, %7 offset:8192\n\t"
-                             "ds_read_b128 %5, %7 offset:10240\n\t"
-                             "ds_read_b128 %6, %7 offset:12288"
-                             : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "=&v"(dstq[3]), "=&v"(dstq[4]), "=&v"(dstq[5]), "=&v"(dstq[6])
-                             : "v"(a)
-                             : "memory");
-        };
-#define KA_RING_WAIT_N(N_)                                                                                                          \
-        do {                                                                                                                        \
-                if (NRES <= 8) asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");          \
-                else asm volatile("s_waitcnt lgkmcnt(" #N_ ")" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory"); \
-        } while (0)
-        auto ring_wait_n = [&](float4v* qq, auto n_tag) {
-                constexpr int N = decltype(n_tag)::value;
-                static_assert(N == 4 || N == 7, "outstanding-read count");
-                if (N == 4) KA_RING_WAIT_N(4); else KA_RING_WAIT_N(7);
-        };
-#undef KA_RING_WAIT_N
 
         // ---- HO: batches through LDS (see the head of ka_strip) ----
         const unsigned ho_out_u = wlds_u + KA_HO_RING;                // my ring (I produce)
@@ -477,16 +462,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                 // ---- column data for column v ----
                 float copen, cext, ctext;
                 if (KIND == KA_PP) {
-                        if (KA_RING_EARLY) {
-                                const int tn = t + 1;
-                                if (EV && (tn & (KA_RING_BATCH - 1)) == 0) {
-                                        __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);      // batch tn/32 (issued >= 32 steps ago) has landed
-                                        ring_issue((tn >> 5) + 1);
-                                }
-                                constexpr int NRD = (NRES <= 8) ? 4 : 7;
-                                ring_read_early(q[1 - P], ST ? (v + 1) : min(max(v + 1, 0), ncols));
-                                ring_wait_n(q[P], std::integral_constant<int, NRD>());
-                        } else ring_wait(q[P]);                       // this step's column record (issued one step ago)
+                        ring_wait(q[P]);                       // this step's column record (issued one step ago)
 #ifdef KA_PROF
                         if (EV && ST && pslot && lane == 0) pslot[256 + 0] += __builtin_amdgcn_s_memtime() - tq0;      // (head slot reused: top-of-step wait)
 #endif
@@ -617,7 +593,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 // half (loaded one step ago) also waits for the fresh loads and exposes the whole
                                 // LDS latency every step.  sched_barrier pins the machine scheduler; the fake
                                 // dependency on acc keeps the IR passes from sinking the chain below the loads.
-                                if (!KA_RING_EARLY) {
+                                {
                                 __builtin_amdgcn_sched_barrier(0);
                                 const int tn = t + 1;
 #ifdef KA_PROF
@@ -691,7 +667,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                                 }
                                 if (NB) { const int jb = (dir == KA_FWD) ? (startb + v) : (endb - v); a1 += bonA.template at<!ST>(jb); }
                                 // next step's column record: after the chain, as in the two-row step
-                                if (!KA_RING_EARLY) {
+                                {
                                 __builtin_amdgcn_sched_barrier(0);
                                 const int tn = t + 1;
                                 if (EV && (tn & (KA_RING_BATCH - 1)) == 0) __builtin_amdgcn_s_waitcnt(KA_WAIT_VM0);
@@ -785,7 +761,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 #ifdef KA_PROF
                 const long long tri0 = __builtin_amdgcn_s_memtime();
 #endif
-                if (KIND == KA_PP && !KA_RING_EARLY && EV && ((t + 1) & (KA_RING_BATCH - 1)) == 0) ring_issue(((t + 1) >> 5) + 1);
+                if (KIND == KA_PP && EV && ((t + 1) & (KA_RING_BATCH - 1)) == 0) ring_issue(((t + 1) >> 5) + 1);
 #ifdef KA_PROF
                 if (EV && ST && pslot && lane == 0) pslot[256 + 6] += __builtin_amdgcn_s_memtime() - tri0;
 #endif

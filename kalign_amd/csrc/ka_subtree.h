@@ -135,8 +135,7 @@ __device__ __forceinline__ KaState ka_sub_state(const int code, const KaState ro
 // 1 << sshift lanes apiece, ONE DP row per lane (the level's passes have at most 1 << sshift rows), in lock-step.
 // The cell is ka_packed's; the profile-profile dot product packs two residues per v_pk_mul_f32 and adds the two
 // products one after the other (as ka_strip<.., Q = 1>).  The column record of the NEXT step is fetched behind the
-// dot-product chain with untracked ds_read_b128 (the compiler's own wait for this step's record would otherwise
-// also wait for the fresh loads: lgkmcnt is one in-order counter).
+// dot-product chain (loads the compiler tracks; KA_UNTRACKED_READS in ka_pass.h has the history).
 template <int KIND, int NRES>
 __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, const int npass, const int pass0, const int sshift, const int lane, const float* tss)
 {
@@ -206,6 +205,14 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
         const unsigned cols_u = (unsigned)(unsigned long long)X.colsL;
         auto rec_addr = [&](int vcol) -> unsigned { const int vv = min(max(vcol, 0), ncols); return cols_u + (unsigned)(SREC(vv) * (RW * 4)); };
         auto pp_read = [&](float4v* dstq, unsigned a, auto& dep) {
+                if (!KA_UNTRACKED_READS) {
+                        // (tracked loads: see KA_UNTRACKED_READS in ka_pass.h)
+                        const ka_lf4* const cr = (const ka_lf4*)(unsigned long)a;
+                        asm volatile("" : "+v"(dep) : : "memory");
+#pragma unroll
+                        for (int ch = 0; ch <= NV; ++ch) dstq[ch] = cr[ch];
+                        return;
+                }
                 if (NV == 2) {
                         asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32"
                                      : "=&v"(dstq[0]), "=&v"(dstq[1]), "=&v"(dstq[2]), "+v"(dep) : "v"(a) : "memory");
@@ -221,6 +228,12 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                 }
         };
         auto pp_wait = [&](float4v* qq) {
+                if (!KA_UNTRACKED_READS) {
+                        if (NV == 2) asm volatile("" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]) : : "memory");
+                        else if (NV == 5) asm volatile("" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]) : : "memory");
+                        else asm volatile("" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");
+                        return;
+                }
                 if (NV == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]) : : "memory");
                 else if (NV == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]) : : "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3]), "+v"(qq[4]), "+v"(qq[5]), "+v"(qq[6]) : : "memory");

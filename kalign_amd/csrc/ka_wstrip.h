@@ -73,6 +73,17 @@ typedef float float3v __attribute__((ext_vector_type(3)));
 #ifndef KA_W_NOINLINE
 #define KA_W_NOINLINE 0
 #endif
+// KA_W_UNTRACKED_EDGE=1 rebuilds round 4's bug on purpose (untracked LDS reads in the head / tail octets too, where the
+// allocator spills): what tools/check_lds_hazards.py is tested against.  Never in a product build.
+// KA_W_UNTRACKED (1): the steady-state octets issue the next step's reads as inline asm the compiler does not track, right
+// behind the step's wait (KA_UNTRACKED_READS in ka_pass.h has the hazard this can open; tools/check_lds_hazards.py must
+// find the built objects clean).  0: plain loads there too.
+#ifndef KA_W_UNTRACKED
+#define KA_W_UNTRACKED 1
+#endif
+#ifndef KA_W_UNTRACKED_EDGE
+#define KA_W_UNTRACKED_EDGE 0
+#endif
 #if KA_W_NOINLINE
 #define KA_W_CALL __attribute__((noinline))
 #else
@@ -269,7 +280,9 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
 #endif
         };
         auto prefetch_words = [&]() {
-                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(gv), "=&v"(iv) : "v"(go_u), "v"(in_word_u) : "memory");
+                // (plain loads: they are in flight across the octet loop's back edge and its exit, where the compiler may move registers)
+                gv = *(const volatile ka_lint*)(unsigned long)go_u;
+                iv = *(const volatile ka_lint*)(unsigned long)in_word_u;
         };
         auto publish = [&](const int tdone) {
                 asm volatile("ds_write_b32 %0, %1" : : "v"(tpub_u), "v"(tdone) : "memory");
@@ -371,7 +384,7 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                 // records in the first steps of a strip, a wrong prefix of its last row (schedule stress test, 1 run in 8).
                 auto next_reads = [&](auto& dep) {
                         const int vcol = FORM != 3 ? (v + 1) : min(max(v + 1, 0), ncols);
-                        if constexpr (FORM == 0 && I >= 0) {
+                        if constexpr (KA_W_UNTRACKED && (FORM == 0 || KA_W_UNTRACKED_EDGE) && I >= 0) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 ring_read(q[1 - P], vcol, dep);
                                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(bq[1 - P]) : "v"(in_oct), "n"(I * 16) : "memory");
@@ -471,7 +484,7 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                 for (; t < tend && (t & (KA_W_CH - 1)); ++t) single(t, st_tag, lb_tag);
                 for (; t + KA_W_CH <= tend; t += KA_W_CH) octet(t, st_tag, lb_tag);
                 // (the last octet's untracked reads have landed before anything but an octet step may touch their registers)
-                if (decltype(st_tag)::value == 0) { ring_wait(q[0], bq[0]); ring_wait(q[1], bq[1]); }
+                if (KA_W_UNTRACKED && decltype(st_tag)::value == 0) { ring_wait(q[0], bq[0]); ring_wait(q[1], bq[1]); }
                 for (; t < tend; ++t) single(t, st_tag, lb_tag);
         };
         auto singles = [&](int& t, const int tend, auto st_tag, auto lb_tag) {
