@@ -1,0 +1,520 @@
+// ka_profile.h -- sum-of-pairs score of a trial, P4 profile merge, leaf profiles, the anchor-consistency bonus entries of a task, the residue -> column tables.
+// One of the text sections of the task kernels, included by ka_kernels.hip in this order: ka_shared.h, ka_pass.h, ka_best.h,
+// ka_subtree.h, ka_wstrip.h, ka_meetup.h, ka_hirschberg.h, ka_path.h, ka_profile.h, ka_task.h.  Not a stand-alone header.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// compute_sp_score (sp_score.c:22-201): residue counts per column of both groups from the members' residue -> column
+// tables (build_profile expands every member through its gaps[]; D.colof is the same information), then ONE sequential
+// fp32 walk along the coded path -- substitution terms in (i, j) order, then the gap term, exactly as the reference
+// accumulates them (the total decides which trial wins; it is not reassociated).
+// S.sp_freq: [col][24] for operand a (23 counts + residues in the column), then the same for b.
+// ------------------------------------------------------------------------------------------
+__device__ void ka_sp_build(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+{
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const long long total = 24ll * (S.len_a + S.len_b);
+        for (long long x = tid; x < total; x += KA_NT) S.sp_freq[x] = 0;
+        __syncthreads();
+        const int na = T.nsip_a, nb = T.nsip_b;
+        const int* ma = D.sip + D.sip_off[T.a];
+        const int* mb = D.sip + D.sip_off[T.b];
+        for (int m = wave; m < na + nb; m += KA_NW) {
+                const bool in_a = m < na;
+                const int si = in_a ? ma[m] : mb[m - na];
+                int* fr = S.sp_freq + (in_a ? 0 : 24 * S.len_a);
+                const int* col = D.colof + D.seq_off[si];
+                const uint8_t* res = D.codes + D.seq_off[si];
+                const int len = D.node_len[si];
+                for (int p = lane; p < len; p += 64) {
+                        const int c = col[p], r = res[p];
+                        if (r < 23) { atomicAdd(&fr[24 * c + r], 1); atomicAdd(&fr[24 * c + 23], 1); }
+                }
+        }
+        __syncthreads();
+}
+
+// The walk adds ONE term at a time to ONE float (sp_score.c:134-189): the order of the additions is part of the result
+// and the chain cannot be split.  What can be parallel is everything around the additions: one thread per path column
+// works out its column's terms -- the (i, j) products in the reference's order, then the gap term(s), with the sign
+// folded in (x - y == x + (-y)) -- into an LDS buffer, and one thread adds the buffer up in order (loads run ahead of
+// the dependent adds: the chain costs an add per term instead of a trip to L2 per term).
+// lds: KA_SP_TB floats + 2 * blockDim.x ints.
+#define KA_SP_TB 24576
+__device__ void ka_sp_score(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds)
+{
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        float* const buf = (float*)lds;
+        int* const wtot = (int*)(buf + KA_SP_TB);                     // per-wave totals of the scan
+        const int* path = S.coded;
+        const int* fa0 = S.sp_freq;
+        const int* fb0 = S.sp_freq + 24 * S.len_a;
+        const int nsa = T.nsip_a, nsb = T.nsip_b;
+        const float gpo = T.gpo, gpe = T.gpe, tgpe = T.tgpe;
+        const float* subm = D.subm;
+        const int plen = path[0];
+        float total = 0.0f;                                            // (thread 0's)
+        for (int c0 = 1; c0 <= plen; c0 += KA_NT) {
+                const int c = c0 + tid;
+                const bool in = c <= plen;
+                const int code = in ? path[c] : 0;
+                const int step = code & 3;
+                const float pen = (code & 32) ? tgpe : gpe;
+                const int prev = (in && c > 1) ? (path[c - 1] & 3) : 0;
+                const int* fa = fa0 + 24 * ((in && step != 1) ? S.srcA[c] - 1 : 0);
+                const int* fb = fb0 + 24 * ((in && step != 2) ? S.srcB[c] - 1 : 0);
+                // the column's term count
+                int nza = 0, nzb = 0, cnt = 0;
+                if (in) {
+                        if (step == 0) {
+                                for (int i = 0; i < 23; ++i) nza += fa[i] != 0;
+                                for (int j = 0; j < 23; ++j) nzb += fb[j] != 0;
+                                cnt = nza * nzb + 1;
+                        } else if (step == 1) cnt = (prev == 1) ? 1 : 2;
+                        else cnt = (prev == 2) ? 1 : 2;
+                }
+                // exclusive scan over the block
+                int sc = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sc, d, 64); if (lane >= d) sc += y; }
+                __syncthreads();                                       // (the previous block's sum is done with buf / wtot)
+                if (lane == 63) wtot[wave] = sc;
+                __syncthreads();
+                int off = sc - cnt, all = 0;
+                for (int w = 0; w < KA_NW; ++w) { const int x = wtot[w]; if (w < wave) off += x; all += x; }
+                for (int base = 0; base < all; base += KA_SP_TB) {
+                        // this thread's terms with a buffer index in [base, base + KA_SP_TB)
+                        if (in && off < base + KA_SP_TB && off + cnt > base) {
+                                int k = off - base;
+                                auto put = [&](float v) { if (k >= 0 && k < KA_SP_TB) buf[k] = v; ++k; };
+                                if (step == 0) {
+                                        for (int i = 0; i < 23; ++i) {
+                                                const int ai = fa[i];
+                                                if (ai == 0) continue;
+                                                for (int j = 0; j < 23; ++j) {
+                                                        const int bj = fb[j];
+                                                        if (bj == 0) continue;
+                                                        put((float)(ai * bj) * subm[i * 23 + j]);
+                                                }
+                                        }
+                                        const int n_res_a = fa[23], n_res_b = fb[23];
+                                        const int n_gap_a = nsa - n_res_a, n_gap_b = nsb - n_res_b;
+                                        put(-((float)(n_res_a * n_gap_b + n_gap_a * n_res_b) * pen));
+                                } else if (step == 1) {
+                                        const int n_pairs = nsa * fb[23];
+                                        if (prev != 1) put(-((float)n_pairs * gpo));
+                                        put(-((float)n_pairs * pen));
+                                } else {
+                                        const int n_pairs = fa[23] * nsb;
+                                        if (prev != 2) put(-((float)n_pairs * gpo));
+                                        put(-((float)n_pairs * pen));
+                                }
+                        }
+                        __syncthreads();
+                        if (tid == 0) {
+                                const int n = min(KA_SP_TB, all - base);
+                                int k = 0;
+                                for (; k + 8 <= n; k += 8) {
+                                        const float4v x = *(const float4v*)(buf + k), y = *(const float4v*)(buf + k + 4);
+                                        total += x.x; total += x.y; total += x.z; total += x.w;
+                                        total += y.x; total += y.y; total += y.z; total += y.w;
+                                }
+                                for (; k < n; ++k) total += buf[k];
+                        }
+                        if (base + KA_SP_TB < all) __syncthreads();        // the buffer is refilled
+                }
+        }
+        if (tid == 0) S.sp_value = total;
+        __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// P4: update_n (aln_setup.c:230-436), one thread per (output column, field).
+// ------------------------------------------------------------------------------------------
+__device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen)
+{
+        const float* pa = S.profa;
+        const float* pb = S.profb;
+        float* np = S.newp;
+        const float sipa = (float)T.nsip_a, sipb = (float)T.nsip_b;
+        float sA = 1.0f, sB = 1.0f;
+        bool rebalance = false;
+        if (D.usw > 0.0f && T.nsip_a > 0 && T.nsip_b > 0) {
+                const float pseudo = D.usw;
+                const float total = (float)(T.nsip_a + T.nsip_b);
+                const float denom = total + 2.0f * pseudo;
+                sA = total * (sipa + pseudo) / (denom * sipa);
+                sB = total * (sipb + pseudo) / (denom * sipb);
+                rebalance = true;
+        }
+        // fields 27..29 of an operand as the reference would see them at this point: zero for a
+        // leaf (make_profile_n), [55..57] * nsip_other for a profile (set_gap_penalties_n ran on it
+        // for this merge, aln_run.c:239-253).  They are dead values (always rewritten before
+        // use) but part of the merged record, so they are reproduced for bit-identical profiles.
+        const bool leaf_a = (T.nsip_a == 1), leaf_b = (T.nsip_b == 1);
+        auto fa = [&](const float* rec, int k) -> float {
+                if (k >= 27 && k <= 29) return leaf_a ? 0.0f : rec[k + 28] * sipb;
+                return rec[k];
+        };
+        auto fb = [&](const float* rec, int k) -> float {
+                if (k >= 27 && k <= 29) return leaf_b ? 0.0f : rec[k + 28] * sipa;
+                return rec[k];
+        };
+        // one thread per (output column, 4 consecutive fields): the column's op code and source
+        // records are looked up once, the four field values are independent
+        const float* __restrict__ pa_r = pa;
+        const float* __restrict__ pb_r = pb;
+        float* __restrict__ np_r = np;
+        const int* __restrict__ coded = S.coded;
+        const int* __restrict__ srcA = S.srcA;
+        const int* __restrict__ srcB = S.srcB;
+        auto elem = [&](const int c, const int k, const int code, const float* __restrict__ ra, const float* __restrict__ rb) -> float {
+                float val;
+                if (c == 0 || c == alnlen + 1) {
+                        const float va = fa(ra, k), vb = fb(rb, k);
+                        val = (rebalance && k < 23) ? (va * sA + vb * sB) : (va + vb);
+                } else if (!code) {
+                        if (rebalance && k < 23) {
+                                val = ra[k] * sA + rb[k] * sB;
+                        } else {
+                                val = fa(ra, k) + fb(rb, k);
+                                if (rebalance && k >= 32 && k < 55) {
+                                        const float dA = sA - 1.0f, dB = sB - 1.0f;
+                                        const int jj = k - 32;
+                                        float delta = 0.0f;
+                                        for (int aa = 0; aa < 23; ++aa) {
+                                                delta += (ra[aa] * dA + rb[aa] * dB) * D.subm[23 * aa + jj];
+                                        }
+                                        val += delta;
+                                }
+                        }
+                } else {
+                        const bool gap_in_a = (code & 1) != 0;
+                        const float sip = gap_in_a ? sipa : sipb;
+                        val = gap_in_a ? fb(rb, k) : fa(ra, k);
+                        // as the reference: up to two successive adjustments (close, then open)
+                        if (!(code & 20)) {
+                                if (code & 32) {
+                                        if (k == 25) val += sip;
+                                        if (k >= 32 && k < 55) val -= D.tgpe0 * sip;
+                                } else {
+                                        if (k == 24) val += sip;
+                                        if (k >= 32 && k < 55) val -= D.gpe0 * sip;
+                                }
+                        } else {
+                                for (int pass = 0; pass < 2; ++pass) {
+                                        const int bit = pass == 0 ? 16 : 4;
+                                        if (!(code & bit)) continue;
+                                        float gp;
+                                        if (code & 32) {
+                                                if (k == 25) val += sip;
+                                                gp = D.tgpe0 * sip;
+                                                if (k == 23) val += sip;
+                                                gp += D.gpo0 * sip;
+                                        } else {
+                                                if (k == 23) val += sip;
+                                                gp = D.gpo0 * sip;
+                                        }
+                                        if (k >= 32 && k < 55) val -= gp;
+                                }
+                        }
+                }
+                return val;
+        };
+        const long long total4 = (long long)(alnlen + 2) * 16;
+        const float gpe_a = D.gpe0 * sipa, gpe_b = D.gpe0 * sipb, tgpe_a = D.tgpe0 * sipa, tgpe_b = D.tgpe0 * sipb;
+        for (long long x4 = (long long)S.member * KA_NT + threadIdx.x; x4 < total4; x4 += (long long)S.G * KA_NT) {
+                const int c = (int)(x4 >> 4);
+                const int k4 = (int)(x4 & 15) << 2;
+                int code = 0;
+                const float* ra;
+                const float* rb;
+                if (c == 0) { ra = pa_r; rb = pb_r; }
+                else if (c == alnlen + 1) { ra = pa_r + ((long long)(S.len_a + 1) << 6); rb = pb_r + ((long long)(S.len_b + 1) << 6); }
+                else {
+                        code = coded[c];
+                        const int ia = srcA[c], ib = srcB[c];
+                        ra = pa_r + ((long long)(ia < 0 ? 0 : ia) << 6);
+                        rb = pb_r + ((long long)(ib < 0 ? 0 : ib) << 6);
+                }
+                float4v out;
+                if (!rebalance && !(code & 20)) {
+                        // The common case (no sequence weights; the coded path carries only the flags the reference
+                        // really sets), four fields at a time -- same operations as elem() below, without the per-field
+                        // branching: a match / boundary column is the sum of the two records, a gap column the present
+                        // side with its gap counter bumped and the scores lowered by (t)gpe * members of the absent side.
+                        float4v A = *(const float4v*)(ra + k4), B = *(const float4v*)(rb + k4);
+                        if (k4 == 24) {                                  // field 27 (see fa / fb)
+                                A.w = leaf_a ? 0.0f : ra[55] * sipb; B.w = leaf_b ? 0.0f : rb[55] * sipa;
+                        } else if (k4 == 28) {                           // fields 28, 29
+                                A.x = leaf_a ? 0.0f : ra[56] * sipb; A.y = leaf_a ? 0.0f : ra[57] * sipb;
+                                B.x = leaf_b ? 0.0f : rb[56] * sipa; B.y = leaf_b ? 0.0f : rb[57] * sipa;
+                        }
+                        if (c == 0 || c == alnlen + 1 || !code) {
+                                out = A + B;
+                        } else {
+                                const bool gap_in_a = (code & 1) != 0, term = (code & 32) != 0;
+                                const float sip = gap_in_a ? sipa : sipb;
+                                const float g = term ? (gap_in_a ? tgpe_a : tgpe_b) : (gap_in_a ? gpe_a : gpe_b);
+                                out = gap_in_a ? B : A;
+                                if (k4 == 24) { if (term) out.y += sip; else out.x += sip; }        // [25] / [24]
+                                else if (k4 >= 32 && k4 < 52) { out.x -= g; out.y -= g; out.z -= g; out.w -= g; }
+                                else if (k4 == 52) { out.x -= g; out.y -= g; out.z -= g; }           // [55] is not a score
+                        }
+                } else {
+                        out.x = elem(c, k4 + 0, code, ra, rb);
+                        out.y = elem(c, k4 + 1, code, ra, rb);
+                        out.z = elem(c, k4 + 2, code, ra, rb);
+                        out.w = elem(c, k4 + 3, code, ra, rb);
+                }
+                *(float4v*)(np_r + (x4 << 2)) = out;
+        }
+}
+
+// Leaf profile (make_profile_n, aln_setup.c:40-99), one float4 per thread.  The pre-summed
+// substitution scores subm[c][j] - soff come from the seq-seq table in LDS (same expression, same
+// bits).  Non-leaf operands need nothing here: set_gap_penalties_n is folded into the loads.
+__device__ void ka_make_leaf_profile(float* __restrict__ prof, int len, const uint8_t* __restrict__ seq,
+                                     float gpo, float gpe, float tgpe, const float* tss)
+{
+        const long long total4 = (long long)(len + 2) * 16;
+        for (long long x4 = threadIdx.x; x4 < total4; x4 += KA_NT) {
+                const int r = (int)(x4 >> 4);
+                const int k4 = (int)(x4 & 15) << 2;
+                const bool inner = (r >= 1 && r <= len);
+                const int c = inner ? seq[r - 1] : 0;
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                        const int k = k4 + u;
+                        float val = 0.0f;
+                        if (k == 55) val = -gpo;
+                        else if (k == 56) val = -gpe;
+                        else if (k == 57) val = -tgpe;
+                        else if (inner) {
+                                if (k == c) val = 1.0f;
+                                else if (k >= 32 && k < 55) val = tss[c * KA_T_STRIDE + (k - 32)];
+                        }
+                        v[u] = val;
+                }
+                float4v out; out.x = v[0]; out.y = v[1]; out.z = v[2]; out.w = v[3];
+                *(float4v*)(prof + (x4 << 2)) = out;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// Anchor consistency, per task (anchor_consistency.c:352-561 + do_align's bonus block,
+// aln_run.c:262-295).  The reference materialises a dense La x Lb bonus matrix on the host for
+// every task; per anchor every row has at most ONE non-zero entry, so the device keeps <= K
+// (column, value) entries per DP row instead and the passes carry them in registers.
+//
+// ka_cons_votes = get_node_anchor_positions for both operands and all anchors: for a leaf the
+// position map itself; for a profile a vote over its member sequences, where "best" is the anchor
+// position of the FIRST member (in the reference's sip order) that has one in the column.  Being
+// first in a fixed order is a min-reduction over the member index, and `agree` / `total` are
+// counts, so the vote runs in parallel over (member, residue) with LDS atomics:
+// key = member_index << 32 | position, counts = total | agree << 16.  Which column a residue sits
+// in comes from D.colof (kept up to date by ka_update_colof).  The workgroups of a cluster share
+// the work by operand and by anchor; tables that do not fit into LDS live in the task's HBM scratch.
+// ------------------------------------------------------------------------------------------
+template <bool LEAN>
+__device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const long long lds_bytes)
+{
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int K = D.cons_K;
+        const long long n = (long long)S.len_a + S.len_b + 8;           // stride of the per-anchor arrays
+        const int half = (S.G >= 2) ? (S.G >> 1) : 1;
+        for (int side = 0; side < 2; ++side) {
+                if (S.G >= 2 && side != S.member / half) continue;
+                const int sub = (S.G >= 2) ? (S.member % half) : 0;
+                const bool is_rows = (side == 0);
+                const int node = (is_rows != (S.swapped != 0)) ? T.a : T.b;  // rows: a unless swapped
+                const int nmem = (node == T.a) ? T.nsip_a : T.nsip_b;
+                const int dp_len = is_rows ? S.La : S.Lb;
+                int* apos = is_rows ? S.apos_r : S.apos_c;
+                float* conf = is_rows ? S.conf_r : S.conf_c;
+                // this workgroup's anchors: sub, sub + half, ...  (closed form: an indexed array would live in scratch
+                // memory and put a scratch load in front of every gather)
+                const int nk = (K - sub + half - 1) / half;
+#define KS(b_) (sub + (b_) * half)
+                if (nmem == 1) {
+                        // leaf: direct lookup (a leaf's dp_len is its length)
+                        for (int b = 0; b < nk; ++b) {
+                                const int* map = D.cons_maps + D.cons_map_off[node] + (long long)KS(b) * dp_len;
+                                for (int i = tid; i < dp_len; i += KA_NT) {
+                                        const int a = map[i];
+                                        apos[KS(b) * n + i] = a; conf[KS(b) * n + i] = (a >= 0) ? 1.0f : 0.0f;
+                                }
+                        }
+                        continue;
+                }
+                if (LEAN) continue;                                      // lean levels hold leaf-leaf tasks only
+                // a cell's `total` and `agree` counts share one 32-bit word (16 bits each) -- below 65536 members; from there on
+                // `agree` has a word of its own (anchor_consistency.c:352-470 counts in ints)
+                const bool wide = nmem >= 65536;
+                const long long cell = wide ? 16 : 12;
+                const int* members = D.sip + D.sip_off[node];
+                int fit = (int)(lds_bytes / (cell * dp_len));             // anchors whose tables fit into LDS together
+                const bool in_lds = fit >= 1;
+                if (!in_lds) fit = nk;
+                for (int b0 = 0; b0 < nk; b0 += fit) {
+                        const int nb = min(fit, nk - b0);
+                        unsigned long long* key = in_lds ? (unsigned long long*)lds : (unsigned long long*)S.vote;
+                        unsigned int* cnt = (unsigned int*)(key + (long long)nb * dp_len);
+                        unsigned int* agr = cnt + (long long)nb * dp_len;        // (wide only)
+                        for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; if (wide) agr[x] = 0u; }
+                        __syncthreads();
+                        // Two sweeps over (member, residue): [0] first-member key + total, [1] agreement with the
+                        // winner.  Latency-bound gathers, so each wave pre-loads the metadata of 64 of its
+                        // members lane-parallel and keeps 4 x 64 residues of loads in flight before the atomics.
+                        for (int sweep = 0; sweep < 2; ++sweep) {
+                                const int mine = (nmem - wave + KA_NW - 1) / KA_NW;          // members of this wave
+                                for (int base = 0; base < mine; base += 64) {
+                                        const int ml = min(base + lane, mine - 1);
+                                        const int mi_l = wave + KA_NW * ml;
+                                        const int si_l = members[mi_l];
+                                        const int len_l = D.node_len[si_l];
+                                        const long long mo_l = D.cons_map_off[si_l];
+                                        const int so_l = D.seq_off[si_l];
+                                        const int cntm = min(64, mine - base);
+                                        for (int jm = 0; jm < cntm; ++jm) {
+                                                const int mi = wave + KA_NW * (base + jm);
+                                                const int len = __shfl(len_l, jm, 64);
+                                                const long long mo = __shfl(mo_l, jm, 64);
+                                                const int* map = D.cons_maps + mo;
+                                                const int* col = D.colof + __shfl(so_l, jm, 64);
+                                                for (int p0 = lane; p0 < len; p0 += 256) {
+                                                        int cc[4], aa[4][KA_NB - 1];
+#pragma unroll
+                                                        for (int u = 0; u < 4; ++u) {
+                                                                const int pp = p0 + 64 * u;
+                                                                const bool ok = pp < len;
+                                                                cc[u] = ok ? col[pp] : 0;
+#pragma unroll
+                                                                for (int b = 0; b < KA_NB - 1; ++b)
+                                                                        aa[u][b] = (ok && b < nb) ? map[(long long)KS(b0 + b) * len + pp] : -1;
+                                                        }
+#pragma unroll
+                                                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                                                                for (int b = 0; b < KA_NB - 1; ++b) {
+                                                                        const int a = aa[u][b];
+                                                                        if (a < 0) continue;
+                                                                        const int x = b * dp_len + cc[u];
+                                                                        if (sweep == 0) {
+                                                                                atomicMin(&key[x], ((unsigned long long)(unsigned int)mi << 32) | (unsigned int)a);
+                                                                                atomicAdd(&cnt[x], 1u);
+                                                                        } else {
+                                                                                // (HBM tables: the atomics were performed at L2; read them back past the L1)
+                                                                                const unsigned long long kk = in_lds ? key[x]
+                                                                                        : __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) { if (wide) atomicAdd(&agr[x], 1u); else atomicAdd(&cnt[x], 0x10000u); }
+                                                                        }
+                                                                }
+                                                        }
+                                                }
+                                        }
+                                }
+                                __syncthreads();
+                        }
+                        for (int x = tid; x < nb * dp_len; x += KA_NT) {
+                                const int b = x / dp_len, c = x - b * dp_len;
+                                unsigned long long kk;
+                                unsigned int cc, ca = 0u;
+                                if (in_lds) { kk = key[x]; cc = cnt[x]; if (wide) ca = agr[x]; }
+                                else {
+                                        kk = __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        cc = __hip_atomic_load(&cnt[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (wide) ca = __hip_atomic_load(&agr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                const int tot = wide ? (int)cc : (int)(cc & 0xffffu), ag = wide ? (int)ca : (int)(cc >> 16);
+                                const long long o = KS(b0 + b) * n + c;
+                                if (tot > 0 && ag > 0) { apos[o] = (int)(unsigned int)(kk & 0xffffffffull); conf[o] = (float)ag / (float)tot; }
+                                else { apos[o] = -1; conf[o] = 0.0f; }
+                        }
+                        __syncthreads();
+                }
+        }
+}
+
+#undef KS
+
+// anchor_consistency_get_bonus_profile in sparse form (first workgroup of the cluster, after the votes).
+// After it S.ent[row][0..KA_NB) holds the row's non-zero bonus cells with distinct columns: entries of
+// different anchors that hit the same cell are summed in anchor order (the dense matrix accumulates
+// k = 0..K-1 into a zeroed cell), and slot KA_NB-1 carries the cell the reference reaches when a forward
+// pass indexes column Lb of row i -- flat index i*Lb + Lb is cell (i+1, 0) (aln_seqseq.c:83-85 uses the
+// 1-based column).
+__device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
+{
+        const int tid = threadIdx.x;
+        const int K = D.cons_K;
+        const int rows = S.La, cols = S.Lb;
+        const long long n = (long long)S.len_a + S.len_b + 8;
+        const int ml = D.cons_maxlen + 8;
+        const float paw = D.cons_paw;
+        // inverse maps anchor position -> column; of several columns the last one wins (:521-526)
+        for (int x = tid; x < K * ml; x += KA_NT) S.invj[x] = -1;
+        __syncthreads();
+        for (int x = tid; x < K * cols; x += KA_NT) {
+                const int k = x / cols, j = x - k * cols;
+                const int a = S.apos_c[k * n + j];
+                if (a >= 0) atomicMax(&S.invj[k * ml + a], j);
+        }
+        __syncthreads();
+        for (int i = tid; i < rows; i += KA_NT) {
+                int mc[KA_NB];
+                float mv[KA_NB];
+                int cnt = 0;
+                for (int k = 0; k < K; ++k) {
+                        const int a = S.apos_r[k * n + i];
+                        if (a < 0) continue;
+                        const int bj = __hip_atomic_load(&S.invj[k * ml + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (bj < 0) continue;
+                        const float val = paw * S.conf_r[k * n + i] * S.conf_c[k * n + bj];                // :534-535
+                        int hit = -1;
+                        for (int m = 0; m < cnt; ++m) if (mc[m] == bj) hit = m;
+                        if (hit >= 0) mv[hit] += val;
+                        else { mc[cnt] = bj; mv[cnt] = 0.0f + val; ++cnt; }
+                }
+                int2* e = S.ent + (long long)i * KA_NB;
+                for (int m = 0; m < KA_NB - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
+        }
+        __syncthreads();
+        for (int i = tid; i < rows; i += KA_NT) {
+                int2 w = make_int2(-1, 0);
+                if (i + 1 < rows) {
+                        const int2* nx = S.ent + (long long)(i + 1) * KA_NB;
+                        for (int m = 0; m < KA_NB - 1; ++m) if (nx[m].x == 0) w = make_int2(cols, nx[m].y);
+                }
+                S.ent[(long long)i * KA_NB + KA_NB - 1] = w;
+        }
+        __syncthreads();
+}
+
+// make_seq / update_gaps (weave_alignment.c:41-112) in the device's form: after the merge of a and
+// b, residue p of a member of a moves from column col to amap[col].  S.raw / S.raw2 (dead after the
+// path coding) receive amap / bmap.  All workgroups of the cluster share the members.
+__device__ void ka_update_colof(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen)
+{
+        const int tid = threadIdx.x;
+        if (S.member == 0) {
+                for (int j = 1 + tid; j <= alnlen; j += KA_NT) {
+                        const int ia = S.srcA[j], ib = S.srcB[j];
+                        if (ia >= 1) S.raw[ia - 1] = j - 1;
+                        if (ib >= 1) S.raw2[ib - 1] = j - 1;
+                }
+        }
+        ka_cluster_sync(S);
+        const int lane = tid & 63, wave = tid >> 6;
+        const int na = T.nsip_a, nb = T.nsip_b;
+        const int* ma = D.sip + D.sip_off[T.a];
+        const int* mb = D.sip + D.sip_off[T.b];
+        for (int m = S.member * KA_NW + wave; m < na + nb; m += KA_NW * S.G) {
+                const int si = (m < na) ? ma[m] : mb[m - na];
+                const int* mp = (m < na) ? S.raw : S.raw2;
+                int* col = D.colof + D.seq_off[si];
+                const int len = D.node_len[si];
+                for (int p = lane; p < len; p += 64) col[p] = mp[col[p]];
+        }
+}

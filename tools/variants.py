@@ -1,5 +1,6 @@
 """One job, many KA_* settings: ms per step, per-launch times and a parity check between the variants.
 usage: variants.py NSEQ LEN DNA 'K=V,K=V;K=V;...'   (';' separates variants, an empty variant = the defaults).
+VAR_COPIES=n: n independent copies of the job in flight as one forest (the saturation leg of bench.py under the variants).
 Run on the GPU box from the repo root."""
 import os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,13 @@ STEPS = int(os.environ.get("VAR_STEPS", "8"))
 ctx = kalign_amd.Context(0)
 job = bench.make_job(ctx, NSEQ, LEN, DNA, seed=1)
 subm, scal = bench.scoring(DNA)
-ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+COPIES = int(os.environ.get("VAR_COPIES", "1"))
+if COPIES > 1:
+    from kalign_amd import guide
+    fc, ft, fd, _ = guide.forest([(job["codes"], job["tasks"], job["seq_distances"])] * COPIES)
+    ctx.tree_upload(fc, ft, subm, scal, fd)
+else:
+    ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
 ref = None
 touched = set()
 for v in variants:
