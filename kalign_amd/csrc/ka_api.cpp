@@ -84,6 +84,7 @@ struct KaEnv {
         bool no_staging = false, no_wdfs = false, no_ls0 = false, no_inc = false, no_ldfs = false, refine_serial = false;
         int chain_tasks = 0;           // KA_CHAIN_TASKS: the chained launch starts at the first level with at most this many tasks (0: CUs - 8)
         int max_cluster = 0;           // KA_MAX_CLUSTER: workgroups one task may use (0: the default, 16)
+        int crit_greedy = 1;           // KA_CRIT_GREEDY: spare chain workgroups by a simulated schedule first (0: by the ranking alone)
         int crit_top = 0;              // KA_CRIT_TOP: workgroups of the chain entry with the longest way to the root (0: default)
         int prof_task = -1;            // KA_PROF_TASK: the task whose per-level times KA_FLAG_TIMING keeps (-1: the root)
         int q1 = -1;                   // KA_Q1 (-1: the default -- 4 for protein jobs: 64-row strips per recursion level where every strip still gets a helper wave, 0 for nucleotides): 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
@@ -105,7 +106,7 @@ static void read_env(KaEnv& v)
         v.no_half = getenv("KA_NO_HALF") != nullptr; v.no_lean = getenv("KA_NO_LEAN") != nullptr; v.chain_g1 = getenv("KA_CHAIN_G1") != nullptr;
         v.no_crit = getenv("KA_NO_CRIT") != nullptr; v.no_staging = getenv("KA_NO_STAGING") != nullptr;
         v.no_wdfs = getenv("KA_NO_WDFS") != nullptr; v.no_ls0 = getenv("KA_NO_LS0") != nullptr; v.no_inc = getenv("KA_NO_INC") != nullptr; v.no_ldfs = getenv("KA_NO_LDFS") != nullptr; v.refine_serial = getenv("KA_REFINE_SERIAL") != nullptr;
-        v.chain_tasks = env_int("KA_CHAIN_TASKS", 0); v.max_cluster = env_int("KA_MAX_CLUSTER", 0); v.crit_top = env_int("KA_CRIT_TOP", 0);
+        v.chain_tasks = env_int("KA_CHAIN_TASKS", 0); v.max_cluster = env_int("KA_MAX_CLUSTER", 0); v.crit_top = env_int("KA_CRIT_TOP", 0); v.crit_greedy = env_int("KA_CRIT_GREEDY", 1);
         v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", -1); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
@@ -488,10 +489,89 @@ static int plan_launches(ka_ctx* c)
                 if (!c->env.no_crit && spare > 0 && !order.empty()) {
                         std::vector<double> len(2 * numseq - 1, 0.0), up(n_tasks, 0.0);
                         for (int i = 0; i < numseq; i++) len[i] = c->lens[i];
+                        if (c->env.crit_greedy) {
+                                // profile lengths are only known on the device; the estimate: the longest member sequence times
+                                // (1 + 0.1 sqrt(members)) -- the growth of the DSSim sets with their indel-rich tails (13151 columns for
+                                // 4096 x 2000 nt, 2965 for 4096 x 400 aa), harmless where alignments stay shorter
+                                std::vector<double> lmax(2 * numseq - 1, 0.0), nmem(2 * numseq - 1, 1.0);
+                                for (int i = 0; i < numseq; i++) lmax[i] = c->lens[i];
+                                for (int t = 0; t < n_tasks; t++) {
+                                        const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                                        lmax[cc] = std::max(lmax[a], lmax[b]); nmem[cc] = nmem[a] + nmem[b];
+                                        len[cc] = lmax[cc] * (1.0 + 0.1 * std::sqrt(nmem[cc]));
+                                }
+                        } else
                         for (int t = 0; t < n_tasks; t++) len[abc[3 * t + 2]] = 1.1 * std::max(len[abc[3 * t]], len[abc[3 * t + 1]]);
                         for (int t = n_tasks - 1; t >= 0; t--) {               // parents come after their children in the task list
                                 const double la = len[abc[3 * t]], lb = len[abc[3 * t + 1]];
                                 up[t] = 2.0 * std::max(la, lb) + std::min(la, lb) + (c->descs[t].parent >= 0 ? up[c->descs[t].parent] : 0.0);
+                        }
+                        // Round 4: first a GREEDY pass on a simulated schedule.  The ranking below only knows how LONG an entry's way
+                        // to the root is, not how it will be staffed: a caterpillar spine that absorbs siblings finished by earlier
+                        // launches stays on the one workgroup of its entry through level after level of 2400 x 2300 tasks (C3: six
+                        // of them at 3.8 ms, a third of the launch, next to ~200 idle CUs) while a spine fed by subtrees of THIS
+                        // launch collects their workgroups at every join.  Model: a task on G workgroups takes
+                        // a * (2 max + min) + b * la * lb / G (fitted on C3's and the headline's task times: the first term the
+                        // wavefront's dependent steps, the second the cells shared by the cluster; b / a = 0.02), a parent has the
+                        // workgroups of its children in this launch (up to the limit) and starts when the later one ends.  One spare
+                        // workgroup at a time goes to the entry under the simulated critical path, until it stops paying; what is
+                        // left goes out by the ranking.  KA_CRIT_GREEDY=0: the ranking alone (round 3).
+                        if (c->env.crit_greedy) {
+                                std::vector<int> entry_of(n_tasks, -1);
+                                for (size_t r = 0; r < order.size(); r++) entry_of[order[r]] = (int)r;
+                                auto in_chain = [&](int t) { return t >= 0 && act(t) && c->task_level[t] >= c->chain_level; };
+                                std::vector<double> fin(n_tasks, 0.0);
+                                std::vector<int> Gt(n_tasks, 0), crit_child(n_tasks, -1);
+                                auto simulate = [&]() -> int {
+                                        int last = -1;
+                                        for (int t = 0; t < n_tasks; t++) {                  // children come before their parents
+                                                if (!in_chain(t)) continue;
+                                                double start = 0.0; int cc = -1, G = 0;
+                                                if (entry_of[t] >= 0) G = G0 + extra[entry_of[t]];
+                                                else {
+                                                        for (int k = 0; k < 2; k++) {
+                                                                const int ch = abc[3 * t + k];
+                                                                const int tc = ch >= numseq ? task_of[ch] : -1;
+                                                                if (!in_chain(tc)) continue;
+                                                                G += Gt[tc];
+                                                                if (fin[tc] >= start) { start = fin[tc]; cc = tc; }
+                                                        }
+                                                        G = std::max(1, std::min(G, c->max_cluster));
+                                                }
+                                                const double la = len[abc[3 * t]], lb = len[abc[3 * t + 1]];
+                                                fin[t] = start + 2.0 * std::max(la, lb) + std::min(la, lb) + 0.02 * la * lb / G;
+                                                Gt[t] = G; crit_child[t] = cc;
+                                                if (last < 0 || fin[t] > fin[last]) last = t;
+                                        }
+                                        return last;                                       // the task that ends last (a root)
+                                };
+                                // (several paths can be critical at once: a workgroup that shortens ONE of them leaves the end where it was.
+                                // Keep going -- the next round takes the next path -- and fall back to the best state seen when a
+                                // stretch of eight additions has not moved the end.)
+                                int given = 0, since_best = 0;
+                                std::vector<int> best_extra = extra;
+                                int best_spare = spare;
+                                double best_end = -1.0;
+                                { const int t = simulate(); if (t >= 0) best_end = fin[t]; }
+                                while (spare > 0 && best_end > 0.0 && since_best < 8) {
+                                        int t = simulate();
+                                        if (t < 0) break;
+                                        while (crit_child[t] >= 0) t = crit_child[t];        // down the critical path to its entry
+                                        const int r = entry_of[t];
+                                        if (r < 0 || G0 + extra[r] >= c->max_cluster) break;
+                                        extra[r] += 1; spare -= 1;
+                                        const int t2 = simulate();
+                                        if (fin[t2] < best_end * (1.0 - 1e-4)) { best_end = fin[t2]; best_extra = extra; best_spare = spare; since_best = 0; }
+                                        else since_best += 1;
+                                }
+                                extra = best_extra; spare = best_spare;
+                                for (size_t r = 0; r < order.size(); r++) given += extra[r];
+                                if (getenv("KA_PLAN_VERBOSE")) {
+                                        const int t = simulate();
+                                        fprintf(stderr, "chain plan: greedy pass gave %d workgroups, %d left for the ranking; simulated end %.0f\n", given, spare, t >= 0 ? fin[t] : 0.0);
+                                        for (size_t r = 0; r < order.size(); r++) if (extra[r] > 0)
+                                                fprintf(stderr, "  entry task %d (node %d) level %d: +%d\n", order[r], abc[3 * order[r] + 2], c->task_level[order[r]], extra[r]);
+                                }
                         }
                         std::vector<int> by_up(order.size());
                         for (size_t r = 0; r < order.size(); r++) by_up[r] = (int)r;
@@ -500,8 +580,16 @@ static int plan_launches(ka_ctx* c)
                         if (c->env.crit_top > 0) top_g = std::min(c->max_cluster, c->env.crit_top);   // experiments
                         for (size_t i = 0; i < by_up.size() && spare > 0; i++) {
                                 // (never beyond the cluster limit: surplus workgroups would only spin at a join and leave)
-                                const int want = std::min(spare, std::max(0, std::min(c->max_cluster, i == 0 ? top_g : 2 * G0) - G0));
-                                extra[by_up[i]] = want; spare -= want;
+                                const int want = std::min(spare, std::max(0, std::min(c->max_cluster, i == 0 ? top_g : 2 * G0) - G0 - extra[by_up[i]]));
+                                extra[by_up[i]] += want; spare -= want;
+                        }
+                        if (getenv("KA_PLAN_VERBOSE")) {
+                                fprintf(stderr, "chain plan: level %d, %zu entries, G0 %d, spare after extras %d, top_g %d\n", c->chain_level, order.size(), G0, spare, top_g);
+                                for (size_t i = 0; i < by_up.size() && i < 12; i++) {
+                                        const int t = order[by_up[i]];
+                                        fprintf(stderr, "  rank %zu: task %d (node %d) level %d lens %.0f x %.0f up %.0f extra %d\n", i, t, abc[3 * t + 2], c->task_level[t],
+                                                len[abc[3 * t]], len[abc[3 * t + 1]], up[t], extra[by_up[i]]);
+                                }
                         }
                 }
                 int n_extra = 0;
@@ -2002,6 +2090,7 @@ extern "C" int ka_bpm_batch(ka_ctx* c, const uint8_t* codes, const int* off, con
 // =================================================================================================================
 #include <dlfcn.h>
 #include <climits>
+#include <cmath>
 #include <condition_variable>
 #include <deque>
 #include <map>
