@@ -433,7 +433,17 @@ static int plan_launches(ka_ctx* c)
         }
 
         // ---- workgroup tables, one per dependency level (build_blocks) ----
-        c->max_cluster = c->env.max_cluster > 0 ? std::min(16, c->env.max_cluster) : 16;
+        // Workgroups one task may use: 16, or 32 for jobs whose top tasks are big enough to be work-bound at 16 (round 4: a
+        // 9000 x 9700 task of C3 takes 5.8 ms on 16 workgroups, of which ~1.6 ms are the wavefront's dependent steps) -- by the
+        // estimated root (longest sequence x (1 + 0.1 sqrt(sequences)), squared): >= 6e7 cells.  Measured, limit 16 -> 32
+        // (profiles/r04_max_cluster.log): C3 81.9 -> 74.8 ms, 1024 x 2000 nt 34.9 -> 33.0, 512 x 3000 nt 43.6 -> 41.9; 16384 x 500 aa
+        // and 2048 x 1000 aa unchanged; 4096 x 400 aa and 8192 x 300 aa 1-2 % slower (surplus members waiting at the joins).
+        {
+                double lmax = 0.0;
+                for (int i = 0; i < numseq; i++) lmax = std::max(lmax, (double)c->lens[i]);
+                const double root = lmax * (1.0 + 0.1 * std::sqrt((double)numseq));
+                c->max_cluster = c->env.max_cluster > 0 ? std::min(32, c->env.max_cluster) : (root * root >= 6e7 ? 32 : 16);
+        }
         if (c->shared_gpu) c->max_cluster = 1;
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
         for (auto& L : levels) {

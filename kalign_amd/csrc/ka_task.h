@@ -692,7 +692,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
 // as soon as both operands exist instead of at the next launch, clusters grow as the tree narrows, and the
 // whole upper tree is one launch.  All workgroups are resident from the start (<= one per CU), so the waits
 // cannot starve anybody; they are bounded all the same (device watchdog).
-#define KA_MAX_G 16
+#define KA_MAX_G 32
 template <bool LEAN, int NB>
 __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __restrict__ blocks, const int chain)
 {
