@@ -254,6 +254,19 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         // (ho_mode 2, experiments: four strips per workgroup whatever the table says -- costs protein 7 %.)
                         const int s2 = ka_strips_of(S.La / 2, srows) + ka_strips_of(S.La - S.La / 2, srows);
                         g_eff = (S.ho_ok && D.ho_mode >= 2) ? max((s2 + 3) / 4, 1) : max(g_eff, (s2 + 3) / 4);
+                        // Helper-wave strips want at most four items per workgroup on EVERY level they serve: rows halve and passes
+                        // double, but the last strip of a pass is partial, so the count creeps up with the depth (the root of C3:
+                        // 98, 100, 104, 112, 128 strips on levels 0 .. 4; at 25 workgroups level 2 fell back to ka_strip and took
+                        // as long as level 1).  The widest of the first levels decides, if the launch gave that many workgroups.
+                        if (S.hw_ok && !q1_lvl) {
+                                int need = s2;
+                                for (int l = 1; l < 5; ++l) {
+                                        const int rows = (S.La + (2 << l) - 1) >> (l + 1);
+                                        if (rows < 2 * srows) break;
+                                        need = max(need, (2 << l) * ka_strips_of(rows, srows));
+                                }
+                                g_eff = max(g_eff, min(g_launch, (need + 3) / 4));
+                        }
                 }
                 // experiments (KA_PER): strips per workgroup at the task's top level -> workgroups used
                 if (Q1 && D.per_target > 0 && kind == KA_PP) {
