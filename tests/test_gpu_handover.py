@@ -20,7 +20,9 @@ pytestmark = pytest.mark.gpu
 MODES = [{"KA_HO": "1"}, {"KA_HO": "2"}, {"KA_HO": "0"}, {"KA_HO": "1", "KA_Q1": "3"}, {"KA_HO": "2", "KA_Q1": "1"},
          {"KA_HO": "1", "KA_MAX_CLUSTER": "1"}, {"KA_HO": "1", "KA_NO_CHAIN": "1"},
          {"KA_HW": "0"}, {"KA_HW": "0", "KA_HO": "2"}, {"KA_HW": "0", "KA_HO": "0"}, {"KA_HW": "0", "KA_MAX_CLUSTER": "1"},
-         {"KA_HW": "1", "KA_MAX_CLUSTER": "2"}, {"KA_HW": "1", "KA_MAX_CLUSTER": "4"}]
+         {"KA_HW": "1", "KA_MAX_CLUSTER": "2"}, {"KA_HW": "1", "KA_MAX_CLUSTER": "4"},
+         # (round 4: clusters of up to 32 workgroups -- the default of big jobs -- and the spare workgroups by the ranking alone)
+         {"KA_MAX_CLUSTER": "32"}, {"KA_MAX_CLUSTER": "24", "KA_CRIT_GREEDY": "0"}]
 
 
 def reference_gaps(codes, tasks, dist, dna):

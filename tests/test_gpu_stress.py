@@ -14,7 +14,7 @@ from util import Golden, compare_recs, cons_cases, tree_cases
 pytestmark = pytest.mark.gpu
 
 EXACT = ["plen", "kind", "swapped", "meet", "transition", "score", "fhash", "bhash"]
-SWITCHES = {"KA_MAX_CLUSTER": ["1", "2", "4", "8", "16", None], "KA_NO_HALF": ["1", None], "KA_NO_QUEUE": ["1", None],
+SWITCHES = {"KA_MAX_CLUSTER": ["1", "2", "4", "8", "16", "24", "32", None], "KA_CRIT_GREEDY": ["0", None, None], "KA_NO_HALF": ["1", None], "KA_NO_QUEUE": ["1", None],
             "KA_NO_CHAIN": ["1", None, None], "KA_NO_LEAN": ["1", None, None], "KA_LEAN4": ["0", None], "KA_SUBTREE": ["0", None, None],
             "KA_MW": ["0", None, None], "KA_Q1": ["0", "1", "2", "3", "4", None], "KA_CHAIN_G1": ["1", None], "KA_NO_CRIT": ["1", None],
             "KA_HO": ["0", "1", "2", None], "KA_HW": ["0", "1", None]}
@@ -60,7 +60,7 @@ def test_randomised_schedules_give_the_reference_answer(name, monkeypatch):
 # waves: write-through stores + flags; ka_strip: release fences), the multi-wave meetup scan over thousands of columns, four
 # strips per workgroup, tasks beyond 4000 rows -- none of which the goldens (<= 64 sequences, <= 300 columns) reach.  Live
 # reference (oracle/_ref: the real create_msa_tree), the same randomised switches, gap arrays bit for bit every time.
-BIG_SWITCHES = dict(SWITCHES, KA_MAX_CLUSTER=["2", "8", "16", None, None], KA_HO=["0", "1", "2", None], KA_HW=["0", "1", None, None],
+BIG_SWITCHES = dict(SWITCHES, KA_MAX_CLUSTER=["2", "8", "16", "32", None, None], KA_HO=["0", "1", "2", None], KA_HW=["0", "1", None, None],
                     KA_Q1=["0", "4", None, None], KA_MW=["0", None, None])
 
 
