@@ -156,7 +156,7 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const KaSub* sp = qc + subi;
                                 const int dir = dk >> 16, k = dk & 0xffff;
                                 if (dir == KA_ITEM_SUBTREE) {
-                                        ka_subtree<KIND, NRES>(S, *sp, lane, S.sub_base + wave * S.sub_stride, tss);
+                                        ka_subtree<KIND, NRES, NB>(S, *sp, lane, S.sub_base + wave * S.sub_stride, tss);
                                         continue;
                                 }
                                 const int sa = __builtin_amdgcn_readfirstlane(sp->starta);

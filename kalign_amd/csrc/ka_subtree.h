@@ -136,8 +136,12 @@ __device__ __forceinline__ KaState ka_sub_state(const int code, const KaState ro
 // The cell is ka_packed's; the profile-profile dot product packs two residues per v_pk_mul_f32 and adds the two
 // products one after the other (as ka_strip<.., Q = 1>).  The column record of the NEXT step is fetched behind the
 // dot-product chain (loads the compiler tracks; KA_UNTRACKED_READS in ka_pass.h has the history).
-template <int KIND, int NRES>
-__device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, const int npass, const int pass0, const int sshift, const int lane, const float* tss)
+// NB > 0 (round 4): the anchor-consistency bonus of the lane's row (aln_profileprofile.c:108-110 and its seq-seq / seq-profile
+// twins: added behind the substitution terms), the row's entries held in registers as in ka_strip / ka_packed -- until then a job
+// with a consistency table ran its deep recursion levels level by level across the workgroup.
+template <int KIND, int NRES, int NB = 0>
+__device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, const int npass, const int pass0, const int sshift, const int lane, const float* tss,
+                                            const int2* ent = nullptr)
 {
         constexpr int RW = (KIND == KA_PP) ? 4 * ((NRES + 3) / 4) + 4 : (KIND == KA_SP ? 28 : 0);
         constexpr int G0 = RW - 4;                                     // the gap chunk of a record
@@ -169,6 +173,8 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
         const int recA = min(max(iA + 1, 0), X.R + 1);
         const int prevA = min(max((dir == KA_FWD) ? recA - 1 : recA + 1, 0), X.R + 1);
 
+        KaBonus<NB> bon;
+        if (NB) bon.load(ent, min(max(X.a0 + iA, 0), X.La - 1));
         float oA, eA, tA, orpA;
         float2v p1p[KIND == KA_PP ? (NPAIR > 0 ? NPAIR : 1) : 1];     // the counts of residues (2i, 2i+1)
         float p1last = 0.0f;
@@ -296,6 +302,7 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                         pp_read(q[1 - P], rec_addr(v + 1), a1);
                         __builtin_amdgcn_sched_barrier(0);
                 }
+                if (NB) { const int jb = (dir == KA_FWD) ? (X.b0 + sb + v) : (X.b0 + eb - v); a1 += bon.template at<true>(jb); }
                 const bool at0 = (v == 0), atN = (v == ncols);
                 const bool edge = at0 | atN;
                 const bool term = (at0 & near_t) | (atN & far_t);           // (bitwise: as short-circuit logic this became exec-masked branches in every edge step)
@@ -543,7 +550,7 @@ __device__ __forceinline__ void ka_sub_setup(TaskShared& S, const KaSub& root, c
 }
 
 // The whole subtree below `root` by the calling wave.  area: the wave's LDS region (KA_WAVE_LDS bytes).
-template <int KIND, int NRES>
+template <int KIND, int NRES, int NB = 0>
 __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, const int lane, char* area, const float* tss)
 {
         KaSubCtx X;
@@ -569,7 +576,7 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
                 while ((1 << sshift) < maxrows) ++sshift;
                 long long tl0 = 0, tl1 = 0;
                 if (tmg) tl0 = __builtin_amdgcn_s_memtime();
-                for (int p0 = 0; p0 < npass; p0 += 64 >> sshift) ka_sub_pass<KIND, NRES>(X, qc, npass, p0, sshift, lane, tss);
+                for (int p0 = 0; p0 < npass; p0 += 64 >> sshift) ka_sub_pass<KIND, NRES, NB>(X, qc, npass, p0, sshift, lane, tss, S.ent);
                 ka_wave_lds_sync();
                 if (tmg) tl1 = __builtin_amdgcn_s_memtime();
                 // ---- meetups and children ----

@@ -1,6 +1,7 @@
 """One job, many KA_* settings: ms per step, per-launch times and a parity check between the variants.
 usage: variants.py NSEQ LEN DNA 'K=V,K=V;K=V;...'   (';' separates variants, an empty variant = the defaults).
 VAR_COPIES=n: n independent copies of the job in flight as one forest (the saturation leg of bench.py under the variants).
+VAR_ANCHORS=k: default mode -- the consistency table (k anchors, weight 2) is built once, the timed steps are the task tree with the bonus.
 Run on the GPU box from the repo root."""
 import os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +22,8 @@ if COPIES > 1:
     ctx.tree_upload(fc, ft, subm, scal, fd)
 else:
     ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
+if int(os.environ.get("VAR_ANCHORS", "0")) > 0:
+    ctx.tree_build_consistency(int(os.environ["VAR_ANCHORS"]), 2.0)
 ref = None
 touched = set()
 for v in variants:
