@@ -383,10 +383,12 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                                                 const long long mo = __shfl(mo_l, jm, 64);
                                                 const int* map = D.cons_maps + mo;
                                                 const int* col = D.colof + __shfl(so_l, jm, 64);
-                                                for (int p0 = lane; p0 < len; p0 += 256) {
-                                                        int cc[4], aa[4][KA_NB - 1];
+                                                // (round 4: eight residues per lane in flight instead of four -- a 400-residue member is one trip)
+                                                constexpr int KU = 8;
+                                                for (int p0 = lane; p0 < len; p0 += 64 * KU) {
+                                                        int cc[KU], aa[KU][KA_NB - 1];
 #pragma unroll
-                                                        for (int u = 0; u < 4; ++u) {
+                                                        for (int u = 0; u < KU; ++u) {
                                                                 const int pp = p0 + 64 * u;
                                                                 const bool ok = pp < len;
                                                                 cc[u] = ok ? col[pp] : 0;
@@ -395,7 +397,7 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                                                                         aa[u][b] = (ok && b < nb) ? map[(long long)KS(b0 + b) * len + pp] : -1;
                                                         }
 #pragma unroll
-                                                        for (int u = 0; u < 4; ++u) {
+                                                        for (int u = 0; u < KU; ++u) {
 #pragma unroll
                                                                 for (int b = 0; b < KA_NB - 1; ++b) {
                                                                         const int a = aa[u][b];
