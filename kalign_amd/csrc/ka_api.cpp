@@ -442,7 +442,9 @@ static int plan_launches(ka_ctx* c)
                 double lmax = 0.0;
                 for (int i = 0; i < numseq; i++) lmax = std::max(lmax, (double)c->lens[i]);
                 const double root = lmax * (1.0 + 0.1 * std::sqrt((double)numseq));
-                c->max_cluster = c->env.max_cluster > 0 ? std::min(32, c->env.max_cluster) : (root * root >= 6e7 ? 32 : 16);
+                // (... and for big jobs with a consistency table: the votes of their top tasks share by member ranges from 20 workgroups on)
+                const bool big_cons = c->cons_K > 0 && numseq >= 2048;
+                c->max_cluster = c->env.max_cluster > 0 ? std::min(32, c->env.max_cluster) : ((root * root >= 6e7 || big_cons) ? 32 : 16);
         }
         if (c->shared_gpu) c->max_cluster = 1;
         c->blocks_flat.clear(); c->blocks_off.assign(1, 0); c->level_lean.clear();
@@ -1942,6 +1944,10 @@ extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float we
         if (!c->have_colof && setup_colof(c)) return KA_FAIL;
         c->cons_K = K; c->cons_weight = weight;
         c->ran = false; c->synced = false; c->state_valid = false;
+        // the launch plan knows about the table (cluster limit of big jobs, plan_launches): plan again if it would come out differently
+        if (c->env.max_cluster <= 0 && !c->shared_gpu && N >= 2048 && c->max_cluster < 32) {
+                if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
+        }
         return KA_OK;
 }
 

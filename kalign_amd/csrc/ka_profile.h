@@ -317,12 +317,147 @@ __device__ void ka_make_leaf_profile(float* __restrict__ prof, int len, const ui
 // in comes from D.colof (kept up to date by ka_update_colof).  The workgroups of a cluster share
 // the work by operand and by anchor; tables that do not fit into LDS live in the task's HBM scratch.
 // ------------------------------------------------------------------------------------------
+// The two sweeps over the (member, residue) pairs of members [m0, m1) of `node` for ONE anchor `anchor` (table index tb of the
+// tables at key / cnt / agr, dp_len cells each): sweep 0 first-member key + total, sweep 1 agreement with the winner.
+// Latency-bound gathers: each wave pre-loads the metadata of 64 of its members lane-parallel and keeps 8 x 64 residues of loads
+// in flight before the atomics.  NBL anchors at a time (the tables of anchors KS0 + b * KSTEP, b < nb).
+template <int NBL>
+__device__ __forceinline__ void ka_vote_sweep(const KaTreeDev& D, const int* members, const int m0, const int m1, const int sweep,
+                                              unsigned long long* key, unsigned int* cnt, unsigned int* agr, const bool wide, const bool in_lds,
+                                              const int dp_len, const int nb, const int ks0, const int kstep)
+{
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int mine = (m1 - m0 - wave + KA_NW - 1) / KA_NW;          // members of this wave
+        for (int base = 0; base < mine; base += 64) {
+                const int ml = min(base + lane, mine - 1);
+                const int mi_l = m0 + wave + KA_NW * ml;
+                const int si_l = members[mi_l];
+                const int len_l = D.node_len[si_l];
+                const long long mo_l = D.cons_map_off[si_l];
+                const int so_l = D.seq_off[si_l];
+                const int cntm = min(64, mine - base);
+                for (int jm = 0; jm < cntm; ++jm) {
+                        const int mi = m0 + wave + KA_NW * (base + jm);
+                        const int len = __shfl(len_l, jm, 64);
+                        const long long mo = __shfl(mo_l, jm, 64);
+                        const int* map = D.cons_maps + mo;
+                        const int* col = D.colof + __shfl(so_l, jm, 64);
+                        // (round 4: eight residues per lane in flight instead of four -- a 400-residue member is one trip)
+                        constexpr int KU = 8;
+                        for (int p0 = lane; p0 < len; p0 += 64 * KU) {
+                                int cc[KU], aa[KU][NBL];
+#pragma unroll
+                                for (int u = 0; u < KU; ++u) {
+                                        const int pp = p0 + 64 * u;
+                                        const bool ok = pp < len;
+                                        cc[u] = ok ? col[pp] : 0;
+#pragma unroll
+                                        for (int b = 0; b < NBL; ++b)
+                                                aa[u][b] = (ok && b < nb) ? map[(long long)(ks0 + b * kstep) * len + pp] : -1;
+                                }
+#pragma unroll
+                                for (int u = 0; u < KU; ++u) {
+#pragma unroll
+                                        for (int b = 0; b < NBL; ++b) {
+                                                const int a = aa[u][b];
+                                                if (a < 0) continue;
+                                                const int x = b * dp_len + cc[u];
+                                                if (sweep == 0) {
+                                                        atomicMin(&key[x], ((unsigned long long)(unsigned int)mi << 32) | (unsigned int)a);
+                                                        atomicAdd(&cnt[x], 1u);
+                                                } else {
+                                                        // (HBM tables: the atomics were performed at L2; read them back past the L1)
+                                                        const unsigned long long kk = in_lds ? key[x]
+                                                                : __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                        if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) { if (wide) atomicAdd(&agr[x], 1u); else atomicAdd(&cnt[x], 0x10000u); }
+                                                }
+                                        }
+                                }
+                        }
+                }
+        }
+}
+
+// Round 4: R >= 2 workgroups per (operand, anchor) -- clusters of 4K workgroups and more at the top of a big tree, where one
+// workgroup per unit takes ~0.75 us per member of the bigger operand (7 ms of the 10 ms root task of a 16384-sequence tree).
+// Every workgroup votes over its range of the members into tables in LDS, the R partial tables of a unit meet in the task's
+// HBM table (16 B per column: key, total, agree) behind cluster barriers: first member = min over the partial keys, totals add
+// up; the merged keys come back into LDS for the agreement sweep, whose counts add up the same way.  Same numbers as the
+// one-workgroup path: min and + do not care how the members were grouped.
+__device__ void ka_cons_votes_split(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const int R)
+{
+        const int tid = threadIdx.x;
+        const int K = D.cons_K;
+        const long long n = (long long)S.len_a + S.len_b + 8;
+        const int unit = S.member / R, chunk = S.member % R;
+        const bool active = unit < 2 * K;
+        const bool is_rows = unit < K;
+        const int anchor = is_rows ? unit : unit - K;
+        const int node = (is_rows != (S.swapped != 0)) ? T.a : T.b;
+        const int nmem = (node == T.a) ? T.nsip_a : T.nsip_b;
+        const int dp_len = is_rows ? S.La : S.Lb;
+        int* apos = is_rows ? S.apos_r : S.apos_c;
+        float* conf = is_rows ? S.conf_r : S.conf_c;
+        // the unit's table in the task's HBM scratch: rows-side units first ([K][La]), then the columns side ([K][Lb])
+        char* hb = S.vote + (is_rows ? (long long)anchor * S.La : (long long)K * S.La + (long long)anchor * S.Lb) * 16;
+        unsigned long long* hkey = (unsigned long long*)hb;
+        unsigned int* hcnt = (unsigned int*)(hkey + dp_len);
+        unsigned int* hagr = hcnt + dp_len;
+        const bool leaf = nmem == 1;
+        const bool voting = active && !leaf;
+        unsigned long long* key = (unsigned long long*)lds;
+        unsigned int* cnt = (unsigned int*)(key + dp_len);
+        const int* members = D.sip + D.sip_off[node];
+        const int m0 = (int)((long long)chunk * nmem / R), m1 = (int)((long long)(chunk + 1) * nmem / R);
+        if (active && leaf && chunk == 0) {
+                const int* map = D.cons_maps + D.cons_map_off[node] + (long long)anchor * dp_len;
+                for (int i = tid; i < dp_len; i += KA_NT) { const int a = map[i]; apos[anchor * n + i] = a; conf[anchor * n + i] = (a >= 0) ? 1.0f : 0.0f; }
+        }
+        if (voting) {
+                for (int x = chunk * KA_NT + tid; x < dp_len; x += R * KA_NT) { hkey[x] = ~0ull; hcnt[x] = 0u; hagr[x] = 0u; }
+                for (int x = tid; x < dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; }
+                __syncthreads();
+                ka_vote_sweep<1>(D, members, m0, m1, 0, key, cnt, nullptr, false, true, dp_len, 1, anchor, 1);
+                __syncthreads();
+        }
+        ka_cluster_sync(S);                                                  // the HBM tables are initialised
+        if (voting) {
+                for (int x = tid; x < dp_len; x += KA_NT)
+                        if (cnt[x]) { atomicMin(&hkey[x], key[x]); atomicAdd(&hcnt[x], cnt[x]); }
+        }
+        ka_cluster_sync(S);                                                  // first members and totals of every unit are complete
+        if (voting) {
+                for (int x = tid; x < dp_len; x += KA_NT) { key[x] = __hip_atomic_load(&hkey[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cnt[x] = 0u; }
+                __syncthreads();
+                ka_vote_sweep<1>(D, members, m0, m1, 1, key, cnt, nullptr, false, true, dp_len, 1, anchor, 1);
+                __syncthreads();
+                for (int x = tid; x < dp_len; x += KA_NT)
+                        if (cnt[x] >> 16) atomicAdd(&hagr[x], cnt[x] >> 16);
+        }
+        ka_cluster_sync(S);                                                  // agreement counts complete
+        if (voting) {
+                for (int x = chunk * KA_NT + tid; x < dp_len; x += R * KA_NT) {
+                        const unsigned long long kk = __hip_atomic_load(&hkey[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int tot = (int)__hip_atomic_load(&hcnt[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int ag = (int)__hip_atomic_load(&hagr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const long long o = (long long)anchor * n + x;
+                        if (tot > 0 && ag > 0) { apos[o] = (int)(unsigned int)(kk & 0xffffffffull); conf[o] = (float)ag / (float)tot; }
+                        else { apos[o] = -1; conf[o] = 0.0f; }
+                }
+        }
+        __syncthreads();
+}
+
 template <bool LEAN>
 __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const long long lds_bytes)
 {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x;
         const int K = D.cons_K;
         const long long n = (long long)S.len_a + S.len_b + 8;           // stride of the per-anchor arrays
+        if (!LEAN && K > 0 && S.G >= 4 * K && max(T.nsip_a, T.nsip_b) < 65536 && 12ll * max(S.La, S.Lb) <= lds_bytes) {
+                ka_cons_votes_split(S, D, T, lds, S.G / (2 * K));
+                return;
+        }
         const int half = (S.G >= 2) ? (S.G >> 1) : 1;
         for (int side = 0; side < 2; ++side) {
                 if (S.G >= 2 && side != S.member / half) continue;
@@ -364,59 +499,8 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                         unsigned int* agr = cnt + (long long)nb * dp_len;        // (wide only)
                         for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; if (wide) agr[x] = 0u; }
                         __syncthreads();
-                        // Two sweeps over (member, residue): [0] first-member key + total, [1] agreement with the
-                        // winner.  Latency-bound gathers, so each wave pre-loads the metadata of 64 of its
-                        // members lane-parallel and keeps 4 x 64 residues of loads in flight before the atomics.
                         for (int sweep = 0; sweep < 2; ++sweep) {
-                                const int mine = (nmem - wave + KA_NW - 1) / KA_NW;          // members of this wave
-                                for (int base = 0; base < mine; base += 64) {
-                                        const int ml = min(base + lane, mine - 1);
-                                        const int mi_l = wave + KA_NW * ml;
-                                        const int si_l = members[mi_l];
-                                        const int len_l = D.node_len[si_l];
-                                        const long long mo_l = D.cons_map_off[si_l];
-                                        const int so_l = D.seq_off[si_l];
-                                        const int cntm = min(64, mine - base);
-                                        for (int jm = 0; jm < cntm; ++jm) {
-                                                const int mi = wave + KA_NW * (base + jm);
-                                                const int len = __shfl(len_l, jm, 64);
-                                                const long long mo = __shfl(mo_l, jm, 64);
-                                                const int* map = D.cons_maps + mo;
-                                                const int* col = D.colof + __shfl(so_l, jm, 64);
-                                                // (round 4: eight residues per lane in flight instead of four -- a 400-residue member is one trip)
-                                                constexpr int KU = 8;
-                                                for (int p0 = lane; p0 < len; p0 += 64 * KU) {
-                                                        int cc[KU], aa[KU][KA_NB - 1];
-#pragma unroll
-                                                        for (int u = 0; u < KU; ++u) {
-                                                                const int pp = p0 + 64 * u;
-                                                                const bool ok = pp < len;
-                                                                cc[u] = ok ? col[pp] : 0;
-#pragma unroll
-                                                                for (int b = 0; b < KA_NB - 1; ++b)
-                                                                        aa[u][b] = (ok && b < nb) ? map[(long long)KS(b0 + b) * len + pp] : -1;
-                                                        }
-#pragma unroll
-                                                        for (int u = 0; u < KU; ++u) {
-#pragma unroll
-                                                                for (int b = 0; b < KA_NB - 1; ++b) {
-                                                                        const int a = aa[u][b];
-                                                                        if (a < 0) continue;
-                                                                        const int x = b * dp_len + cc[u];
-                                                                        if (sweep == 0) {
-                                                                                atomicMin(&key[x], ((unsigned long long)(unsigned int)mi << 32) | (unsigned int)a);
-                                                                                atomicAdd(&cnt[x], 1u);
-                                                                        } else {
-                                                                                // (HBM tables: the atomics were performed at L2; read them back past the L1)
-                                                                                const unsigned long long kk = in_lds ? key[x]
-                                                                                        : __hip_atomic_load(&key[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                                                                if ((unsigned int)a == (unsigned int)(kk & 0xffffffffull)) { if (wide) atomicAdd(&agr[x], 1u); else atomicAdd(&cnt[x], 0x10000u); }
-                                                                        }
-                                                                }
-                                                        }
-                                                }
-                                        }
-                                }
+                                ka_vote_sweep<KA_NB - 1>(D, members, 0, nmem, sweep, key, cnt, agr, wide, in_lds, dp_len, nb, KS(b0), half);
                                 __syncthreads();
                         }
                         for (int x = tid; x < nb * dp_len; x += KA_NT) {

@@ -276,7 +276,12 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // Jobs with a consistency table: the votes of a task (ka_cons_votes) are shared by operand and by anchor -- ten units
                 // at five anchors -- and take 2 ms at the root of a 4096-sequence tree when one workgroup has two of them: a cluster of
                 // two workgroups per anchor where the members are many and the launch gave that many workgroups.
-                if (NB && D.cons_K > 0 && T.nsip_a + T.nsip_b >= 128) g_eff = max(g_eff, 2 * D.cons_K);
+                if (NB && D.cons_K > 0 && T.nsip_a + T.nsip_b >= 128) {
+                        // (two / three workgroups per (operand, anchor) where one would spend a millisecond and more on the bigger
+                        // operand's members: ka_cons_votes_split)
+                        const int mem = max(T.nsip_a, T.nsip_b);
+                        g_eff = max(g_eff, 2 * D.cons_K * (mem >= 1536 ? 3 : (mem >= 384 ? 2 : 1)));
+                }
                 if (g_eff > g_launch) g_eff = g_launch;
                 S.srows = srows;
                 // wave-local subtrees (ka_subtree.h): every kernel shape has a region per wave behind the workgroup's scratch

@@ -77,6 +77,15 @@ def test_config1_default_mode_512x400_matches_reference():
     run_case(512, 400, False, n_anchors=5)
 
 
+def test_default_mode_2304_sequences_votes_shared_by_member_ranges_match_reference(monkeypatch):
+    """Default mode on a tree of >= 2048 sequences: the top tasks run on clusters of 20 / 30 workgroups and the votes of an
+    (operand, anchor) pair are shared by member ranges (ka_cons_votes_split: partial tables in LDS, merged through the task's
+    HBM table).  Against the reference, and the same job with the cluster limit at 16 (one workgroup per pair)."""
+    run_case(2304, 120, False, n_anchors=5)
+    monkeypatch.setenv("KA_MAX_CLUSTER", "16")
+    run_case(2304, 120, False, n_anchors=5)
+
+
 def test_config2_full_size_dna_4096x2000_properties():
     """configs[2] at its full size (4096 DNA x ~2000, 2e10 useful cells, root profile > 10k columns): no CPU
     run of this size fits a test, so the size-independent properties decide: every coded path consumes
