@@ -25,10 +25,23 @@ extern "C" void ka_unit1_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, int nqueue, hipStream_t stream);   // half (4 waves, 2 per CU)
 extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // lean (seq-seq levels)
 extern "C" void ka_unit4_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, hipStream_t stream);    // refinement pass (one workgroup per task)
+// the consistency kernels once more with room for ten anchors per DP row (units 6..9; K > KA_NB - 1)
+extern "C" void ka_unit6_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream);
+extern "C" void ka_unit7_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int nqueue, hipStream_t stream);
+extern "C" void ka_unit8_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
+extern "C" void ka_unit9_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
+extern "C" long long ka_scratch_bytes_host_nb(long long la, long long lb, long long cons_maxlen, int nb);
+static bool ka_cons_big(const KaTreeDev* D) { return D->cons_K > KA_NB - 1; }
 // kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
 static void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
 {
         const int cons = D->cons_K > 0;
+        if (ka_cons_big(D)) {
+                if (kind == 1) ka_unit8_launch(D, blocks_dev, nblocks, stream);
+                else if (kind == 2) ka_unit7_launch(D, blocks_dev, nblocks, 0, stream);
+                else ka_unit6_launch(D, blocks_dev, nblocks, chain, stream);
+                return;
+        }
         if (kind == 1) ka_unit3_launch(D, blocks_dev, nblocks, cons, stream);
         else if (kind == 2) ka_unit2_launch(D, blocks_dev, nblocks, cons, 0, stream);
         else if (cons) ka_unit1_launch(D, blocks_dev, nblocks, chain, stream);
@@ -952,14 +965,16 @@ static int tree_launch(ka_ctx* c, bool reset = true)
                 if (!reset && (int)L == c->queue_first) HIPCHK(hipMemsetAsync(c->d_counters.p + 4, 0, sizeof(unsigned long long), c->stream));   // (the queue's head)
                 if (c->refine_mode) {
                         // refinement pass: one launch per tree level (see refine_blocks)
-                        ka_unit4_launch(&D, c->d_refine_blocks.p + c->refine_off[L], c->refine_off[L + 1] - c->refine_off[L], D.cons_K > 0, c->stream);
+                        if (ka_cons_big(&D)) ka_unit9_launch(&D, c->d_refine_blocks.p + c->refine_off[L], c->refine_off[L + 1] - c->refine_off[L], c->stream);
+                        else ka_unit4_launch(&D, c->d_refine_blocks.p + c->refine_off[L], c->refine_off[L + 1] - c->refine_off[L], D.cons_K > 0, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         continue;
                 }
                 if ((int)L == c->queue_first) {
                         // levels queue_first .. chain_level-1: one launch, two workgroups per CU pulling from the ordered list
                         const int nwg = std::min(c->queue_n, 2 * c->n_cus);
-                        ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
+                        if (ka_cons_big(&D)) ka_unit7_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
+                        else ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         L = (size_t)c->chain_level - 1;
                         continue;
@@ -1859,7 +1874,7 @@ extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float we
         cons_part_seqs(c, part, nparts, &part_lo, &part_hi);
         // the reference silently declines in these cases (anchor_consistency.c:206-217)
         if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
-        if (n_anchors > KA_NB - 1) return fail("this build carries at most 5 consistency anchors per DP row");
+        if (n_anchors > KA_NB_BIG - 1) return fail("this build carries at most 10 consistency anchors per DP row");
         // One table per alignment.  A forest job holds several: every tree selects its own anchors among its own
         // sequences (in ascending index order = that alignment's own order); map k of a sequence is always against
         // anchor k of ITS tree, so the kernels need no notion of trees.

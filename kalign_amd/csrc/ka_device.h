@@ -103,6 +103,7 @@ struct KaTreeDev {
 };
 
 #define KA_NB 6                        // bonus entries a DP row carries: <= 5 anchors + the wrap-around entry
+#define KA_NB_BIG 11                   // ... of the second set of consistency kernels (round 4): <= 10 anchors (`--consistency K`, 5 < K <= 10)
 
 struct KaPairDev {
         const uint8_t* codes;

@@ -38,7 +38,7 @@
 //   unit 0: ka_task_kernel            unit 1: ka_task_kernel_cons
 //   unit 2: the two half kernels      unit 3: the two lean kernels + ka_pair_kernel
 #ifndef KA_UNIT
-#error "compile with -DKA_UNIT=0..5 (see csrc/Makefile)"
+#error "compile with -DKA_UNIT=0..9 (see csrc/Makefile)"
 #endif
 
 // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
@@ -224,5 +224,65 @@ extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
         static bool done = false;
         if (ka_optin(ka_pair_kernel, KA_LDS_PAIR, &done) != hipSuccess) return;
         hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *P);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
+// Units 6..9 (round 4): the four kernels that carry the anchor-consistency bonus once more, with room for ten anchors per DP row
+// (KA_NB_BIG = 11 entries: `--consistency K`, 5 < K <= 10).  Twice the bonus registers: slower steps than the K <= 5 set
+// (the allocator spills in the strips), same results; the host picks the set by K (ka_tree_build_consistency).
+// ------------------------------------------------------------------------------------------
+#if KA_UNIT == 6
+__global__ __launch_bounds__(KA_BLOCK) void ka_task_kernel_cons_big(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<false, KA_NB_BIG>(D, blocks, chain);
+}
+extern "C" void ka_unit6_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int chain, hipStream_t stream)
+{
+        static bool done = false;
+        if (ka_optin(ka_task_kernel_cons_big, KA_LDS_TOTAL, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_task_kernel_cons_big, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
+}
+extern "C" long long ka_scratch_bytes_host_nb(long long la, long long lb, long long cons_maxlen, int nb) { return ka_scratch_bytes(la, lb, cons_maxlen, 1, false, false, nb); }
+#endif
+
+#if KA_UNIT == 7
+__global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons_big(const KaTreeDev D, const int2* __restrict__ blocks, const int nqueue)
+{
+        ka_task_queue_entry<false, KA_NB_BIG>(D, blocks, nqueue);
+}
+extern "C" void ka_unit7_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int nqueue, hipStream_t stream)
+{
+        static bool done = false;
+        if (ka_optin(ka_task_kernel_half_cons_big, KA_LDS_HALF, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_task_kernel_half_cons_big, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
+}
+#endif
+
+#if KA_UNIT == 8
+// (two workgroups of four waves per CU: the entries of ten anchors do not fit the three-per-CU budget of the K <= 5 kernel)
+__global__ __launch_bounds__(KA_PAIR_BLOCK, 2) void ka_task_kernel_lean_cons_big(const KaTreeDev D, const int2* __restrict__ blocks, const int chain)
+{
+        ka_task_entry<true, KA_NB_BIG>(D, blocks, 0);
+}
+extern "C" void ka_unit8_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream)
+{
+        static bool done = false;
+        if (ka_optin(ka_task_kernel_lean_cons_big, KA_LDS_PAIR, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_task_kernel_lean_cons_big, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+}
+#endif
+
+#if KA_UNIT == 9
+__global__ __launch_bounds__(KA_BLOCK) void ka_refine_kernel_cons_big(const KaTreeDev D, const int2* __restrict__ blocks, const int unused)
+{
+        const int2 blk = blocks[blockIdx.x];
+        if (blk.x >= 0) ka_task_body_refine<KA_NB_BIG>(D, blk.x, blk.y & 0xff, blk.y >> 8);
+}
+extern "C" void ka_unit9_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream)
+{
+        static bool done = false;
+        if (ka_optin(ka_refine_kernel_cons_big, KA_LDS_TOTAL, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_refine_kernel_cons_big, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, 0);
 }
 #endif

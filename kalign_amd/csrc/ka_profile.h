@@ -448,7 +448,7 @@ __device__ void ka_cons_votes_split(TaskShared& S, const KaTreeDev& D, const KaT
         __syncthreads();
 }
 
-template <bool LEAN>
+template <bool LEAN, int NBK = KA_NB>
 __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, char* lds, const long long lds_bytes)
 {
         const int tid = threadIdx.x;
@@ -500,7 +500,7 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                         for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; if (wide) agr[x] = 0u; }
                         __syncthreads();
                         for (int sweep = 0; sweep < 2; ++sweep) {
-                                ka_vote_sweep<KA_NB - 1>(D, members, 0, nmem, sweep, key, cnt, agr, wide, in_lds, dp_len, nb, KS(b0), half);
+                                ka_vote_sweep<NBK - 1>(D, members, 0, nmem, sweep, key, cnt, agr, wide, in_lds, dp_len, nb, KS(b0), half);
                                 __syncthreads();
                         }
                         for (int x = tid; x < nb * dp_len; x += KA_NT) {
@@ -531,6 +531,7 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
 // k = 0..K-1 into a zeroed cell), and slot KA_NB-1 carries the cell the reference reaches when a forward
 // pass indexes column Lb of row i -- flat index i*Lb + Lb is cell (i+1, 0) (aln_seqseq.c:83-85 uses the
 // 1-based column).
+template <int NBK = KA_NB>
 __device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
 {
         const int tid = threadIdx.x;
@@ -549,8 +550,8 @@ __device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
         }
         __syncthreads();
         for (int i = tid; i < rows; i += KA_NT) {
-                int mc[KA_NB];
-                float mv[KA_NB];
+                int mc[NBK];
+                float mv[NBK];
                 int cnt = 0;
                 for (int k = 0; k < K; ++k) {
                         const int a = S.apos_r[k * n + i];
@@ -563,17 +564,17 @@ __device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
                         if (hit >= 0) mv[hit] += val;
                         else { mc[cnt] = bj; mv[cnt] = 0.0f + val; ++cnt; }
                 }
-                int2* e = S.ent + (long long)i * KA_NB;
-                for (int m = 0; m < KA_NB - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
+                int2* e = S.ent + (long long)i * NBK;
+                for (int m = 0; m < NBK - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
         }
         __syncthreads();
         for (int i = tid; i < rows; i += KA_NT) {
                 int2 w = make_int2(-1, 0);
                 if (i + 1 < rows) {
-                        const int2* nx = S.ent + (long long)(i + 1) * KA_NB;
-                        for (int m = 0; m < KA_NB - 1; ++m) if (nx[m].x == 0) w = make_int2(cols, nx[m].y);
+                        const int2* nx = S.ent + (long long)(i + 1) * NBK;
+                        for (int m = 0; m < NBK - 1; ++m) if (nx[m].x == 0) w = make_int2(cols, nx[m].y);
                 }
-                S.ent[(long long)i * KA_NB + KA_NB - 1] = w;
+                S.ent[(long long)i * NBK + NBK - 1] = w;
         }
         __syncthreads();
 }

@@ -41,6 +41,7 @@
 /* the reference's own definitions, renamed by the drop-in build (oracle/Makefile) */
 extern int kalign_ref_finalise_alignment(struct msa* msa);
 extern int kalign_ref_refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int refine_mode);
+extern int kalign_ref_create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t);
 extern int kalign_ref_create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int n_trials);
 extern int kalign_ref_compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr);
 extern int kalign_ref_build_tree_from_pairwise(struct msa* msa, struct aln_tasks** tasks, float** dm);
@@ -49,10 +50,10 @@ extern int kalign_ref_anchor_consistency_build(struct msa* msa, struct aln_param
 /* how often each seam ran on the device / fell back to the reference (tests/test_gpu_dropin.py reads them) */
 enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF,
        GLUE_CONS, GLUE_CONS_REF, GLUE_KMEANS, GLUE_KMEANS_NOISY, GLUE_ALNDIST, GLUE_ALNDIST_REF, GLUE_ALNTREE, GLUE_ALNTREE_REF, GLUE_INLINE_REF,
-       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_N };
+       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_TREE_REF, GLUE_N };
 static const char* glue_names[GLUE_N] = { "tree", "inline", "refine", "refine_ref", "finalise", "finalise_ref",
                                           "cons", "cons_ref", "kmeans", "kmeans_noisy", "alndist", "alndist_ref", "alntree", "alntree_ref", "inline_ref",
-                                          "tree_multi", "cons_multi" };
+                                          "tree_multi", "cons_multi", "tree_ref" };
 static int glue_counts[GLUE_N];
 int kalign_amd_glue_count(int which)
 {
@@ -263,7 +264,7 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         }else
         if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0) ||
            ka_tree_build_consistency(glue_ctx, K, weight)){
-                /* a request the library does not take (more than 5 anchors ...): the reference's own function, like every
+                /* a request the library does not take (more than 10 anchors ...): the reference's own function, like every
                    other seam; the dispatcher then rebuilds the table it needs or declines alike (glue_ct_resident stays NULL) */
                 MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc);
                 glue_counts[GLUE_CONS_REF]++;
@@ -460,8 +461,21 @@ ERROR:
         return FAIL;
 }
 
+/* a consistency table with more anchors than a DP row of the device kernels carries (KA_CONS_MAX_ANCHORS; such a table was
+   built by the reference's own stage, cons_ref): the reference's dispatcher, like every other seam the library does not take */
+static int glue_table_too_wide(const struct msa* msa)
+{
+        const struct consistency_table* ct = (const struct consistency_table*)msa->consistency_table;
+        return ct && ct->n_anchors > KA_CONS_MAX_ANCHORS;
+}
+
 int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
 {
+        if(glue_table_too_wide(msa)){
+                glue_job_msa = NULL;
+                glue_counts[GLUE_TREE_REF]++;
+                return kalign_ref_create_msa_tree(msa, ap, t);
+        }
         return glue_tree(msa, ap, t, 0);
 }
 
@@ -470,7 +484,7 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
  */
 int create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int n_trials)
 {
-        if(n_trials < 1 || n_trials > 255){
+        if(n_trials < 1 || n_trials > 255 || glue_table_too_wide(msa)){
                 glue_job_msa = NULL;
                 glue_counts[GLUE_INLINE_REF]++;
                 return kalign_ref_create_msa_tree_inline_refine(msa, ap, t, n_trials);

@@ -84,6 +84,8 @@ CLI_CASES = [
     ("BB11001.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "confident"]),
     ("BB12006.tfa", ["--fast", "--refine", "confident"]), ("BB12006.tfa", ["--refine", "all", "--realign", "1"]),
     ("BB30014.tfa", ["--refine", "all", "--adaptive-budget"]), ("BB12006.tfa", ["--refine", "confident", "--adaptive-budget"]),
+    # more than five anchors (round 4): the second set of consistency kernels
+    ("BB11001.tfa", ["--consistency", "8"]), ("BB30014.tfa", ["--consistency", "10", "--refine", "all"]), ("BB12006.tfa", ["--consistency", "6", "--realign", "1"]),
 ]
 
 
@@ -98,8 +100,22 @@ def test_cli_output_is_byte_identical(tmp_path, name, flags):
     _device_ran(c, flags)
 
 
+def test_cli_with_more_anchors_than_the_kernels_carry_takes_the_reference_seams(tmp_path):
+    """`--consistency 12`: the library declines the table (cons_ref), the dispatcher hands the trees to the reference's own
+    create_msa_tree (tree_ref) -- same bytes, no error."""
+    from kalign_amd import synth
+    inp = str(tmp_path / "in.fa")
+    _write_fasta(inp, synth.dssim(40, 150, dna=False, seed=3))   # (the reference caps the anchors at the number of sequences)
+    c = {}
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), "--consistency", "12", counters=c)
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), "--consistency", "12")
+    assert got == want
+    assert c["cons_ref"] >= 1 and c["tree_ref"] >= 1 and c["cons"] == 0, c
+
+
 @pytest.mark.parametrize("dna,n,length,flags", [(False, 32, 200, []), (False, 32, 200, ["--fast"]),
-                                                (True, 16, 300, ["--type", "dna"]), (False, 200, 150, [])])
+                                                (True, 16, 300, ["--type", "dna"]), (False, 200, 150, []),
+                                                (False, 40, 150, ["--consistency", "8"]), (True, 24, 300, ["--type", "dna", "--consistency", "10", "--refine", "all"])])
 def test_cli_on_dssim_sets(tmp_path, dna, n, length, flags):
     from kalign_amd import synth
     inp = str(tmp_path / "in.fa")

@@ -86,6 +86,13 @@ def test_default_mode_2304_sequences_votes_shared_by_member_ranges_match_referen
     run_case(2304, 120, False, n_anchors=5)
 
 
+@pytest.mark.parametrize("nseq,length,dna,k", [(384, 200, False, 8), (96, 900, True, 10), (160, 300, False, 6)])
+def test_more_than_five_anchors_match_reference(nseq, length, dna, k):
+    """`--consistency K` with 5 < K <= 10: the second set of consistency kernels (room for ten bonus entries per DP row,
+    KA_NB_BIG) -- anchor selection, position maps, votes, bonus entries and the whole tree against the reference."""
+    run_case(nseq, length, dna, n_anchors=k)
+
+
 def test_config2_full_size_dna_4096x2000_properties():
     """configs[2] at its full size (4096 DNA x ~2000, 2e10 useful cells, root profile > 10k columns): no CPU
     run of this size fits a test, so the size-independent properties decide: every coded path consumes

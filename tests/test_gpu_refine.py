@@ -205,8 +205,8 @@ def test_refine_argument_errors(ctx):
 
 
 @pytest.mark.parametrize("mode,anchors,nseq,length,dna", [(1, 0, 768, 300, False), (2, 5, 384, 300, False), (3, 0, 384, 250, False),
-                                                          (1, 5, 256, 600, True)],
-                         ids=["all_768x300", "confident_cons_384x300", "inline_384x250", "all_cons_dna256x600"])
+                                                          (1, 5, 256, 600, True), (1, 8, 192, 250, False)],
+                         ids=["all_768x300", "confident_cons_384x300", "inline_384x250", "all_cons_dna256x600", "all_cons8_192x250"])
 def test_refinement_against_the_live_reference(ctx, mode, anchors, nseq, length, dna):
     """bigger trees than the goldens (levels with more edges than CUs: serial trials; upper levels: trials in parallel),
     against refine_alignment / create_msa_tree_inline_refine of the real reference run on the box's host cores: gap arrays,
