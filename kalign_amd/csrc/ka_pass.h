@@ -49,6 +49,9 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 // enough (four waves streaming 7 KB per step each) -- the intermittent wrong rows round 4 chased in ka_wstrip.  The tracked
 // form keeps the reads where they were (sched_barrier) and marks the old wait's place with an empty asm that USES the
 // registers: the compiler puts the s_waitcnt it needs in front of it, and in front of any copy it makes before.
+#ifndef KA_BONUS_ASM
+#define KA_BONUS_ASM 1
+#endif
 #ifndef KA_UNTRACKED_READS
 #define KA_UNTRACKED_READS 0
 #endif
@@ -131,12 +134,37 @@ struct KaBonus {
         }
         // EDGE = false: the wrap-around entry (slot NB-1, column Lb) is left out -- it can only match in the last column
         // of a pass, which steady-state steps never are
+        // Five entries at a time as five compares into five SGPR pairs, then five selects: written as `(col[e] == j) ? val[e] : b`
+        // the compiler makes cmp -> vcc -> cndmask pairs, and a VALU write of vcc wants two wait states before a cndmask reads it
+        // (gfx950): 14 s_nop in the 117-instruction steady step of the default-mode strip.  Here every select reads a mask
+        // written five instructions earlier.  (KA_BONUS_ASM=0: the plain form.)
         template <bool EDGE>
         __device__ __forceinline__ float at(int j) const
         {
                 float b = 0.0f;
+                constexpr int N = EDGE ? NB : NB - 1;
+                int e0 = 0;
+#if KA_BONUS_ASM
 #pragma unroll
-                for (int e = 0; e < (EDGE ? NB : NB - 1); ++e) b = (col[e] == j) ? val[e] : b;
+                for (; e0 + 5 <= N; e0 += 5) {
+                        unsigned long long m0, m1, m2, m3, m4;
+                        asm("v_cmp_eq_u32_e64 %1, %6, %7\n\t"
+                            "v_cmp_eq_u32_e64 %2, %6, %8\n\t"
+                            "v_cmp_eq_u32_e64 %3, %6, %9\n\t"
+                            "v_cmp_eq_u32_e64 %4, %6, %10\n\t"
+                            "v_cmp_eq_u32_e64 %5, %6, %11\n\t"
+                            "v_cndmask_b32_e64 %0, %0, %12, %1\n\t"
+                            "v_cndmask_b32_e64 %0, %0, %13, %2\n\t"
+                            "v_cndmask_b32_e64 %0, %0, %14, %3\n\t"
+                            "v_cndmask_b32_e64 %0, %0, %15, %4\n\t"
+                            "v_cndmask_b32_e64 %0, %0, %16, %5"
+                            : "+v"(b), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4)
+                            : "v"(j), "v"(col[e0]), "v"(col[e0 + 1]), "v"(col[e0 + 2]), "v"(col[e0 + 3]), "v"(col[e0 + 4]),
+                              "v"(val[e0]), "v"(val[e0 + 1]), "v"(val[e0 + 2]), "v"(val[e0 + 3]), "v"(val[e0 + 4]));
+                }
+#endif
+#pragma unroll
+                for (int e = e0; e < N; ++e) b = (col[e] == j) ? val[e] : b;
                 return b;
         }
 };
