@@ -82,6 +82,27 @@ def test_default_mode_2304_sequences_votes_shared_by_member_ranges_match_referen
     (operand, anchor) pair are shared by member ranges (ka_cons_votes_split: partial tables in LDS, merged through the task's
     HBM table).  Against the reference, and the same job with the cluster limit at 16 (one workgroup per pair)."""
     run_case(2304, 120, False, n_anchors=5)
+    # the same job again and again on one context: the partial tables meet through atomics in HBM behind cluster barriers --
+    # a race would show as a run that differs
+    import bench
+    import kalign_amd
+    codes, tasks, dist = bench.make_workload(2304, 120, False, 1)
+    subm, scal = bench.scoring(False)
+    ctx = kalign_amd.Context(0)
+    try:
+        ctx.tree_upload(codes, tasks, subm, scal, dist)
+        ctx.tree_build_consistency(5, 2.0)
+        first = None
+        for rep in range(6):
+            ctx.tree_run()
+            recs, paths, _ = ctx.tree_download(want_gaps=False)
+            sig = (np.ascontiguousarray(paths).tobytes(), tuple((r.plen, r.meet, r.transition, r.score) for r in recs))
+            if first is None:
+                first = sig
+            assert sig == first, rep
+        assert ctx.fallback_runs() == 0
+    finally:
+        ctx.close()
     monkeypatch.setenv("KA_MAX_CLUSTER", "16")
     run_case(2304, 120, False, n_anchors=5)
 
