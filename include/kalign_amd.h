@@ -228,7 +228,7 @@ int ka_tree_launch_ms(ka_ctx* ctx, float* ms, int cap);
  * the position maps in HBM; from then on every DP of ka_tree_run adds the consistency bonus that do_align
  * builds with anchor_consistency_get_bonus_profile (aln_run.c:262-295).  Like the reference it declines
  * silently (returns OK, no table) when n_anchors <= 0, numseq < 3 or there are no seq_distances.
- * n_anchors <= 5 (the reference's default is 5, src/parameters.c:72-73; weight 2.0).  Any number of sequences per
+ * n_anchors <= KA_CONS_MAX_ANCHORS (the reference's default is 5, src/parameters.c:72-73; weight 2.0).  Any number of sequences per
  * alignment: the member votes of a node count in 16 bits below 65536 members and in 32 bits from there on.
  * In a forest job every alignment gets its own table (its own anchors among its own sequences).
  * ka_tree_upload drops the table again.
