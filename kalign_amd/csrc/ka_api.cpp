@@ -537,7 +537,7 @@ static int plan_launches(ka_ctx* c)
                         // of them at 3.8 ms, a third of the launch, next to ~200 idle CUs) while a spine fed by subtrees of THIS
                         // launch collects their workgroups at every join.  Model: a task on G workgroups takes
                         // a * (2 max + min) + b * la * lb / G (fitted on C3's and the headline's task times: the first term the
-                        // wavefront's dependent steps, the second the cells shared by the cluster; b / a = 0.02), a parent has the
+                        // wavefront's dependent steps, the second the cells shared by the cluster; b / a = 0.02 from the fit, 0.01 in use), a parent has the
                         // workgroups of its children in this launch (up to the limit) and starts when the later one ends.  One spare
                         // workgroup at a time goes to the entry under the simulated critical path, until it stops paying; what is
                         // left goes out by the ranking.  KA_CRIT_GREEDY=0: the ranking alone (round 3).
@@ -547,6 +547,7 @@ static int plan_launches(ka_ctx* c)
                                 auto in_chain = [&](int t) { return t >= 0 && act(t) && c->task_level[t] >= c->chain_level; };
                                 std::vector<double> fin(n_tasks, 0.0);
                                 std::vector<int> Gt(n_tasks, 0), crit_child(n_tasks, -1);
+                                const double ba = 1e-3 * (double)env_int("KA_CRIT_BA", 10);   // (b / a of the model, per mille; 10 from a sweep over five job shapes, profiles/r04_crit_ba.log)
                                 auto simulate = [&]() -> int {
                                         int last = -1;
                                         for (int t = 0; t < n_tasks; t++) {                  // children come before their parents
@@ -564,7 +565,7 @@ static int plan_launches(ka_ctx* c)
                                                         G = std::max(1, std::min(G, c->max_cluster));
                                                 }
                                                 const double la = len[abc[3 * t]], lb = len[abc[3 * t + 1]];
-                                                fin[t] = start + 2.0 * std::max(la, lb) + std::min(la, lb) + 0.02 * la * lb / G;
+                                                fin[t] = start + 2.0 * std::max(la, lb) + std::min(la, lb) + ba * la * lb / G;
                                                 Gt[t] = G; crit_child[t] = cc;
                                                 if (last < 0 || fin[t] > fin[last]) last = t;
                                         }
