@@ -190,6 +190,11 @@ int ka_tree_set_node_cols(ka_ctx* ctx, int node, const int* cols);
 int ka_tree_download_tasks(ka_ctx* ctx, const int* task_ids, int n, ka_task_rec* recs, int* paths_out,
                            long long paths_cap, long long* used_out);
 int ka_weave_gaps(int numseq, const int* lens, int n_tasks, const ka_task_rec* recs, const int* paths, int* gaps_out);
+/* After a run made elsewhere (a sharded tree: records gathered, gap arrays woven on the host) this context -- same uploaded
+ * job -- becomes the holder of the finished alignment: recs[n_tasks] (plen, c) and gaps (ka_tree_download's layout) in;
+ * ka_tree_aligned_rows, ka_aln_guide_tree and ka_tree_refine then carry on here as after ka_tree_run + ka_tree_sync
+ * (finalise_alignment msa_op.c:546-598, refine_alignment aln_refine.c:36-88, compute_aln_pairwise_dist aln_apair_dist.c:9-86). */
+int ka_tree_adopt_alignment(ka_ctx* ctx, const ka_task_rec* recs, const int* gaps);
 
 /* Merged profile of node `node` ((plen+2)*64 floats) after a run. */
 int ka_tree_get_profile(ka_ctx* ctx, int node, float* out, long long cap_floats);
@@ -414,6 +419,10 @@ int ka_multi_tree_run(ka_multi* m, int numseq, const uint8_t* codes, const int* 
                       int n_anchors, float weight);
 long long ka_multi_paths_size(ka_multi* m);
 int ka_multi_download(ka_multi* m, int numseq, const int* lens, int n_tasks, ka_task_rec* recs, int* paths_out, long long paths_cap, int* gaps_out);
+/* rank r's single-GPU context (borrowed: ka_multi_destroy frees it); ka_multi_adopt: rank 0's context takes the alignment of the
+ * last sharded run over (recs / gaps as ka_multi_download returned them), see ka_tree_adopt_alignment */
+ka_ctx* ka_multi_ctx(ka_multi* m, int rank);
+int ka_multi_adopt(ka_multi* m, const ka_task_rec* recs, const int* gaps);
 
 #ifdef __cplusplus
 }

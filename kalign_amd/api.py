@@ -52,7 +52,8 @@ EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_
            "ka_dist_consistency", "ka_dist_tree_run", "ka_dist_paths_size", "ka_dist_download", "ka_dist_last_ms", "ka_dist_retries",
            "ka_dist_loopback_new", "ka_dist_loopback_free", "ka_dist_create_loopback",
            "ka_guide_last_bisect_ms", "ka_device_count", "ka_multi_create", "ka_multi_destroy", "ka_multi_world", "ka_multi_runs", "ka_multi_last_error",
-           "ka_multi_consistency", "ka_multi_tree_run", "ka_multi_paths_size", "ka_multi_download"]
+           "ka_multi_consistency", "ka_multi_tree_run", "ka_multi_paths_size", "ka_multi_download", "ka_multi_ctx", "ka_multi_adopt",
+           "ka_tree_adopt_alignment"]
 
 
 def lib_path():
@@ -139,6 +140,10 @@ def load_library():
     L.ka_multi_paths_size.argtypes = [vp]
     L.ka_multi_paths_size.restype = C.c_longlong
     L.ka_multi_download.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, C.c_longlong, vp]
+    L.ka_multi_ctx.argtypes = [vp, C.c_int]
+    L.ka_multi_ctx.restype = vp
+    L.ka_multi_adopt.argtypes = [vp, vp, vp]
+    L.ka_tree_adopt_alignment.argtypes = [vp, vp, vp]
     L.ka_dist_loopback_new.argtypes = [C.c_int]
     L.ka_dist_loopback_new.restype = vp
     L.ka_dist_loopback_free.argtypes = [vp]
@@ -198,10 +203,27 @@ class Context:
             self.L.ka_ctx_set_shared(self.h, 1)
         self._job = None
 
+    @classmethod
+    def borrowed(cls, handle, job=None):
+        """A view of a context somebody else owns (Multi.ctx): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = load_library()
+        self.h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self._job = job
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.ka_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.L.ka_ctx_destroy(self.h)
             self.h = None
+
+    def adopt_alignment(self, recs, gaps):
+        """ka_tree_adopt_alignment: this context (same uploaded job) takes over an alignment made elsewhere."""
+        arr = (TaskRec * len(recs))(*recs)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32) for g in gaps]), np.int32)
+        self._chk(self.L.ka_tree_adopt_alignment(self.h, arr, _ptr(flat)))
 
     def __del__(self):
         try:
@@ -772,6 +794,20 @@ class Multi:
 
     def runs(self):
         return int(self.L.ka_multi_runs(self.h))
+
+    def ctx(self, rank=0):
+        """rank's single-GPU context as a borrowed Context (ka_multi_ctx)"""
+        h = self.L.ka_multi_ctx(self.h, int(rank))
+        if not h:
+            raise RuntimeError("ka_multi_ctx: bad rank")
+        flat, off, lens, tasks, sd, sub, sc = self._job["keep"]
+        return Context.borrowed(h, job=dict(lens=lens, ntasks=len(tasks), n=len(lens)))
+
+    def adopt(self, recs, gaps):
+        """ka_multi_adopt: rank 0's context takes the alignment of the last sharded run over"""
+        arr = (TaskRec * len(recs))(*recs)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32) for g in gaps]), np.int32)
+        self._chk(self.L.ka_multi_adopt(self.h, arr, _ptr(flat)))
 
     def close(self):
         if self.h:

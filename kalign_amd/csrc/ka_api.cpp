@@ -108,6 +108,7 @@ struct KaEnv {
         int hw = 1;                    // KA_HW: profile-profile strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode)
         int hw_prio = 3;               // KA_HW_PRIO: s_setprio of a strip wave that has a helper (experiments)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
+        int qw = 4, lw = 4, pw = 4;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
         bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
 };
@@ -123,6 +124,8 @@ static void read_env(KaEnv& v)
         v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", -1); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
+        v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 4);
+        for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;
         v.mw = env_int("KA_MW", 1);
         v.ho = env_int("KA_HO", -1);
         v.per = env_int("KA_PER", 0);
@@ -235,7 +238,7 @@ static void node_members(const ka_ctx* c, int node, long long* lo, long long* hi
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
 struct ka_ctx;
 int ka_ctx_device_stream(ka_ctx* c, int* device, hipStream_t* stream);    // (library-internal: ka_guide.cpp)
-extern "C" int ka_abi_version(void) { return 7; }
+extern "C" int ka_abi_version(void) { return 8; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
@@ -907,6 +910,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : (c->nres > 5 ? 4 : 0);     // (nucleotides: five residues -- a one-row step is 0.85 of a two-row one: not worth twice the strips)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
+        D.qw = c->env.qw; D.lw = c->env.lw;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
@@ -973,7 +977,10 @@ static int tree_launch(ka_ctx* c, bool reset = true)
                 }
                 if ((int)L == c->queue_first) {
                         // levels queue_first .. chain_level-1: one launch, two workgroups per CU pulling from the ordered list
-                        const int nwg = std::min(c->queue_n, 2 * c->n_cus);
+                        // (workgroups per CU: two of four waves; of narrower ones as many as the registers (eight waves) and the LDS (160 KB) hold)
+                        // (more than fit is harmless: a workgroup that starts late finds the rest of the list, or nothing)
+                        const int per_cu = c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8);
+                        const int nwg = std::min(c->queue_n, per_cu * c->n_cus);
                         if (ka_cons_big(&D)) ka_unit7_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
                         else ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
@@ -1284,6 +1291,35 @@ extern "C" int ka_tree_download(ka_ctx* c, ka_task_rec* recs, int* paths_out, lo
         return KA_OK;
 }
 
+
+// After a run made ELSEWHERE -- the sharded tree of ka_dist_* / ka_multi_*: records and coded paths gathered, the gap arrays
+// woven on the host -- this context, which holds the same uploaded job, becomes the holder of the finished alignment: the
+// records go to HBM, every residue's column follows from gaps[] (make_linear_sequence, msa_op.c:578-598: column of residue p =
+// p + gaps[0] + .. + gaps[p]).  ka_tree_aligned_rows, ka_aln_guide_tree and ka_tree_refine then carry on here as after ka_tree_run.
+extern "C" int ka_tree_adopt_alignment(ka_ctx* c, const ka_task_rec* recs, const int* gaps)
+{
+        if (!c || !c->have_job) return fail("no uploaded job");
+        if (!recs || !gaps) return fail("ka_tree_adopt_alignment: null argument");
+        HIPCHK(hipSetDevice(c->device));
+        if (c->ran && !c->synced) HIPCHK(hipStreamSynchronize(c->stream));
+        if (!c->have_colof && setup_colof(c)) return KA_FAIL;
+        std::vector<int> col(c->colof_n, 0);
+        long long g = 0;
+        for (int i = 0; i < c->numseq; i++) {
+                int at = 0;
+                for (int p = 0; p < c->lens[i]; p++) { at += gaps[g + p]; col[(size_t)c->off[i] + p] = at + p; }
+                g += c->lens[i] + 1;
+        }
+        for (int t = 0; t < c->n_tasks; t++)
+                if (recs[t].c != c->abc[3 * t + 2]) return fail("ka_tree_adopt_alignment: the records are not this job's (task order)");
+        HIPCHK(hipMemcpy(c->d_colof.p, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_recs.p, recs, sizeof(ka_task_rec) * c->n_tasks, hipMemcpyHostToDevice));
+        c->flags |= KA_FLAG_DEVICE_GAPS;
+        c->h_counters[2] = 0;                                         // (no coded paths of its own)
+        c->ran = true; c->synced = true; c->partial = false; c->state_valid = false;
+        c->rows_n = 0;
+        return KA_OK;
+}
 
 // ---- finalise_alignment (msa_op.c:546-598): the aligned rows, built on the device from the residue->column tables ----
 // alignment length per sequence of the finished run (checks included)
@@ -2036,7 +2072,7 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
         P.subm = d_subm.p; P.gpo = gpo; P.gpe = gpe; P.tgpe = tgpe;
         P.scratch = d_scr.p; P.scratch_stride = stride;
         P.paths_out = d_paths.p; P.poff = d_poff.p; P.scores = d_scores.p; P.npairs = npairs;
-        P.error = d_err.p;
+        P.error = d_err.p; P.pw = c->env.pw;
         PCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), c->stream));
         PCHK(hipEventRecord(c->ev0, c->stream));
         ka_launch_pairs(&P, c->stream);

@@ -90,6 +90,7 @@ struct KaTreeDev {
         int ho_mode;                   // neighbouring strips of a pass hand over through LDS rings (ka_strip<.., HO>): 0 off, 1 on,
                                        // 2 on with four strips per workgroup (KA_HO in the environment)
         int hw_mode;                   // strips with helper waves (ka_wstrip.h) on levels with at most four items per workgroup: 0 off, 1 on (KA_HW in the environment)
+        int qw, lw;                    // waves per workgroup of the queued launch (KA_QW: 4, 2 or 1) / of the seq-seq leaf levels (KA_LW)
         int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
         int cons_K;                    // anchors
         int cons_maxlen;               // longest sequence: bounds every anchor position
@@ -120,4 +121,5 @@ struct KaPairDev {
         float* scores;
         int* error;
         int npairs;
+        int pw;                        // waves per workgroup (KA_PW: 4, 2 or 1)
 };

@@ -132,12 +132,14 @@ __global__ __launch_bounds__(KA_HALF_BLOCK, 2) void ka_task_kernel_half_cons(con
 extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int cons, int nqueue, hipStream_t stream)
 {
         static bool done0 = false, done1 = false;
+        // a queued launch may run on narrower workgroups (KaTreeDev::qw waves: same kernel, a ring per wave, more workgroups per CU)
+        const int qw = (nqueue > 0 && D->qw >= 1 && D->qw <= KA_HALF_BLOCK / 64) ? D->qw : KA_HALF_BLOCK / 64;
         if (cons) {
                 if (ka_optin(ka_task_kernel_half_cons, KA_LDS_HALF, &done1) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
+                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(64 * qw), KA_LDS_WAVES + qw * KA_WAVE_LDS, stream, *D, blocks_dev, nqueue);
         } else {
                 if (ka_optin(ka_task_kernel_half, KA_LDS_HALF, &done0) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
+                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(64 * qw), KA_LDS_WAVES + qw * KA_WAVE_LDS, stream, *D, blocks_dev, nqueue);
         }
 }
 #endif
@@ -163,7 +165,8 @@ extern "C" void ka_unit3_launch(const KaTreeDev* D, const int2* blocks_dev, int 
         static bool done0 = false, done1 = false, done2 = false;
         if (!cons && D->lean4) {
                 if (ka_optin(ka_task_kernel_lean4, KA_LDS_PAIR, &done2) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_lean4, dim3(nblocks), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *D, blocks_dev, 0);
+                const int lw = (D->lw >= 1 && D->lw <= KA_PAIR_BLOCK / 64) ? D->lw : KA_PAIR_BLOCK / 64;
+                hipLaunchKernelGGL(ka_task_kernel_lean4, dim3(nblocks), dim3(64 * lw), KA_LDS_WAVES + KA_LEAN_SCRATCH(64 * lw) + lw * KA_WAVE_LDS_LEAN, stream, *D, blocks_dev, 0);
                 return;
         }
         if (cons) {
@@ -223,7 +226,8 @@ extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream)
 {
         static bool done = false;
         if (ka_optin(ka_pair_kernel, KA_LDS_PAIR, &done) != hipSuccess) return;
-        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(KA_PAIR_BLOCK), KA_LDS_PAIR, stream, *P);
+        const int pw = (P->pw >= 1 && P->pw <= KA_PAIR_BLOCK / 64) ? P->pw : KA_PAIR_BLOCK / 64;
+        hipLaunchKernelGGL(ka_pair_kernel, dim3(P->npairs), dim3(64 * pw), KA_LDS_WAVES + KA_LEAN_SCRATCH(64 * pw) + pw * KA_WAVE_LDS_LEAN, stream, *P);
 }
 #endif
 

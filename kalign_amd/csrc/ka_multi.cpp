@@ -11,7 +11,9 @@
 //
 // Built on the public C ABI only (include/kalign_amd.h).  `loopback` puts every rank on device 0 over the in-process
 // transport (RCCL refuses two ranks on one device): how the one-GPU test boxes run worlds of 2 and 4 through this layer.
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +29,12 @@ struct ka_multi {
         std::vector<ka_ctx*> ctx;
         std::vector<ka_dist*> dist;
         bool cons_resident = false;              // every rank's context holds the consistency table of the sequences uploaded last
+        // the ranks agree on the outcome of every rank-local stage (upload, planning) BEFORE they enter a stage that talks
+        // (ka_dist_consistency, ka_dist_tree_run): a rank that failed alone would leave the others inside a collective for good
+        std::mutex agree_mu;
+        std::condition_variable agree_cv;
+        int agree_arrived = 0, agree_failed = 0, agree_verdict = 0;
+        long long agree_round = 0;
         long long runs = 0;                      // sharded tree runs so far (the drop-in's seam counter reads it)
         std::string err;
 };
@@ -50,6 +58,23 @@ static int run_ranks(ka_multi* m, F f)
         for (int r = 0; r < m->world; r++)
                 if (rc[r]) { g_multi_err = "rank " + std::to_string(r) + ": " + why[r]; return rc[r]; }
         return KA_OK;
+}
+
+// Barrier + OR over the ranks' local return codes: every rank leaves with the same answer (true: all fine).
+static bool ranks_agree(ka_multi* m, int local_rc)
+{
+        std::unique_lock<std::mutex> lk(m->agree_mu);
+        const long long round = m->agree_round;
+        if (local_rc) m->agree_failed++;
+        if (++m->agree_arrived == m->world) {
+                m->agree_verdict = m->agree_failed;
+                m->agree_arrived = 0; m->agree_failed = 0;
+                m->agree_round++;
+                m->agree_cv.notify_all();
+        } else {
+                m->agree_cv.wait(lk, [&] { return m->agree_round != round; });
+        }
+        return m->agree_verdict == 0;
 }
 
 extern "C" void ka_multi_destroy(ka_multi* m)
@@ -111,7 +136,8 @@ extern "C" int ka_multi_consistency(ka_multi* m, int numseq, const uint8_t* code
         if (!m) { g_multi_err = "ka_multi_consistency: null"; return -1; }
         m->cons_resident = false;
         int rc = run_ranks(m, [&](int r) {
-                if (ka_tree_upload(m->ctx[r], numseq, codes, off, lens, seq_distances, n_tasks, tasks_abc, subm, scal, flags)) return (int)KA_FAIL;
+                const int up = ka_tree_upload(m->ctx[r], numseq, codes, off, lens, seq_distances, n_tasks, tasks_abc, subm, scal, flags);
+                if (!ranks_agree(m, up)) return up ? up : (int)KA_FAIL;       // (one rank could not upload -- out of memory, say: nobody enters the collectives)
                 return ka_dist_consistency(m->dist[r], n_anchors, weight);
         });
         if (rc) return -1;
@@ -136,14 +162,31 @@ extern "C" int ka_multi_tree_run(ka_multi* m, int numseq, const uint8_t* codes, 
         const int up_flags = (flags & ~KA_FLAG_KEEP_CONSISTENCY) | (keep ? KA_FLAG_KEEP_CONSISTENCY : 0);
         if (!keep) m->cons_resident = false;
         const int rc = run_ranks(m, [&](int r) {
-                if (ka_tree_upload(m->ctx[r], numseq, codes, off, lens, seq_distances, n_tasks, tasks_abc, subm, scal, up_flags)) return (int)KA_FAIL;
-                if (n_anchors > 0 && !keep && ka_dist_consistency(m->dist[r], n_anchors, weight)) return (int)KA_FAIL;
-                if (ka_dist_plan(m->dist[r])) return (int)KA_FAIL;
+                const int up = ka_tree_upload(m->ctx[r], numseq, codes, off, lens, seq_distances, n_tasks, tasks_abc, subm, scal, up_flags);
+                if (!ranks_agree(m, up)) return up ? up : (int)KA_FAIL;
+                // (ka_dist_consistency fails on every rank alike when one part cannot be built)
+                const int co = (n_anchors > 0 && !keep) ? ka_dist_consistency(m->dist[r], n_anchors, weight) : 0;
+                const int pl = co ? co : ka_dist_plan(m->dist[r]);
+                if (!ranks_agree(m, pl)) return pl ? pl : (int)KA_FAIL;
                 return ka_dist_tree_run(m->dist[r]);
         });
-        if (rc) return rc;
+        if (rc) { m->cons_resident = false; return rc; }
         if (n_anchors > 0) m->cons_resident = true;
         m->runs++;
+        return KA_OK;
+}
+
+// The context of rank r (its device's single-GPU context): what the caller continues on after a sharded run, and what an
+// ensemble member that runs on device r alone uses (kalign_ensemble's member loop, lib/src/ensemble.c:286-339).
+extern "C" ka_ctx* ka_multi_ctx(ka_multi* m, int rank) { return (m && rank >= 0 && rank < m->world) ? m->ctx[rank] : nullptr; }
+
+// After ka_multi_tree_run + ka_multi_download: rank 0's context -- it holds the job, the complete consistency table and the
+// gathered records -- takes the finished alignment over (ka_tree_adopt_alignment), so that the stages behind the dispatcher
+// (refine_alignment, finalise_alignment, the identity distances of a realignment pass) stay on a device with more than one rank.
+extern "C" int ka_multi_adopt(ka_multi* m, const ka_task_rec* recs, const int* gaps)
+{
+        if (!m || !recs || !gaps) { g_multi_err = "ka_multi_adopt: bad arguments"; return KA_FAIL; }
+        if (ka_tree_adopt_alignment(m->ctx[0], recs, gaps)) { g_multi_err = ka_last_error(); return KA_FAIL; }
         return KA_OK;
 }
 

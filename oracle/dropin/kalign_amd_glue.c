@@ -70,6 +70,8 @@ static void glue_report(void)
 }
 
 static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
+static ka_ctx* glue_job_ctx = NULL;           /* the context that holds glue_job_msa's alignment: glue_ctx, or rank 0's after a sharded run */
+static ka_ctx* glue_rows_ctx = NULL;          /* ... and the one whose HBM holds the finalised rows of glue_rows_msa */
 static const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
 static int glue_job_numseq = 0;
 static const struct msa* glue_rows_msa;        /* (defined with the realignment seams below) */
@@ -103,16 +105,30 @@ static int glue_same_job(const struct msa* msa)
  * path (ka_dist_*: subtree cut, RCCL hand-overs above the cut, gathered records and paths) per device, the ranks as threads
  * of this process.  KALIGN_AMD_DEVICES=n limits / forces the number of devices (1: this path off); KALIGN_AMD_GLUE_WORLD=n
  * runs n ranks on device 0 over the library's in-process transport (tests on one-GPU boxes).  The result does not depend on
- * the number of ranks.  The seams that work on a job resident on ONE device (refinement, finalise, the realignment
- * distances) then take the reference's own functions: after a sharded run no single GPU holds the whole alignment.
+ * the number of ranks.  After a sharded run rank 0's context -- it holds the job, the whole consistency table and the gathered
+ * records -- takes the finished alignment over (ka_multi_adopt: the gap arrays woven on the host go back as residue -> column
+ * tables), so that the seams behind the dispatcher (refinement, finalise, the realignment distances) stay on a device.
+ *
+ * A node's worth of devices costs something to open (a communicator, a context and an upload per rank, a thread per rank and
+ * call): without KALIGN_AMD_DEVICES the path is taken only for jobs of at least KALIGN_AMD_MULTI_MIN sequences (default
+ * 2048); KALIGN_AMD_DEVICES=n (n > 1) or KALIGN_AMD_GLUE_WORLD=n takes it for every job.
  */
 static ka_multi* glue_multi = NULL;
 static int glue_multi_tried = 0;
-static ka_multi* glue_multi_context(void)
+static int glue_multi_min = 0;                  /* sequences a job needs before the node is opened for it (0: any) */
+static void glue_release(void)
+{
+        /* (at exit: the communicators, contexts and threads' buffers go before the HIP runtime does) */
+        if(glue_multi){ ka_multi_destroy(glue_multi); glue_multi = NULL; }
+        if(glue_ctx){ ka_ctx_destroy(glue_ctx); glue_ctx = NULL; }
+        glue_job_ctx = NULL; glue_rows_ctx = NULL;
+}
+static ka_multi* glue_multi_context(int numseq)
 {
         if(!glue_multi_tried){
                 const char* w = getenv("KALIGN_AMD_GLUE_WORLD");
                 const char* d = getenv("KALIGN_AMD_DEVICES");
+                const char* mn = getenv("KALIGN_AMD_MULTI_MIN");
                 int world = 0;
                 int loopback = 0;
                 glue_multi_tried = 1;
@@ -124,13 +140,20 @@ static ka_multi* glue_multi_context(void)
                         if(world > ka_device_count()){
                                 world = ka_device_count();
                         }
+                        if(!d){
+                                glue_multi_min = mn ? atoi(mn) : 2048;
+                        }
+                }
+                if(world > 1 && numseq < glue_multi_min){
+                        glue_multi_tried = 0;            /* (a small job: decided again for the next one) */
+                        return NULL;
                 }
                 if(world > 1 && ka_multi_create(world, NULL, loopback, &glue_multi)){
                         WARNING_MSG("kalign_amd: %d devices could not be opened together (%s): one GPU", world, ka_multi_last_error());
                         glue_multi = NULL;
                 }
         }
-        return glue_multi;
+        return (glue_multi && numseq >= glue_multi_min) ? glue_multi : NULL;
 }
 
 static int glue_context(void)
@@ -138,6 +161,7 @@ static int glue_context(void)
         static int registered = 0;
         if(!registered){
                 registered = 1;
+                atexit(glue_release);
                 if(getenv("KALIGN_AMD_GLUE_REPORT")){
                         atexit(glue_report);
                 }
@@ -211,7 +235,10 @@ static void glue_params(struct aln_param* ap, float* subm, float* scal)
         scal[3] = ap->dist_scale; scal[4] = ap->vsm_amax; scal[5] = ap->use_seq_weights;
 }
 
-static const struct consistency_table* glue_ct_resident = NULL;   /* the table the device holds right now */
+/* the table the device(s) hold right now -- per device set: the single-GPU context and the ranks of the node are different
+   contexts, and a table built on one says nothing about the other */
+static const struct consistency_table* glue_ct_single = NULL;
+static const struct consistency_table* glue_ct_multi = NULL;
 
 /*
  * anchor_consistency_build (anchor_consistency.c:200-275).  The reference aligns every sequence to K anchors here,
@@ -252,8 +279,9 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         glue_params(ap, subm, scal);
         glue_job_msa = NULL;
         glue_rows_msa = NULL;                            /* (a new job: the rows of the last one leave HBM) */
-        glue_ct_resident = NULL;
-        if(K <= KA_CONS_MAX_ANCHORS && glue_multi_context()){
+        glue_ct_single = NULL;
+        glue_ct_multi = NULL;
+        if(K <= KA_CONS_MAX_ANCHORS && glue_multi_context(n)){
                 /* the N x K batch sharded over the devices, every rank's share of the maps broadcast in place (ka_dist_consistency) */
                 MMALLOC(ids_multi, sizeof(int) * K);
                 MMALLOC(maps, sizeof(int) * (total * K + 1));
@@ -265,7 +293,7 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0) ||
            ka_tree_build_consistency(glue_ctx, K, weight)){
                 /* a request the library does not take (more than 10 anchors ...): the reference's own function, like every
-                   other seam; the dispatcher then rebuilds the table it needs or declines alike (glue_ct_resident stays NULL) */
+                   other seam; the dispatcher then rebuilds the table it needs or declines alike (no table is resident) */
                 MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc);
                 glue_counts[GLUE_CONS_REF]++;
                 return kalign_ref_anchor_consistency_build(msa, ap, n_anchors, weight, ct_out);
@@ -307,7 +335,11 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
         if(!msa->quiet){
                 LOG_MSG("Anchor consistency: K=%d, weight=%.1f", K, weight);
         }
-        glue_ct_resident = ct;
+        if(ids_multi){
+                glue_ct_multi = ct;
+        }else{
+                glue_ct_single = ct;
+        }
         *ct_out = ct;
         MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc); MFREE(maps);
         if(ids_multi) MFREE(ids_multi);
@@ -330,7 +362,7 @@ ERROR:
  * seq_distances, the task list; leaves sequences[i]->gaps[], nsip[], sip[][], plen[], task confidence -- exactly
  * the state the reference's dispatcher leaves.  Merged profiles stay in HBM.
  */
-static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total, int multi);
+static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total, ka_ctx* from);
 
 /* inline_refine: 0 = create_msa_tree, n > 0 = create_msa_tree_inline_refine with n trials per edge */
 static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t, int inline_refine)
@@ -362,44 +394,45 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         }
         glue_params(ap, subm, scal);
 
-        if(!inline_refine && (!ct || ct->n_anchors <= KA_CONS_MAX_ANCHORS) && glue_multi_context()){
+        if(!inline_refine && (!ct || ct->n_anchors <= KA_CONS_MAX_ANCHORS) && glue_multi_context(n)){
                 /* the whole node: every rank uploads the job, runs its subtrees and its share of the tasks above the cut; records
-                   and coded paths come back gathered, the gap arrays are woven on the host.  The table the ranks hold from
+                   and coded paths come back gathered, the gap arrays are woven on the host.  The table the RANKS hold from
                    anchor_consistency_build is kept when it is this msa's. */
-                int mflags = (ct && ct == glue_ct_resident) ? KA_FLAG_KEEP_CONSISTENCY : 0;
+                int mflags = (ct && ct == glue_ct_multi) ? KA_FLAG_KEEP_CONSISTENCY : 0;
+                glue_ct_multi = NULL;
                 if(ka_multi_tree_run(glue_multi, n, codes, off, lens, msa->seq_distances, nt, abc, subm, scal, mflags, ct ? ct->n_anchors : 0, ct ? ct->weight : 0.0f)){
                         ERROR_MSG("kalign_amd: %s", ka_multi_last_error());
                 }
-                glue_ct_resident = ct;
-                RUN(glue_collect(msa, t, lens, total, 1));
+                glue_ct_multi = ct;
+                /* (glue_collect hands the alignment to rank 0's context: the seams behind the dispatcher carry on there) */
+                RUN(glue_collect(msa, t, lens, total, NULL));
                 glue_counts[GLUE_TREE_MULTI]++;
                 MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
-                return OK;                                /* (glue_job_msa stays NULL: no single device holds this alignment) */
+                return OK;
         }
         /* the table anchor_consistency_build left in HBM for these sequences is kept across the upload (also by the
            realignment passes of kalign_run_realign, aln_wrap.c:449-504: same sequences, new tree); if another job has
-           used the device since, it is built again (same anchors, same maps) */
-        if(ct && ct == glue_ct_resident){
+           used the device since -- or the table sits on the ranks of the node, not on this context -- it is built again
+           (same anchors, same maps) */
+        if(ct && ct == glue_ct_single){
                 flags |= KA_FLAG_KEEP_CONSISTENCY;
         }
         if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, nt, abc, subm, scal, flags)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
-        if(ct && ct != glue_ct_resident){
+        if(ct && ct != glue_ct_single){
+                glue_ct_single = NULL;
                 if(ka_tree_build_consistency(glue_ctx, ct->n_anchors, ct->weight)){
                         ERROR_MSG("kalign_amd: %s", ka_last_error());
                 }
         }
-        glue_ct_resident = ct;                           /* NULL: this upload dropped whatever table there was */
+        glue_ct_single = ct;                             /* NULL: this upload dropped whatever table there was */
         /* do_align_inline_refine (aln_run.c:515-790) is do_align with three flip trials per edge: mode 3 of ka_tree_refine */
         if((inline_refine ? ka_tree_refine(glue_ctx, 3 | KA_REFINE_TRIALS(inline_refine), NULL) : ka_tree_run(glue_ctx)) || ka_tree_sync(glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
-        RUN(glue_collect(msa, t, lens, total, 0));
+        RUN(glue_collect(msa, t, lens, total, glue_ctx));
         glue_counts[inline_refine ? GLUE_INLINE : GLUE_TREE]++;
-        glue_job_msa = msa;
-        glue_job_numseq = n;
-        glue_job_stamp = glue_stamp(msa);
         MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
         return OK;
 ERROR:
@@ -410,9 +443,11 @@ ERROR:
         return FAIL;
 }
 
-/* leave exactly the state do_align leaves (aln_run.c:391-436): gaps[], plen[], nsip[], sip[][], task confidence */
-static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total, int multi)
+/* leave exactly the state do_align leaves (aln_run.c:391-436): gaps[], plen[], nsip[], sip[][], task confidence.
+   from: the context that ran the job; NULL: the node (ka_multi_*), whose rank 0 then takes the alignment over. */
+static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, long long total, ka_ctx* from)
 {
+        int multi = from == NULL;
         int n = msa->numseq;
         int nt = t->n_tasks;
         int* gaps = NULL;
@@ -420,7 +455,7 @@ static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, l
         ka_task_rec* recs = NULL;
         long long cap;
         int i, j, g;
-        cap = multi ? ka_multi_paths_size(glue_multi) : ka_tree_paths_size(glue_ctx);
+        cap = multi ? ka_multi_paths_size(glue_multi) : ka_tree_paths_size(from);
         MMALLOC(recs, sizeof(ka_task_rec) * nt);
         MMALLOC(gaps, sizeof(int) * (total + n));
         MMALLOC(paths, sizeof(int) * (cap + 1));
@@ -429,8 +464,20 @@ static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, l
                         ERROR_MSG("kalign_amd: %s", ka_multi_last_error());
                 }
         }else
-        if(ka_tree_download(glue_ctx, recs, paths, cap, gaps)){
+        if(ka_tree_download(from, recs, paths, cap, gaps)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
+        }
+        glue_job_msa = NULL;
+        if(multi){
+                if(ka_multi_adopt(glue_multi, recs, gaps)){
+                        WARNING_MSG("kalign_amd: %s: the stages behind the dispatcher run on the host", ka_multi_last_error());
+                }else{
+                        glue_job_ctx = ka_multi_ctx(glue_multi, 0);
+                        glue_job_msa = msa;
+                }
+        }else{
+                glue_job_ctx = from;
+                glue_job_msa = msa;
         }
         for(i = 0, g = 0; i < n; i++){
                 memcpy(msa->sequences[i]->gaps, gaps + g, sizeof(int) * (lens[i] + 1));
@@ -452,9 +499,12 @@ static int glue_collect(struct msa* msa, struct aln_tasks* t, const int* lens, l
                         msa->sip[c][k++] = msa->sip[b][j];
                 }
         }
+        glue_job_numseq = n;
+        glue_job_stamp = glue_stamp(msa);
         MFREE(recs); MFREE(gaps); MFREE(paths);
         return OK;
 ERROR:
+        glue_job_msa = NULL;
         if(recs) MFREE(recs);
         if(gaps) MFREE(gaps);
         if(paths) MFREE(paths);
@@ -510,7 +560,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         if(refine_mode == 0){                            /* KALIGN_REFINE_NONE */
                 return OK;
         }
-        if(!glue_same_job(msa) || !glue_ctx || (refine_mode != 1 && refine_mode != 2)){
+        if(!glue_same_job(msa) || !glue_job_ctx || (refine_mode != 1 && refine_mode != 2)){
                 glue_job_msa = NULL;                     /* the host state moves on without the device */
                 glue_counts[GLUE_REFINE_REF]++;
                 return kalign_ref_refine_alignment(msa, ap, t, refine_mode);
@@ -521,11 +571,11 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
                 lens[i] = msa->sequences[i]->len;
                 total += lens[i];
         }
-        if(ka_tree_refine(glue_ctx, refine_mode | (ap->adaptive_budget ? KA_REFINE_ADAPTIVE : 0), NULL) || ka_tree_sync(glue_ctx)){
+        if(ka_tree_refine(glue_job_ctx, refine_mode | (ap->adaptive_budget ? KA_REFINE_ADAPTIVE : 0), NULL) || ka_tree_sync(glue_job_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
-        RUN(glue_collect(msa, t, lens, total, 0));
-        glue_job_stamp = glue_stamp(msa);                /* the refined gaps are what the device holds now */
+        /* (after a sharded first pass the refinement pass ran on rank 0's context: a job of that context from here on) */
+        RUN(glue_collect(msa, t, lens, total, glue_job_ctx));   /* the refined gaps are what the device holds now */
         glue_counts[GLUE_REFINE]++;
         MFREE(lens);
         return OK;
@@ -661,7 +711,7 @@ static uint64_t glue_rows_stamp(const struct msa* msa)
 
 static int glue_same_rows(const struct msa* msa)
 {
-        return msa == glue_rows_msa && msa->numseq == glue_rows_numseq && msa->alnlen == glue_rows_alnlen
+        return glue_rows_ctx && msa == glue_rows_msa && msa->numseq == glue_rows_numseq && msa->alnlen == glue_rows_alnlen
                && glue_rows_stamp(msa) == glue_rows_stamp_v;
 }
 
@@ -678,7 +728,7 @@ int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
         uint8_t* rows = NULL;
         int n = msa->numseq;
         int i;
-        if(!glue_ctx || msa->aligned != ALN_STATUS_FINAL || n < 2){
+        if(msa->aligned != ALN_STATUS_FINAL || n < 2 || glue_context() != OK || !glue_ctx){
                 glue_counts[GLUE_ALNDIST_REF]++;
                 return kalign_ref_compute_aln_pairwise_dist(msa, dm_ptr);
         }
@@ -692,8 +742,8 @@ int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
         MMALLOC(glue_dm_abc, sizeof(int) * 3 * (n - 1));
         MMALLOC(glue_dm_sd, sizeof(float) * n);
         if(glue_same_rows(msa)){
-                /* the rows are where ka_tree_aligned_rows left them */
-                if(ka_aln_guide_tree(glue_ctx, n, NULL, 0, 0, '-', glue_dm_abc, glue_dm_sd, flat)){
+                /* the rows are where ka_tree_aligned_rows left them (on rank 0's device after a sharded run) */
+                if(ka_aln_guide_tree(glue_rows_ctx, n, NULL, 0, 0, '-', glue_dm_abc, glue_dm_sd, flat)){
                         ERROR_MSG("kalign_amd: %s", ka_last_error());
                 }
         }else{
@@ -778,7 +828,7 @@ int finalise_alignment(struct msa* msa)
         long long o = 0;
         int width = 0;
         int i;
-        if(!glue_same_job(msa) || !glue_ctx){
+        if(!glue_same_job(msa) || !glue_job_ctx){
                 glue_counts[GLUE_FINALISE_REF]++;
                 glue_rows_msa = NULL;
                 return kalign_ref_finalise_alignment(msa);
@@ -786,6 +836,7 @@ int finalise_alignment(struct msa* msa)
         glue_counts[GLUE_FINALISE]++;
         glue_job_msa = NULL;                             /* the rows below replace seq->seq: one shot */
         glue_rows_msa = msa;                             /* ... and stay in HBM for the realignment loop's distances */
+        glue_rows_ctx = glue_job_ctx;
         ASSERT(msa->aligned == ALN_STATUS_ALIGNED, "Sequences are not aligned");
         for(i = 0; i < n; i++){
                 total += msa->sequences[i]->len;
@@ -796,7 +847,7 @@ int finalise_alignment(struct msa* msa)
                 memcpy(letters + o, msa->sequences[i]->seq, msa->sequences[i]->len);
                 o += msa->sequences[i]->len;
         }
-        if(ka_tree_aligned_rows(glue_ctx, letters, '-', NULL, 0, alnlen)){      /* size query */
+        if(ka_tree_aligned_rows(glue_rows_ctx, letters, '-', NULL, 0, alnlen)){      /* size query */
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         for(i = 0; i < n; i++){
@@ -805,7 +856,7 @@ int finalise_alignment(struct msa* msa)
                 }
         }
         MMALLOC(rows, (size_t)n * (width + 1));
-        if(ka_tree_aligned_rows(glue_ctx, letters, '-', rows, width + 1, alnlen)){
+        if(ka_tree_aligned_rows(glue_rows_ctx, letters, '-', rows, width + 1, alnlen)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         for(i = 0; i < n; i++){

@@ -93,6 +93,11 @@ int ko_update_profile(const float* pa, const float* pb, float* out, const int* c
                       float gpo, float gpe, float tgpe, float use_seq_weights);
 
 uint64_t ko_fnv1a(const void* p, uint64_t n);
+/* Hirschberg prefix reuse (kalign_oracle.c: ko_hirschberg_r): on = 1, the passes a child can take over from its parent's are
+   not run; every result must stay bit-identical (tests/test_oracle_golden.py).  The counters: DP cells of the passes that ran /
+   that were taken over since the switch was last set. */
+void ko_set_prefix_reuse(int on);
+void ko_prefix_reuse_cells(long long* run, long long* reused);
 
 /* distance estimation: bpm_block (lib/src/bpm.c:356-582) and calc_distance's pair rule
    (sequence_distance.c:150-162: the longer sequence is the text).  Codes < 13. */

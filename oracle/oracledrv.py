@@ -78,8 +78,24 @@ def lib():
         L.ko_tree_from_pairwise.argtypes = [vp, C.c_int, vp, vp]
         L.ko_fnv1a.argtypes = [vp, C.c_uint64]
         L.ko_fnv1a.restype = C.c_uint64
+        L.ko_set_prefix_reuse.argtypes = [C.c_int]
+        L.ko_set_prefix_reuse.restype = None
+        L.ko_prefix_reuse_cells.argtypes = [vp, vp]
+        L.ko_prefix_reuse_cells.restype = None
         _lib = L
     return _lib
+
+
+def set_prefix_reuse(on):
+    """Hirschberg prefix reuse in the oracle's recursion (the device's rule; results must not change)."""
+    lib().ko_set_prefix_reuse(1 if on else 0)
+
+
+def prefix_reuse_cells():
+    """(DP cells of the passes that ran, of the passes taken over) since set_prefix_reuse"""
+    run, reused = C.c_longlong(0), C.c_longlong(0)
+    lib().ko_prefix_reuse_cells(C.byref(run), C.byref(reused))
+    return run.value, reused.value
 
 
 def _ptr(a):

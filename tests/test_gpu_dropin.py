@@ -210,7 +210,7 @@ def test_library_kalign_run_with_refinement(tmp_path, refine):
 # cons_multi counters), the single-device forms of those seams must NOT have run, and the FASTA must be the reference's.
 MULTI_CASES = [("BB11001.tfa", []), ("BB11001.tfa", ["--fast"]), ("BB30014.tfa", []), ("BB30014.tfa", ["--fast"]),
                ("BB12006.tfa", []), ("BB12006.tfa", ["--fast", "--realign", "2"]), ("BB11001.tfa", ["--ensemble=3"]),
-               ("BB30014.tfa", ["--refine", "all"])]
+               ("BB30014.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "confident", "--realign", "1"])]
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -227,6 +227,55 @@ def test_cli_with_several_ranks_under_the_dropin(tmp_path, name, flags, world):
     assert c["tree_multi"] >= members * (1 + realign) and c["tree"] == 0, c
     if "--fast" not in flags and members == 1:
         assert c["cons_multi"] >= 1 and c["cons"] == 0 and c["cons_ref"] == 0, c
+    # round 5: after a sharded run rank 0's context takes the alignment over (ka_multi_adopt) -- the stages behind the
+    # dispatcher stay on the device, exactly as the single-device cases assert
+    for k in ("refine_ref", "finalise_ref", "alndist_ref", "alntree_ref"):
+        assert c[k] == 0, (k, c)
+    assert c["finalise"] >= members * (1 + realign), c
+    if realign:
+        assert c["alndist"] >= members * realign and c["alntree"] == c["alndist"], c
+    if "--refine" in flags:
+        assert c["refine"] >= 1, c
+
+
+_SEEDED_SCRIPT = r"""
+import ctypes as C, sys
+lib, inp, out, refine, anchors = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+L = C.CDLL(lib)
+L.kalign_read_input.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_int]
+L.kalign_run_seeded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_uint64, C.c_float,
+                                C.c_float, C.c_float, C.c_float, C.c_int, C.c_float]
+L.kalign_write_msa.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+msa = C.c_void_p()
+assert L.kalign_read_input(inp.encode(), C.byref(msa), 1) == 0
+assert L.kalign_run_seeded(msa, 4, 8, -1.0, -1.0, -1.0, refine, 0, 0, 0.0, 0.0, -1.0, -1.0, anchors, 2.0) == 0
+assert L.kalign_write_msa(msa, out.encode(), b"fasta") == 0
+if hasattr(L, "kalign_amd_glue_count"):
+    print("COUNTS", " ".join(str(L.kalign_amd_glue_count(k)) for k in range(19)))
+"""
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_inline_refinement_with_consistency_under_several_ranks(tmp_path, world):
+    """kalign_run_seeded(refine = KALIGN_REFINE_INLINE, 5 anchors) -- anchor_consistency_build runs on the
+    ranks of the node, create_msa_tree_inline_refine on the single-GPU context, which never saw that table: it must build its
+    own instead of trusting a table that lives on other contexts (the output silently lost its bonus before round 5)."""
+    import sys
+    inp = os.path.join(DATA, "BB30014.tfa")
+    script = tmp_path / "seeded.py"
+    script.write_text(_SEEDED_SCRIPT)
+    outs = {}
+    for name, lib, env in (("dropin", "dropin/libkalign.so.3", {"KALIGN_AMD_GLUE_WORLD": str(world)}), ("ref", "libkalign_ref.so", {})):
+        out = str(tmp_path / (name + ".fa"))
+        r = subprocess.run([sys.executable, str(script), _need(lib), inp, out, "3", "5"], env=dict(os.environ, OMP_NUM_THREADS="4", **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[name] = (open(out, "rb").read(), r.stdout.decode())
+    assert len(outs["ref"][0]) > 100 and outs["dropin"][0] == outs["ref"][0]
+    counts = [int(x) for x in outs["dropin"][1].split("COUNTS")[1].split()]
+    # (enum order of kalign_amd_glue.c: 1 inline, 6 cons, 7 cons_ref, 14 inline_ref, 16 cons_multi)
+    assert counts[1] == 1 and counts[14] == 0 and counts[7] == 0, counts
+    assert (counts[16] if world > 1 else counts[6]) == 1, counts
 
 
 @pytest.mark.parametrize("flags", [[], ["--fast"]], ids=["default", "fast"])

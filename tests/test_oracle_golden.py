@@ -169,3 +169,61 @@ def test_refinement_matches_reference(oracle, name):
     for i, r in enumerate(g.ranks):
         rows[int(r)] = rows_sorted[i]
     assert rows == [str(x) for x in g.rows]
+
+
+# ---- Hirschberg prefix reuse (round 5): the rule the kernels use, proven exact on the CPU first ----
+@pytest.fixture
+def reuse(oracle):
+    oracle.set_prefix_reuse(True)
+    yield oracle
+    oracle.set_prefix_reuse(False)
+
+
+@pytest.mark.parametrize("name", tree_cases())
+def test_prefix_reuse_leaves_every_tree_golden_bit_identical(reuse, name):
+    """A child takes its parent's saved row (forward: after (n-1)/2 rows, backward: after n/2 rows; last column's ga := -FLT_MAX)
+    instead of running the pass -- ~21 % of the DP cells are never computed, and nothing the reference produces changes:
+    coded paths, meetups, scores, merged profiles, gap arrays (aln_controller.c:194-436, aln_seqseq.c:40-58,108-117)."""
+    g = Golden(name)
+    recs, paths, gaps, dump = reuse.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, dump_task=int(g.dump_task))
+    run, reused = reuse.prefix_reuse_cells()
+    assert compare_recs(g, recs, paths, EXACT) == []
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert reused > 0 and reused < run
+    # (2 x rows x columns without reuse; ~1.58 x with it on square tasks: at least a tenth of the cells must have gone)
+    assert reused / float(run + reused) > 0.10, (run, reused)
+
+
+@pytest.mark.parametrize("name", cons_cases())
+def test_prefix_reuse_with_the_consistency_bonus(reuse, name):
+    """... with the bonus matrix in every pass, incl. its 1-based / 0-based column quirk and the wrap-around cell"""
+    g = Golden(name)
+    recs, paths, gaps, ids, maps, bh = reuse.msa_tree_cons(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, int(g.n_anchors), float(g.weight))
+    assert np.array_equal(bh, g.bonus_hash)
+    assert compare_recs(g, recs, paths, EXACT) == []
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", pair_cases())
+def test_prefix_reuse_in_the_pair_batch(reuse, name):
+    g = Golden(name)
+    paths, scores = reuse.pairwise_batch(g.codes, g.ia, g.ib, g.subm, float(g.scal[0]), float(g.scal[1]), float(g.scal[2]))
+    o = 0
+    for k, p in enumerate(paths):
+        n = int(g.plen[k]) + 2
+        assert np.array_equal(p, g.paths[o:o + n]), k
+        o += n
+
+
+@pytest.mark.parametrize("name", refine_cases()[:8])
+def test_prefix_reuse_in_refinement_trials(reuse, name):
+    """flip trials (aln_seqseq.c:376-414): a flipped meetup changes the children's windows, never what a saved row holds --
+    the rule only asks that the child's pass have the row count the parent saved"""
+    g = Golden(name)
+    recs, paths, gaps = reuse.msa_tree_refine(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, mode=int(g.mode),
+                                              conf_in=g.conf_before, n_anchors=int(g.n_anchors), weight=float(g.weight))
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
