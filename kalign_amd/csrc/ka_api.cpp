@@ -108,7 +108,8 @@ struct KaEnv {
         int hw = 1;                    // KA_HW: profile-profile strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode)
         int hw_prio = 3;               // KA_HW_PRIO: s_setprio of a strip wave that has a helper (experiments)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
-        int qw = 4, lw = 4, pw = 4;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
+        int reuse = 1;                 // KA_REUSE: Hirschberg prefix reuse in the 4-wave kernels (queued levels, seq-seq leaves, pair batch)
+        int qw = 4, lw = 4, pw = 2;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
         bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
 };
@@ -124,7 +125,8 @@ static void read_env(KaEnv& v)
         v.prof_task = env_int("KA_PROF_TASK", -1); v.q1 = env_int("KA_Q1", -1); v.lean4 = env_int("KA_LEAN4", 1);
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
-        v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 4);
+        v.reuse = env_int("KA_REUSE", 1);
+        v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 2);
         for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;
         v.mw = env_int("KA_MW", 1);
         v.ho = env_int("KA_HO", -1);
@@ -910,7 +912,7 @@ static KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : (c->nres > 5 ? 4 : 0);     // (nucleotides: five residues -- a one-row step is 0.85 of a two-row one: not worth twice the strips)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
-        D.qw = c->env.qw; D.lw = c->env.lw;
+        D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
@@ -2072,7 +2074,7 @@ static int pairwise_on_device(ka_ctx* c, const uint8_t* codes, const int* off, c
         P.subm = d_subm.p; P.gpo = gpo; P.gpe = gpe; P.tgpe = tgpe;
         P.scratch = d_scr.p; P.scratch_stride = stride;
         P.paths_out = d_paths.p; P.poff = d_poff.p; P.scores = d_scores.p; P.npairs = npairs;
-        P.error = d_err.p; P.pw = c->env.pw;
+        P.error = d_err.p; P.pw = c->env.pw; P.reuse = c->env.reuse;
         PCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), c->stream));
         PCHK(hipEventRecord(c->ev0, c->stream));
         ka_launch_pairs(&P, c->stream);

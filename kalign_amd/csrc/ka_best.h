@@ -20,11 +20,11 @@ struct KaInc {
         int* ucnt;         // [sorted position] uncertain meetups in front of it (n + 1)
         int* raw0;         // the baseline's raw path
 };
-__device__ __host__ inline long long ka_inc_bytes(long long n) { return 88 * n + 64; }
+__device__ __host__ inline long long ka_inc_bytes(long long n) { return (40 + (long long)sizeof(KaSub)) * n + 64; }
 __device__ __forceinline__ KaInc ka_inc_from(char* base, const long long n)
 {
         KaInc I;
-        I.win = (KaSub*)base; base += 48 * n;
+        I.win = (KaSub*)base; base += (long long)sizeof(KaSub) * n;
         I.mx = (int2*)base; base += 8 * n;
         I.msort = (int*)base; base += 4 * n;
         I.skey = (int*)base; base += 4 * n;
@@ -35,7 +35,7 @@ __device__ __forceinline__ KaInc ka_inc_from(char* base, const long long n)
         I.raw0 = (int*)base;
         return I;
 }
-static_assert(sizeof(KaSub) == 48, "KaInc::win stride");
+static_assert(sizeof(KaSub) % 8 == 0, "KaInc::win stride keeps the arrays behind it 8-byte aligned");
 
 __device__ __forceinline__ KaInc ka_inc_view(const TaskShared& S) { return ka_inc_from(S.inc, (long long)S.len_a + S.len_b + 8); }
 

@@ -44,6 +44,10 @@ struct KaSub {
         KaState fin, bin;
         int roff;                      // offset of its f/b row slices in the task's row buffers
         int pad;
+        // Hirschberg prefix reuse (round 5; ka_meetup.h): >= 0 -- this sub-problem's forward / backward row is not computed by a pass
+        // of its own: it is the row its parent's pass saved on the way, at this offset of the PARENT level's save buffer
+        // (TaskShared::sfbuf / sbbuf); -1: the pass runs
+        int fsrc, bsrc;
 };
 
 struct KaCtl;
@@ -90,6 +94,7 @@ struct KaTreeDev {
         int ho_mode;                   // neighbouring strips of a pass hand over through LDS rings (ka_strip<.., HO>): 0 off, 1 on,
                                        // 2 on with four strips per workgroup (KA_HO in the environment)
         int hw_mode;                   // strips with helper waves (ka_wstrip.h) on levels with at most four items per workgroup: 0 off, 1 on (KA_HW in the environment)
+        int reuse;                     // Hirschberg prefix reuse in the 4-wave kernels (KA_REUSE=0: off)
         int qw, lw;                    // waves per workgroup of the queued launch (KA_QW: 4, 2 or 1) / of the seq-seq leaf levels (KA_LW)
         int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
         int cons_K;                    // anchors
@@ -122,4 +127,5 @@ struct KaPairDev {
         int* error;
         int npairs;
         int pw;                        // waves per workgroup (KA_PW: 4, 2 or 1)
+        int reuse;                     // Hirschberg prefix reuse (KA_REUSE=0: off)
 };

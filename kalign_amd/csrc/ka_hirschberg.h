@@ -34,7 +34,8 @@ __device__ void ka_cluster_sync(TaskShared& S)
 // The passes of one recursion level: its work items (strips, packed jobs) dealt to / pulled by the waves of the team.
 // Q1: the kernel also carries the one-row-per-lane strip (TaskShared::srows == 64 selects it per task)
 // HO: strips dealt to neighbouring waves of a workgroup hand over through LDS rings (ka_strip<.., HO>; TaskShared::ho_ok)
-template <int KIND, int NRES, int NB, bool Q1 = false, bool HO = false, bool HW = false>
+// RU: Hirschberg prefix reuse (ka_meetup.h) -- a strip that holds the row its pass leaves for the sub-problem's child writes it out
+template <int KIND, int NRES, int NB, bool Q1 = false, bool HO = false, bool HW = false, bool RU = false>
 __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cur, const int level, const KaSub* qc, char* lds_waves,
                                              const float* tss, long long* pslot)
 {
@@ -180,6 +181,14 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const bool in_lds = ho_lvl && prod_local && wave > 0;
                                 const bool out_lds = ho_lvl && cons_local && wave + 1 < KA_NW;
                                 int* const ho_ctl_w = (int*)(lds_waves - KA_LDS_HO_BACK) + wave;
+                                // prefix reuse: the row after (n - 1) / 2 rows of a forward pass, after n / 2 rows of a backward one
+                                KaState* sv = nullptr;
+                                int sv_rows = 0;
+                                if (RU && __builtin_amdgcn_readfirstlane(S.reuse_ok) != 0) {
+                                        const int n_ = dir == KA_FWD ? mid_ - sa : ea - mid_;
+                                        sv_rows = dir == KA_FWD ? (n_ - 1) / 2 : n_ / 2;
+                                        if (sv_rows >= 1) sv = ka_uniform_ptr((dir == KA_FWD ? S.sfbuf[level & 1] : S.sbbuf[level & 1]) + roff);
+                                }
                                 if constexpr (HW && KIND == KA_PP) {
                                         if (wmode && (dir == KA_FWD ? mid_ - sa : ea - mid_) > 0) {
                                                 const unsigned ctl_u = (unsigned)(unsigned long long)(lds_waves - KA_LDS_HO_BACK);
@@ -197,15 +206,15 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                         }
                                 }
                                 if (Q1 && srows == KA_STRIP1_ROWS)
-                                        ka_strip<KIND, NRES, NB, 1, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                        ka_strip<KIND, NRES, NB, 1, HO, RU>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                              ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
                                                              lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
-                                                             in_lds, out_lds, ho_ctl_w);
+                                                             in_lds, out_lds, ho_ctl_w, sv, sv_rows);
                                 else
-                                        ka_strip<KIND, NRES, NB, 2, HO>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
+                                        ka_strip<KIND, NRES, NB, 2, HO, RU>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                              ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
                                                              lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
-                                                             in_lds, out_lds, ho_ctl_w);
+                                                             in_lds, out_lds, ho_ctl_w, sv, sv_rows);
                         }
         }
 }
@@ -214,7 +223,7 @@ __device__ const int ka_pow3[20] = { 1, 3, 9, 27, 81, 243, 729, 2187, 6561, 1968
                                      43046721, 129140163, 387420489, 1162261467 };
 #define KA_REC_DEPTH 19                                              // recursion levels the keys of ka_meetup<.., REC> can tell apart
 
-template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false, bool HO = false, bool HW = false>
+template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false, bool HO = false, bool HW = false, bool RU = false>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
         const int tid = threadIdx.x;
@@ -234,7 +243,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
                 root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
-                root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
+                root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0; root.fsrc = -1; root.bsrc = -1;
                 S.q[0][0] = root;
                 for (int par = 0; par < 2; ++par) {
                         S.ctl->lvl[par].nsub = 0; S.ctl->lvl[par].rowalloc = 0; S.ctl->lvl[par].nitems = 0;
@@ -310,7 +319,7 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
 #ifdef KA_PROF
                 if (S.prof && lead && level < 4) { pslot = S.prof + (level * 8 + wave) * 8; if (lane == 0) { pslot[0] = tp0; pslot[1] = 0; pslot[2] = 0; pslot[3] = 0; pslot[4] = 0; pslot[5] = 0; pslot[6] = 0; pslot[7] = 0; if (level < 4) for (int x = 0; x < 8; ++x) pslot[256 + x] = 0; } }
 #endif
-                ka_run_items<KIND, NRES, NB, Q1, HO, HW>(S, cur, level, qc, lds_waves, tss, pslot);
+                ka_run_items<KIND, NRES, NB, Q1, HO, HW, RU && !REC>(S, cur, level, qc, lds_waves, tss, pslot);
 #ifdef KA_PROF
                 if (pslot && lane == 0) pslot[3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -342,17 +351,17 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 if (S.member_w == 0)
                                         for (int k = 0; k < ncur; ++k) {
                                                 __syncthreads();
-                                                ka_meetup<KIND, 64, false, REC, true>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
+                                                ka_meetup<KIND, 64, false, REC, true, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
                                         }
                         } else if (est_cols > 48) {
                                 for (int k = S.member_w * KA_NW + wave; k < ncur; k += KA_NW * S.Gw)
-                                        ka_meetup<KIND, 64, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
+                                        ka_meetup<KIND, 64, false, REC, false, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
                         } else if (est_cols > 6) {
                                 for (int k = (S.member_w * KA_NW + wave) * 4; k < ncur; k += KA_NW * S.Gw * 4)
-                                        ka_meetup<KIND, 16, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
+                                        ka_meetup<KIND, 16, false, REC, false, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
                         } else {
                                 for (int k = (S.member_w * KA_NW + wave) * 16; k < ncur; k += KA_NW * S.Gw * 16)
-                                        ka_meetup<KIND, 4, false, REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig);
+                                        ka_meetup<KIND, 4, false, REC, false, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
                         }
                 }
                 ka_cluster_sync(S);
@@ -481,6 +490,7 @@ __device__ __forceinline__ int ka_dfs_decide(TaskShared& S, const KaSub& sb, con
         c1.enda = c1.starta; c1.endb = c1.startb; c1.bin = Z;
         c2.starta = c2.enda; c2.startb = c2.endb; c2.fin = Z;
         c1.pad = 0; c2.pad = 0; c1.roff = 0; c2.roff = 0;
+        c1.fsrc = -1; c1.bsrc = -1; c2.fsrc = -1; c2.bsrc = -1;
         int* path = S.raw;
         switch (tr) {
         case 1:
@@ -609,8 +619,8 @@ __device__ __forceinline__ void ka_hirschberg_dfs(TaskShared& S, char* lds_waves
                 KaSub root;
                 const KaState Z = { 0.0f, -KA_F, -KA_F };
                 root.starta = 0; root.enda = S.La; root.startb = 0; root.endb = S.Lb;
-                root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0;
-                if (seed) { root = *seed; root.roff = 0; root.pad = 0; }
+                root.fin = Z; root.bin = Z; root.roff = 0; root.pad = 0; root.fsrc = -1; root.bsrc = -1;
+                if (seed) { root = *seed; root.roff = 0; root.pad = 0; root.fsrc = -1; root.bsrc = -1; }
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.dfs_top = 0;
                 if (!seed) {

@@ -134,12 +134,13 @@ extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int 
         static bool done0 = false, done1 = false;
         // a queued launch may run on narrower workgroups (KaTreeDev::qw waves: same kernel, a ring per wave, more workgroups per CU)
         const int qw = (nqueue > 0 && D->qw >= 1 && D->qw <= KA_HALF_BLOCK / 64) ? D->qw : KA_HALF_BLOCK / 64;
+        const int qlds = KA_LDS_WAVES + qw * KA_WAVE_LDS;
         if (cons) {
                 if (ka_optin(ka_task_kernel_half_cons, KA_LDS_HALF, &done1) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(64 * qw), KA_LDS_WAVES + qw * KA_WAVE_LDS, stream, *D, blocks_dev, nqueue);
+                hipLaunchKernelGGL(ka_task_kernel_half_cons, dim3(nblocks), dim3(64 * qw), qlds, stream, *D, blocks_dev, nqueue);
         } else {
                 if (ka_optin(ka_task_kernel_half, KA_LDS_HALF, &done0) != hipSuccess) return;
-                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(64 * qw), KA_LDS_WAVES + qw * KA_WAVE_LDS, stream, *D, blocks_dev, nqueue);
+                hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(64 * qw), qlds, stream, *D, blocks_dev, nqueue);
         }
 }
 #endif
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
                 const int len_i = P.seq_len[i], len_j = P.seq_len[j];
                 const int swapped = !(len_i <= len_j);
                 S.ctl = &S.ctl_lds; S.G = 1; S.member = 0; S.bar_phase = 0; S.srows = KA_STRIP_ROWS; S.q1_lvl = 0; S.lvl_srows[0] = KA_STRIP_ROWS; S.lvl_srows[1] = KA_STRIP_ROWS;
+                S.reuse_ok = P.reuse ? 1 : 0;
                 S.sub_ok = 1; S.rec_on = 0; S.nres_t = 23; S.sub_stride = KA_WAVE_LDS_LEAN; S.sub_base = lds_waves + KA_LEAN_SCRATCH(KA_NT); S.sub_tm = 0; S.mw_ok = 1;
                 S.lctl = S.ctl; S.Gw = 1; S.member_w = 0; S.split = 0;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(KA_PAIR_BLOCK, 4) void ka_pair_kernel(const KaPairD
         }
         ka_build_tss(tss, P.subm, 0.0f);
         __syncthreads();
-        ka_hirschberg<KA_SS, 23, 0>(S, nullptr, lds_waves, tss, nullptr);
+        ka_hirschberg<KA_SS, 23, 0, false, false, false, false, true>(S, nullptr, lds_waves, tss, nullptr);
         __syncthreads();
         ka_code_path(S, (int*)lds_waves);
         if (tid == 0 && P.scores) P.scores[k] = S.ctl->top_score;

@@ -19,6 +19,7 @@
 // sets, one for all candidates, the acceptance rule on the host (40 scores per set), one launch that gathers the winners'
 // lists into the next level's sample buffer.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -305,6 +306,7 @@ struct Buf {
 };
 }  // namespace
 
+#define KM_MAX_DEVICES 64
 #define KMCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 
 // dm: numseq x 32 floats (host).  nodes[0] is the root; a node with left < 0 is a leaf cluster (its members in `cluster`, in
@@ -312,14 +314,19 @@ struct Buf {
 int ka_kmeans_device(int device, hipStream_t stream, const float* dm, int numseq, std::vector<KaKmNode>& nodes, std::string& err)
 {
         KMCHK(hipSetDevice(device));
-        {
-                // the row tiles of the big shape take 128 KiB of dynamic LDS: opt in once
-                static bool opted = false;
-                if (!opted) {
-                        KMCHK(hipFuncSetAttribute((const void*)km_centroid_kernel<512, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * KM_PAD * sizeof(float)));
-                        KMCHK(hipFuncSetAttribute((const void*)km_split_kernel<512, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * KM_PAD * sizeof(float)));
-                        opted = true;
-                }
+        if (device < 0 || device >= KM_MAX_DEVICES) { err = "ka_kmeans_device: device index out of range"; return 1; }
+        // One pool of buffers and one LDS opt-in PER DEVICE, process-wide, used under the device's lock: the guide tree may be asked
+        // for from several threads and devices at once (ka_multi_*, ensemble members side by side), the opt-in is a per-device
+        // attribute, and buffers owned by a thread would be freed from its destructors -- possibly after the runtime is gone.
+        // (Never freed: they live as long as the process, like the runtime they belong to.)
+        static std::mutex dev_mu[KM_MAX_DEVICES];
+        static bool dev_opted[KM_MAX_DEVICES];
+        std::lock_guard<std::mutex> dev_lock(dev_mu[device]);
+        if (!dev_opted[device]) {
+                // the row tiles of the big shape take 128 KiB of dynamic LDS
+                KMCHK(hipFuncSetAttribute((const void*)km_centroid_kernel<512, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * KM_PAD * sizeof(float)));
+                KMCHK(hipFuncSetAttribute((const void*)km_split_kernel<512, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * KM_PAD * sizeof(float)));
+                dev_opted[device] = true;
         }
         // (the buffers live as long as the process: a guide tree is built per alignment, the allocations cost more than a level)
         struct Pool {
@@ -329,12 +336,10 @@ int ka_kmeans_device(int device, hipStream_t stream, const float* dm, int numseq
                 Buf<long long> d_list_off, d_src_off, d_dst_off;
                 Buf<unsigned char> d_assign;
                 Buf<int2> d_cand_n, d_src_n;
-                int device = -1;
-                void release_all() { d_dm.release(); d_wmean.release(); d_mind.release(); d_score.release(); d_samples[0].release(); d_samples[1].release(); d_lists.release(); d_cand_set.release();
-                                     d_sets.release(); d_list_off.release(); d_src_off.release(); d_dst_off.release(); d_assign.release(); d_cand_n.release(); d_src_n.release(); }
         };
-        static thread_local Pool pool;
-        if (pool.device != device) { pool.release_all(); pool.device = device; }
+        static Pool* pools[KM_MAX_DEVICES];
+        if (!pools[device]) pools[device] = new Pool();
+        Pool& pool = *pools[device];
         Buf<float>&d_dm = pool.d_dm, &d_wmean = pool.d_wmean, &d_mind = pool.d_mind, &d_score = pool.d_score;
         Buf<int>(&d_samples)[2] = pool.d_samples; Buf<int>&d_lists = pool.d_lists, &d_cand_set = pool.d_cand_set;
         Buf<KmSet>& d_sets = pool.d_sets;

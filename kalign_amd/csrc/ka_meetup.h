@@ -90,9 +90,22 @@ __device__ __forceinline__ KaLevelOut ka_level_out(TaskShared& S, int parity, bo
 // thousands of candidate columns -- every wave scans every NW-th block of 64 columns, the partial (best, second best)
 // pairs meet in TaskShared::mw_* behind a workgroup barrier, and wave 0 merges them (the merge ranks by value and scan
 // position, so it does not depend on who found what) and carries on alone: decision, path entries, children.
-template <int KIND, int GL, bool FLIP = false, bool REC = false, bool MW = false>
+//
+// RU (round 5): HIRSCHBERG PREFIX REUSE.  A child shares one corner with its parent: the top-left child ([starta, mid') x
+// [startb, meet']) starts its forward pass from the parent's forward start state, so its forward rows are the parent's forward
+// rows restricted to its columns -- except in its LAST column, where a pass writes ga = -FLT_MAX (aln_seqseq.c:108-117,
+// aln_profileprofile.c:128-151) while the parent computed an inner ga there (the terminal rule of that column can only differ
+// when it is not the parent's last column too, and then it is off on both sides; the meetup never reads the forward ga of its
+// last column, and the backward one -- the first column of the window -- is overwritten below).  The bottom-right child shares
+// the backward corner the same way.  So a strip pass that RUNS leaves, besides its last row, the row its usual child will want:
+// after (n - 1) / 2 of its n rows going forward (child rows [starta, mid - 1)), after n / 2 going backward (child rows
+// [mid + 1, enda)) -- ka_strip<.., SAVE> -- and a child whose own pass would have exactly that many rows takes that row
+// (KaSub::fsrc / bsrc) and gets no pass item.  One level deep: a pass that was taken over has left nothing.  ~21 % of the DP
+// cells are never computed; oracle/kalign_oracle.c:ko_hirschberg_r restates the rule on the CPU and tests/test_oracle_golden.py
+// shows it bit-exact on every golden.  lvl: the recursion level of the meetups (the parent's passes ran at lvl - 1).
+template <int KIND, int GL, bool FLIP = false, bool REC = false, bool MW = false, bool RU = false>
 __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const int k0, const int ncur, KaSub* qnext,
-                                          const KaLevelOut& lout, const int wlane, const bool top_level, const int kdig = 0)
+                                          const KaLevelOut& lout, const int wlane, const bool top_level, const int kdig = 0, const int lvl = 0)
 {
         static_assert(!MW || GL == 64, "the multi-wave scan works on 64-lane groups");
         const int lane = wlane % GL;                                 // lane within the sub-problem's group
@@ -105,8 +118,10 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         const bool is_top = top_level && ksub == 0;
         const int startb = sb.startb, endb = sb.endb;
         const int mid = ((sb.enda - sb.starta) / 2) + sb.starta;
-        const KaState* f = S.fbuf + sb.roff;
-        const KaState* b = S.bbuf + sb.roff;
+        const bool ru = RU && S.reuse_ok != 0;
+        const bool f_taken = ru && sb.fsrc >= 0, b_taken = ru && sb.bsrc >= 0;
+        const KaState* f = f_taken ? S.sfbuf[(lvl + 1) & 1] + sb.fsrc : S.fbuf + sb.roff;
+        const KaState* b = b_taken ? S.sbbuf[(lvl + 1) & 1] + sb.bsrc : S.bbuf + sb.roff;
         const float middle = (float)(endb - startb) / 2.0f + (float)startb;
         const int rrec = mid + 1;
         float g3, g7, g6n, g6f;
@@ -123,7 +138,10 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         Best B = { -KA_F, -KA_F, 0x7fffffff, 0x7fffffff };
         const int mw_wave = MW ? (int)(threadIdx.x >> 6) : 0, mw_nw = MW ? KA_NW : 1;
         for (int i = startb + lane + GL * mw_wave; valid && i <= endb; i += GL * mw_nw) {
-                const KaState fi = f[i - startb], bi = b[i - startb];
+                KaState fi = f[i - startb], bi = b[i - startb];
+                // (a row taken over from the parent: the last column of the child's pass has no ga state -- the forward one is never
+                // read there, the backward one is)
+                if (RU) { if (b_taken && i == startb) bi.ga = -KA_F; if (f_taken && i == endb) fi.ga = -KA_F; }
                 float sub = fabsf(middle - (float)i);
                 sub = sub / 1000.0f;
                 const int kb = (i - startb) * 8;
@@ -204,6 +222,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         c1.enda = c1.starta; c1.endb = c1.startb; c1.bin = Z;          // empty unless a transition fills them in
         c2.starta = c2.enda; c2.startb = c2.endb; c2.fin = Z;
         c1.pad = rec ? sb.pad + kdig : 0; c2.pad = rec ? sb.pad + 2 * kdig : 0; c1.roff = 0; c2.roff = 0;
+        c1.fsrc = -1; c1.bsrc = -1; c2.fsrc = -1; c2.bsrc = -1;
         if (tr > 0) {
                 int* path = S.raw;
                 switch (tr) {
@@ -255,9 +274,20 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
         const bool st2 = !FLIP && !rec && v2 && ka_child_is_subtree(lout, c2.enda - c2.starta, c2.endb - c2.startb);
         if (st1) need[2] += 1;
         if (st2) need[2] += 1;
+        // prefix reuse: what this sub-problem's own passes left (they ran as strips, ka_run_items), and which child takes it
+        bool take_f1 = false, take_b2 = false;
+        if (RU && ru && !FLIP && !rec) {
+                const int nfp = mid - sb.starta, nbp = sb.enda - mid, pcols = endb - startb;
+                const int rs_f = (nfp - 1) / 2, rs_b = nbp / 2;
+                take_f1 = v1 && !st1 && !f_taken && rs_f >= 1 && ka_pass_is_strip(nfp, pcols) && pr[0] == rs_f;
+                take_b2 = v2 && !st2 && !b_taken && rs_b >= 1 && ka_pass_is_strip(nbp, pcols) && pr[3] == rs_b;
+                if (take_f1) c1.fsrc = sb.roff;
+                if (take_b2) c2.bsrc = sb.roff + (c2.startb - startb);
+        }
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
                 if (!((x < 2) ? v1 : v2) || ((x < 2) ? st1 : st2)) continue;
+                if (RU && ((x == 0 && take_f1) || (x == 3 && take_b2))) continue;
                 if (ka_pass_is_strip(pr[x], pc[x])) need[2] += ka_strips_of(pr[x], lout.srows);
                 else if (pr[x] > 8) need[3] += 1;
                 else need[4] += 1;
@@ -307,6 +337,7 @@ __device__ __forceinline__ void ka_meetup(TaskShared& S, const KaSub* qc, const 
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                         const int nrows = pr[2 * ch + x], ncols = pc[2 * ch + x], dir = x ? KA_BWD : KA_FWD;
+                        if (RU && ((ch == 0 && x == 0 && take_f1) || (ch == 1 && x == 1 && take_b2))) continue;   // (taken over: no pass)
                         if (ka_pass_is_strip(nrows, ncols)) {
                                 const int ns = ka_strips_of(nrows, lout.srows);
                                 for (int k = 0; k < ns; ++k) { lout.items[ip + k] = make_int2(slot, (dir << 16) | k); lout.prog[ip + k] = 0; }

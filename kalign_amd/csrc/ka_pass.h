@@ -195,12 +195,16 @@ struct KaBonus {
 #define KA_LDS_HO_BACK 64                                       // control words, this many bytes below the wave regions: [wave] columns written, [8 + wave] columns read
 static_assert(KA_HO_RING + KA_HO_SLOTS * 16 <= KA_WAVE_LDS, "hand-over ring outgrew the wave's LDS region");
 
-template <int KIND, int NRES, int NB, int Q = 2, bool HO = false>
+// SAVE (round 5, Hirschberg prefix reuse, ka_meetup.h): svrows != nullptr -- the pass leaves the row after `sv_rows` of its rows in
+// svrows[0 .. ncols] (indexed like `rows`): the strip that holds that row has its owner lane store the fresh state every step
+// (one exec-narrowed 12-byte store next to ~100 instructions; the strips of the pass that do not hold it do nothing).
+template <int KIND, int NRES, int NB, int Q = 2, bool HO = false, bool SAVE = false>
 __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, const int enda, const int startb, const int endb,
                                          const float inj_a, const float inj_ga, const float inj_gb,
                                          const int dir, const int k, KaState* rows, int* prog,
                                          const int lane, char* wlds, const float* tss, const bool acq_agent, const bool rel_agent,
-                                         long long* pslot = nullptr, const bool in_lds = false, const bool out_lds = false, int* ho_ctl_w = nullptr)
+                                         long long* pslot = nullptr, const bool in_lds = false, const bool out_lds = false, int* ho_ctl_w = nullptr,
+                                         KaState* svrows = nullptr, const int sv_rows = 0)
 {
         const int ncols = endb - startb;
         const int mid = ((enda - starta) / 2) + starta;
@@ -255,6 +259,12 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         const bool last_is_b = (Q == 2) && (nr & 1) == 0;
         const bool first = (k == 0);
         const bool last_strip = (u0 + SROWS >= nrows);                // no strip below this one
+        // SAVE: the pass row sv_rows - 1, if this strip holds it: its lane, and which of the lane's two rows it is
+        const int sv_u = sv_rows - 1 - u0;
+        const bool sv_on = SAVE && svrows != nullptr && sv_u >= 0 && sv_u < nr;
+        const int sv_lane = (Q == 2) ? (sv_u >> 1) : sv_u;
+        const bool sv_b = (Q == 2) && (sv_u & 1) != 0;
+        ka_gfloat* const gsv = (ka_gfloat*)svrows;
         // Hand-over batches: a strip starts 63 columns (the lane skew) plus one batch behind the strip above it, and every
         // hand-over is an event step on both sides (a flush behind a release fence; a wait and a reload) that breaks the
         // branch-free step pairs.  64 columns per batch, inside a workgroup as well as across workgroups: 16-column batches
@@ -721,6 +731,19 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
                         copen_prev = copen;
                 }
 
+                // ---- SAVE: the row the pass leaves for the sub-problem's child (prefix reuse) ----
+                if constexpr (SAVE) {
+                        if (sv_on) {
+                                const int vs = t - sv_lane;                    // (wave-uniform: the owner's column)
+                                if (ST || (vs >= 0 && vs <= ncols)) {
+                                        if (lane == sv_lane) {
+                                                ka_gfloat* w = gsv + 3 * IDX(vs);
+                                                if (Q == 2 && sv_b) { w[0] = cBa; w[1] = cBga; w[2] = cBgb; }
+                                                else { w[0] = cAa; w[1] = cAga; w[2] = cAgb; }
+                                        }
+                                }
+                        }
+                }
                 // ---- collect the strip's last row and hand it on 64 columns at a time (through the row buffer, or through LDS) ----
                 const int vL = t - lastl;
 #ifdef KA_PROF

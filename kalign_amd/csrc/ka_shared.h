@@ -91,6 +91,11 @@ struct TaskShared {
         KaState* bbuf;
         KaState* xfbuf;                // hand-over rows between strips of one pass that run in DIFFERENT workgroups with helper waves (ka_whelper):
         KaState* xbbuf;                //   written and read past the caches (agent-scope atomics) -- kept apart from fbuf / bbuf, which plain loads read
+        // Hirschberg prefix reuse (ka_meetup.h): the row a pass of recursion level L leaves for the sub-problem's usual child, by level
+        // parity (the children read it in level L+1's meetups while that level's own passes fill the other one); sliced by KaSub::roff
+        KaState* sfbuf[2];
+        KaState* sbbuf[2];
+        int reuse_ok;                  // ... enabled for this task (a kernel built with it, one workgroup, no recursion-order records)
         KaSub* q[2];
         int* raw;
         int* raw2;

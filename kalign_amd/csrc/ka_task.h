@@ -3,6 +3,9 @@
 // ka_subtree.h, ka_wstrip.h, ka_meetup.h, ka_hirschberg.h, ka_path.h, ka_profile.h, ka_task.h.  Not a stand-alone header.
 #pragma once
 
+#ifndef KA_RU_TREE
+#define KA_RU_TREE 0                                                // Hirschberg prefix reuse in the 4-wave TREE kernels (see ka_task_body): measured, off
+#endif
 // dynamic-LDS layout of a workgroup
 #define KA_LDS_DBG 1400
 #define KA_LDS_TSS 1408
@@ -54,6 +57,10 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         S.bbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
         S.xfbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
         S.xbbuf = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+        for (int par = 0; par < 2; ++par) {
+                S.sfbuf[par] = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+                S.sbbuf[par] = (KaState*)(base + o); o += ka_align_up(n * 12, 16);
+        }
         const long long nq = (long long)(la < lb ? la : lb) + 20;
         S.q[0] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
         S.q[1] = (KaSub*)(base + o); o += ka_align_up(nq * (long long)sizeof(KaSub), 16);
@@ -110,7 +117,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 20;
         const long long ni = 2 * nq + 2 * (n / KA_STRIP1_ROWS + 2);
-        long long b = 5 * ((n * 4 + 15) / 16 * 16) + 4 * ((n * 12 + 15) / 16 * 16)
+        long long b = 5 * ((n * 4 + 15) / 16 * 16) + 8 * ((n * 12 + 15) / 16 * 16)
              + 2 * ((nq * (long long)sizeof(KaSub) + 15) / 16 * 16)
              + 2 * ((ni * 8 + 15) / 16 * 16) + 2 * ((ni * 4 + 15) / 16 * 16)
              + 4 * ((2 * nq * 8 + 15) / 16 * 16) + 64;
@@ -290,6 +297,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // wave-local subtrees do not keep those records: off.
                 S.rec_on = (D.flags & KA_FLAG_EXACT_CONFIDENCE) ? 1 : 0;
                 S.sub_ok = (D.sub_mode && !S.rec_on) ? 1 : 0;
+                S.reuse_ok = (KA_RU_TREE && !Q1 && D.reuse && g_eff == 1 && !S.rec_on) ? 1 : 0;
                 S.nres_t = (D.nres <= 5) ? 5 : ((D.nres <= 20) ? 20 : 23);
                 S.sub_stride = LEAN ? KA_WAVE_LDS_LEAN : KA_WAVE_LDS;
                 S.sub_base = LEAN ? (lds_waves + KA_LEAN_SCRATCH(KA_NT)) : lds_waves;
@@ -344,13 +352,18 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 2);
 
         // P2
-        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, false, Q1>(S, s_dbg, lds_waves, tss, D.trace);
-        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1, Q1 && NB == 0, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        // (last template argument: Hirschberg prefix reuse.  Built for the 4-wave tree kernels too -- -DKA_RU_TREE=1 -- and measured
+        // there: 11 % fewer VALU instructions in the queued launch, 8 % in the leaf launch, and NO time gained (16 trees in flight:
+        // 77.0 against 75.9 ms; profiles/r05_prefix_reuse.log) -- those launches wait (46 % of the wave cycles parked, VALU busy 32 %),
+        // they do not issue, and a task's critical path through its levels is as long with half the passes.  The seq-seq pair batch,
+        // whose workgroups are two waves wide, gains 14 %: on there, off here.)
+        if (LEAN || S.kind == KA_SS) ka_hirschberg<KA_SS, 23, NB, false, Q1, false, false, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (S.kind == KA_SP) ka_hirschberg<KA_SP, 23, NB, false, Q1, false, false, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
         // no B / Z / X in the job (the usual case): every profile's counts [20..22] are zero and the reference skips
         // zero counts (aln_profileprofile.c:70-77) -- 20 terms per cell instead of 23
-        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1, Q1 && NB == 0, Q1>(S, s_dbg, lds_waves, tss, D.trace);
-        else ka_hirschberg<KA_PP, 23, NB, false, Q1, Q1 && NB == 0, Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
+        else ka_hirschberg<KA_PP, 23, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         // exact confidence: the cluster's last barrier (inside ka_hirschberg) has published every member's records
         bool conf_exact = false;
@@ -493,6 +506,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.La = swapped ? len_b : len_a;
                 S.Lb = swapped ? len_a : len_b;
                 S.G = 1; S.member = 0; S.bar_phase = 0; S.Gw = 1; S.member_w = 0; S.split = 0; S.srows = KA_STRIP_ROWS; S.q1_lvl = 0; S.lvl_srows[0] = KA_STRIP_ROWS; S.lvl_srows[1] = KA_STRIP_ROWS;
+                S.reuse_ok = 0;
                 S.sub_ok = 0; S.rec_on = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #ifdef HAVE_OPENMP
 #include <omp.h>
 #endif
@@ -35,8 +36,15 @@
 #include "aln_param.h"
 #include "anchor_consistency.h"
 #include "tlrng.h"
+#include "msa_op.h"
+#include "msa_check.h"
+#include "aln_wrap.h"
 
 #include "kalign_amd.h"
+
+/* What the device holds belongs to the calling THREAD: the members of an ensemble run side by side (kalign_ensemble below), each
+   thread on a device context of its own. */
+#define GLUE_TLS __thread
 
 /* the reference's own definitions, renamed by the drop-in build (oracle/Makefile) */
 extern int kalign_ref_finalise_alignment(struct msa* msa);
@@ -46,15 +54,19 @@ extern int kalign_ref_create_msa_tree_inline_refine(struct msa* msa, struct aln_
 extern int kalign_ref_compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr);
 extern int kalign_ref_build_tree_from_pairwise(struct msa* msa, struct aln_tasks** tasks, float** dm);
 extern int kalign_ref_anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchors, float weight, struct consistency_table** ct_out);
+extern int kalign_ref_kalign_ensemble(struct msa* msa, int n_threads, int type, int n_runs, float gpo, float gpe, float tgpe, uint64_t seed, int min_support,
+                                      const char* save_poar_path, int refine, float dist_scale, float vsm_amax, int realign, float use_seq_weights,
+                                      int consistency_anchors, float consistency_weight);
 
 /* how often each seam ran on the device / fell back to the reference (tests/test_gpu_dropin.py reads them) */
 enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF,
        GLUE_CONS, GLUE_CONS_REF, GLUE_KMEANS, GLUE_KMEANS_NOISY, GLUE_ALNDIST, GLUE_ALNDIST_REF, GLUE_ALNTREE, GLUE_ALNTREE_REF, GLUE_INLINE_REF,
-       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_TREE_REF, GLUE_N };
+       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_TREE_REF, GLUE_ENSEMBLE_MULTI, GLUE_MEMBER_AHEAD, GLUE_N };
 static const char* glue_names[GLUE_N] = { "tree", "inline", "refine", "refine_ref", "finalise", "finalise_ref",
                                           "cons", "cons_ref", "kmeans", "kmeans_noisy", "alndist", "alndist_ref", "alntree", "alntree_ref", "inline_ref",
-                                          "tree_multi", "cons_multi", "tree_ref" };
+                                          "tree_multi", "cons_multi", "tree_ref", "ensemble_multi", "member_ahead" };
 static int glue_counts[GLUE_N];
+#define GLUE_COUNT(which) __atomic_fetch_add(&glue_counts[which], 1, __ATOMIC_RELAXED)
 int kalign_amd_glue_count(int which)
 {
         return (which >= 0 && which < GLUE_N) ? glue_counts[which] : -1;
@@ -69,13 +81,13 @@ static void glue_report(void)
         fprintf(stderr, "\n");
 }
 
-static ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
-static ka_ctx* glue_job_ctx = NULL;           /* the context that holds glue_job_msa's alignment: glue_ctx, or rank 0's after a sharded run */
-static ka_ctx* glue_rows_ctx = NULL;          /* ... and the one whose HBM holds the finalised rows of glue_rows_msa */
-static const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
-static int glue_job_numseq = 0;
-static const struct msa* glue_rows_msa;        /* (defined with the realignment seams below) */
-static uint64_t glue_job_stamp = 0;            /* FNV-1a over the lengths and gap arrays the device job left in that msa */
+static GLUE_TLS ka_ctx* glue_ctx = NULL;               /* one context per process / GPU */
+static GLUE_TLS ka_ctx* glue_job_ctx = NULL;           /* the context that holds glue_job_msa's alignment: glue_ctx, or rank 0's after a sharded run */
+static GLUE_TLS ka_ctx* glue_rows_ctx = NULL;          /* ... and the one whose HBM holds the finalised rows of glue_rows_msa */
+static GLUE_TLS const struct msa* glue_job_msa = NULL;  /* the msa whose alignment the device currently holds */
+static GLUE_TLS int glue_job_numseq = 0;
+static GLUE_TLS const struct msa* glue_rows_msa;        /* (defined with the realignment seams below) */
+static GLUE_TLS uint64_t glue_job_stamp = 0;            /* FNV-1a over the lengths and gap arrays the device job left in that msa */
 
 /* The device job is recognised by more than the msa's address: an msa freed without finalise_alignment leaves a stale
    pointer that a later allocation can reuse, and the host may edit gaps[] between the seams.  The stamp covers what the
@@ -116,15 +128,25 @@ static int glue_same_job(const struct msa* msa)
 static ka_multi* glue_multi = NULL;
 static int glue_multi_tried = 0;
 static int glue_multi_min = 0;                  /* sequences a job needs before the node is opened for it (0: any) */
+#define GLUE_MAX_MEMBERS 16
+static ka_ctx* glue_member_ctx[GLUE_MAX_MEMBERS];  /* one single-GPU context per member slot (device), made on first use */
 static void glue_release(void)
 {
+        int i;
         /* (at exit: the communicators, contexts and threads' buffers go before the HIP runtime does) */
+        for(i = 0; i < GLUE_MAX_MEMBERS; i++){
+                if(glue_member_ctx[i]){ ka_ctx_destroy(glue_member_ctx[i]); glue_member_ctx[i] = NULL; }
+        }
         if(glue_multi){ ka_multi_destroy(glue_multi); glue_multi = NULL; }
         if(glue_ctx){ ka_ctx_destroy(glue_ctx); glue_ctx = NULL; }
         glue_job_ctx = NULL; glue_rows_ctx = NULL;
 }
+static GLUE_TLS int glue_in_member = 0;          /* this thread runs ONE ensemble member on one device (kalign_ensemble below) */
 static ka_multi* glue_multi_context(int numseq)
 {
+        if(glue_in_member){
+                return NULL;
+        }
         if(!glue_multi_tried){
                 const char* w = getenv("KALIGN_AMD_GLUE_WORLD");
                 const char* d = getenv("KALIGN_AMD_DEVICES");
@@ -156,16 +178,18 @@ static ka_multi* glue_multi_context(int numseq)
         return (glue_multi && numseq >= glue_multi_min) ? glue_multi : NULL;
 }
 
+static void glue_register(void)
+{
+        atexit(glue_release);
+        if(getenv("KALIGN_AMD_GLUE_REPORT")){
+                atexit(glue_report);
+        }
+}
+
 static int glue_context(void)
 {
-        static int registered = 0;
-        if(!registered){
-                registered = 1;
-                atexit(glue_release);
-                if(getenv("KALIGN_AMD_GLUE_REPORT")){
-                        atexit(glue_report);
-                }
-        }
+        static pthread_once_t once = PTHREAD_ONCE_INIT;
+        pthread_once(&once, glue_register);
         if(!glue_ctx && ka_ctx_create(0, &glue_ctx)){
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
@@ -237,8 +261,8 @@ static void glue_params(struct aln_param* ap, float* subm, float* scal)
 
 /* the table the device(s) hold right now -- per device set: the single-GPU context and the ranks of the node are different
    contexts, and a table built on one says nothing about the other */
-static const struct consistency_table* glue_ct_single = NULL;
-static const struct consistency_table* glue_ct_multi = NULL;
+static GLUE_TLS const struct consistency_table* glue_ct_single = NULL;
+static GLUE_TLS const struct consistency_table* glue_ct_multi = NULL;
 
 /*
  * anchor_consistency_build (anchor_consistency.c:200-275).  The reference aligns every sequence to K anchors here,
@@ -288,18 +312,18 @@ int anchor_consistency_build(struct msa* msa, struct aln_param* ap, int n_anchor
                 if(ka_multi_consistency(glue_multi, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0, K, weight, ids_multi, maps) != K){
                         ERROR_MSG("kalign_amd: %s", ka_multi_last_error());
                 }
-                glue_counts[GLUE_CONS_MULTI]++;
+                GLUE_COUNT(GLUE_CONS_MULTI);
         }else
         if(ka_tree_upload(glue_ctx, n, codes, off, lens, msa->seq_distances, n - 1, abc, subm, scal, 0) ||
            ka_tree_build_consistency(glue_ctx, K, weight)){
                 /* a request the library does not take (more than 10 anchors ...): the reference's own function, like every
                    other seam; the dispatcher then rebuilds the table it needs or declines alike (no table is resident) */
                 MFREE(codes); MFREE(off); MFREE(lens); MFREE(abc);
-                glue_counts[GLUE_CONS_REF]++;
+                GLUE_COUNT(GLUE_CONS_REF);
                 return kalign_ref_anchor_consistency_build(msa, ap, n_anchors, weight, ct_out);
         }
         if(!ids_multi){
-                glue_counts[GLUE_CONS]++;
+                GLUE_COUNT(GLUE_CONS);
         }
         MMALLOC(ct, sizeof(struct consistency_table));
         ct->pos_maps = NULL;
@@ -406,7 +430,7 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
                 glue_ct_multi = ct;
                 /* (glue_collect hands the alignment to rank 0's context: the seams behind the dispatcher carry on there) */
                 RUN(glue_collect(msa, t, lens, total, NULL));
-                glue_counts[GLUE_TREE_MULTI]++;
+                GLUE_COUNT(GLUE_TREE_MULTI);
                 MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
                 return OK;
         }
@@ -432,7 +456,7 @@ static int glue_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
                 ERROR_MSG("kalign_amd: %s", ka_last_error());
         }
         RUN(glue_collect(msa, t, lens, total, glue_ctx));
-        glue_counts[inline_refine ? GLUE_INLINE : GLUE_TREE]++;
+        GLUE_COUNT(inline_refine ? GLUE_INLINE : GLUE_TREE);
         MFREE(off); MFREE(lens); MFREE(codes); MFREE(abc);
         return OK;
 ERROR:
@@ -523,7 +547,7 @@ int create_msa_tree(struct msa* msa, struct aln_param* ap, struct aln_tasks* t)
 {
         if(glue_table_too_wide(msa)){
                 glue_job_msa = NULL;
-                glue_counts[GLUE_TREE_REF]++;
+                GLUE_COUNT(GLUE_TREE_REF);
                 return kalign_ref_create_msa_tree(msa, ap, t);
         }
         return glue_tree(msa, ap, t, 0);
@@ -536,7 +560,7 @@ int create_msa_tree_inline_refine(struct msa* msa, struct aln_param* ap, struct 
 {
         if(n_trials < 1 || n_trials > 255 || glue_table_too_wide(msa)){
                 glue_job_msa = NULL;
-                glue_counts[GLUE_INLINE_REF]++;
+                GLUE_COUNT(GLUE_INLINE_REF);
                 return kalign_ref_create_msa_tree_inline_refine(msa, ap, t, n_trials);
         }
         return glue_tree(msa, ap, t, n_trials);
@@ -562,7 +586,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         }
         if(!glue_same_job(msa) || !glue_job_ctx || (refine_mode != 1 && refine_mode != 2)){
                 glue_job_msa = NULL;                     /* the host state moves on without the device */
-                glue_counts[GLUE_REFINE_REF]++;
+                GLUE_COUNT(GLUE_REFINE_REF);
                 return kalign_ref_refine_alignment(msa, ap, t, refine_mode);
         }
         RUN(sort_tasks(t, TASK_ORDER_TREE));
@@ -576,7 +600,7 @@ int refine_alignment(struct msa* msa, struct aln_param* ap, struct aln_tasks* t,
         }
         /* (after a sharded first pass the refinement pass ran on rank 0's context: a job of that context from here on) */
         RUN(glue_collect(msa, t, lens, total, glue_job_ctx));   /* the refined gaps are what the device holds now */
-        glue_counts[GLUE_REFINE]++;
+        GLUE_COUNT(GLUE_REFINE);
         MFREE(lens);
         return OK;
 ERROR:
@@ -636,7 +660,7 @@ ERROR:
 
 int build_tree_kmeans(struct msa* msa, struct aln_tasks** tasks)
 {
-        glue_counts[GLUE_KMEANS]++;
+        GLUE_COUNT(GLUE_KMEANS);
         return glue_kmeans(msa, tasks, NULL);
 }
 
@@ -652,7 +676,7 @@ int build_tree_kmeans_noisy(struct msa* msa, struct aln_tasks** tasks, uint64_t 
         int na = n < 32 ? n : 32;                        /* pick_anchor, bisectingKmeans.c */
         int i, j, rc;
         if(seed == 0 || noise_sigma <= 0.0f){
-                glue_counts[GLUE_KMEANS_NOISY]++;
+                GLUE_COUNT(GLUE_KMEANS_NOISY);
                 return glue_kmeans(msa, tasks, NULL);
         }
         MMALLOC(scale, sizeof(float) * (size_t)n * na);
@@ -667,7 +691,7 @@ int build_tree_kmeans_noisy(struct msa* msa, struct aln_tasks** tasks, uint64_t 
                 }
                 free_rng(rng);
         }
-        glue_counts[GLUE_KMEANS_NOISY]++;
+        GLUE_COUNT(GLUE_KMEANS_NOISY);
         rc = glue_kmeans(msa, tasks, scale);
         MFREE(scale);
         return rc;
@@ -682,14 +706,14 @@ ERROR:
  * (ka_aln_guide_tree).  The reference's interface splits that in two, so the first seam returns the distances in the
  * reference's layout and keeps the tree; the second hands the tree over when it is asked about that very matrix.
  */
-static float** glue_dm = NULL;                   /* the matrix the last compute_aln_pairwise_dist returned */
-static int* glue_dm_abc = NULL;
-static float* glue_dm_sd = NULL;
-static int glue_dm_n = 0;
-static const struct msa* glue_rows_msa = NULL;   /* the msa whose finalised rows the device holds */
-static int glue_rows_numseq = 0;
-static int glue_rows_alnlen = 0;
-static uint64_t glue_rows_stamp_v = 0;
+static GLUE_TLS float** glue_dm = NULL;                   /* the matrix the last compute_aln_pairwise_dist returned */
+static GLUE_TLS int* glue_dm_abc = NULL;
+static GLUE_TLS float* glue_dm_sd = NULL;
+static GLUE_TLS int glue_dm_n = 0;
+static GLUE_TLS const struct msa* glue_rows_msa = NULL;   /* the msa whose finalised rows the device holds */
+static GLUE_TLS int glue_rows_numseq = 0;
+static GLUE_TLS int glue_rows_alnlen = 0;
+static GLUE_TLS uint64_t glue_rows_stamp_v = 0;
 
 /* The rows in HBM are recognised by more than the msa's address (as glue_same_job does for the job): a freed msa's address
    can come back with an alignment read from a file.  numseq, alnlen and FNV-1a over up to 64 evenly spaced rows. */
@@ -729,7 +753,7 @@ int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
         int n = msa->numseq;
         int i;
         if(msa->aligned != ALN_STATUS_FINAL || n < 2 || glue_context() != OK || !glue_ctx){
-                glue_counts[GLUE_ALNDIST_REF]++;
+                GLUE_COUNT(GLUE_ALNDIST_REF);
                 return kalign_ref_compute_aln_pairwise_dist(msa, dm_ptr);
         }
         {
@@ -768,7 +792,7 @@ int compute_aln_pairwise_dist(struct msa* msa, float*** dm_ptr)
         }
         MFREE(flat);
         glue_dm = dm; glue_dm_n = n;
-        glue_counts[GLUE_ALNDIST]++;
+        GLUE_COUNT(GLUE_ALNDIST);
         *dm_ptr = dm;
         return OK;
 ERROR:
@@ -789,7 +813,7 @@ int build_tree_from_pairwise(struct msa* msa, struct aln_tasks** tasks, float** 
         int n = msa->numseq;
         int i;
         if(dm == NULL || dm != glue_dm || n != glue_dm_n || !glue_dm_abc){
-                glue_counts[GLUE_ALNTREE_REF]++;
+                GLUE_COUNT(GLUE_ALNTREE_REF);
                 return kalign_ref_build_tree_from_pairwise(msa, tasks, dm);
         }
         if(!t){
@@ -807,7 +831,7 @@ int build_tree_from_pairwise(struct msa* msa, struct aln_tasks** tasks, float** 
         t->n_tasks = n - 1;
         *tasks = t;
         glue_dm = NULL;                                  /* (the caller frees the matrix next; its address may come back) */
-        glue_counts[GLUE_ALNTREE]++;
+        GLUE_COUNT(GLUE_ALNTREE);
         return OK;
 ERROR:
         return FAIL;
@@ -829,11 +853,11 @@ int finalise_alignment(struct msa* msa)
         int width = 0;
         int i;
         if(!glue_same_job(msa) || !glue_job_ctx){
-                glue_counts[GLUE_FINALISE_REF]++;
+                GLUE_COUNT(GLUE_FINALISE_REF);
                 glue_rows_msa = NULL;
                 return kalign_ref_finalise_alignment(msa);
         }
-        glue_counts[GLUE_FINALISE]++;
+        GLUE_COUNT(GLUE_FINALISE);
         glue_job_msa = NULL;                             /* the rows below replace seq->seq: one shot */
         glue_rows_msa = msa;                             /* ... and stay in HBM for the realignment loop's distances */
         glue_rows_ctx = glue_job_ctx;
@@ -875,5 +899,225 @@ ERROR:
         if(letters) MFREE(letters);
         if(alnlen) MFREE(alnlen);
         if(rows) MFREE(rows);
+        return FAIL;
+}
+
+
+/*
+ * kalign_ensemble's member loop (lib/src/ensemble.c:286-339; `--ensemble n`, `--precise`): n_runs complete alignments of the same
+ * sequences with their own gap penalties and noisy guide trees, one after the other in the reference -- BASELINE config 5 wants
+ * one member per GPU.  The seam has two halves:
+ *   * kalign_ensemble (this definition; the reference's is kalign_ref_kalign_ensemble): with G >= 2 member devices it runs the
+ *     members AHEAD OF TIME, member k on device k mod G, every device's members on a thread of their own -- each through the
+ *     reference's own kalign_run_seeded / kalign_run_realign, i.e. through the seams above on that thread's context (guide tree,
+ *     consistency, task tree, rows: no collective, weak scaling) -- and then calls the reference's function;
+ *   * the two calls of its member loop come here instead (kalign_amd_member_run_*, redirected when ensemble.c is compiled,
+ *     oracle/Makefile): a member that was run ahead hands its finished alignment over (the msa structs trade contents), anything
+ *     else -- a single device, the winner's re-run with KALIGN_REFINE_CONFIDENT (:403-451) -- is the reference's call as it was.
+ * POAR extraction, scoring, consensus and the confidence values stay the reference's, on what the members produced.
+ * The penalties of member k (resolve_run_params and its table, ensemble.c:32-76) are restated here: k = 0 the base values
+ * (aln_param_init's, :262-268), k > 0 scaled per entry k mod 12, tree seed + k, tree noise per entry.
+ * Devices: ka_device_count(), KALIGN_AMD_DEVICES=n; KALIGN_AMD_GLUE_WORLD=n: n member contexts on device 0 (one-GPU test boxes).
+ */
+static const float glue_member_scale[12][4] = {
+        {1.0f, 1.0f, 1.0f, 0.0f}, {0.5f, 1.5f, 0.8f, 0.20f}, {1.5f, 0.5f, 1.2f, 0.20f}, {0.7f, 0.7f, 0.5f, 0.25f},
+        {1.4f, 1.4f, 1.5f, 0.25f}, {0.8f, 1.2f, 1.0f, 0.30f}, {1.3f, 0.8f, 0.7f, 0.30f}, {0.6f, 1.0f, 1.3f, 0.15f},
+        {1.0f, 0.6f, 0.6f, 0.15f}, {1.8f, 1.0f, 1.0f, 0.35f}, {1.0f, 1.8f, 1.8f, 0.35f}, {0.4f, 0.4f, 0.3f, 0.20f},
+};
+
+struct glue_member {
+        struct msa* aln;                         /* the finished member (NULL: not run / handed over) */
+        float gpo, gpe, tgpe, noise;
+        uint64_t seed;
+        int rc;
+};
+struct glue_member_args {                        /* what every member call of one ensemble shares */
+        int n_threads, type, refine, realign, anchors;
+        float dist_scale, vsm_amax, usw, weight;
+};
+static struct glue_member* glue_members = NULL;  /* the members run ahead of the reference's loop (main thread only) */
+static int glue_n_members = 0;
+static struct glue_member_args glue_margs;
+
+struct glue_slot_job { int slot, n_slots, device, shared; };
+
+static void* glue_member_thread(void* p)
+{
+        struct glue_slot_job* j = (struct glue_slot_job*)p;
+        int k;
+        glue_in_member = 1;
+        if(!glue_member_ctx[j->slot]){
+                if(ka_ctx_create(j->device, &glue_member_ctx[j->slot])){
+                        glue_member_ctx[j->slot] = NULL;
+                }else if(j->shared){
+                        ka_ctx_set_shared(glue_member_ctx[j->slot], 1);     /* several contexts on one GPU: no co-residency assumptions */
+                }
+        }
+        glue_ctx = glue_member_ctx[j->slot];
+        for(k = j->slot; k < glue_n_members; k += j->n_slots){
+                struct glue_member* m = &glue_members[k];
+                if(!glue_ctx || !m->aln){
+                        m->rc = FAIL;
+                        continue;
+                }
+                if(glue_margs.realign > 0){
+                        m->rc = kalign_run_realign(m->aln, glue_margs.n_threads, glue_margs.type, m->gpo, m->gpe, m->tgpe, glue_margs.refine, 0,
+                                                   glue_margs.dist_scale, glue_margs.vsm_amax, glue_margs.realign, glue_margs.usw,
+                                                   glue_margs.anchors, glue_margs.weight);
+                }else{
+                        m->rc = kalign_run_seeded(m->aln, glue_margs.n_threads, glue_margs.type, m->gpo, m->gpe, m->tgpe, glue_margs.refine, 0,
+                                                  m->seed, m->noise, glue_margs.dist_scale, glue_margs.vsm_amax, glue_margs.usw,
+                                                  glue_margs.anchors, glue_margs.weight);
+                }
+        }
+        /* (this thread's view of the device ends here; the context stays in the pool) */
+        glue_dm_free();
+        glue_ctx = NULL; glue_job_ctx = NULL; glue_rows_ctx = NULL; glue_job_msa = NULL; glue_rows_msa = NULL;
+        glue_ct_single = NULL;
+        return NULL;
+}
+
+static void glue_members_free(void)
+{
+        int k;
+        if(glue_members){
+                for(k = 0; k < glue_n_members; k++){
+                        if(glue_members[k].aln){
+                                kalign_free_msa(glue_members[k].aln);
+                        }
+                }
+                MFREE(glue_members);
+        }
+        glue_members = NULL;
+        glue_n_members = 0;
+}
+
+/* the member the reference's loop asks for next, if it was run ahead: the finished alignment goes into `msa` */
+static int glue_member_take(struct msa* msa, float gpo, float gpe, float tgpe, int refine, uint64_t seed, float noise, int realign)
+{
+        int k;
+        if(!glue_members || refine != glue_margs.refine || realign != glue_margs.realign){
+                return 0;
+        }
+        for(k = 0; k < glue_n_members; k++){
+                struct glue_member* m = &glue_members[k];
+                if(m->aln && m->rc == OK && m->gpo == gpo && m->gpe == gpe && m->tgpe == tgpe && (realign > 0 || (m->seed == seed && m->noise == noise))
+                   && m->aln->numseq == msa->numseq){
+                        struct msa tmp = *msa;           /* `msa` is the reference's fresh deep copy of the same input: trade contents */
+                        *msa = *m->aln;
+                        *m->aln = tmp;
+                        kalign_free_msa(m->aln);
+                        m->aln = NULL;
+                        GLUE_COUNT(GLUE_MEMBER_AHEAD);
+                        return 1;
+                }
+        }
+        return 0;
+}
+
+int kalign_amd_member_run_seeded(struct msa* msa, int n_threads, int type, float gpo, float gpe, float tgpe, int refine, int adaptive_budget,
+                                 uint64_t tree_seed, float tree_noise, float dist_scale, float vsm_amax, float use_seq_weights,
+                                 int consistency_anchors, float consistency_weight)
+{
+        if(!adaptive_budget && glue_member_take(msa, gpo, gpe, tgpe, refine, tree_seed, tree_noise, 0)){
+                return OK;
+        }
+        return kalign_run_seeded(msa, n_threads, type, gpo, gpe, tgpe, refine, adaptive_budget, tree_seed, tree_noise, dist_scale, vsm_amax,
+                                 use_seq_weights, consistency_anchors, consistency_weight);
+}
+
+int kalign_amd_member_run_realign(struct msa* msa, int n_threads, int type, float gpo, float gpe, float tgpe, int refine, int adaptive_budget,
+                                  float dist_scale, float vsm_amax, int realign_iterations, float use_seq_weights,
+                                  int consistency_anchors, float consistency_weight)
+{
+        if(!adaptive_budget && glue_member_take(msa, gpo, gpe, tgpe, refine, 0, 0.0f, realign_iterations)){
+                return OK;
+        }
+        return kalign_run_realign(msa, n_threads, type, gpo, gpe, tgpe, refine, adaptive_budget, dist_scale, vsm_amax, realign_iterations,
+                                  use_seq_weights, consistency_anchors, consistency_weight);
+}
+
+int kalign_ensemble(struct msa* msa, int n_threads, int type, int n_runs, float gpo, float gpe, float tgpe, uint64_t seed, int min_support,
+                    const char* save_poar_path, int refine, float dist_scale, float vsm_amax, int realign, float use_seq_weights,
+                    int consistency_anchors, float consistency_weight)
+{
+        struct aln_param* ap = NULL;
+        pthread_t th[GLUE_MAX_MEMBERS];
+        struct glue_slot_job jobs[GLUE_MAX_MEMBERS];
+        const char* w = getenv("KALIGN_AMD_GLUE_WORLD");
+        const char* d = getenv("KALIGN_AMD_DEVICES");
+        int slots = 0, shared = 0, started = 0;
+        int k, rc;
+        if(w && atoi(w) > 1){
+                slots = atoi(w);
+                shared = 1;
+        }else{
+                slots = d ? atoi(d) : ka_device_count();
+                if(slots > ka_device_count()){
+                        slots = ka_device_count();
+                }
+        }
+        if(slots > GLUE_MAX_MEMBERS){
+                slots = GLUE_MAX_MEMBERS;
+        }
+        if(slots > n_runs){
+                slots = n_runs;
+        }
+        glue_members_free();
+        if(msa != NULL && n_runs >= 2 && slots >= 2 && glue_context() == OK){
+                /* the prologue of the reference's function (ensemble.c:240-270), so that the members below start from what its loop
+                   would copy: checked input, alphabet known, base penalties resolved.  It runs again inside the reference; both are
+                   idempotent. */
+                float usw = use_seq_weights < 0.0f ? 0.0f : use_seq_weights;
+                float base[3];
+                RUN(kalign_essential_input_check(msa, 0));
+                if(msa->biotype == ALN_BIOTYPE_UNDEF){
+                        RUN(detect_alphabet(msa));
+                }
+                RUN(aln_param_init(&ap, msa->biotype, n_threads, type, gpo, gpe, tgpe));
+                base[0] = ap->gpo; base[1] = ap->gpe; base[2] = ap->tgpe;
+                aln_param_free(ap);
+                ap = NULL;
+                MMALLOC(glue_members, sizeof(struct glue_member) * n_runs);
+                glue_n_members = n_runs;
+                for(k = 0; k < n_runs; k++){
+                        const float* sc = glue_member_scale[k % 12];
+                        struct glue_member* m = &glue_members[k];
+                        m->aln = NULL; m->rc = FAIL;
+                        m->gpo = k ? base[0] * sc[0] : base[0];
+                        m->gpe = k ? base[1] * sc[1] : base[1];
+                        m->tgpe = k ? base[2] * sc[2] : base[2];
+                        m->seed = k ? seed + (uint64_t)k : 0;
+                        m->noise = k ? sc[3] : 0.0f;
+                }
+                for(k = 0; k < n_runs; k++){
+                        RUN(msa_cpy(&glue_members[k].aln, msa));
+                        glue_members[k].aln->quiet = 1;
+                }
+                glue_margs.n_threads = n_threads; glue_margs.type = type; glue_margs.refine = refine; glue_margs.realign = realign;
+                glue_margs.anchors = consistency_anchors; glue_margs.dist_scale = dist_scale; glue_margs.vsm_amax = vsm_amax;
+                glue_margs.usw = usw; glue_margs.weight = consistency_weight;
+                for(k = 0; k < slots; k++){
+                        jobs[k].slot = k; jobs[k].n_slots = slots; jobs[k].device = shared ? 0 : k; jobs[k].shared = shared;
+                        if(pthread_create(&th[k], NULL, glue_member_thread, &jobs[k]) != 0){
+                                break;
+                        }
+                        started++;
+                }
+                for(k = 0; k < started; k++){
+                        pthread_join(th[k], NULL);
+                }
+                /* (members of a slot whose thread did not start, or that failed, stay with rc != OK: the reference's loop runs them) */
+                GLUE_COUNT(GLUE_ENSEMBLE_MULTI);
+        }
+        rc = kalign_ref_kalign_ensemble(msa, n_threads, type, n_runs, gpo, gpe, tgpe, seed, min_support, save_poar_path, refine, dist_scale, vsm_amax,
+                                        realign, use_seq_weights, consistency_anchors, consistency_weight);
+        glue_members_free();
+        return rc;
+ERROR:
+        if(ap){
+                aln_param_free(ap);
+        }
+        glue_members_free();
         return FAIL;
 }

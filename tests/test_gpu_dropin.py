@@ -210,7 +210,8 @@ def test_library_kalign_run_with_refinement(tmp_path, refine):
 # cons_multi counters), the single-device forms of those seams must NOT have run, and the FASTA must be the reference's.
 MULTI_CASES = [("BB11001.tfa", []), ("BB11001.tfa", ["--fast"]), ("BB30014.tfa", []), ("BB30014.tfa", ["--fast"]),
                ("BB12006.tfa", []), ("BB12006.tfa", ["--fast", "--realign", "2"]), ("BB11001.tfa", ["--ensemble=3"]),
-               ("BB30014.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "confident", "--realign", "1"])]
+               ("BB30014.tfa", ["--refine", "all"]), ("BB30014.tfa", ["--refine", "confident", "--realign", "1"]),
+               ("BB11001.tfa", ["--ensemble=8"]), ("BB11001.tfa", ["--precise"]), ("BB30014.tfa", ["--ensemble=5", "--fast"])]
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -224,7 +225,16 @@ def test_cli_with_several_ranks_under_the_dropin(tmp_path, name, flags, world):
     realign = int(flags[flags.index("--realign") + 1]) if "--realign" in flags else 0
     ens = [f for f in flags if f.startswith("--ensemble=")]
     members = int(ens[0].split("=")[1]) if ens else 1
-    assert c["tree_multi"] >= members * (1 + realign) and c["tree"] == 0, c
+    precise = "--precise" in flags
+    if precise:                                               # ensemble of 3 + one realignment (src/run_kalign.c:375-383)
+        members, realign = 3, 1
+    if members > 1:
+        # round 5: the members of an ensemble run side by side, member k on device (here: context) k mod G, each through the
+        # single-device seams on its own thread (kalign_ensemble in the glue); the reference's loop then takes them over
+        assert c["ensemble_multi"] == 1 and c["member_ahead"] == members, c
+        assert c["tree"] >= members * (1 + realign), c
+    else:
+        assert c["tree_multi"] >= members * (1 + realign) and c["tree"] == 0, c
     if "--fast" not in flags and members == 1:
         assert c["cons_multi"] >= 1 and c["cons"] == 0 and c["cons_ref"] == 0, c
     # round 5: after a sharded run rank 0's context takes the alignment over (ka_multi_adopt) -- the stages behind the
