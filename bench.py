@@ -164,6 +164,32 @@ def roofline_of(res, key, workload=None):
             "avg_launch_ms": res["kern_ms"] / max(res["n_launch"], 1), "kernel_ms_per_step": res["kern_ms"]}
 
 
+# VALU instructions per 128-cell wavefront step of the strips (ISA listings, DESIGN.md sections 4, 4f, 7): profile-profile 78 (20
+# residues, helper-wave strips; 100 in ka_strip), seq-profile 36, seq-seq 31.5 -- and Hirschberg executes ~2.06 x the useful cells
+# of a task in the tree kernels (1.6 x in the pair batch, which takes rows over from the parent's pass).
+VALU_PER_STEP = {0: 31.5, 1: 36.0, 2: 78.0}
+EXECUTED_PER_USEFUL = 2.06
+ISSUE_PER_S = 256 * 4 * 2.4e9 / 4.0                                   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles
+
+
+def roofline_valu(recs, gcups, copies=1):
+    """The roofline that binds this path (at 200 GCUPS the task mix still moves only 20 % of the HBM peak): VALU
+    issue.  `peak` = useful cells per second if every SIMD issued strip steps back to back at full lane occupancy, for THIS task mix:
+    sum over kinds of useful cells x 2.06 executed per useful x instructions per cell.  What separates `achieved` from it: lanes
+    idle in partial strips and at the ends of a pass, the recursion's barriers and meetups, path coding and merges, and -- for one
+    tree -- the dependency chain of the guide tree."""
+    cells = [0.0, 0.0, 0.0]
+    for r in recs:
+        cells[r.kind] += float(r.len_a) * r.len_b
+    instr = sum(c * EXECUTED_PER_USEFUL * VALU_PER_STEP[k] / 128.0 for k, c in enumerate(cells))
+    total = sum(cells)
+    peak = total / (instr / ISSUE_PER_S) / 1e9
+    return {"bound": "valu_issue", "achieved": gcups, "peak": peak, "unit": "GCUPS", "frac": gcups / peak,
+            "executed_cells_per_useful_cell": EXECUTED_PER_USEFUL,
+            "valu_instructions_per_128_cell_step": {"seq_seq": VALU_PER_STEP[0], "seq_profile": VALU_PER_STEP[1], "profile_profile": VALU_PER_STEP[2]},
+            "useful_cells_by_kind": {"seq_seq": cells[0] * copies, "seq_profile": cells[1] * copies, "profile_profile": cells[2] * copies}}
+
+
 def workload_name(job, res):
     kinds = np.bincount([r.kind for r in res["recs"]], minlength=3)
     return ("%d %s seqs x ~%d (DSSim), --fast mode, the reference's k-means guide tree; whole tree per step: %d seq-seq + %d "
@@ -638,6 +664,66 @@ def c4_single_gpu_leg(ctx, steps=3):
     return out
 
 
+# kalign_ensemble's member table (ensemble.c:32-45): (gpo, gpe, tgpe) multipliers and the tree-noise sigma of member k mod 12
+ENSEMBLE_MEMBERS = [(1.0, 1.0, 1.0, 0.0), (0.5, 1.5, 0.8, 0.20), (1.5, 0.5, 1.2, 0.20), (0.7, 0.7, 0.5, 0.25), (1.4, 1.4, 1.5, 0.25),
+                    (0.8, 1.2, 1.0, 0.30), (1.3, 0.8, 0.7, 0.30), (0.6, 1.0, 1.3, 0.15), (1.0, 0.6, 0.6, 0.15), (1.8, 1.0, 1.0, 0.35),
+                    (1.0, 1.8, 1.8, 0.35), (0.4, 0.4, 0.3, 0.20)]
+
+
+def c5_ensemble_leg(local_rank, n_members=8, nseq=2048, length=300):
+    """BASELINE config 5 on ONE GPU: `--precise --ensemble 8` on 2048 x ~300 -- eight complete members (noisy guide tree, 5-anchor
+    consistency, task tree, rows, one realignment pass on the UPGMA tree of the rows: kalign_run_realign, aln_wrap.c:361-527), each
+    with its own gap penalties (ensemble.c:32-76).  Members are independent: no collective.  Measured one after the other on one
+    context, and side by side on eight contexts (eight host threads; what the drop-in's kalign_ensemble does with one context per
+    device on a node -- here the contexts share the one GPU, i.e. the GPU is given eight members' worth of independent work)."""
+    import threading
+    import kalign_amd
+    from kalign_amd import guide, dist
+    inp = workload_letters(nseq, length, False, 5)
+    order = sorted(range(len(inp)), key=lambda i: (-len(inp[i]), i))
+    seqs = [inp[i] for i in order]
+    tcodes, codes = guide.encode_tree(seqs, dna=False), guide.encode(seqs, dna=False)
+    subm, scal = scoring(False)
+    rng = np.random.default_rng(7)
+    members = []
+    for k in range(n_members):
+        g, e, t, sigma = ENSEMBLE_MEMBERS[k % 12]
+        sc = np.array(scal, np.float32).copy()
+        sc[0], sc[1], sc[2] = scal[0] * g, scal[1] * e, scal[2] * t
+        members.append({"scal": sc, "dm_scale": None if not k else np.maximum(rng.normal(1.0, sigma, (len(seqs), min(32, len(seqs)))), 0.1).astype(np.float32)})
+    lens = np.array([len(c) for c in codes], np.int64)
+    ctxs = [kalign_amd.Context(local_rank, shared=True) for _ in range(n_members)]
+    runs = [dist.member_on_context(c, tcodes, codes, seqs, subm, n_anchors=5, weight=2.0, n_threads=max(host_threads() // n_members, 1), realign=1) for c in ctxs]
+    cells = [0.0] * n_members
+
+    pair = 5.0 * float(lens.sum()) * float(lens.mean())           # the N x 5 seq-seq batch (anchors are about as long as the rest)
+    try:
+        for k in range(n_members):                                 # warm-up (allocations) + the cells of every member
+            runs[k](members[k])
+            cells[k] = 2.0 * float(ctxs[k].tree_cells() or 0.0) + pair
+        t0 = time.perf_counter()
+        for k in range(n_members):
+            runs[0](members[k])
+        serial = time.perf_counter() - t0
+        th = [threading.Thread(target=runs[k], args=(members[k],)) for k in range(n_members)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        side = time.perf_counter() - t0
+    finally:
+        for c in ctxs:
+            c.close()
+    total = float(sum(cells))
+    return {"workload": "%d ensemble members (`--precise --ensemble %d`: 5 anchors, one realignment pass) on %d protein seqs x ~%d, one GPU" % (n_members, n_members, nseq, length),
+            "members": n_members, "useful_cells": total,
+            "ms_one_after_the_other": serial * 1e3, "gcups_one_after_the_other": total / serial / 1e9,
+            "ms_side_by_side": side * 1e3, "gcups_side_by_side": total / side / 1e9,
+            "note": "guide trees (distances on the device, bisection / UPGMA on the host) are inside these times; the consensus stage (POAR, host) is not; "
+                    "useful cells = 2 x the first tree's (the realignment pass aligns the same sequences again) + the N x 5 seq-seq batch"}
+
+
 def api_bisect():
     from kalign_amd import api
     return api.guide_last_bisect()
@@ -680,6 +766,7 @@ def sharding_projection(ctx, job, subm, scal, lens, cons_ms, worlds=(2, 4, 8)):
         for i, r in enumerate(recs):
             if i not in top:
                 sub[run_rank[i]] = max(sub[run_rank[i]], chain[r.c])
+        chain_ms = float(sub.max())                             # the longest dependency chain inside any rank's subtrees
         sub = np.maximum(sub, work / concurrency)
         done = {}
         for i, r in enumerate(recs):                             # (task order = dependency order)
@@ -693,7 +780,7 @@ def sharding_projection(ctx, job, subm, scal, lens, cons_ms, worlds=(2, 4, 8)):
         tree_ms = done[recs[-1].c]
         cons = cons_ms / w + table_mb / 1e3 / 100.0 * 1e3 * (w - 1) / w
         gather_ms = 0.3
-        out["n%d" % w] = {"consistency_ms": cons, "subtree_ms": float(sub.max()), "top_ms": float(tree_ms - sub.max()), "gather_ms": gather_ms,
+        out["n%d" % w] = {"consistency_ms": cons, "subtree_ms": float(sub.max()), "subtree_chain_ms": chain_ms, "top_ms": float(tree_ms - sub.max()), "gather_ms": gather_ms,
                           "ms_per_step": cons + tree_ms + gather_ms,
                           "speedup_vs_one_gpu": (cons_ms + kern_ms) / (cons + tree_ms + gather_ms)}
     ctx.tree_upload(job["codes"], job["tasks"], subm, scal, job["seq_distances"])
@@ -710,11 +797,14 @@ def main():
     ap.add_argument("--dna", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline line only (profiling runs)")
+    ap.add_argument("--quick", action="store_true", help="= --no-legs --no-cpu: the headline line in seconds (profiling iterations)")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
     ap.add_argument("--scale-workload", action="store_true", help="N > 1: shard --nseq x --len instead of C4 (tests)")
     ap.add_argument("--scale-fast", action="store_true", help="N > 1: --fast mode instead of the default mode")
     args = ap.parse_args()
+    if args.quick:
+        args.no_legs = args.no_cpu = True
 
     import torch
     import kalign_amd
@@ -764,6 +854,7 @@ def main():
             "gcups_profile_profile_lower_bound": pp_share(res) * cells * args.steps / elapsed / 1e9,
         },
         "roofline": roofline_of(res, key, workload_name(job, res)),
+        "roofline_valu": roofline_valu(res["recs"], cells * args.steps / elapsed / 1e9),
     }
     out["config"]["gcups_profile_profile"] = pp_rate_leg(ctx, job, subm, scal)
     if not args.no_legs:
@@ -774,6 +865,7 @@ def main():
         out["value_survey_8d_bracket"] = out["t_dp_with_transfers"]["gcups"]
         out["ms_per_step_survey_8d_bracket"] = out["t_dp_with_transfers"]["ms"]
         out["saturation"] = saturation_leg(job, subm, scal, local_rank, cells)
+        out["saturation"]["roofline_valu"] = roofline_valu(res["recs"], out["saturation"]["gcups_saturated"], out["saturation"]["at_trees_in_flight"])
         out["default_mode"] = default_mode_leg(ctx, job["codes"], job["tasks"], subm, scal, job["seq_distances"], args)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(job["codes"], job["tasks"], job["seq_distances"], args.dna, cells, gpu_gaps=res["gaps"])
@@ -792,6 +884,7 @@ def main():
             out["c3_4096x2000_dna"], _ = secondary_tree_leg(ctx, "c3_dna_4096x2000", 4096, 2000, True, args, steps=3, warmup=1)
         if not args.no_c4:
             out["c4_single_gpu"] = c4_single_gpu_leg(ctx)
+            out["c5_ensemble8_2048x300"] = c5_ensemble_leg(local_rank)
     print(json.dumps(out))
     ctx.close()
 

@@ -30,7 +30,6 @@ extern "C" void ka_unit6_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 extern "C" void ka_unit7_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int nqueue, hipStream_t stream);
 extern "C" void ka_unit8_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
 extern "C" void ka_unit9_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
-extern "C" long long ka_scratch_bytes_host_nb(long long la, long long lb, long long cons_maxlen, int nb);
 static bool ka_cons_big(const KaTreeDev* D) { return D->cons_K > KA_NB - 1; }
 // kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
 static void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
@@ -1913,7 +1912,7 @@ extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float we
         cons_part_seqs(c, part, nparts, &part_lo, &part_hi);
         // the reference silently declines in these cases (anchor_consistency.c:206-217)
         if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
-        if (n_anchors > KA_NB_BIG - 1) return fail("this build carries at most 10 consistency anchors per DP row");
+        if (n_anchors > KA_CONS_MAX_ANCHORS) return fail("this build takes at most 32 consistency anchors (KA_CONS_MAX_ANCHORS)");
         // One table per alignment.  A forest job holds several: every tree selects its own anchors among its own
         // sequences (in ascending index order = that alignment's own order); map k of a sequence is always against
         // anchor k of ITS tree, so the kernels need no notion of trees.
@@ -2611,7 +2610,11 @@ static int dist_tree_attempt(ka_dist* d, int* status, int* grow)
                                 HIPCHK(hipStreamSynchronize(c->stream));
                                 int plen = d->h_head[0];
                                 long long po; memcpy(&po, d->h_head + 2, sizeof(po));
+                                const bool missing = d->h_head[8] == 0 && !stop && (plen < 1 || po < 0);
                                 if (stop || d->h_head[8] != 0 || plen < 1 || po < 0) { plen = 0; stop = true; }   // (its status comes from the device error word below)
+                                // a profile that was never made although no kernel of this rank reported anything (a bug, not an arena to grow):
+                                // this rank says so -- the receiver reports "repeat", and repeating cannot cure it
+                                if (missing) { *status = 2; fail("sharded tree: the profile of node " + std::to_string(m.child) + " was never made on the rank that owns it"); }
                                 d->h_head[12] = plen;
                                 HIPCHK(hipMemcpyAsync(d->d_hdr.p, d->h_head + 12, sizeof(int), hipMemcpyHostToDevice, c->stream));
                                 // (plain stream-ordered point-to-point operations, matched in order with the receiver's: every rank
@@ -2670,7 +2673,14 @@ static int dist_tree_attempt(ka_dist* d, int* status, int* grow)
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy(&err, c->d_error.p, sizeof(int), hipMemcpyDeviceToHost));
         if (err >= 1 && err <= 4) { *status = std::max(*status, 1); *grow |= (err == 1) ? 1 : (err == 2 ? 2 : (err == 3 ? 4 : 8)); }
-        else if (err != 0) { *status = 2; fail(err == 5 ? "device watchdog: a strip pipeline stopped making progress" : "device watchdog: a wait between workgroups never completed"); }
+        else if (err != 0) {
+                // (the device's error words, ka_device.h: 5 / 6 the two watchdogs, 7 the vote table of a profile that outgrew its LDS slot)
+                *status = 2;
+                fail(err == 5 ? "device watchdog: a strip pipeline stopped making progress"
+                   : err == 6 ? "device watchdog: a wait between workgroups never completed"
+                   : err == 7 ? "anchor consistency: a vote table did not fit its LDS slot"
+                   : "device error " + std::to_string(err));
+        }
         (void)n_tasks;
         return KA_OK;
 }

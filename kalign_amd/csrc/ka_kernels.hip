@@ -249,7 +249,6 @@ extern "C" void ka_unit6_launch(const KaTreeDev* D, const int2* blocks_dev, int 
         if (ka_optin(ka_task_kernel_cons_big, KA_LDS_TOTAL, &done) != hipSuccess) return;
         hipLaunchKernelGGL(ka_task_kernel_cons_big, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
 }
-extern "C" long long ka_scratch_bytes_host_nb(long long la, long long lb, long long cons_maxlen, int nb) { return ka_scratch_bytes(la, lb, cons_maxlen, 1, false, false, nb); }
 #endif
 
 #if KA_UNIT == 7

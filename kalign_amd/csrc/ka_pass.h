@@ -123,14 +123,47 @@ __device__ __forceinline__ int ka_strips_of(int nrows, int srows) { return nrows
 // NB > 0: anchor-consistency build -- every DP row carries NB (column, value) bonus entries with distinct
 // columns (ka_cons_prepare); the cell at s-index j adds the value of the entry whose column is j, which
 // is what the reference's dense `pa += consistency[i*stride + j]` adds (aln_seqseq.c:83-85,199-201).
+//
+// NB > KA_NB (round 5: the kernels for more than five anchors): STREAM -- the row's entries are not held in registers but walked.  They
+// lie sorted by column in the row's slice of S.ent (ka_cons_entries: [1] = (INT_MIN, count), [2 .. count + 1] the entries ascending,
+// [count + 2] = (INT_MAX, 0), pads at [0] and [count + 3]); a lane's column only ever moves one way during a pass, so it keeps the
+// entry it will meet next (and the one after, already fetched: the load of a new one is a trip to L2 whose latency then hides behind a
+// step) and advances past the columns it has left behind.  Eight registers per DP row for any number of anchors.
 template <int NB>
 struct KaBonus {
-        int col[NB > 0 ? NB : 1];
-        float val[NB > 0 ? NB : 1];
-        __device__ __forceinline__ void load(const int2* ent, int row)
+        static constexpr bool STREAM = NB > KA_NB;
+        int col[(NB > 0 && !STREAM) ? NB : 1];
+        float val[(NB > 0 && !STREAM) ? NB : 1];
+        const int2* sp;                                  // STREAM: the entry after `n*` (the next one to fetch is sp + sstep)
+        int sstep, ccol, ncol;
+        float cval, nval;
+        __device__ __forceinline__ void load(const int2* ent, int row, int dir = KA_FWD)
         {
+                if constexpr (STREAM) {
+                        const int2* e = ent + (long long)row * NB;
+                        const int cnt = e[1].y;
+                        sstep = (dir == KA_FWD) ? 1 : -1;
+                        const int2* c = (dir == KA_FWD) ? e + 2 : e + 1 + cnt;       // first entry in walking order (a sentinel when there is none)
+                        const int2 x = c[0], y = c[sstep];
+                        ccol = x.x; cval = __int_as_float(x.y); ncol = y.x; nval = __int_as_float(y.y);
+                        sp = c + sstep;
+                        return;
+                }
 #pragma unroll
                 for (int e = 0; e < NB; ++e) { const int2 x = ent[(long long)row * NB + e]; col[e] = x.x; val[e] = __int_as_float(x.y); }
+        }
+        // STREAM: the value of the entry at column j, after leaving the entries behind j behind.  (A lane outside its column range asks
+        // for columns before the window -- no advance -- or beyond it -- it runs into the sentinel; what it gets is never used.)
+        __device__ __forceinline__ float at_stream(int j)
+        {
+                while (sstep > 0 ? (ccol < j) : (ccol > j)) {
+                        ccol = ncol; cval = nval;
+                        // (never past the pads: an advance happens only while ccol is not yet the sentinel the walk ends on)
+                        sp += sstep;
+                        const int2 y = *sp;
+                        ncol = y.x; nval = __int_as_float(y.y);
+                }
+                return ccol == j ? cval : 0.0f;
         }
         // EDGE = false: the wrap-around entry (slot NB-1, column Lb) is left out -- it can only match in the last column
         // of a pass, which steady-state steps never are
@@ -139,8 +172,9 @@ struct KaBonus {
         // (gfx950): 14 s_nop in the 117-instruction steady step of the default-mode strip.  Here every select reads a mask
         // written five instructions earlier.  (KA_BONUS_ASM=0: the plain form.)
         template <bool EDGE>
-        __device__ __forceinline__ float at(int j) const
+        __device__ __forceinline__ float at(int j)
         {
+                if constexpr (STREAM) return at_stream(j);
                 float b = 0.0f;
                 constexpr int N = EDGE ? NB : NB - 1;
                 int e0 = 0;
@@ -366,7 +400,7 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
         }
 
         KaBonus<NB> bonA, bonB;
-        if (NB) { bonA.load(S.ent, iA); if (Q == 2) bonB.load(S.ent, iB); }
+        if (NB) { bonA.load(S.ent, iA, dir); if (Q == 2) bonB.load(S.ent, iB, dir); }
 
         // sequence columns: the three column gap terms are task constants.  Read them from the LDS-resident
         // TaskShared ONCE -- inside the step the compiler re-loads them (ds_read + s_waitcnt) every step.
@@ -1017,7 +1051,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
         }
 
         KaBonus<NB> bonA, bonB;
-        if (NB) { bonA.load(S.ent, min(max(iA, 0), S.La - 1)); bonB.load(S.ent, min(max(iB, 0), S.La - 1)); }
+        if (NB) { bonA.load(S.ent, min(max(iA, 0), S.La - 1), dir); bonB.load(S.ent, min(max(iB, 0), S.La - 1), dir); }
         float kc_open = 0.0f, kc_ext = 0.0f, kc_text = 0.0f;           // see ka_strip
         if (KIND != KA_PP) {
                 col_terms<KIND>(S, 0, kc_open, kc_ext, kc_text);

@@ -492,6 +492,10 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                 int fit = (int)(lds_bytes / (cell * dp_len));             // anchors whose tables fit into LDS together
                 const bool in_lds = fit >= 1;
                 if (!in_lds) fit = nk;
+                // (a sweep keeps the positions of its anchors in registers, KU x NBL of them: five anchors at a time, as in the kernels of
+                // the default mode -- with ten, the round-4 form of the second set, the sweep alone spilled ~1000 VGPRs)
+                constexpr int NBL = (NBK - 1 > 5) ? 5 : NBK - 1;
+                if (fit > NBL) fit = NBL;
                 for (int b0 = 0; b0 < nk; b0 += fit) {
                         const int nb = min(fit, nk - b0);
                         unsigned long long* key = in_lds ? (unsigned long long*)lds : (unsigned long long*)S.vote;
@@ -500,7 +504,7 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
                         for (int x = tid; x < nb * dp_len; x += KA_NT) { key[x] = ~0ull; cnt[x] = 0u; if (wide) agr[x] = 0u; }
                         __syncthreads();
                         for (int sweep = 0; sweep < 2; ++sweep) {
-                                ka_vote_sweep<NBK - 1>(D, members, 0, nmem, sweep, key, cnt, agr, wide, in_lds, dp_len, nb, KS(b0), half);
+                                ka_vote_sweep<NBL>(D, members, 0, nmem, sweep, key, cnt, agr, wide, in_lds, dp_len, nb, KS(b0), half);
                                 __syncthreads();
                         }
                         for (int x = tid; x < nb * dp_len; x += KA_NT) {
@@ -565,9 +569,45 @@ __device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
                         else { mc[cnt] = bj; mv[cnt] = 0.0f + val; ++cnt; }
                 }
                 int2* e = S.ent + (long long)i * NBK;
-                for (int m = 0; m < NBK - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
+                if constexpr (KaBonus<NBK>::STREAM) {
+                        // the streamed layout (KaBonus::STREAM): [1] = (INT_MIN, count), the entries from [2] on -- sorted below, once
+                        // the wrap-around entry has joined them
+                        e[1] = make_int2((int)0x80000000, cnt);
+                        for (int m = 0; m < cnt; ++m) e[2 + m] = make_int2(mc[m], __float_as_int(mv[m]));
+                } else {
+                        for (int m = 0; m < NBK - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
+                }
         }
         __syncthreads();
+        if constexpr (KaBonus<NBK>::STREAM) {
+                // the wrap-around entry of row i -- what row i + 1 holds at column 0 (see above) -- first into the pad slot [0] (the rows
+                // still read each other's unsorted lists), then, behind a barrier, into the list, which is sorted by column and closed
+                for (int i = tid; i < rows; i += KA_NT) {
+                        int2 w = make_int2(-1, 0);
+                        if (i + 1 < rows) {
+                                const int2* nx = S.ent + (long long)(i + 1) * NBK;
+                                const int nc = nx[1].y;
+                                for (int m = 0; m < nc; ++m) if (nx[2 + m].x == 0) w = make_int2(cols, nx[2 + m].y);
+                        }
+                        S.ent[(long long)i * NBK] = w;
+                }
+                __syncthreads();
+                for (int i = tid; i < rows; i += KA_NT) {
+                        int2* e = S.ent + (long long)i * NBK;
+                        int cnt = e[1].y;
+                        if (e[0].x >= 0) { e[2 + cnt] = e[0]; ++cnt; }
+                        for (int m = 1; m < cnt; ++m) {                           // insertion sort by column (distinct columns, <= K + 1 entries)
+                                const int2 x = e[2 + m];
+                                int q = m - 1;
+                                while (q >= 0 && e[2 + q].x > x.x) { e[2 + q + 1] = e[2 + q]; --q; }
+                                e[2 + q + 1] = x;
+                        }
+                        e[1] = make_int2((int)0x80000000, cnt);
+                        e[2 + cnt] = make_int2(0x7fffffff, 0);
+                }
+                __syncthreads();
+                return;
+        }
         for (int i = tid; i < rows; i += KA_NT) {
                 int2 w = make_int2(-1, 0);
                 if (i + 1 < rows) {

@@ -174,7 +174,7 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
         const int prevA = min(max((dir == KA_FWD) ? recA - 1 : recA + 1, 0), X.R + 1);
 
         KaBonus<NB> bon;
-        if (NB) bon.load(ent, min(max(X.a0 + iA, 0), X.La - 1));
+        if (NB) bon.load(ent, min(max(X.a0 + iA, 0), X.La - 1), dir);
         float oA, eA, tA, orpA;
         float2v p1p[KIND == KA_PP ? (NPAIR > 0 ? NPAIR : 1) : 1];     // the counts of residues (2i, 2i+1)
         float p1last = 0.0f;

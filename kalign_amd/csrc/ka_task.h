@@ -44,7 +44,9 @@ __device__ __host__ inline long long ka_private_bytes(long long la, long long lb
 }
 
 // carve the per-task scratch region (cons_maxlen > 0: the job has a consistency table)
-__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen, bool refine = false, bool rec = false, int nb = KA_NB)
+// nb: bonus entries per DP row (the stride of S.ent: the kernels' NB); kanch: anchors the per-anchor tables are made for (-1: nb - 1 -- the
+// streamed set, KA_NB_BIG, passes the job's own count)
+__device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int cons_maxlen, bool refine = false, bool rec = false, int nb = KA_NB, int kanch = -1)
 {
         const long long n = (long long)la + lb + 8;
         long long o = 0;
@@ -101,7 +103,7 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         S.ent = nullptr; S.apos_r = nullptr; S.conf_r = nullptr; S.apos_c = nullptr; S.conf_c = nullptr; S.invj = nullptr; S.vote = nullptr;
         if (cons_maxlen > 0) {
                 S.ent = (int2*)(base + o);    o += ka_align_up(n * 8 * nb, 16);
-                const long long KM = nb - 1;                         // anchors
+                const long long KM = kanch >= 0 ? kanch : nb - 1;    // anchors
                 S.apos_r = (int*)(base + o);  o += ka_align_up(KM * n * 4, 16);
                 S.conf_r = (float*)(base + o); o += ka_align_up(KM * n * 4, 16);
                 S.apos_c = (int*)(base + o);  o += ka_align_up(KM * n * 4, 16);
@@ -112,8 +114,9 @@ __device__ long long ka_carve(TaskShared& S, char* base, int la, int lb, int con
         return o;
 }
 
-__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1, bool refine = false, bool rec = false, long long nb = KA_NB)
+__device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb, long long cons_maxlen, long long g = 1, bool refine = false, bool rec = false, long long nb = KA_NB, long long kanch = -1)
 {
+        const long long km = kanch >= 0 ? kanch : nb - 1;
         const long long n = la + lb + 8;
         const long long nq = (la < lb ? la : lb) + 20;
         const long long ni = 2 * nq + 2 * (n / KA_STRIP1_ROWS + 2);
@@ -124,7 +127,7 @@ __device__ __host__ inline long long ka_scratch_bytes(long long la, long long lb
         if (g > 1) b += g * ka_private_bytes(la, lb);
         if (refine) b += 3 * ((n * 4 + 15) / 16 * 16) + (n * 24 * 4 + 15) / 16 * 16 + (n * 8 + 15) / 16 * 16 + (ka_inc_bytes(n) + 15) / 16 * 16;
         if (rec && !refine) b += (n * 8 + 15) / 16 * 16;
-        if (cons_maxlen > 0) b += (n * 8 * nb + 15) / 16 * 16 + 4 * (((nb - 1) * n * 4 + 15) / 16 * 16) + ((nb - 1) * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + ((nb - 1) * n * 16 + 15) / 16 * 16;
+        if (cons_maxlen > 0) b += (n * 8 * nb + 15) / 16 * 16 + 4 * ((km * n * 4 + 15) / 16 * 16) + (km * (cons_maxlen + 8) * 4 + 15) / 16 * 16 + (km * n * 16 + 15) / 16 * 16;
         return b;
 }
 
@@ -311,7 +314,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.nrec = 0; }
                 s_dbg = nullptr;
                 if (member == 0) {
-                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff, false, (D.flags & KA_FLAG_EXACT_CONFIDENCE) != 0, NB ? NB : KA_NB);
+                        const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff, false, (D.flags & KA_FLAG_EXACT_CONFIDENCE) != 0, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
                         const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                         if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
                         // an earlier task of this run already failed (arena overflow): its outputs -- possibly this
@@ -330,7 +333,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         if (S.member >= S.G) return 2;                       // surplus workgroup of an over-provisioned cluster
         ka_cluster_sync(S);
         if (S.ctl->fail) return 1;
-        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0, false, S.rec_on != 0, NB ? NB : KA_NB);
+        if (tid == 0) ka_carve(S, D.scratch + S.ctl->scratch_off, S.len_a, S.len_b, NB ? D.cons_maxlen : 0, false, S.rec_on != 0, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
 
         // P1
         ka_build_tss(tss, D.subm, T.soff);
@@ -510,12 +513,12 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.sub_ok = 0; S.rec_on = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
                 S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
-                const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true, false, NB ? NB : KA_NB);
+                const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true, false, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
                 const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                 if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
                 if (__hip_atomic_load(D.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.ctl->fail = 1;
                 S.ctl->scratch_off = (long long)so;
-                if (!S.ctl->fail) ka_carve(S, D.scratch + so, len_a, len_b, NB ? D.cons_maxlen : 0, true, false, NB ? NB : KA_NB);
+                if (!S.ctl->fail) ka_carve(S, D.scratch + so, len_a, len_b, NB ? D.cons_maxlen : 0, true, false, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
         }
         __syncthreads();
         if (S.ctl->fail) return;

@@ -205,7 +205,7 @@ __device__ KA_W_CALL void ka_wstrip(const KaWStripArgs a)
                 }
         }
         KaBonus<NB> bonA, bonB;
-        if (NB) { bonA.load(a.ent, iA); if (Q == 2) bonB.load(a.ent, iB); }
+        if (NB) { bonA.load(a.ent, iA, dir); if (Q == 2) bonB.load(a.ent, iB, dir); }
 
         float cAa = -KA_F, cAga = -KA_F, cAgb = -KA_F;
         float cBa = -KA_F, cBga = -KA_F, cBgb = -KA_F;

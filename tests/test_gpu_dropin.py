@@ -86,6 +86,8 @@ CLI_CASES = [
     ("BB30014.tfa", ["--refine", "all", "--adaptive-budget"]), ("BB12006.tfa", ["--refine", "confident", "--adaptive-budget"]),
     # more than five anchors (round 4): the second set of consistency kernels
     ("BB11001.tfa", ["--consistency", "8"]), ("BB30014.tfa", ["--consistency", "10", "--refine", "all"]), ("BB12006.tfa", ["--consistency", "6", "--realign", "1"]),
+    # round 5: any K up to 32 on the device (the entries of a DP row are walked, not held in registers)
+    ("BB30014.tfa", ["--consistency", "16"]), ("BB30014.tfa", ["--consistency", "32", "--refine", "confident"]),
 ]
 
 
@@ -101,14 +103,14 @@ def test_cli_output_is_byte_identical(tmp_path, name, flags):
 
 
 def test_cli_with_more_anchors_than_the_kernels_carry_takes_the_reference_seams(tmp_path):
-    """`--consistency 12`: the library declines the table (cons_ref), the dispatcher hands the trees to the reference's own
-    create_msa_tree (tree_ref) -- same bytes, no error."""
+    """`--consistency 40` (the device kernels walk up to KA_CONS_MAX_ANCHORS = 32 entries per DP row): the library declines the table
+    (cons_ref), the dispatcher hands the trees to the reference's own create_msa_tree (tree_ref) -- same bytes, no error."""
     from kalign_amd import synth
     inp = str(tmp_path / "in.fa")
-    _write_fasta(inp, synth.dssim(40, 150, dna=False, seed=3))   # (the reference caps the anchors at the number of sequences)
+    _write_fasta(inp, synth.dssim(48, 150, dna=False, seed=3))   # (the reference caps the anchors at the number of sequences)
     c = {}
-    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), "--consistency", "12", counters=c)
-    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), "--consistency", "12")
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), "--consistency", "40", counters=c)
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), "--consistency", "40")
     assert got == want
     assert c["cons_ref"] >= 1 and c["tree_ref"] >= 1 and c["cons"] == 0, c
 

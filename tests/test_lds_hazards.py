@@ -23,6 +23,17 @@ def test_no_use_of_lds_reads_in_flight():
     assert "suspicious uses in total: 0" in r.stdout, tail
 
 
+def test_steady_octets_of_the_helper_wave_strips_carry_no_scratch_access():
+    """tools/check_hot_loops.py on unit 0 (the 8-wave fast-mode task kernel): the steady-state octets of ka_wstrip -- what a pass
+    spends its time in -- have no scratch_load / scratch_store, and the edge forms (which do spill) no more than a known bound."""
+    obj = os.path.join(ROOT, "kalign_amd", "csrc", "build", "ka_kernels_u0.o")
+    if not os.path.exists(obj) or not os.path.exists(LLVM + "llvm-objdump"):
+        pytest.skip("no built kernel object / no llvm-objdump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_hot_loops.py"), obj], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:]
+    assert "scratch-free:" in r.stdout
+
+
 def test_the_checker_sees_a_use_before_the_wait(tmp_path):
     """The analysis itself, on a ten-line kernel with the hazard built in (and the same kernel with the wait in place)."""
     if not os.path.exists("/opt/rocm/bin/hipcc"):

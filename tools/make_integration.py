@@ -18,13 +18,15 @@ SEAMS = [
     ("1e. `finalise_alignment` (`lib/src/msa_op.c:546-576`)", ["finalise_alignment"]),
     ("1f. `compute_aln_pairwise_dist` (`lib/src/aln_apair_dist.c:9-86`) and `build_tree_from_pairwise` (`lib/src/bisectingKmeans.c:1150-1200`)",
      ["compute_aln_pairwise_dist", "build_tree_from_pairwise"]),
+    ("1g. The member loop of `kalign_ensemble` (`lib/src/ensemble.c:286-339`): members side by side, one device each",
+     ["glue_member_thread", "glue_member_take", "kalign_amd_member_run_seeded", "kalign_amd_member_run_realign", "kalign_ensemble"]),
 ]
 
 
 def function_text(src, name):
     """the definition of `name` (not a prototype) with the comment block directly above it"""
     m = None
-    for m in re.finditer(r"^(?:static )?int %s\([^;{]*\)\n\{" % re.escape(name), src, re.M):
+    for m in re.finditer(r"^(?:static )?(?:int|void\*?) %s\([^;{]*\)\n\{" % re.escape(name), src, re.M):
         break
     assert m, name
     start = m.start()
