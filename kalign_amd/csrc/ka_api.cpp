@@ -99,6 +99,8 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         for (int k = 0; k < 2; k++) { if (c->pin[k]) (void)hipHostFree(c->pin[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
         if (c->h_trace) (void)hipHostFree(c->h_trace);
         for (hipEvent_t e : c->launch_ev) (void)hipEventDestroy(e);
+        if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
+        for (hipEvent_t e : { c->e_fork, c->e_chain }) if (e) (void)hipEventDestroy(e);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
@@ -207,6 +209,7 @@ KaTreeDev tree_dev(ka_ctx* c)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
         D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse;
+        D.overlap = c->overlap_plan ? 1 : 0;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
@@ -240,11 +243,11 @@ void build_blocks(const ka_ctx* c, const std::vector<int>& L, std::vector<int2>&
 }
 
 // KA_LAUNCH_EV: an event behind launch number c->n_launches of the run (measurements; ka_tree_launch_ms)
-static int mark_launch(ka_ctx* c)
+static int mark_launch(ka_ctx* c, hipStream_t s = nullptr)
 {
         if (!c->env.launch_ev) return KA_OK;
         while ((int)c->launch_ev.size() < c->n_launches) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->launch_ev.push_back(e); }
-        HIPCHK(hipEventRecord(c->launch_ev[c->n_launches - 1], c->stream));
+        HIPCHK(hipEventRecord(c->launch_ev[c->n_launches - 1], s ? s : c->stream));
         return KA_OK;
 }
 
@@ -259,10 +262,24 @@ int tree_launch(ka_ctx* c, bool reset)
         c->partial = !reset;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         c->n_launches = 0;
+        // Overlapping launches (KA_OVERLAP, round 5): the chained launch goes out on a stream of its own (lowest priority) together with
+        // the queued launch instead of behind it.  Its workgroups want a CU each: they become resident as the queue's workgroups leave,
+        // and its tasks wait for the done flags of whatever the queued launch makes for them (KaTreeDev::overlap) -- the queue's last,
+        // partly filled round of tasks and the first level of the chain share the GPU.  The queue never waits for the chain, so
+        // whatever the dispatcher does first, both finish.
+        const bool ov = c->overlap_plan && reset && !c->refine_mode && c->queue_first >= 0 && c->chain_level > c->queue_first;
+        if (ov && !c->s_chain) {
+                int lo = 0, hi = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));            // (lo: the numerically greatest = least urgent)
+                HIPCHK(hipStreamCreateWithPriority(&c->s_chain, hipStreamNonBlocking, lo));
+                HIPCHK(hipEventCreateWithFlags(&c->e_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&c->e_chain, hipEventDisableTiming));
+        }
         for (size_t L = 0; L < c->plan_levels.size(); L++) {
                 const int n = (int)c->plan_levels[L].size();
                 if (!n) continue;
-                if (L || !reset) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
+                // (the scratch arena starts again with every launch -- the chained launch that overlaps the queue shares the queue's)
+                if ((L || !reset) && !(ov && (int)L == c->chain_level)) HIPCHK(hipMemsetAsync(c->d_counters.p + 1, 0, sizeof(unsigned long long), c->stream));
                 if (!reset && (int)L == c->queue_first) HIPCHK(hipMemsetAsync(c->d_counters.p + 4, 0, sizeof(unsigned long long), c->stream));   // (the queue's head)
                 if (c->refine_mode) {
                         // refinement pass: one launch per tree level (see refine_blocks)
@@ -277,6 +294,11 @@ int tree_launch(ka_ctx* c, bool reset)
                         // (more than fit is harmless: a workgroup that starts late finds the rest of the list, or nothing)
                         const int per_cu = c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8);
                         const int nwg = std::min(c->queue_n, per_cu * c->n_cus);
+                        if (ov) {
+                                // (the chain's stream forks here: behind the leaf levels and the counter resets, beside the queue)
+                                HIPCHK(hipEventRecord(c->e_fork, c->stream));
+                                HIPCHK(hipStreamWaitEvent(c->s_chain, c->e_fork, 0));
+                        }
                         if (ka_cons_big(&D)) ka_unit7_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
                         else ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
@@ -285,8 +307,13 @@ int tree_launch(ka_ctx* c, bool reset)
                 }
                 if ((int)L == c->chain_level) {
                         // this level and everything above it: one launch, tasks chained through their join points
-                        ka_launch_task_level(&D, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, c->stream);
-                        c->n_launches++; if (mark_launch(c)) return KA_FAIL;
+                        hipStream_t cs = ov ? c->s_chain : c->stream;
+                        ka_launch_task_level(&D, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, cs);
+                        c->n_launches++; if (mark_launch(c, cs)) return KA_FAIL;
+                        if (cs != c->stream) {
+                                HIPCHK(hipEventRecord(c->e_chain, c->s_chain));
+                                HIPCHK(hipStreamWaitEvent(c->stream, c->e_chain, 0));
+                        }
                         break;
                 }
                 ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->level_lean[L], 0, c->stream);

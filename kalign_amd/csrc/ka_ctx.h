@@ -105,6 +105,7 @@ struct KaEnv {
         int hw = 1;                    // KA_HW: profile-profile strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode)
         int hw_prio = 3;               // KA_HW_PRIO: s_setprio of a strip wave that has a helper (experiments)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
+        int overlap = 1;               // KA_OVERLAP: the chained launch goes out beside the queued launch (a stream of its own, ordered by the tasks' done flags)
         int reuse = 1;                 // KA_REUSE: Hirschberg prefix reuse in the 4-wave kernels (queued levels, seq-seq leaves, pair batch)
         int qw = 4, lw = 4, pw = 2;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
@@ -123,6 +124,7 @@ static inline void read_env(KaEnv& v)
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
         v.reuse = env_int("KA_REUSE", 1);
+        v.overlap = env_int("KA_OVERLAP", 1);
         v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 2);
         for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;
         v.mw = env_int("KA_MW", 1);
@@ -196,6 +198,11 @@ struct ka_ctx {
         std::vector<int> injected;       // nodes whose profile came from ka_tree_set_profile
         std::vector<int> task_level;
         DevBuf<int2> d_blocks_tmp;
+        // overlapping launches (KA_OVERLAP): the chained launch on a stream of its own (lowest priority) beside the queued launch, events to
+        // fork from / join into the context's stream; overlap_plan: the current plan carries the dependencies for it
+        hipStream_t s_chain = nullptr;
+        hipEvent_t e_fork = nullptr, e_chain = nullptr;
+        int overlap_plan = 0;
         int n_launches = 0;
         double cells = 0.0;
         float pair_ms = 0.0f;                        // kernel time of the last ka_pairwise_batch

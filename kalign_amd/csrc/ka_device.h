@@ -22,7 +22,8 @@ struct KaTaskDesc {
         float gap_scale;
         int parent;                    // task that consumes node c (-1: root)
         int chain_need;                // chained launch: how many children of this task run inside the same launch (0: entry task)
-        int qa, qb;                    // queued launch: the tasks of the same launch that produce operands a / b (-1: ready before it starts)
+        int qa, qb;                    // queued launch: the tasks of the same launch that produce operands a / b (-1: ready before it starts);
+                                       // overlapping launches (KaTreeDev::overlap): of ANY launch of the run but the task's own chained launch
         int wait_mult;                 // chained launch: multiplier of the join watchdog (~2 s each), from the estimated DP cells below this task
         int refine;                    // refinement pass, KALIGN_REFINE_CONFIDENT: this edge is refined (confidence at or below the median)
 };
@@ -95,6 +96,8 @@ struct KaTreeDev {
                                        // 2 on with four strips per workgroup (KA_HO in the environment)
         int hw_mode;                   // strips with helper waves (ka_wstrip.h) on levels with at most four items per workgroup: 0 off, 1 on (KA_HW in the environment)
         int reuse;                     // Hirschberg prefix reuse in the 4-wave kernels (KA_REUSE=0: off)
+        int overlap;                   // round 5: the launches of a run go out TOGETHER on streams of their own and order themselves by the tasks' done flags
+                                       // (KaJoin::go): every task sets its flag, every task waits for the flags of the tasks that make its operands (qa / qb)
         int qw, lw;                    // waves per workgroup of the queued launch (KA_QW: 4, 2 or 1) / of the seq-seq leaf levels (KA_LW)
         int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
         int cons_K;                    // anchors

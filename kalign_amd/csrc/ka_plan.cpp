@@ -87,6 +87,7 @@ int plan_launches(ka_ctx* c)
                 // KA_NO_QUEUE=1 keeps one launch per level.
                 for (int t = 0; t < n_tasks; t++) { c->descs[t].qa = -1; c->descs[t].qb = -1; }
                 c->queue_first = -1;
+                c->overlap_plan = 0;
                 if (c->chain_level >= 1 && !c->env.no_queue && !c->env.no_half) {
                         int L0 = 0;
                         while (L0 < c->chain_level) {                       // skip the leading seq-seq levels (lean kernel)
@@ -99,11 +100,25 @@ int plan_launches(ka_ctx* c)
                         if ((int)levels[L0].size() <= c->n_cus) ok = false;   // (the queue's first level must fill the GPU; later ones need not)
                         if (ok) {
                                 c->queue_first = L0;
+                                // Overlapping launches (KA_OVERLAP; whole-tree plans only): the chained launch goes out beside the queued one, and
+                                // its tasks wait for the done flags of what the QUEUE makes for them (qa / qb of a chain task: its operands'
+                                // producers in the queued launch; inside the chain the join points order things as before).
+                                c->overlap_plan = (c->env.overlap > 0 && c->plan_active.empty() && !c->env.no_lean && !c->shared_gpu) ? c->env.overlap : 0;
+                                const int lo = L0;
                                 for (int t = 0; t < n_tasks; t++) {
-                                        if (c->task_level[t] < L0 || c->task_level[t] >= c->chain_level || !act(t)) continue;
+                                        if (c->task_level[t] < L0 || !act(t)) continue;
+                                        // (a task of the chained launch: only what OTHER launches make -- inside the chain the join points order things)
+                                        const bool in_chain = c->task_level[t] >= c->chain_level;
+                                        if (in_chain && !c->overlap_plan) continue;
                                         const int a = abc[3 * t], b = abc[3 * t + 1];
-                                        if (a >= numseq && act(task_of[a]) && c->task_level[task_of[a]] >= L0) c->descs[t].qa = task_of[a];
-                                        if (b >= numseq && act(task_of[b]) && c->task_level[task_of[b]] >= L0) c->descs[t].qb = task_of[b];
+                                        auto dep = [&](int node) -> int {
+                                                if (node < numseq || !act(task_of[node])) return -1;
+                                                const int lv = c->task_level[task_of[node]];
+                                                if (lv < lo || (in_chain && lv >= c->chain_level)) return -1;
+                                                return task_of[node];
+                                        };
+                                        c->descs[t].qa = dep(a);
+                                        c->descs[t].qb = dep(b);
                                 }
                         }
                 }
@@ -136,8 +151,28 @@ int plan_launches(ka_ctx* c)
 
         c->queue_off = (int)c->blocks_flat.size(); c->queue_n = 0;
         if (c->queue_first >= 0) {
-                for (int L = c->queue_first; L < c->chain_level; L++)
-                        for (int t : levels[L]) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
+                // Within a level the tasks with the longest way to the root go first (estimated wavefront steps of the task and of
+                // everything above it, as for the chain's spare workgroups below): what the chained launch waits for longest -- the
+                // spine of a caterpillar tree -- then leaves the queue early instead of wherever the task list put it.  KA_QORDER=0: list order.
+                std::vector<double> qlen(2 * numseq - 1, 0.0), qup(n_tasks, 0.0);
+                if (env_int("KA_QORDER", 1)) {
+                        std::vector<double> lmax(2 * numseq - 1, 0.0), nmem(2 * numseq - 1, 1.0);
+                        for (int i = 0; i < numseq; i++) { lmax[i] = c->lens[i]; qlen[i] = c->lens[i]; }
+                        for (int t = 0; t < n_tasks; t++) {
+                                const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                                lmax[cc] = std::max(lmax[a], lmax[b]); nmem[cc] = nmem[a] + nmem[b];
+                                qlen[cc] = lmax[cc] * (1.0 + 0.1 * std::sqrt(nmem[cc]));
+                        }
+                        for (int t = n_tasks - 1; t >= 0; t--) {               // parents come after their children in the task list
+                                const double la = qlen[abc[3 * t]], lb = qlen[abc[3 * t + 1]];
+                                qup[t] = 2.0 * std::max(la, lb) + std::min(la, lb) + ((act(t) && c->descs[t].parent >= 0) ? qup[c->descs[t].parent] : 0.0);
+                        }
+                }
+                for (int L = c->queue_first; L < c->chain_level; L++) {
+                        std::vector<int> lv(levels[L].begin(), levels[L].end());
+                        std::stable_sort(lv.begin(), lv.end(), [&](int x, int y) { return qup[x] > qup[y]; });
+                        for (int t : lv) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
+                }
         }
         if (c->chain_level >= 0) {
                 // Every task of the chain's first level starts on a single workgroup; clusters form on the way up.
@@ -448,6 +483,8 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (c->chain_level >= 0) scr = scr_level * (long long)std::min(max_level - c->chain_level, 8);
         if (c->max_cluster > 1 && !c->shared_gpu) scr *= 2;          // clusters: every member's private queues and row buffers
         if (c->queue_first >= 0) scr = std::max(scr, scr_level * (long long)(c->chain_level - c->queue_first));
+        // (overlapping launches share the arena without a reset in between: the leaf levels', the queue's and the chain's needs add up)
+        if (c->overlap_plan) scr += scr_level * (long long)(c->chain_level - c->queue_first);
         c->scratch_cap = std::max(c->scratch_cap, scr);
         if (c->test_hooks & KA_DEBUG_SMALL_ARENAS) {
                 // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run

@@ -194,6 +194,20 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
 
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 1);
         if (tid == 0) {
+                if (D.overlap) {
+                        // the launches of this run overlap: the tasks that make this task's operands may still be running -- in another
+                        // kernel, on another stream -- or not have started; they were launched, so they finish whatever this workgroup does
+                        const int dep[2] = { T.qa, T.qb };
+                        for (int k = 0; k < 2; ++k) {
+                                if (dep[k] < 0) continue;
+                                int spins = 0;
+                                while (__hip_atomic_load(&D.join[dep[k]].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                        __builtin_amdgcn_s_sleep(32);
+                                        if (ka_spin_expired(D.error, ++spins, (1 << 21) * max(1, min(D.tasks[dep[k]].wait_mult, 64)), 6, true)) break;
+                                }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
                 // (a chained launch reads what other workgroups of the SAME launch wrote: go past L1 / scalar cache)
                 const int len_a = __hip_atomic_load(&D.node_len[T.a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int len_b = __hip_atomic_load(&D.node_len[T.b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
