@@ -79,7 +79,31 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                         // Helper mode (ka_wstrip.h): every item of the level is dealt statically, at most four per workgroup
                         // (waves 0..3, one per SIMD) -- wave w + 4 serves the strip of wave w.  The same for every workgroup of the
                         // cluster (ntotal, Gw and per are), so both ends of a hand-over between workgroups speak the same protocol.
-                        const bool wmode = HW && KIND == KA_PP && KA_NW == 8 && ntotal <= nslots && per <= KA_NW / 2
+                        // WIDE-SUBTREE LEVEL (round 5).  A window of 65 .. 128 rows used to go one more recursion level as strips before its
+                        // halves were small enough for a wave's LDS region -- the level with the worst lanes-per-strip of the whole task (38-row
+                        // passes: 19 of 64 lanes), and, with eight passes on a workgroup, no helper waves: 88 us for a level that holds 6 % of a
+                        // 618 x 451 task's cells, then 55 us more for the subtrees below it.  When EVERY sub-problem of a level has at most 128
+                        // rows and fits TWO wave regions (its passes then have at most 64 rows: one per lane), the level's pass items are left
+                        // alone and every even wave runs whole subtrees -- its own region and its idle neighbour's; the sub-problems are
+                        // marked like emitted subtrees (this level's meetups skip them, nothing is emitted below).  Decided here, by every wave
+                        // alike, from the level's sub-problem records: the emitting meetups cannot know what else the level will hold.
+                        int wide_n = 0;
+                        // (never the task's top level: its rows stay in HBM -- the record's meetup and score, the tests' row hashes)
+                        if (KA_WIDE_SUB && level >= 1 && KA_NW >= 2 && Gw == 1 && __builtin_amdgcn_readfirstlane(S.sub_ok) != 0 && __builtin_amdgcn_readfirstlane(S.sub_ok) != 2) {
+                                const int ns = __builtin_amdgcn_readfirstlane(cur->nsub);
+                                if (ns >= 1 && ns <= 64) {
+                                        const int two = 2 * __builtin_amdgcn_readfirstlane(S.sub_stride);
+                                        bool fits = true, gains = false;
+                                        if (lane < ns) {
+                                                const KaSub* sq = qc + lane;
+                                                const int rr = sq->enda - sq->starta, cc = sq->endb - sq->startb;
+                                                fits = rr >= 1 && rr <= KA_SUB_WIDEROWS && cc >= 1 && cc < 4096 && ka_sub_bytes(KIND, NRES, rr, cc) <= two;
+                                                gains = sq->pad != KA_SUB_MARK;                  // (it would run as passes)
+                                        }
+                                        if (__ballot(!fits) == 0ull && __ballot(gains) != 0ull) wide_n = ns;
+                                }
+                        }
+                        const bool wmode = !wide_n && HW && KIND == KA_PP && KA_NW == 8 && ntotal <= nslots && per <= KA_NW / 2
                                            && __builtin_amdgcn_readfirstlane(S.hw_ok) != 0
                                            && (__builtin_amdgcn_readfirstlane(S.lvl_srows[level & 1]) == KA_STRIP_ROWS || __builtin_amdgcn_readfirstlane(S.q1_lvl) != 0);
                         // (64-row strips with helper waves only in the per-level experiment, KaTreeDev::q1_mode 4)
@@ -123,7 +147,14 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 }
                                 return;
                         }
+                        int wide_k = wave >> 1;                                 // wide-subtree level: the next sub-problem of this (even) wave
                         while (true) {
+                                int2 item;
+                                if (wide_n) {
+                                        if ((wave & 1) || wide_k >= wide_n) break;
+                                        item = make_int2(wide_k, KA_ITEM_SUBTREE << 16);
+                                        wide_k += KA_NW >> 1;
+                                } else {
                                 // One lane takes the next item, then it is broadcast.  The puller lane is
                                 // compared through an opaque copy: with a plain `lane == 0` the optimiser
                                 // threads this test with the `lane == 0` regions inside ka_strip, splits the
@@ -150,14 +181,17 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                         ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
                                         continue;
                                 }
+                                item = items[it];
+                                }
                                 // everything about the item is wave-uniform: keep it in SGPRs
-                                const int2 item = items[it];
                                 const int subi = __builtin_amdgcn_readfirstlane(item.x);
                                 const int dk = __builtin_amdgcn_readfirstlane(item.y);
                                 const KaSub* sp = qc + subi;
                                 const int dir = dk >> 16, k = dk & 0xffff;
                                 if (dir == KA_ITEM_SUBTREE) {
+                                        // (a wide-subtree level: the wave's region and its idle neighbour's are one area)
                                         ka_subtree<KIND, NRES, NB>(S, *sp, lane, S.sub_base + wave * S.sub_stride, tss);
+                                        if (wide_n && lane == 0) ((KaSub*)sp)->pad = KA_SUB_MARK;
                                         continue;
                                 }
                                 const int sa = __builtin_amdgcn_readfirstlane(sp->starta);

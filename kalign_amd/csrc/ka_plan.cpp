@@ -483,8 +483,9 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         if (c->chain_level >= 0) scr = scr_level * (long long)std::min(max_level - c->chain_level, 8);
         if (c->max_cluster > 1 && !c->shared_gpu) scr *= 2;          // clusters: every member's private queues and row buffers
         if (c->queue_first >= 0) scr = std::max(scr, scr_level * (long long)(c->chain_level - c->queue_first));
-        // (overlapping launches share the arena without a reset in between: the leaf levels', the queue's and the chain's needs add up)
-        if (c->overlap_plan) scr += scr_level * (long long)(c->chain_level - c->queue_first);
+        // (the chained launch that overlaps the queue shares its arena: where the two together outgrow the larger one's estimate the run
+        // reports an overflow, ka_tree_sync doubles the arena and repeats it -- once per job shape; adding the two estimates up asked
+        // for more than the GPU holds on a 16-tree forest)
         c->scratch_cap = std::max(c->scratch_cap, scr);
         if (c->test_hooks & KA_DEBUG_SMALL_ARENAS) {
                 // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run

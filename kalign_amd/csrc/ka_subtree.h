@@ -15,8 +15,14 @@
 // aln_seqseq.c:241-420, aln_controller.c:194-436): the sub-problems of a level are independent given their windows.
 #pragma once
 
-#define KA_SUB_MAXROWS 64
+#define KA_SUB_MAXROWS 64                                       // a subtree in ONE wave region: decided when the sub-problem is emitted (ka_child_is_subtree)
+#define KA_SUB_WIDEROWS 128                                     // ... in TWO regions (round 5): decided per recursion level at run time (ka_run_items)
 #define KA_SUB_NQ 72                                            // queue entries per level: a level has at most one sub-problem per row
+#ifndef KA_WIDE_SUB
+#define KA_WIDE_SUB 0                                           // measured: slower everywhere (profiles/r05_wide_subtree_levels.log) -- the engine below pays ~1300 cycles per step
+#endif
+__device__ __forceinline__ int ka_sub_nq(int R) { return R + 8 > KA_SUB_NQ ? R + 8 : KA_SUB_NQ; }
+__device__ __forceinline__ int ka_sub_rowcells(int R, int C) { return C + 1 + (R > KA_SUB_MAXROWS ? R : KA_SUB_MAXROWS); }   // row-buffer cells of a level: one per column and sub-problem
 
 // compact sub-problem: window relative to the subtree root's (starta, startb); boundary states as codes
 // (0 = the root's own injected state, 1 = Z, 2 = GA, 3 = GB: a child inherits one side and gets a constant on the other)
@@ -40,8 +46,8 @@ __device__ __forceinline__ int ka_sub_bytes(int kind, int nres, int R, int C)
         int b = 0;
         b += (kind == KA_SS) ? ((R + 2 + 15) & ~15) : (R + 2) * rw * 4;                  // rows: residues or records
         b += (kind == KA_PP) ? (C + 2) * rw * 4 : ((C + 3 + 15) & ~15);                  // columns: records or residues
-        b += 2 * KA_SUB_NQ * (int)sizeof(KaSubL);
-        b += 2 * (((C + 1 + KA_SUB_MAXROWS) * 12 + 15) & ~15);
+        b += 2 * ka_sub_nq(R) * (int)sizeof(KaSubL);
+        b += 2 * ((ka_sub_rowcells(R, C) * 12 + 15) & ~15);
         return b;
 }
 
@@ -496,9 +502,9 @@ __device__ __forceinline__ void ka_sub_setup(TaskShared& S, const KaSub& root, c
         o += (KIND == KA_SS) ? ((X.R + 2 + 15) & ~15) : (X.R + 2) * RW * 4;
         X.colsL = (ka_lf*)(area + o); X.colres = (ka_lu8*)(area + o);
         o += (KIND == KA_PP) ? (X.C + 2) * RW * 4 : ((X.C + 3 + 15) & ~15);
-        X.q[0] = (ka_li*)(area + o); o += KA_SUB_NQ * (int)sizeof(KaSubL);
-        X.q[1] = (ka_li*)(area + o); o += KA_SUB_NQ * (int)sizeof(KaSubL);
-        const int rbytes = ((X.C + 1 + KA_SUB_MAXROWS) * 12 + 15) & ~15;
+        X.q[0] = (ka_li*)(area + o); o += ka_sub_nq(X.R) * (int)sizeof(KaSubL);
+        X.q[1] = (ka_li*)(area + o); o += ka_sub_nq(X.R) * (int)sizeof(KaSubL);
+        const int rbytes = (ka_sub_rowcells(X.R, X.C) * 12 + 15) & ~15;
         X.F = (ka_lf*)(area + o); o += rbytes;
         X.B = (ka_lf*)(area + o);
 

@@ -313,7 +313,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // with its place in that order; sorted and added up in fp32 after the recursion (ka_margins_in_order).  The
                 // wave-local subtrees do not keep those records: off.
                 S.rec_on = (D.flags & KA_FLAG_EXACT_CONFIDENCE) ? 1 : 0;
-                S.sub_ok = (D.sub_mode && !S.rec_on) ? 1 : 0;
+                S.sub_ok = (D.sub_mode && !S.rec_on) ? D.sub_mode : 0;     // (KA_SUBTREE: 1 subtrees incl. the wide-subtree levels of round 5, 2 without those)
                 S.reuse_ok = (KA_RU_TREE && !Q1 && D.reuse && g_eff == 1 && !S.rec_on) ? 1 : 0;
                 S.nres_t = (D.nres <= 5) ? 5 : ((D.nres <= 20) ? 20 : 23);
                 S.sub_stride = LEAN ? KA_WAVE_LDS_LEAN : KA_WAVE_LDS;

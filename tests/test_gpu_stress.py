@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 EXACT = ["plen", "kind", "swapped", "meet", "transition", "score", "fhash", "bhash"]
 SWITCHES = {"KA_MAX_CLUSTER": ["1", "2", "4", "8", "16", "24", "32", None], "KA_CRIT_GREEDY": ["0", None, None], "KA_NO_HALF": ["1", None], "KA_NO_QUEUE": ["1", None],
-            "KA_NO_CHAIN": ["1", None, None], "KA_NO_LEAN": ["1", None, None], "KA_LEAN4": ["0", None], "KA_SUBTREE": ["0", None, None],
+            "KA_NO_CHAIN": ["1", None, None], "KA_NO_LEAN": ["1", None, None], "KA_LEAN4": ["0", None], "KA_SUBTREE": ["0", "2", None, None],
             "KA_MW": ["0", None, None], "KA_Q1": ["0", "1", "2", "3", "4", None], "KA_CHAIN_G1": ["1", None], "KA_NO_CRIT": ["1", None],
             "KA_HO": ["0", "1", "2", None], "KA_HW": ["0", "1", None],
             # round 5: launch shapes of the 4-wave kernels, the chained launch beside the queued one, the queue's order

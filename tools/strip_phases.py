@@ -11,7 +11,9 @@ subm, scal = bench.scoring(False)
 ctx = kalign_amd.Context(0)
 rng = np.random.RandomState(3)
 JOBS = []
-for rows, cols in [(1000, 3000), (500, 500)]:
+# PHASES_SHAPES=618x451,917x825: other task shapes than the two built in
+SHAPES = [tuple(int(v) for v in x.split("x")) for x in os.environ["PHASES_SHAPES"].split(",")] if os.environ.get("PHASES_SHAPES") else [(1000, 3000), (500, 500)]
+for rows, cols in SHAPES:
     base_r = rng.randint(0, 20, rows).astype(np.uint8); base_c = rng.randint(0, 20, cols).astype(np.uint8)
     def mutate(b):
         x = b.copy(); m = rng.rand(len(x)) < 0.2; x[m] = rng.randint(0, 20, m.sum()); return x
@@ -34,7 +36,7 @@ for hw in os.environ.get("PHASES_HW", "1,0").split(","):
             ctx.tree_upload(codes, tasks, subm, scal, np.full(4, 0.5, np.float32), flags=api.FLAG_TIMING)
         for _ in range(3): ctx.tree_run(); ctx.tree_sync()
         ctx.tree_timing()
-        print("%d x %d: level 0 pass %.0f us, level 1 %.0f us, level 2 %.0f us" % (rows, cols, ctx.root_levels[0][1] / 2.4e3, ctx.root_levels[1][1] / 2.4e3, ctx.root_levels[2][1] / 2.4e3))
+        print("%d x %d: " % (rows, cols) + ", ".join("level %d: n %d pass %.0f us meet %.0f us" % (l, ctx.root_levels[l][0], ctx.root_levels[l][1] / 2.4e3, ctx.root_levels[l][2] / 2.4e3) for l in range(8) if ctx.root_levels[l][0]))
         for lvl in range(int(os.environ.get("PHASES_LEVELS", "1"))):
             for w in range(8):
                 p = ctx.prof[lvl][w]
