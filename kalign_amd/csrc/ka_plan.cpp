@@ -63,7 +63,11 @@ int plan_launches(ka_ctx* c)
                         for (int L = 0; L + 1 < max_level; L++) {
                                 bool all_ss = true;
                                 for (int t : levels[L]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
-                                int chain_tasks = c->n_cus - 8;
+                                // (one tree: the chain starts where a level has at most 200 tasks -- the ~50 workgroups that leaves free go to the
+                                // entries under the critical path, and since the chain overlaps the queue (round 5) a later start costs little:
+                                // 4096 x 400 aa 14.70 -> 14.61 ms, default mode 21.4 -> 20.6, 4096 x 2000 nt 71.8 -> 70.2, 1024 x 2000 nt 33.3 -> 31.9;
+                                // a forest keeps every CU it can get: four 4096 x 2000 nt trees 183 -> 191 with 200; profiles/r05_chain_start.log)
+                                int chain_tasks = (c->n_trees <= 1) ? std::min(c->n_cus - 8, 200) : c->n_cus - 8;
                                 if (c->env.chain_tasks > 0) chain_tasks = std::min(chain_tasks, c->env.chain_tasks);   // experiments
                                 if (!all_ss && (int)levels[L].size() <= chain_tasks) { c->chain_level = L; break; }   // one workgroup per CU, all resident
                         }
