@@ -100,6 +100,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         if (c->h_trace) (void)hipHostFree(c->h_trace);
         for (hipEvent_t e : c->launch_ev) (void)hipEventDestroy(e);
         if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
         for (hipEvent_t e : { c->e_fork, c->e_chain }) if (e) (void)hipEventDestroy(e);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -114,12 +115,20 @@ extern "C" int ka_ctx_set_shared(ka_ctx* c, int shared)
 {
         if (!c) return fail("null ctx");
         c->shared_gpu = shared != 0; c->shared_by_fallback = false;
+        // Contexts of one process that stay on the null stream run one after the other however many host threads drive them.  A
+        // shared context whose caller gave it no stream gets its own (non-blocking: it does not order against the null stream either).
+        if (c->shared_gpu && !c->stream) {
+                HIPCHK(hipSetDevice(c->device));
+                HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+                c->own_stream = true;
+        }
         return KA_OK;
 }
 
 extern "C" int ka_ctx_set_stream(ka_ctx* c, void* s)
 {
         if (!c) return fail("null ctx");
+        if (c->own_stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
         c->stream = (hipStream_t)s;
         return KA_OK;
 }

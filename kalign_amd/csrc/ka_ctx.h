@@ -139,6 +139,7 @@ struct ka_ctx {
         KaEnv env;
         int device = 0;
         hipStream_t stream = nullptr;
+        bool own_stream = false;                     // `stream` was created by ka_ctx_set_shared (destroyed with the context)
         // ---- tree job ----
         bool have_job = false;
         int numseq = 0, n_tasks = 0, flags = 0;

@@ -152,7 +152,8 @@ int ka_dist::all_reduce_i32(int* buf, size_t count, bool take_max)
                 for (size_t i = 0; i < count; i++) acc[i] = take_max ? std::max(acc[i], tmp[i]) : acc[i] + tmp[i];
         }
         loop->barrier(lk);                                          // everybody has read every buffer
-        HIPCHK(hipMemcpy(buf, acc.data(), sizeof(int) * count, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(buf, acc.data(), sizeof(int) * count, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
         return KA_OK;
 }
 int ka_dist::broadcast_i32(int* buf, size_t count, int root)
@@ -163,7 +164,12 @@ int ka_dist::broadcast_i32(int* buf, size_t count, int root)
         std::unique_lock<std::mutex> lk(loop->m);
         loop->bufs[rank] = buf;
         loop->barrier(lk);
-        if (rank != root) HIPCHK(hipMemcpy(buf, loop->bufs[root], sizeof(int) * count, hipMemcpyDeviceToDevice));
+        // (on this rank's stream and complete before anybody moves on: a plain hipMemcpy between device buffers is ordered in the null
+        // stream only and need not have happened when it returns -- the rank's own, non-blocking stream would read stale words)
+        if (rank != root) {
+                HIPCHK(hipMemcpyAsync(buf, loop->bufs[root], sizeof(int) * count, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+        }
         loop->barrier(lk);
         return KA_OK;
 }
@@ -188,7 +194,8 @@ int ka_dist::recv(void* buf, size_t bytes, int peer)
         KaLoopback::Msg* msg = q.front();
         q.pop_front();
         if (msg->bytes != bytes) { msg->taken = true; loop->cv.notify_all(); return fail("ka_dist loopback: message size mismatch"); }
-        const hipError_t e = hipMemcpy(buf, msg->ptr, bytes, hipMemcpyDeviceToDevice);
+        hipError_t e = hipMemcpyAsync(buf, msg->ptr, bytes, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // (the sender reuses its buffer once the message is taken)
         msg->taken = true;
         loop->cv.notify_all();
         if (e != hipSuccess) return fail(std::string("ka_dist loopback: ") + hipGetErrorString(e));

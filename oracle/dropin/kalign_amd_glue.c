@@ -918,7 +918,20 @@ ERROR:
  * The penalties of member k (resolve_run_params and its table, ensemble.c:32-76) are restated here: k = 0 the base values
  * (aln_param_init's, :262-268), k > 0 scaled per entry k mod 12, tree seed + k, tree noise per entry.
  * Devices: ka_device_count(), KALIGN_AMD_DEVICES=n; KALIGN_AMD_GLUE_WORLD=n: n member contexts on device 0 (one-GPU test boxes).
+ * ONE GPU (round 5): the members still run ahead, on up to GLUE_SHARED_MEMBERS contexts that share the device (ka_ctx_set_shared:
+ * own stream each, no workgroup ever waits for another one, so any interleaving of the members' launches is safe).  A member's
+ * second tree (`--precise`: UPGMA on the rows, a chain of ~70 dependent profile-profile tasks for 2048 sequences) keeps a few
+ * workgroups busy; eight members side by side fill the gaps: 2048 x ~300 protein, 8 members with one realignment pass: 132 ms per
+ * member alone, 56 ms side by side (profiles/r05_ensemble_phases.log).  KALIGN_AMD_ENSEMBLE_SLOTS=n overrides (1: one after the other).
+ * The HIP runtime multiplexes streams onto 4 hardware queues by default -- members 5..8 would wait behind 1..4 -- so the glue asks
+ * for 8 (GPU_MAX_HW_QUEUES, only when the user has not set it) before the runtime starts.
  */
+#define GLUE_SHARED_MEMBERS 8
+__attribute__((constructor)) static void glue_hw_queues(void)
+{
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 static const float glue_member_scale[12][4] = {
         {1.0f, 1.0f, 1.0f, 0.0f}, {0.5f, 1.5f, 0.8f, 0.20f}, {1.5f, 0.5f, 1.2f, 0.20f}, {0.7f, 0.7f, 0.5f, 0.25f},
         {1.4f, 1.4f, 1.5f, 0.25f}, {0.8f, 1.2f, 1.0f, 0.30f}, {1.3f, 0.8f, 0.7f, 0.30f}, {0.6f, 1.0f, 1.3f, 0.15f},
@@ -1055,6 +1068,11 @@ int kalign_ensemble(struct msa* msa, int n_threads, int type, int n_runs, float 
                 slots = d ? atoi(d) : ka_device_count();
                 if(slots > ka_device_count()){
                         slots = ka_device_count();
+                }
+                if(slots == 1){                  /* one GPU: the members share it */
+                        const char* es = getenv("KALIGN_AMD_ENSEMBLE_SLOTS");
+                        slots = es ? atoi(es) : GLUE_SHARED_MEMBERS;
+                        shared = 1;
                 }
         }
         if(slots > GLUE_MAX_MEMBERS){

@@ -58,6 +58,9 @@ def _device_ran(c, flags):
     assert c["tree"] + c["inline"] >= members * (1 + realign), c
     assert c["finalise"] >= members * (1 + realign), c
     assert c["kmeans"] + c["kmeans_noisy"] >= members, c
+    if members > 1:
+        # the members ran ahead of the reference's loop, side by side on contexts sharing the GPU (kalign_ensemble in the glue)
+        assert c["ensemble_multi"] == 1 and c["member_ahead"] == members, c
     if members > 1 and not realign:
         assert c["kmeans_noisy"] >= 1, c                      # kalign_run_seeded: members after the first build their trees on noisy distances
     if realign:
