@@ -41,18 +41,34 @@ if tr:
     last = r[-LAUNCHES:]
     tot = 0.0
     with open(os.path.join(here, pre + "_last_step_launches.csv"), "w") as g:
-        g.write("kernel,grid,workgroup,lds_bytes,vgprs,sgprs,duration_us\n")
+        g.write("kernel,grid,workgroup,lds_bytes,vgprs,sgprs,start_us,duration_us\n")
         for x in last:
             us = (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3
             tot += us
-            g.write("%s,%s,%s,%s,%s,%s,%.1f\n" % (x["Kernel_Name"].split("(")[0], x["Grid_Size_X"], x["Workgroup_Size_X"], x.get("LDS_Block_Size", ""),
-                                            x.get("VGPR_Count", ""), x.get("SGPR_Count", ""), us))
+            g.write("%s,%s,%s,%s,%s,%s,%.1f,%.1f\n" % (x["Kernel_Name"].split("(")[0], x["Grid_Size_X"], x["Workgroup_Size_X"], x.get("LDS_Block_Size", ""),
+                                            x.get("VGPR_Count", ""), x.get("SGPR_Count", ""), (int(x["Start_Timestamp"]) - int(last[0]["Start_Timestamp"])) / 1e3, us))
     # mean over every traced step (13 = 3 warm-up + 10 timed)
     nsteps = len(r) // LAUNCHES if LAUNCHES else 0
     if nsteps:
         allus = sum((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in r)
-        print("kernel-trace: %d task-kernel launches = %d steps x %d; mean kernel time per step %.3f ms (last step %.3f ms); bench kernel_ms_per_step %.3f" % (
-            len(r), nsteps, LAUNCHES, allus / nsteps / 1e3, tot / 1e3, bench["roofline"]["kernel_ms_per_step"] if bench else -1))
+        # Round 5: the chained launch runs on its own stream beside the queued one (it starts with it and waits for its operands),
+        # so the durations of a step's launches overlap and their sum is more than the step takes.  What bench.py times with HIP
+        # events -- and what the roofline divides by -- is the time the step's launches COVER: the union of their intervals.
+        cover = 0.0
+        for s in range(nsteps):
+            iv = sorted((int(x["Start_Timestamp"]), int(x["End_Timestamp"])) for x in r[s * LAUNCHES:(s + 1) * LAUNCHES])
+            lo, hi = iv[0]
+            for a, b in iv[1:]:
+                if a > hi:
+                    cover += hi - lo; lo, hi = a, b
+                else:
+                    hi = max(hi, b)
+            cover += hi - lo
+        line = ("kernel-trace: %d task-kernel launches = %d steps x %d; time covered by a step's launches %.3f ms (bench.py's HIP events: kernel_ms_per_step %.3f); "
+                "sum of the launch durations per step %.3f ms (last step %.3f ms) -- the chained launch overlaps the queued one" % (
+                    len(r), nsteps, LAUNCHES, cover / nsteps / 1e6, bench["roofline"]["kernel_ms_per_step"] if bench else -1, allus / nsteps / 1e3, tot / 1e3))
+        print(line)
+        open(os.path.join(here, pre + "_kernel_trace_summary.txt"), "w").write(line + "\n")
 
 
 # ---- PMC: HBM traffic per step ----
