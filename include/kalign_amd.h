@@ -87,7 +87,9 @@ int  ka_ctx_set_stream(ka_ctx* ctx, void* hip_stream);
 /* Tell the context that it does NOT have the GPU to itself (several alignments in flight on different streams /
    processes).  Multi-workgroup tasks and the chained launch make workgroups wait for each other and need all of
    them resident; a shared context runs every task on one workgroup, one launch per guide-tree level -- slower for
-   a single tree, safe under any co-scheduling.  Takes effect at the next ka_tree_upload. */
+   a single tree, safe under any co-scheduling.  Takes effect at the next ka_tree_upload.  A shared context that was
+   given no stream (ka_ctx_set_stream) creates a non-blocking stream of its own: contexts of one process that stay on
+   the null stream run one after the other however many host threads drive them. */
 int  ka_ctx_set_shared(ka_ctx* ctx, int shared);
 /* How often a run of this context fell back to that plan on its own because a wait between workgroups never
    completed (another process was using the GPU): the run is repeated and correct, but slower -- visible here. */

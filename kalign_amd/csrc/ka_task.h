@@ -189,7 +189,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
 #define s_dbg (*s_dbg_p)
         const KaTaskDesc T = D.tasks[task];
         const int tid = threadIdx.x;
-        const long long tk0 = __builtin_amdgcn_s_memtime();
+        long long tk0 = __builtin_amdgcn_s_memtime();
         long long tk1 = 0, tk2 = 0, tk3 = 0;
 
         if (tid == 0 && blockIdx.x == 0) KA_CRUMB(D.trace, 4, 1);
@@ -207,6 +207,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                                 }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        tk0 = __builtin_amdgcn_s_memtime();           // (KA_FLAG_TIMING, thread 0's clock: a task's time starts when its operands exist)
                 }
                 // (a chained launch reads what other workgroups of the SAME launch wrote: go past L1 / scalar cache)
                 const int len_a = __hip_atomic_load(&D.node_len[T.a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -59,7 +59,11 @@ def main():
             tot = np.zeros(7)
             for L in range(1, lv.max() + 1):
                 idx = np.where(lv == L)[0]
-                tot += tm[idx[np.argmax(tm[idx].sum(axis=1))]]
+                top = idx[np.argmax(tm[idx].sum(axis=1))]
+                tot += tm[top]
+                if mode == 1 and os.environ.get("REFINE_LEVELS"):
+                    print("   L%2d n=%4d longest: %5dx%-5d nsip %4d+%-4d k%d  us: prep %4.0f sp tables %5.0f recursions %6.0f coding %4.0f sp scoring %5.0f waiting %4.0f record+merge %4.0f" % (
+                        (L, len(idx), r[top].len_a, r[top].len_b, r[top].nsip_a, r[top].nsip_b, r[top].kind) + tuple(tm[top])))
             print("   longest task per level, summed (us): prep %.0f  sp tables %.0f  recursions %.0f  path coding %.0f  sp scoring %.0f  "
                   "waiting %.0f  record+merge %.0f" % tuple(tot))
     if cpu:
