@@ -86,7 +86,7 @@ extern "C" void ka_ctx_destroy(ka_ctx* c)
         (void)hipSetDevice(c->device);
         c->d_codes.release(); c->d_seq_off.release(); c->d_node_len.release(); c->d_level_ids.release();
         c->d_path_arena.release(); c->d_error.release(); c->d_node_prof.release(); c->d_dbg_off.release();
-        c->d_prof_arena.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
+        c->d_prof_arena.release(); c->d_node_vote.release(); c->d_subm.release(); c->d_dbg_arena.release(); c->d_counters.release();
         c->d_scratch.release(); c->d_tasks.release(); c->d_recs.release(); c->d_timing.release();
         c->d_ctl.release(); c->d_blocks.release(); c->d_blocks_tmp.release(); c->d_join.release();
         c->p_codes.release(); c->p_off.release(); c->p_len.release(); c->p_ia.release(); c->p_ib.release(); c->p_paths.release();
@@ -176,6 +176,7 @@ int tree_reset(ka_ctx* c)
         int zero = 0;
         HIPCHK(hipMemcpyAsync(c->d_node_len.p, node_len.data(), sizeof(int) * nprof, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_node_prof.p, node_prof.data(), sizeof(long long) * nprof, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_node_vote.p, 0xff, sizeof(long long) * nprof, c->stream));          // (-1: no carried vote table yet)
         HIPCHK(hipMemcpyAsync(c->d_counters.p, counters, sizeof(counters), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_error.p, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemsetAsync(c->d_ctl.p, 0, (size_t)ka_ctl_bytes_host() * c->n_tasks, c->stream));
@@ -194,7 +195,7 @@ KaTreeDev tree_dev(ka_ctx* c)
 {
         KaTreeDev D;
         D.codes = c->d_codes.p; D.seq_off = c->d_seq_off.p;
-        D.node_len = c->d_node_len.p; D.node_prof = c->d_node_prof.p;
+        D.node_len = c->d_node_len.p; D.node_prof = c->d_node_prof.p; D.node_vote = c->d_node_vote.p;
         D.prof_arena = c->d_prof_arena.p; D.counters = c->d_counters.p;
         D.prof_cap = c->prof_cap; D.scratch_cap = c->scratch_cap; D.path_cap = c->path_cap; D.dbg_cap = c->dbg_cap;
         D.scratch = c->d_scratch.p; D.path_arena = c->d_path_arena.p;
@@ -217,7 +218,7 @@ KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : (c->nres > 5 ? 4 : 0);     // (nucleotides: five residues -- a one-row step is 0.85 of a two-row one: not worth twice the strips)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
-        D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse;
+        D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse; D.carry = c->env.carry;
         D.overlap = c->overlap_plan ? 1 : 0;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
@@ -946,6 +947,7 @@ extern "C" int ka_tree_set_profile(ka_ctx* c, int node, const float* prof, int p
         HIPCHK(hipMemcpy(c->d_counters.p, &top, sizeof(top), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_node_len.p + node, &plen, sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_node_prof.p + node, &po, sizeof(long long), hipMemcpyHostToDevice));
+        { const long long none = -1; HIPCHK(hipMemcpy(c->d_node_vote.p + node, &none, sizeof(long long), hipMemcpyHostToDevice)); }   // (its votes are counted from its members)
         c->injected.push_back(node);
         return KA_OK;
 }
@@ -985,6 +987,7 @@ extern "C" int ka_tree_reserve_profile_dev(ka_ctx* c, int node, int plen, void**
         HIPCHK(hipMemcpy(c->d_counters.p, &top, sizeof(top), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_node_len.p + node, &plen, sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_node_prof.p + node, &po, sizeof(long long), hipMemcpyHostToDevice));
+        { const long long none = -1; HIPCHK(hipMemcpy(c->d_node_vote.p + node, &none, sizeof(long long), hipMemcpyHostToDevice)); }   // (its votes are counted from its members)
         c->injected.push_back(node);
         *dev_ptr = c->d_prof_arena.p + po;
         return KA_OK;

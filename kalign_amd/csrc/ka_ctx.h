@@ -106,6 +106,7 @@ struct KaEnv {
         int hw_prio = 3;               // KA_HW_PRIO: s_setprio of a strip wave that has a helper (experiments)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         int overlap = 1;               // KA_OVERLAP: the chained launch goes out beside the queued launch (a stream of its own, ordered by the tasks' done flags)
+        int carry = 0;                 // KA_CARRY=1: carried vote tables (ka_votes_merge; measured, off: DESIGN 4i) -- 0: every task counts its members' votes
         int reuse = 1;                 // KA_REUSE: Hirschberg prefix reuse in the 4-wave kernels (queued levels, seq-seq leaves, pair batch)
         int qw = 4, lw = 4, pw = 2;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
@@ -124,6 +125,7 @@ static inline void read_env(KaEnv& v)
         v.launch_ev = getenv("KA_LAUNCH_EV") != nullptr;
         v.subtree = env_int("KA_SUBTREE", 1);
         v.reuse = env_int("KA_REUSE", 1);
+        v.carry = env_int("KA_CARRY", 0);
         v.overlap = env_int("KA_OVERLAP", 1);
         v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 2);
         for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;
@@ -171,7 +173,7 @@ struct ka_ctx {
         int nres = 23;
         DevBuf<uint8_t> d_codes;
         DevBuf<int> d_seq_off, d_node_len, d_level_ids, d_path_arena, d_error;
-        DevBuf<long long> d_node_prof, d_dbg_off, d_timing;
+        DevBuf<long long> d_node_prof, d_node_vote, d_dbg_off, d_timing;
         DevBuf<float> d_prof_arena, d_subm, d_dbg_arena;
         DevBuf<unsigned long long> d_counters;
         DevBuf<char> d_scratch, d_ctl;

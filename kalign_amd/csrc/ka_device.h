@@ -58,6 +58,7 @@ struct KaTreeDev {
         const int* seq_off;
         int* node_len;                 // [2N-1] sequence length / profile length (msa->plen)
         long long* node_prof;          // [2N-1] offset (floats) of the node's profile in prof_arena
+        long long* node_vote;          // [2N-1] offset (floats) of the node's carried vote table in prof_arena (ka_votes_merge), -1: none
         float* prof_arena;
         unsigned long long* counters;  // [0] prof_top, [1] scratch_top, [2] path_top, [3] dbg_top (floats), [4] head of the queued launch
         long long prof_cap, scratch_cap, path_cap, dbg_cap;
@@ -100,6 +101,8 @@ struct KaTreeDev {
                                        // (KaJoin::go): every task sets its flag, every task waits for the flags of the tasks that make its operands (qa / qb)
         int qw, lw;                    // waves per workgroup of the queued launch (KA_QW: 4, 2 or 1) / of the seq-seq leaf levels (KA_LW)
         int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
+        int carry;                     // round 5: a node's anchor votes are carried up the tree (ka_votes_merge) instead of counted again from every
+                                       // member at every task (KA_CARRY=1; off by default: the sweeps that settle its marked cells cost what the votes cost)
         int cons_K;                    // anchors
         int cons_maxlen;               // longest sequence: bounds every anchor position
         float cons_paw;                // weight / (float)K  (per_anchor_weight, anchor_consistency.c:487)

@@ -519,6 +519,7 @@ static int dist_tree_attempt(ka_dist* d, int* status, int* grow)
                                 memcpy(d->h_head + 4, &top_, sizeof(top_)); memcpy(d->h_head + 6, &po, sizeof(po));
                                 HIPCHK(hipMemcpyAsync(c->d_counters.p, d->h_head + 4, sizeof(top_), hipMemcpyHostToDevice, c->stream));
                                 HIPCHK(hipMemcpyAsync(c->d_node_prof.p + m.child, d->h_head + 6, sizeof(po), hipMemcpyHostToDevice, c->stream));
+                                HIPCHK(hipMemsetAsync(c->d_node_vote.p + m.child, 0xff, sizeof(long long), c->stream));   // (no carried vote table comes with it)
                                 HIPCHK(hipMemcpyAsync(c->d_node_len.p + m.child, d->h_head, sizeof(int), hipMemcpyHostToDevice, c->stream));
                                 if (d->recv(c->d_prof_arena.p + po, sizeof(float) * (size_t)need, m.src)) return KA_FAIL;
                                 if (cols && d->recv(d->d_colbuf.p, sizeof(int) * (size_t)m.ncols, m.src)) return KA_FAIL;

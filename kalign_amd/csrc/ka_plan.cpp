@@ -500,7 +500,7 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         c->dbg_cap = (flags & KA_FLAG_DEBUG_ROWS) ? std::max<long long>(c->dbg_cap, 6LL * (cols + 2LL * n_tasks + c->sum_len)) : c->dbg_cap;
 
         if (c->d_codes.alloc((size_t)codes_bytes) || c->d_seq_off.alloc(numseq) || c->d_node_len.alloc(nprof) ||
-            c->d_node_prof.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
+            c->d_node_prof.alloc(nprof) || c->d_node_vote.alloc(nprof) || c->d_level_ids.alloc(c->level_ids_flat.size()) ||
             c->d_tasks.alloc(n_tasks) || c->d_recs.alloc(n_tasks) || c->d_subm.alloc(23 * 23) ||
             c->d_counters.alloc(8) || c->d_timing.alloc(8 * (size_t)n_tasks + 48 + 512) ||
             c->d_ctl.alloc((size_t)ka_ctl_bytes_host() * n_tasks) || c->d_join.alloc(n_tasks) || c->d_blocks.alloc(c->blocks_flat.size()) || c->d_error.alloc(1) || c->d_dbg_off.alloc(n_tasks) ||

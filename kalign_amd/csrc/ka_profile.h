@@ -529,6 +529,174 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
 
 #undef KS
 
+// ------------------------------------------------------------------------------------------
+// Round 5: CARRIED votes.  get_node_anchor_positions (anchor_consistency.c:352-470) counts, per anchor and profile column, over the
+// node's members in sip order: best = the anchor position of the FIRST member that has one there, total = members that have one,
+// agree = members whose position is best.  The member list of a merged node is its operands' lists, each REVERSED, a's first
+// (aln_run.c:428-436: sip[c] = rev(sip[a]) ++ rev(sip[b])) -- the first voter of c in a column is the LAST voter of a there (of b where a
+// has none), the last voter of c the FIRST voter of b (of a).  So a node carries, per anchor and column, both ends of its list:
+//     f / fc = position of its first voter / voters at that position        (what the task that aligns the node reads: best, agree)
+//     l / lc = position of its last voter / voters at that position
+//     n      = voters
+// and a column of c -- a column of a, of b, or one of each -- follows from its operands' without touching a member:
+//     one side only (X):  f = l_X, fc = lc_X, l = f_X, lc = fc_X, n = n_X
+//     both:               f = l_a, fc = lc_a + #{voters of b at l_a};   l = f_b, lc = fc_b + #{voters of a at f_b};   n = n_a + n_b
+//     #{voters of X at p} = fc_X if p == f_X,  lc_X if p == l_X,  0 if the voters at f_X and l_X are all of X's voters,
+//                           otherwise a COUNT over X's members: the cell is marked, and one sweep over the members' residues -- a
+//                           column and K marks per residue, an atomic where a mark and the position match -- settles all marks.
+// The same integers as the reference's loop over all members, member by member.  A node's table -- five planes [K][plen] of ints --
+// lies behind its profile records in the arena (KaTreeDev::node_vote).  A task whose operands are leaves or carry tables reads its
+// anchor positions from them (ka_cons_from_tables) instead of sweeping twice over every member and anchor with LDS atomics
+// (ka_cons_votes: 0.25-0.45 ms of a task with ~2000 members; used for nodes that arrive without a table -- profiles handed over
+// between ranks, injected profiles).
+// MEASURED, OFF BY DEFAULT (KA_CARRY=1 switches it on; bit-identical, tests/test_gpu_stress.py runs it): the votes do shrink (root of a
+// 4096-sequence tree: prep 351 -> 109 us) but in real alignments some cell of nearly every big node is marked, and the sweep that
+// settles the marks -- global atomics instead of LDS ones -- costs what was saved (merge 105 -> 353 us): default-mode tree 20.6 ->
+// 21.2 ms, the realignment tree of a `--precise` member 79.5 -> 78.6 ms, the same tree on one workgroup per task (shared context)
+// 178 -> 220 ms (profiles/r05_carried_votes.log).
+// ------------------------------------------------------------------------------------------
+#define KA_VOTE_MARK 0x80000000u
+struct KaVote { int f, fc, l, lc, n; };
+__device__ __forceinline__ KaVote ka_vote_read(const KaTreeDev& D, const int node, const int* tab, const int plen, const int k, const int i)
+{
+        KaVote v;
+        if (!tab) {                                                   // a leaf: its position map is its table
+                v.f = v.l = D.cons_maps[D.cons_map_off[node] + (long long)k * plen + i];
+                v.fc = v.lc = v.n = (v.f >= 0) ? 1 : 0;
+                return v;
+        }
+        const long long K = D.cons_K, o = (long long)k * plen + i, pl = K * plen;
+        v.f = tab[o];
+        v.fc = (int)((unsigned int)tab[pl + o] & ~KA_VOTE_MARK);
+        v.l = tab[2 * pl + o];
+        v.lc = (int)((unsigned int)tab[3 * pl + o] & ~KA_VOTE_MARK);
+        v.n = tab[4 * pl + o];
+        return v;
+}
+
+__device__ __forceinline__ const int* ka_vote_table(const KaTreeDev& D, const int node, const int nmem)
+{
+        if (nmem == 1) return nullptr;
+        return (const int*)(D.prof_arena + __hip_atomic_load(&D.node_vote[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// both operands are leaves or carry a table (the same answer in every workgroup of a cluster: the tables are final before the task starts)
+__device__ __forceinline__ bool ka_votes_carried(const KaTreeDev& D, const KaTaskDesc& T)
+{
+        if (!D.carry) return false;
+        const bool a = T.nsip_a == 1 || __hip_atomic_load(&D.node_vote[T.a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+        const bool b = T.nsip_b == 1 || __hip_atomic_load(&D.node_vote[T.b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+        return a && b;
+}
+
+// ka_cons_votes' result (apos / conf of both DP sides, all anchors) from the operands' tables; one workgroup
+__device__ void ka_cons_from_tables(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T)
+{
+        const int tid = threadIdx.x;
+        const int K = D.cons_K;
+        const long long n = (long long)S.len_a + S.len_b + 8;
+        for (int side = 0; side < 2; ++side) {
+                const bool is_rows = (side == 0);
+                const int node = (is_rows != (S.swapped != 0)) ? T.a : T.b;
+                const int nmem = (node == T.a) ? T.nsip_a : T.nsip_b;
+                const int dp_len = is_rows ? S.La : S.Lb;
+                int* apos = is_rows ? S.apos_r : S.apos_c;
+                float* conf = is_rows ? S.conf_r : S.conf_c;
+                const int* tab = ka_vote_table(D, node, nmem);
+                for (int x = tid; x < K * dp_len; x += KA_NT) {
+                        const int k = x / dp_len, i = x - k * dp_len;
+                        const KaVote v = ka_vote_read(D, node, tab, dp_len, k, i);
+                        const long long o = (long long)k * n + i;
+                        if (v.n > 0 && v.fc > 0) { apos[o] = v.f; conf[o] = (float)v.fc / (float)v.n; }
+                        else { apos[o] = -1; conf[o] = 0.0f; }
+                }
+        }
+        __syncthreads();
+}
+
+// voters of X at position p, from X's cell alone; false: only a count over X's members tells
+__device__ __forceinline__ bool ka_vote_count_at(const KaVote& x, const int p, int& cnt)
+{
+        if (p == x.f) { cnt = x.fc; return true; }
+        if (p == x.l) { cnt = x.lc; return true; }
+        // nobody else left to ask: one group that is everybody (f == l), or two disjoint groups that are
+        if ((x.f == x.l) ? (x.fc == x.n) : (x.fc + x.lc == x.n)) { cnt = 0; return true; }
+        return false;
+}
+
+// The table of the merged node (all workgroups of the cluster; after ka_update_colof: the members' columns are the merged node's).
+// vt: [5][K][alnlen] ints behind the node's profile records.
+__device__ void ka_votes_merge(TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen, int* vt)
+{
+        const int tid = threadIdx.x;
+        const long long K = D.cons_K, pl = K * alnlen;
+        const int* ta = ka_vote_table(D, T.a, T.nsip_a);
+        const int* tb = ka_vote_table(D, T.b, T.nsip_b);
+        int any = 0;                                                  // bit 0: cells that want b's members counted, bit 1: a's
+        for (long long x = (long long)S.member * KA_NT + tid; x < pl; x += (long long)S.G * KA_NT) {
+                const int k = (int)(x / alnlen), j = (int)(x - (long long)k * alnlen);
+                const int ia = S.srcA[j + 1] - 1, ib = S.srcB[j + 1] - 1;
+                KaVote A = { -1, 0, -1, 0, 0 }, B = { -1, 0, -1, 0, 0 };
+                if (ia >= 0) A = ka_vote_read(D, T.a, ta, S.len_a, k, ia);
+                if (ib >= 0) B = ka_vote_read(D, T.b, tb, S.len_b, k, ib);
+                int f, l, n;
+                unsigned int fc, lc;
+                if (A.n == 0) { f = B.l; fc = (unsigned int)B.lc; l = B.f; lc = (unsigned int)B.fc; n = B.n; }
+                else if (B.n == 0) { f = A.l; fc = (unsigned int)A.lc; l = A.f; lc = (unsigned int)A.fc; n = A.n; }
+                else {
+                        int cnt;
+                        f = A.l; l = B.f; n = A.n + B.n;
+                        if (ka_vote_count_at(B, f, cnt)) fc = (unsigned int)(A.lc + cnt); else { fc = (unsigned int)A.lc | KA_VOTE_MARK; any |= 1; }
+                        if (ka_vote_count_at(A, l, cnt)) lc = (unsigned int)(B.fc + cnt); else { lc = (unsigned int)B.fc | KA_VOTE_MARK; any |= 2; }
+                }
+                vt[x] = f; vt[pl + x] = (int)fc; vt[2 * pl + x] = l; vt[3 * pl + x] = (int)lc; vt[4 * pl + x] = n;
+        }
+        if (any) __hip_atomic_fetch_or(&S.ctl->vote_conf, any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ka_cluster_sync(S);                                           // the table, the marks, and every member's merged columns
+        const int todo = __hip_atomic_load(&S.ctl->vote_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (todo == 0) return;
+        // marked cells: b's members are counted at c's first position (plane 1 at plane 0), a's at c's last (plane 3 at plane 2).
+        // Gathers: four residues per lane and five anchors' marks in flight.  (Eight residues -- forty loads -- tipped the register allocation
+        // of the whole task kernel, everything is inlined into it: 1514 spilled VGPRs against 568, the strips of every default-mode job 14 %
+        // slower, carried votes or not.  hipcc ignores noinline.)
+        const int lane = tid & 63, wave = tid >> 6;
+        const int na = (todo & 2) ? T.nsip_a : 0, nb = (todo & 1) ? T.nsip_b : 0;
+        const int* ma = D.sip + D.sip_off[T.a];
+        const int* mb = D.sip + D.sip_off[T.b];
+        constexpr int KU = 4, KB = 5;
+        for (int m = S.member * KA_NW + wave; m < na + nb; m += KA_NW * S.G) {
+                const bool isb = m >= na;
+                const int si = isb ? mb[m - na] : ma[m];
+                const int* col = D.colof + D.seq_off[si];
+                const int len = D.node_len[si];
+                const int* map = D.cons_maps + D.cons_map_off[si];
+                const int* pos = vt + (isb ? 0 : 2 * pl);
+                int* cntp = vt + (isb ? pl : 3 * pl);
+                for (int p0 = lane; p0 < len; p0 += 64 * KU) {
+                        int jj[KU];
+#pragma unroll
+                        for (int u = 0; u < KU; ++u) { const int pp = p0 + 64 * u; jj[u] = (pp < len) ? col[pp] : -1; }
+                        for (int k0 = 0; k0 < (int)K; k0 += KB) {
+                                int mk[KU][KB];
+#pragma unroll
+                                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                                        for (int q = 0; q < KB; ++q)
+                                                mk[u][q] = (jj[u] >= 0 && k0 + q < (int)K) ? cntp[(long long)(k0 + q) * alnlen + jj[u]] : 0;
+#pragma unroll
+                                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                                        for (int q = 0; q < KB; ++q) {
+                                                if (mk[u][q] >= 0) continue;
+                                                const long long o = (long long)(k0 + q) * alnlen + jj[u];
+                                                const int a = map[(long long)(k0 + q) * len + p0 + 64 * u];
+                                                if (a >= 0 && a == pos[o]) atomicAdd((unsigned int*)&cntp[o], 1u);
+                                        }
+                        }
+                }
+        }
+}
+
 // anchor_consistency_get_bonus_profile in sparse form (first workgroup of the cluster, after the votes).
 // After it S.ent[row][0..KA_NB) holds the row's non-zero bonus cells with distinct columns: entries of
 // different anchors that hit the same cell are summed in anchor order (the dense matrix accumulates

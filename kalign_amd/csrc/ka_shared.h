@@ -70,6 +70,8 @@ struct KaCtl {
         long long scratch_off;          // cluster: scratch block allocated by member 0
         long long newp_off;             // merged profile offset in the arena (-1: root / none)
         long long path_off;             // coded path offset in the path arena
+        int vote_conf;                  // carried votes: some column of the merged node needs the second operand's members counted (ka_votes_merge)
+        int pad2;
 };
 
 // Everything the waves of a workgroup share about the task being aligned.
@@ -95,6 +97,7 @@ struct TaskShared {
         // parity (the children read it in level L+1's meetups while that level's own passes fill the other one); sliced by KaSub::roff
         KaState* sfbuf[2];
         KaState* sbbuf[2];
+        int carried;                   // this task's anchor positions come from its operands' carried vote tables (ka_cons_from_tables)
         int reuse_ok;                  // ... enabled for this task (a kernel built with it, one workgroup, no recursion-order records)
         KaSub* q[2];
         int* raw;

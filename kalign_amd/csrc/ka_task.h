@@ -301,6 +301,9 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 // Jobs with a consistency table: the votes of a task (ka_cons_votes) are shared by operand and by anchor -- ten units
                 // at five anchors -- and take 2 ms at the root of a 4096-sequence tree when one workgroup has two of them: a cluster of
                 // two workgroups per anchor where the members are many and the launch gave that many workgroups.
+                // (round 5: with carried vote tables the votes themselves are a read of K x (La + Lb) cells -- the wide cluster still shares the
+                // members' column updates and the sweep of the marked cells, ka_votes_merge)
+                S.carried = (NB && D.cons_K > 0 && ka_votes_carried(D, T)) ? 1 : 0;
                 if (NB && D.cons_K > 0 && T.nsip_a + T.nsip_b >= 128) {
                         // (two / three workgroups per (operand, anchor) where one would spend a millisecond and more on the bigger
                         // operand's members: ka_cons_votes_split)
@@ -326,7 +329,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
                 S.lctl = S.ctl;
-                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.nrec = 0; }
+                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.nrec = 0; S.ctl_lds.vote_conf = 0; }
                 s_dbg = nullptr;
                 if (member == 0) {
                         const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff, false, (D.flags & KA_FLAG_EXACT_CONFIDENCE) != 0, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
@@ -361,7 +364,8 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         // of every DP row (the first one); the barrier below publishes them
         if (NB) {
                 __syncthreads();
-                ka_cons_votes<LEAN, (NB ? NB : KA_NB)>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_NW * KA_WAVE_LDS);
+                if (S.carried) { if (S.member == 0) ka_cons_from_tables(S, D, T); }
+                else ka_cons_votes<LEAN, (NB ? NB : KA_NB)>(S, D, T, lds_waves, LEAN ? 0 : (long long)KA_NW * KA_WAVE_LDS);
                 ka_cluster_sync(S);
                 if (S.member == 0) ka_cons_entries<(NB ? NB : KA_NB)>(S, D);
         }
@@ -407,10 +411,12 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         S.ctl->newp_off = -1;
                         D.node_len[T.c] = alnlen;
                         if (!T.is_root) {
-                                const unsigned long long fn = pn * 64ull;
+                                // (jobs with a consistency table: the node's carried vote table -- 5 planes of K x alnlen ints -- behind its records)
+                                const bool votes = NB && D.cons_K > 0 && S.carried;
+                                const unsigned long long fn = pn * 64ull + (votes ? 5ull * (unsigned long long)D.cons_K * pn : 0ull);
                                 const unsigned long long fo = atomicAdd(&D.counters[0], fn);
                                 if ((long long)(fo + fn) > D.prof_cap) { S.ctl->fail = 1; atomicExch(D.error, 1); }
-                                else { S.ctl->newp_off = (long long)fo; D.node_prof[T.c] = (long long)fo; }
+                                else { S.ctl->newp_off = (long long)fo; D.node_prof[T.c] = (long long)fo; if (votes) D.node_vote[T.c] = (long long)(fo + pn * 64ull); }
                         }
                         ka_task_rec r;
                         r.a = T.a; r.b = T.b; r.c = T.c;
@@ -441,6 +447,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T, alnlen);
         if ((NB && !T.is_root) || (D.flags & KA_FLAG_DEVICE_GAPS)) ka_update_colof(S, D, T, alnlen);
+        if (NB && D.cons_K > 0 && S.carried && S.newp) ka_votes_merge(S, D, T, alnlen, (int*)(S.newp + ((long long)alnlen + 2) * 64));
         if (D.timing && S.member == 0) {
                 __syncthreads();
                 if (tid == 0) {
@@ -527,7 +534,8 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.reuse_ok = 0;
                 S.sub_ok = 0; S.rec_on = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
-                S.ctl_lds.fail = 0; S.ctl_lds.bar = 0;
+                S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.vote_conf = 0;
+                S.carried = (NB && D.cons_K > 0 && ka_votes_carried(D, T)) ? 1 : 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true, false, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
                 const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);
                 if ((long long)so + need > D.scratch_cap) { S.ctl->fail = 1; atomicExch(D.error, 2); }
@@ -545,7 +553,8 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         if (T.nsip_b == 1) ka_make_leaf_profile(S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, tss);
         if (NB) {
                 __syncthreads();
-                ka_cons_votes<false, (NB ? NB : KA_NB)>(S, D, T, lds_waves, (long long)KA_NW * KA_WAVE_LDS);
+                if (S.carried) ka_cons_from_tables(S, D, T);
+                else ka_cons_votes<false, (NB ? NB : KA_NB)>(S, D, T, lds_waves, (long long)KA_NW * KA_WAVE_LDS);
                 __syncthreads();
                 ka_cons_entries<(NB ? NB : KA_NB)>(S, D);
         }
@@ -695,10 +704,11 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.ctl->newp_off = -1;
                 D.node_len[T.c] = alnlen;
                 if (!T.is_root) {
-                        const unsigned long long fn = pn * 64ull;
+                        const bool votes = NB && D.cons_K > 0 && S.carried;
+                        const unsigned long long fn = pn * 64ull + (votes ? 5ull * (unsigned long long)D.cons_K * pn : 0ull);
                         const unsigned long long fo = atomicAdd(&D.counters[0], fn);
                         if ((long long)(fo + fn) > D.prof_cap) { S.ctl->fail = 1; atomicExch(D.error, 1); }
-                        else { S.ctl->newp_off = (long long)fo; D.node_prof[T.c] = (long long)fo; }
+                        else { S.ctl->newp_off = (long long)fo; D.node_prof[T.c] = (long long)fo; if (votes) D.node_vote[T.c] = (long long)(fo + pn * 64ull); }
                 }
                 ka_task_rec r;
                 r.a = T.a; r.b = T.b; r.c = T.c;
@@ -726,6 +736,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
         for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
         if (S.newp) ka_update_profile(S, D, T, alnlen);
         ka_update_colof(S, D, T, alnlen);
+        if (NB && D.cons_K > 0 && S.carried && S.newp) ka_votes_merge(S, D, T, alnlen, (int*)(S.newp + ((long long)alnlen + 2) * 64));
         if (D.timing) {
                 __syncthreads();
                 lap(6);

@@ -89,6 +89,45 @@ def test_consistency_tree_matches_oracle_seeded(ctx, oracle, n, length, dna, see
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name", cons_cases())
+def test_carried_votes_give_the_reference_answer(name, monkeypatch):
+    """KA_CARRY=1 (off by default): a node's anchor votes follow from its operands' tables (first / last voter per column, marked cells
+    settled by a sweep) instead of a count over all members at every task -- same positions, same confidences, same alignment; then a
+    refinement pass on top of it (the refined nodes rebuild their tables)."""
+    import kalign_amd
+    from kalign_amd import api
+    monkeypatch.setenv("KA_CARRY", "1")
+    c = kalign_amd.Context(0)
+    try:
+        g = Golden(name)
+        c.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, flags=api.FLAG_DEBUG_ROWS)
+        c.tree_build_consistency(int(g.n_anchors), float(g.weight))
+        for _ in range(2):
+            c.tree_run()
+            recs, paths, gaps = c.tree_download()
+            assert compare_recs(g, recs, paths, EXACT) == []
+            for got, want in zip(gaps, g.gaps_list()):
+                assert np.array_equal(got, want)
+        c.tree_refine(1)
+        c.tree_sync()
+        _, _, gaps_carried = c.tree_download()
+    finally:
+        c.close()
+    monkeypatch.delenv("KA_CARRY")
+    c = kalign_amd.Context(0)
+    try:
+        c.tree_upload(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+        c.tree_build_consistency(int(g.n_anchors), float(g.weight))
+        c.tree_run()
+        c.tree_refine(1)
+        c.tree_sync()
+        _, _, gaps_counted = c.tree_download()
+    finally:
+        c.close()
+    for a, b in zip(gaps_carried, gaps_counted):
+        assert np.array_equal(a, b)
+
+
 def test_consistency_declines_like_the_reference(ctx):
     """no seq_distances / fewer than 3 sequences / K <= 0: no table, plain tree (anchor_consistency.c:206-217)"""
     g = Golden("tree_prot32x200")

@@ -19,7 +19,9 @@ SWITCHES = {"KA_MAX_CLUSTER": ["1", "2", "4", "8", "16", "24", "32", None], "KA_
             "KA_MW": ["0", None, None], "KA_Q1": ["0", "1", "2", "3", "4", None], "KA_CHAIN_G1": ["1", None], "KA_NO_CRIT": ["1", None],
             "KA_HO": ["0", "1", "2", None], "KA_HW": ["0", "1", None],
             # round 5: launch shapes of the 4-wave kernels, the chained launch beside the queued one, the queue's order
-            "KA_QW": ["2", "1", None, None], "KA_LW": ["2", "1", None, None], "KA_OVERLAP": ["0", "1", None], "KA_QORDER": ["0", None, None]}
+            "KA_QW": ["2", "1", None, None], "KA_LW": ["2", "1", None, None], "KA_OVERLAP": ["0", "1", None], "KA_QORDER": ["0", None, None],
+            # anchor votes carried up the tree instead of counted at every task (off by default)
+            "KA_CARRY": ["1", None]}
 
 
 @pytest.mark.parametrize("name", tree_cases() + cons_cases())
