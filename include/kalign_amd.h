@@ -94,6 +94,9 @@ int  ka_ctx_set_shared(ka_ctx* ctx, int shared);
 /* How often a run of this context fell back to that plan on its own because a wait between workgroups never
    completed (another process was using the GPU): the run is repeated and correct, but slower -- visible here. */
 int  ka_ctx_fallback_runs(ka_ctx* ctx);
+/* Of the last finished run: tasks of the queued launch that workgroups of the chained launch took over because they were resident
+   before the queue was down to its last round (overlapping launches; normally 0).  -1: nothing finished. */
+long long ka_ctx_helped_tasks(ka_ctx* ctx);
 const char* ka_last_error(void);
 /* ABI revision of this header (bumped when entry points are added) */
 int  ka_abi_version(void);
@@ -212,6 +215,8 @@ int ka_tree_get_timing(ka_ctx* ctx, long long* out);
 #define KA_DEBUG_SMALL_ARENAS 1
 #define KA_DEBUG_STARVE_ROOT_JOIN 2
 #define KA_DEBUG_STARVE_REFINE_MEMBER 4   /* ka_tree_refine: a member of the first multi-workgroup edge never starts (watchdog -> re-plan) */
+#define KA_DEBUG_CHAIN_FIRST 8            /* overlapping launches: the chained launch is enqueued BEFORE the queued one -- its workgroups take the CUs
+                                             first, as a dispatcher that ignores the streams' priorities would have it (they help the queue) */
 int ka_debug_set_hooks(ka_ctx* ctx, int hooks);
 /* Tools and tests: the KA_* environment switches (experiments and measurements; none is needed in production) are read
    once, at ka_ctx_create.  This reads them again and rebuilds the launch plan of the uploaded job. */

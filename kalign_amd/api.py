@@ -40,7 +40,7 @@ class TaskRec(C.Structure):
 DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
 EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_consistency_part",
-           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_debug_reload_env", "ka_ctx_fallback_runs", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
+           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_debug_reload_env", "ka_ctx_fallback_runs", "ka_ctx_helped_tasks", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_refine", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms", "ka_tree_launch_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
@@ -87,6 +87,8 @@ def load_library():
     L.ka_tree_consistency_part_range.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.ka_tree_consistency_maps_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_longlong)]
     L.ka_ctx_fallback_runs.argtypes = [vp]
+    L.ka_ctx_helped_tasks.argtypes = [vp]
+    L.ka_ctx_helped_tasks.restype = C.c_longlong
     L.ka_abi_version.restype = C.c_int
     L.ka_msa_tree.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                               C.POINTER(TaskRec), vp, C.c_longlong, vp]
@@ -232,7 +234,7 @@ class Context:
             pass
 
     def debug_set_hooks(self, hooks):
-        """tests only: ka_debug_set_hooks (KA_DEBUG_SMALL_ARENAS = 1, KA_DEBUG_STARVE_ROOT_JOIN = 2, KA_DEBUG_STARVE_REFINE_MEMBER = 4)"""
+        """tests only: ka_debug_set_hooks (KA_DEBUG_SMALL_ARENAS = 1, KA_DEBUG_STARVE_ROOT_JOIN = 2, KA_DEBUG_STARVE_REFINE_MEMBER = 4, KA_DEBUG_CHAIN_FIRST = 8)"""
         self._chk(self.L.ka_debug_set_hooks(self.h, int(hooks)))
 
     def reload_env(self):
@@ -241,6 +243,10 @@ class Context:
 
     def fallback_runs(self):
         return int(self.L.ka_ctx_fallback_runs(self.h))
+
+    def helped_tasks(self):
+        """queue tasks of the last run that workgroups of the chained launch took over (ka_ctx_helped_tasks)"""
+        return int(self.L.ka_ctx_helped_tasks(self.h))
 
     def _chk(self, rc):
         if rc:

@@ -17,7 +17,7 @@ __attribute__((visibility("hidden"))) int ka_fail_message(const char* m) { retur
 extern "C" const char* ka_last_error(void) { return g_err.c_str(); }
 struct ka_ctx;
 int ka_ctx_device_stream(ka_ctx* c, int* device, hipStream_t* stream);    // (library-internal: ka_guide.cpp)
-extern "C" int ka_abi_version(void) { return 8; }
+extern "C" int ka_abi_version(void) { return 9; }
 
 extern "C" int ka_ctx_create(int device, ka_ctx** out)
 {
@@ -79,6 +79,7 @@ extern "C" int ka_debug_reload_env(ka_ctx* c)
 // How often a run of this context had to fall back to the no-cluster / no-chain plan because workgroups that wait for
 // each other were not all resident (somebody else was using the GPU).
 extern "C" int ka_ctx_fallback_runs(ka_ctx* c) { return c ? c->fallback_runs : -1; }
+extern "C" long long ka_ctx_helped_tasks(ka_ctx* c) { return (c && c->synced) ? (long long)c->h_counters[5] : -1; }
 
 extern "C" void ka_ctx_destroy(ka_ctx* c)
 {
@@ -218,7 +219,7 @@ KaTreeDev tree_dev(ka_ctx* c)
         D.q1_mode = c->env.q1 >= 0 ? c->env.q1 : (c->nres > 5 ? 4 : 0);     // (nucleotides: five residues -- a one-row step is 0.85 of a two-row one: not worth twice the strips)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
-        D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse; D.carry = c->env.carry;
+        D.q_order = nullptr; D.q_n = 0; D.q_slots = 0; D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse; D.carry = c->env.carry;
         D.overlap = c->overlap_plan ? 1 : 0;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
@@ -258,6 +259,25 @@ static int mark_launch(ka_ctx* c, hipStream_t s = nullptr)
         if (!c->env.launch_ev) return KA_OK;
         while ((int)c->launch_ev.size() < c->n_launches) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); c->launch_ev.push_back(e); }
         HIPCHK(hipEventRecord(c->launch_ev[c->n_launches - 1], s ? s : c->stream));
+        return KA_OK;
+}
+
+// the chained launch: a guide-tree level and everything above it, tasks chained through their join points
+static int launch_chain(ka_ctx* c, const KaTreeDev& D, bool ov, bool join_now = true)
+{
+        hipStream_t cs = ov ? c->s_chain : c->stream;
+        KaTreeDev Dc = D;
+        if (ov && c->env.overlap_help) {
+                // (its workgroups help the queue when they arrive before it is down to its last round: ka_task_entry)
+                const int per_cu = c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8);
+                Dc.q_order = c->d_blocks.p + c->queue_off; Dc.q_n = c->queue_n; Dc.q_slots = per_cu * c->n_cus;
+        }
+        ka_launch_task_level(&Dc, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, cs);
+        c->n_launches++; if (mark_launch(c, cs)) return KA_FAIL;
+        if (cs != c->stream) {
+                HIPCHK(hipEventRecord(c->e_chain, c->s_chain));
+                if (join_now) HIPCHK(hipStreamWaitEvent(c->stream, c->e_chain, 0));
+        }
         return KA_OK;
 }
 
@@ -309,21 +329,23 @@ int tree_launch(ka_ctx* c, bool reset)
                                 HIPCHK(hipEventRecord(c->e_fork, c->stream));
                                 HIPCHK(hipStreamWaitEvent(c->s_chain, c->e_fork, 0));
                         }
+                        const bool chain_first = ov && (c->test_hooks & KA_DEBUG_CHAIN_FIRST);
+                        if (chain_first) {                               // (tests: see KA_DEBUG_CHAIN_FIRST)
+                                if (launch_chain(c, D, ov, false)) return KA_FAIL;
+                                // both launches wait for the same event and the queue's stream has the higher priority: enqueued back to back the
+                                // queue would still be dispatched first.  Hold it back until the chain's workgroups have the CUs.
+                                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+                        }
                         if (ka_cons_big(&D)) ka_unit7_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
                         else ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         L = (size_t)c->chain_level - 1;
+                        if (chain_first) { HIPCHK(hipStreamWaitEvent(c->stream, c->e_chain, 0)); break; }
                         continue;
                 }
                 if ((int)L == c->chain_level) {
                         // this level and everything above it: one launch, tasks chained through their join points
-                        hipStream_t cs = ov ? c->s_chain : c->stream;
-                        ka_launch_task_level(&D, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, cs);
-                        c->n_launches++; if (mark_launch(c, cs)) return KA_FAIL;
-                        if (cs != c->stream) {
-                                HIPCHK(hipEventRecord(c->e_chain, c->s_chain));
-                                HIPCHK(hipStreamWaitEvent(c->stream, c->e_chain, 0));
-                        }
+                        if (launch_chain(c, D, ov)) return KA_FAIL;
                         break;
                 }
                 ka_launch_task_level(&D, c->d_blocks.p + c->blocks_off[L], c->blocks_off[L + 1] - c->blocks_off[L], c->level_lean[L], 0, c->stream);

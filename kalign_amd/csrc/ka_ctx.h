@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -106,6 +107,7 @@ struct KaEnv {
         int hw_prio = 3;               // KA_HW_PRIO: s_setprio of a strip wave that has a helper (experiments)
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         int overlap = 1;               // KA_OVERLAP: the chained launch goes out beside the queued launch (a stream of its own, ordered by the tasks' done flags)
+        int overlap_help = 1;          // KA_OVERLAP_HELP: workgroups of the chained launch that arrive before the queue's last round take queue tasks
         int carry = 0;                 // KA_CARRY=1: carried vote tables (ka_votes_merge; measured, off: DESIGN 4i) -- 0: every task counts its members' votes
         int reuse = 1;                 // KA_REUSE: Hirschberg prefix reuse in the 4-wave kernels (queued levels, seq-seq leaves, pair batch)
         int qw = 4, lw = 4, pw = 2;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
@@ -126,6 +128,7 @@ static inline void read_env(KaEnv& v)
         v.subtree = env_int("KA_SUBTREE", 1);
         v.reuse = env_int("KA_REUSE", 1);
         v.carry = env_int("KA_CARRY", 0);
+        v.overlap_help = env_int("KA_OVERLAP_HELP", 1);
         v.overlap = env_int("KA_OVERLAP", 1);
         v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 2);
         for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;

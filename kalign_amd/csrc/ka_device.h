@@ -60,7 +60,7 @@ struct KaTreeDev {
         long long* node_prof;          // [2N-1] offset (floats) of the node's profile in prof_arena
         long long* node_vote;          // [2N-1] offset (floats) of the node's carried vote table in prof_arena (ka_votes_merge), -1: none
         float* prof_arena;
-        unsigned long long* counters;  // [0] prof_top, [1] scratch_top, [2] path_top, [3] dbg_top (floats), [4] head of the queued launch
+        unsigned long long* counters;  // [0] prof_top, [1] scratch_top, [2] path_top, [3] dbg_top (floats), [4] head of the queued launch, [5] queue tasks taken by workgroups of the chained launch
         long long prof_cap, scratch_cap, path_cap, dbg_cap;
         char* scratch;
         int* path_arena;
@@ -99,6 +99,8 @@ struct KaTreeDev {
         int reuse;                     // Hirschberg prefix reuse in the 4-wave kernels (KA_REUSE=0: off)
         int overlap;                   // round 5: the launches of a run go out TOGETHER on streams of their own and order themselves by the tasks' done flags
                                        // (KaJoin::go): every task sets its flag, every task waits for the flags of the tasks that make its operands (qa / qb)
+        const int2* q_order;           // the chained launch of an overlapping run: the queued launch's list, its length and its workgroup slots --
+        int q_n, q_slots;              // a chained workgroup that finds more than a round of the queue still to do helps (ka_task_entry); 0: no
         int qw, lw;                    // waves per workgroup of the queued launch (KA_QW: 4, 2 or 1) / of the seq-seq leaf levels (KA_LW)
         int per_target;                // experiments (KA_PER): strips per workgroup a profile-profile task aims for at its top level (0: the built-in table)
         int carry;                     // round 5: a node's anchor votes are carried up the tree (ka_votes_merge) instead of counted again from every

@@ -768,8 +768,34 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
         if (task < 0) return;
         int member = blk.y & 0xff, g = blk.y >> 8;
         const int tid = threadIdx.x;
+        // Round 5, overlapping launches: this launch went out BESIDE the queued one.  Normally its workgroups become resident as the
+        // queue's leave; when the dispatcher brings them in first (stream priorities are a hint) they would sit on the CUs the queue needs
+        // and wait for it -- a slow round for one tree, seconds for a forest.  So a workgroup that arrives while more than a round of the
+        // queue is still to be handed out takes tasks from the queue's list like one of the queue's own workgroups (same counter, same
+        // done flags, this kernel's task body), and turns to its place in the chain when the list is down to its last round.
+        bool helping = chain && D.q_n > 0;
+        const int own_task = task, own_member = member, own_g = g;
         while (true) {
+                if (helping) {
+                        __syncthreads();
+                        if (tid == 0) {
+                                const long long head = (long long)__hip_atomic_load(&D.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                S.next_member = ((long long)D.q_n - head > (long long)D.q_slots) ? (int)atomicAdd(&D.counters[4], 1ull) : D.q_n;
+                        }
+                        __syncthreads();
+                        const int qi = S.next_member;
+                        __syncthreads();
+                        if (qi < D.q_n) { task = D.q_order[qi].x; member = 0; g = 1; if (tid == 0) atomicAdd(&D.counters[5], 1ull); }
+                        else { helping = false; task = own_task; member = own_member; g = own_g; }
+                }
                 const int st = ka_task_body<LEAN, NB, !LEAN>(D, task, member, g);
+                if (helping) {
+                        // (as the queue does: everything the task wrote is released, then its done flag goes up -- also after a failed task)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        __syncthreads();
+                        if (tid == 0) __hip_atomic_store(&D.join[task].go, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        continue;
+                }
                 if (!chain || st == 1) return;
                 // A workgroup the task had no use for stays with its cluster: it skips the task, waits for the cluster's
                 // role at the parent and moves up with it -- a bigger task further up may need it (in a chain-like

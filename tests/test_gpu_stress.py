@@ -140,3 +140,43 @@ def test_randomised_schedules_on_big_shapes(which, monkeypatch):
         for k in BIG_SWITCHES:
             monkeypatch.delenv(k, raising=False)
         ctx.close()
+
+
+def test_chained_launch_that_arrives_before_the_queue_helps_it():
+    """Overlapping launches (round 5): the chained launch goes out beside the queued one on a low-priority stream.  A dispatcher that
+    brings its workgroups in FIRST leaves the queue eight CUs -- a slow round for one tree, a watchdog fallback for a forest (seen
+    once in bench.py's 16-tree point, reproduced at will with KA_OVERLAP_HELP=0 on four 4096 x 2000 trees).  The chained workgroups
+    therefore take queue tasks while more than a round of the queue is left.  KA_DEBUG_CHAIN_FIRST enqueues the chain BEFORE the queue:
+    same alignment, three launches, no fallback."""
+    import kalign_amd
+    from kalign_amd import api, guide, synth
+    seqs = synth.dssim(4096, 300, dna=False, seed=11)
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), i))
+    seqs = [seqs[i] for i in order]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "param_tables.npz"))
+    subm, scal = z["subm_0_3"], z["scal_0_3"].copy()
+    ctx = kalign_amd.Context(0)
+    try:
+        tasks, sd = ctx.guide_tree(guide.encode_tree(seqs, dna=False), n_threads=8)
+        codes = guide.encode(seqs, dna=False)
+        # two copies as a forest: the queue holds a few rounds of tasks
+        fc, ft, fd, _ = guide.forest([(codes, tasks, sd)] * 2)
+        ctx.tree_upload(fc, ft, subm, scal, fd)
+        ctx.tree_run(); ctx.tree_sync()
+        assert ctx.tree_kernel_ms()[1] == 3
+        recs0, paths0, gaps0 = ctx.tree_download()
+        ctx.debug_set_hooks(8)                                        # KA_DEBUG_CHAIN_FIRST
+        helped = 0
+        for _ in range(3):
+            ctx.tree_run(); ctx.tree_sync()
+            assert ctx.tree_kernel_ms()[1] == 3 and ctx.fallback_runs() == 0
+            helped += ctx.helped_tasks()
+            recs, paths, gaps = ctx.tree_download()
+            assert [r.plen for r in recs] == [r.plen for r in recs0]
+            assert np.array_equal(paths, paths0)
+            for a, b in zip(gaps, gaps0):
+                assert np.array_equal(a, b)
+        ctx.debug_set_hooks(0)
+        assert helped > 0, "the chained launch's workgroups were resident first and took no queue task"
+    finally:
+        ctx.close()
