@@ -270,7 +270,7 @@ static int launch_chain(ka_ctx* c, const KaTreeDev& D, bool ov, bool join_now = 
         if (ov && c->env.overlap_help) {
                 // (its workgroups help the queue when they arrive before it is down to its last round: ka_task_entry)
                 const int per_cu = c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8);
-                Dc.q_order = c->d_blocks.p + c->queue_off; Dc.q_n = c->queue_n; Dc.q_slots = per_cu * c->n_cus;
+                Dc.q_order = c->d_blocks.p + c->queue_off; Dc.q_n = c->queue_n; Dc.q_slots = (c->env.overlap_help >= 2) ? (c->env.overlap_help - 2) : per_cu * c->n_cus;   // (KA_OVERLAP_HELP=2+n: help down to the last n tasks -- experiments)
         }
         ka_launch_task_level(&Dc, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, cs);
         c->n_launches++; if (mark_launch(c, cs)) return KA_FAIL;
