@@ -837,11 +837,108 @@ static ko_cons* ko_cons_build(int N, const uint8_t* codes, const int* off, const
         return ct;
 }
 
-/* get_node_anchor_positions (anchor_consistency.c:352-470) */
+/*
+ * CARRIED VOTES (the device's rule, kalign_amd/csrc/ka_profile.h: ka_votes_merge / ka_cons_from_tables; switched on with
+ * ko_set_carried_votes -- the golden tests run every consistency tree with it and expect the reference's answer).
+ * get_node_anchor_positions counts, per anchor and column, over the node's members in sip order: best = the position of the first
+ * member that has one, total = members that have one, agree = members at best.  sip[c] = rev(sip[a]) ++ rev(sip[b])
+ * (aln_run.c:428-436), so c's first voter is a's LAST one.  A node therefore carries both ends of its list per anchor and column --
+ * f / fc: first voter's position / voters at it; l / lc: the same for the last voter; n: voters -- and a column of c follows from
+ * the columns of a and b it is made of:  one side only (X): f = l_X, fc = lc_X, l = f_X, lc = fc_X, n = n_X;  both: f = l_a,
+ * fc = lc_a + #{voters of b at l_a}, l = f_b, lc = fc_b + #{voters of a at f_b}, n = n_a + n_b, where #{voters of X at p} is fc_X
+ * if p == f_X, lc_X if p == l_X, 0 if the voters at f_X and l_X are all of X's voters, and otherwise has to be COUNTED over X's
+ * members (the device marks the cell and settles all marks with one sweep; here they are counted on the spot and tallied).
+ */
+typedef struct { int f, fc, l, lc, n; } ko_vote;
+static int ko_carried_on = 0;
+static long long ko_carried_cells = 0, ko_carried_counted = 0;
+void ko_set_carried_votes(int on) { ko_carried_on = on; ko_carried_cells = 0; ko_carried_counted = 0; }
+void ko_carried_votes_cells(long long* cells, long long* counted) { *cells = ko_carried_cells; *counted = ko_carried_counted; }
+
+static ko_vote ko_vote_cell(const ko_cons* ct, int node, int nmem, const ko_vote* tab, int plen, int k, int i)
+{
+        ko_vote v;
+        if(nmem == 1){                                             /* a leaf: its position map is its table */
+                v.f = v.l = ct->maps[node * ct->K + k][i];
+                v.fc = v.lc = v.n = (v.f >= 0) ? 1 : 0;
+                return v;
+        }
+        return tab[(size_t)k * (size_t)plen + (size_t)i];
+}
+
+/* voters of node X (members xm[0..xn), alignment in gaps[]) whose position for anchor k in X's column col is p */
+static int ko_vote_count(const ko_cons* ct, const int* xm, int xn, const int* lens, int** gaps, int k, int col, int p)
+{
+        int cnt = 0;
+        for(int mi = 0; mi < xn; mi++){
+                const int si = xm[mi];
+                const int* g = gaps[si];
+                int c = 0;
+                if(si >= ct->N) continue;
+                for(int q = 0; q < lens[si]; q++){
+                        c += g[q];
+                        if(c == col){ if(ct->maps[si * ct->K + k][q] == p) cnt++; break; }
+                        if(c > col) break;
+                        c++;
+                }
+        }
+        return cnt;
+}
+
+static int ko_vote_known(const ko_vote* x, int p, int* cnt)
+{
+        if(p == x->f){ *cnt = x->fc; return 1; }
+        if(p == x->l){ *cnt = x->lc; return 1; }
+        if((x->f == x->l) ? (x->fc == x->n) : (x->fc + x->lc == x->n)){ *cnt = 0; return 1; }
+        return 0;
+}
+
+/* the table of c = merge(a, b) along `coded`; BEFORE weave: gaps[] still hold every member's columns within a and within b */
+static ko_vote* ko_votes_merge(const ko_cons* ct, const int* coded, int a, int na, const int* ma, const ko_vote* ta, int la,
+                               int b, int nb, const int* mb, const ko_vote* tb, int lb, const int* lens, int** gaps)
+{
+        const int K = ct->K, alnlen = coded[0];
+        ko_vote* vt = malloc(sizeof(ko_vote) * (size_t)K * (size_t)alnlen);
+        int ia = 0, ib = 0;
+        for(int j = 0; j < alnlen; j++){
+                const int code = coded[j + 1];
+                const int ca = (code & 1) ? -1 : ia, cb = (!(code & 1) && (code & 2)) ? -1 : ib;
+                for(int k = 0; k < K; k++){
+                        ko_vote A = { -1, 0, -1, 0, 0 }, B = { -1, 0, -1, 0, 0 }, v;
+                        int cnt;
+                        if(ca >= 0) A = ko_vote_cell(ct, a, na, ta, la, k, ca);
+                        if(cb >= 0) B = ko_vote_cell(ct, b, nb, tb, lb, k, cb);
+                        if(A.n == 0){ v.f = B.l; v.fc = B.lc; v.l = B.f; v.lc = B.fc; v.n = B.n; }
+                        else if(B.n == 0){ v.f = A.l; v.fc = A.lc; v.l = A.f; v.lc = A.fc; v.n = A.n; }
+                        else{
+                                v.f = A.l; v.l = B.f; v.n = A.n + B.n;
+                                if(!ko_vote_known(&B, v.f, &cnt)){ cnt = ko_vote_count(ct, mb, nb, lens, gaps, k, cb, v.f); ko_carried_counted++; }
+                                v.fc = A.lc + cnt;
+                                if(!ko_vote_known(&A, v.l, &cnt)){ cnt = ko_vote_count(ct, ma, na, lens, gaps, k, ca, v.l); ko_carried_counted++; }
+                                v.lc = B.fc + cnt;
+                        }
+                        vt[(size_t)k * (size_t)alnlen + (size_t)j] = v;
+                        ko_carried_cells++;
+                }
+                if(ca >= 0) ia++;
+                if(cb >= 0) ib++;
+        }
+        return vt;
+}
+
+/* get_node_anchor_positions (anchor_consistency.c:352-470); tab != NULL: from the node's carried table instead of a count */
 static void ko_node_positions(const ko_cons* ct, int node, int nmem, const int* members, const int* lens,
-                              int** gaps, int dp_len, int k, int* positions, float* conf)
+                              int** gaps, int dp_len, int k, int* positions, float* conf, const ko_vote* tab)
 {
         const int K = ct->K;
+        if(tab && nmem > 1){
+                for(int i = 0; i < dp_len; i++){
+                        const ko_vote v = tab[(size_t)k * (size_t)dp_len + (size_t)i];
+                        if(v.n > 0 && v.fc > 0){ positions[i] = v.f; conf[i] = (float)v.fc / (float)v.n; }
+                        else { positions[i] = -1; conf[i] = 0.0f; }
+                }
+                return;
+        }
         if(nmem == 1){
                 const int* map = ct->maps[node * K + k];
                 const int seq_len = lens[node];
@@ -899,7 +996,7 @@ static void ko_node_positions(const ko_cons* ct, int node, int nmem, const int* 
 /* anchor_consistency_get_bonus_profile (anchor_consistency.c:472-561): dense rows x cols matrix */
 static float* ko_bonus_profile(const ko_cons* ct, const int* lens, int** gaps,
                                int rnode, int rn, const int* rmem, int rows,
-                               int cnode, int cn, const int* cmem, int cols)
+                               int cnode, int cn, const int* cmem, int cols, const ko_vote* rtab, const ko_vote* ctab)
 {
         float* bonus = calloc((size_t)rows * (size_t)cols, sizeof(float));
         int* apos_a = malloc(sizeof(int) * (size_t)rows);
@@ -911,8 +1008,8 @@ static float* ko_bonus_profile(const ko_cons* ct, const int* lens, int** gaps,
                 int anchor_len = 0;
                 int* inv_b;
                 float* inv_conf_b;
-                ko_node_positions(ct, rnode, rn, rmem, lens, gaps, rows, k, apos_a, conf_a);
-                ko_node_positions(ct, cnode, cn, cmem, lens, gaps, cols, k, apos_b, conf_b);
+                ko_node_positions(ct, rnode, rn, rmem, lens, gaps, rows, k, apos_a, conf_a, rtab);
+                ko_node_positions(ct, cnode, cn, cmem, lens, gaps, cols, k, apos_b, conf_b, ctab);
                 for(int i = 0; i < rows; i++) if(apos_a[i] >= anchor_len) anchor_len = apos_a[i] + 1;
                 for(int j = 0; j < cols; j++) if(apos_b[j] >= anchor_len) anchor_len = apos_b[j] + 1;
                 if(anchor_len == 0) continue;
@@ -966,6 +1063,7 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
         int* nsip = calloc((size_t)nprof, sizeof(int));
         int* plen = calloc((size_t)nprof, sizeof(int));
         int** gaps = calloc((size_t)numseq, sizeof(int*));
+        ko_vote** votes = NULL;                                    /* carried vote tables per node (ko_set_carried_votes) */
         long long poff = 0;
         int rc = 0;
         float conf_threshold = 0.0f;
@@ -984,6 +1082,7 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                 free(cf);
         }
 
+        if(ct && ko_carried_on) votes = calloc((size_t)nprof, sizeof(ko_vote*));
         if(ct && anchor_ids_out) for(int k = 0; k < ct->K; k++) anchor_ids_out[k] = ct->anchor_ids[k];
         if(ct && maps_out){
                 int o = 0;
@@ -1067,7 +1166,8 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                 if(ct){
                         /* rows/cols of the bonus follow the DP operands (aln_run.c:262-295) */
                         const int rn = swapped ? b : a, cn = swapped ? a : b;
-                        bonus = ko_bonus_profile(ct, lens, gaps, rn, nsip[rn], sip[rn], d.len_a, cn, nsip[cn], sip[cn], d.len_b);
+                        bonus = ko_bonus_profile(ct, lens, gaps, rn, nsip[rn], sip[rn], d.len_a, cn, nsip[cn], sip[cn], d.len_b,
+                                                 votes ? votes[rn] : NULL, votes ? votes[cn] : NULL);
                         d.bonus = bonus; d.bstride = d.len_b;
                         if(bonus_hash_out) bonus_hash_out[tid] = ko_fnv1a(bonus, sizeof(float) * (uint64_t)d.len_a * (uint64_t)d.len_b);
                 }else if(bonus_hash_out){
@@ -1178,6 +1278,9 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                 }
                 free(prof[a]); free(prof[b]); prof[a] = NULL; prof[b] = NULL;
                 prof[c] = merged;
+                if(votes && tid != n_tasks - 1)
+                        votes[c] = ko_votes_merge(ct, coded, a, nsip[a], sip[a], votes[a], len_a, b, nsip[b], sip[b], votes[b], len_b, lens, gaps);
+                if(votes){ free(votes[a]); free(votes[b]); votes[a] = NULL; votes[b] = NULL; }
                 weave(coded, sip[a], nsip[a], sip[b], nsip[b], lens, gaps);
                 plen[c] = coded[0];
                 nsip[c] = nsip[a] + nsip[b];
@@ -1192,9 +1295,9 @@ static int ko_tree_impl(int numseq, const uint8_t* codes, const int* off, const 
                 int o = 0;
                 for(int i = 0; i < numseq; i++) for(int j = 0; j <= lens[i]; j++) gaps_out[o++] = gaps[i][j];
         }
-        for(int i = 0; i < nprof; i++){ free(prof[i]); free(sip[i]); }
+        for(int i = 0; i < nprof; i++){ free(prof[i]); free(sip[i]); if(votes) free(votes[i]); }
         for(int i = 0; i < numseq; i++) free(gaps[i]);
-        free(prof); free(sip); free(nsip); free(plen); free(gaps);
+        free(prof); free(sip); free(nsip); free(plen); free(gaps); free(votes);
         return rc;
 }
 

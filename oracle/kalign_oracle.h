@@ -97,6 +97,10 @@ uint64_t ko_fnv1a(const void* p, uint64_t n);
    not run; every result must stay bit-identical (tests/test_oracle_golden.py).  The counters: DP cells of the passes that ran /
    that were taken over since the switch was last set. */
 void ko_set_prefix_reuse(int on);
+/* anchor votes carried up the tree (the device's KA_CARRY=1 rule) instead of counted over every member at every task; the second call:
+   cells merged since the switch, and how many of them needed a count over an operand's members (what the device marks) */
+void ko_set_carried_votes(int on);
+void ko_carried_votes_cells(long long* cells, long long* counted);
 void ko_prefix_reuse_cells(long long* run, long long* reused);
 
 /* distance estimation: bpm_block (lib/src/bpm.c:356-582) and calc_distance's pair rule

@@ -82,6 +82,10 @@ def lib():
         L.ko_set_prefix_reuse.restype = None
         L.ko_prefix_reuse_cells.argtypes = [vp, vp]
         L.ko_prefix_reuse_cells.restype = None
+        L.ko_set_carried_votes.argtypes = [C.c_int]
+        L.ko_set_carried_votes.restype = None
+        L.ko_carried_votes_cells.argtypes = [vp, vp]
+        L.ko_carried_votes_cells.restype = None
         _lib = L
     return _lib
 
@@ -89,6 +93,18 @@ def lib():
 def set_prefix_reuse(on):
     """Hirschberg prefix reuse in the oracle's recursion (the device's rule; results must not change)."""
     lib().ko_set_prefix_reuse(1 if on else 0)
+
+
+def set_carried_votes(on):
+    """anchor votes carried up the tree (the device's KA_CARRY=1 rule; results must not change)"""
+    lib().ko_set_carried_votes(1 if on else 0)
+
+
+def carried_votes_cells():
+    """(cells of the vote tables merged, cells that needed a count over an operand's members) since set_carried_votes"""
+    cells, counted = C.c_longlong(0), C.c_longlong(0)
+    lib().ko_carried_votes_cells(C.byref(cells), C.byref(counted))
+    return cells.value, counted.value
 
 
 def prefix_reuse_cells():

@@ -227,3 +227,67 @@ def test_prefix_reuse_in_refinement_trials(reuse, name):
     for got, want in zip(gaps, g.gaps_list()):
         assert np.array_equal(got, want)
     assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+
+
+# ---- carried anchor votes (round 5; the device's KA_CARRY=1): the recurrence, proven exact on the CPU ----
+@pytest.fixture
+def carried(oracle):
+    oracle.set_carried_votes(True)
+    yield oracle
+    oracle.set_carried_votes(False)
+
+
+@pytest.mark.parametrize("name", cons_cases())
+def test_carried_votes_leave_every_consistency_golden_bit_identical(carried, name):
+    """A node's anchor positions from its operands' tables (first / last voter per anchor and column, sip[c] = rev(sip[a]) ++ rev(sip[b]),
+    aln_run.c:428-436) instead of get_node_anchor_positions' count over all members (anchor_consistency.c:352-470): the same bonus
+    matrices (hashes of the reference's dense ones), the same paths, scores, gap arrays."""
+    g = Golden(name)
+    recs, paths, gaps, ids, maps, bh = carried.msa_tree_cons(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, int(g.n_anchors), float(g.weight))
+    cells, counted = carried.carried_votes_cells()
+    assert np.array_equal(bh, g.bonus_hash)
+    assert compare_recs(g, recs, paths, EXACT) == []
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert cells > 0 and counted <= cells
+
+
+@pytest.mark.parametrize("name", [n for n in refine_cases() if int(Golden(n).n_anchors) > 0][:6])
+def test_carried_votes_in_a_refinement_pass(carried, name):
+    g = Golden(name)
+    recs, paths, gaps = carried.msa_tree_refine(g.codes, g.tasks, g.subm, g.scal, g.seq_distances, mode=int(g.mode),
+                                                conf_in=g.conf_before, n_anchors=int(g.n_anchors), weight=float(g.weight))
+    for got, want in zip(gaps, g.gaps_list()):
+        assert np.array_equal(got, want)
+    assert np.array_equal(np.array([r.confidence for r in recs], np.float32), g.conf_after)
+
+
+def test_carried_votes_need_counts_where_voters_disagree(carried):
+    """On a divergent family some cells cannot be settled from the operands' cells alone (the device marks them and sweeps once):
+    the tally says how many -- and the answer is still the count's."""
+    from kalign_amd import synth
+    import os
+    seqs = synth.dssim(48, 120, dna=False, seed=5)
+    alpha = "ARNDCQEGHILKMFPSTWYV"
+    codes = [np.array([alpha.index(ch) for ch in s], np.uint8) for s in seqs]
+    n = len(codes)
+    tasks, nodes, nxt = [], list(range(n)), n
+    rng = np.random.RandomState(3)
+    while len(nodes) > 1:
+        i, j = rng.choice(len(nodes), 2, replace=False)
+        tasks.append((nodes[i], nodes[j], nxt))
+        nodes = [x for q, x in enumerate(nodes) if q not in (i, j)] + [nxt]
+        nxt += 1
+    tasks = np.array(tasks, np.int32)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "param_tables.npz"))
+    subm, scal = z["subm_0_3"], z["scal_0_3"].copy()
+    dist = rng.uniform(0.2, 1.2, size=n).astype(np.float32)
+    out1 = carried.msa_tree_cons(codes, tasks, subm, scal, dist, 5, 2.0)
+    cells, counted = carried.carried_votes_cells()
+    carried.set_carried_votes(False)
+    out0 = carried.msa_tree_cons(codes, tasks, subm, scal, dist, 5, 2.0)
+    assert np.array_equal(out1[5], out0[5])                       # bonus hashes of every task
+    assert np.array_equal(out1[1], out0[1])
+    for a, b in zip(out1[2], out0[2]):
+        assert np.array_equal(a, b)
+    assert 0 < counted < cells, (cells, counted)
