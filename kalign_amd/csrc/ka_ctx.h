@@ -108,7 +108,7 @@ struct KaEnv {
         int subtree = 1;               // KA_SUBTREE: small Hirschberg subtrees run wave-locally in LDS
         int overlap = 1;               // KA_OVERLAP: the chained launch goes out beside the queued launch (a stream of its own, ordered by the tasks' done flags)
         int overlap_help = 1;          // KA_OVERLAP_HELP: workgroups of the chained launch that arrive before the queue's last round take queue tasks
-        int carry = 0;                 // KA_CARRY=1: carried vote tables (ka_votes_merge; measured, off: DESIGN 4i) -- 0: every task counts its members' votes
+        int carry = 0;                 // KA_CARRY=1: carried vote tables (ka_votes_merge; measured, off: DESIGN 4i; 3: marks settled by the sweep only) -- 0: every task counts its members' votes
         int reuse = 1;                 // KA_REUSE: Hirschberg prefix reuse in the 4-wave kernels (queued levels, seq-seq leaves, pair batch)
         int qw = 4, lw = 4, pw = 2;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)

@@ -553,7 +553,8 @@ __device__ void ka_cons_votes(TaskShared& S, const KaTreeDev& D, const KaTaskDes
 // 4096-sequence tree: prep 351 -> 109 us) but in real alignments some cell of nearly every big node is marked, and the sweep that
 // settles the marks -- global atomics instead of LDS ones -- costs what was saved (merge 105 -> 353 us): default-mode tree 20.6 ->
 // 21.2 ms, the realignment tree of a `--precise` member 79.5 -> 78.6 ms, the same tree on one workgroup per task (shared context)
-// 178 -> 220 ms (profiles/r05_carried_votes.log).
+// 178 -> 220 ms (profiles/r05_carried_votes.log).  With few marks settled one by one (below; KA_CARRY=3 keeps the sweep): 20.7 / 75.4 /
+// 220 ms -- the top nodes of a 4096-sequence tree have more marks than that path takes.
 // ------------------------------------------------------------------------------------------
 #define KA_VOTE_MARK 0x80000000u
 struct KaVote { int f, fc, l, lc, n; };
@@ -632,7 +633,16 @@ __device__ void ka_votes_merge(TaskShared& S, const KaTreeDev& D, const KaTaskDe
         const long long K = D.cons_K, pl = K * alnlen;
         const int* ta = ka_vote_table(D, T.a, T.nsip_a);
         const int* tb = ka_vote_table(D, T.b, T.nsip_b);
+        // marked cells are also listed (in the scratch the counted votes use for their tables, 16 B per anchor and column: idle here): few
+        // of them -- 0.1 % of the cells of a DSSim family -- are settled one by one (below), many by a sweep over the members
+        int* mlist = (int*)S.vote;
+        const int mcap = (pl < (1ll << 30)) ? (int)min(K * ((long long)S.len_a + S.len_b), (long long)(1 << 20)) : 0;
         int any = 0;                                                  // bit 0: cells that want b's members counted, bit 1: a's
+        auto mark = [&](const long long x, const int type) {
+                const int slot = atomicAdd(&S.ctl->vote_conf, 1);
+                if (slot < mcap) mlist[slot] = (int)x | (type << 30);
+                any |= 1 << type;
+        };
         for (long long x = (long long)S.member * KA_NT + tid; x < pl; x += (long long)S.G * KA_NT) {
                 const int k = (int)(x / alnlen), j = (int)(x - (long long)k * alnlen);
                 const int ia = S.srcA[j + 1] - 1, ib = S.srcB[j + 1] - 1;
@@ -646,15 +656,44 @@ __device__ void ka_votes_merge(TaskShared& S, const KaTreeDev& D, const KaTaskDe
                 else {
                         int cnt;
                         f = A.l; l = B.f; n = A.n + B.n;
-                        if (ka_vote_count_at(B, f, cnt)) fc = (unsigned int)(A.lc + cnt); else { fc = (unsigned int)A.lc | KA_VOTE_MARK; any |= 1; }
-                        if (ka_vote_count_at(A, l, cnt)) lc = (unsigned int)(B.fc + cnt); else { lc = (unsigned int)B.fc | KA_VOTE_MARK; any |= 2; }
+                        if (ka_vote_count_at(B, f, cnt)) fc = (unsigned int)(A.lc + cnt); else { fc = (unsigned int)A.lc | KA_VOTE_MARK; mark(x, 0); }
+                        if (ka_vote_count_at(A, l, cnt)) lc = (unsigned int)(B.fc + cnt); else { lc = (unsigned int)B.fc | KA_VOTE_MARK; mark(x, 1); }
                 }
                 vt[x] = f; vt[pl + x] = (int)fc; vt[2 * pl + x] = l; vt[3 * pl + x] = (int)lc; vt[4 * pl + x] = n;
         }
-        if (any) __hip_atomic_fetch_or(&S.ctl->vote_conf, any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (any) __hip_atomic_fetch_or(&S.ctl->vote_types, any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ka_cluster_sync(S);                                           // the table, the marks, and every member's merged columns
-        const int todo = __hip_atomic_load(&S.ctl->vote_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (todo == 0) return;
+        const int nm = __hip_atomic_load(&S.ctl->vote_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nm == 0) return;
+        const int todo = __hip_atomic_load(&S.ctl->vote_types, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+                // few marks: every (marked cell, member of the operand it asks about) is one binary search in the member's residue -> column
+                // table (columns grow with the residue) -- at most eight per thread, otherwise the sweep
+                const long long NM = max(T.nsip_a, T.nsip_b);
+                if (nm <= mcap && (long long)nm * NM <= 8ll * S.G * KA_NT && !(D.carry & 2)) {
+                        for (long long idx = (long long)S.member * KA_NT + tid; idx < (long long)nm * NM; idx += (long long)S.G * KA_NT) {
+                                const int e = mlist[idx / NM], m = (int)(idx % NM);
+                                const int type = (e >> 30) & 1;
+                                const long long x = e & 0x3fffffff;
+                                const int nX = type ? T.nsip_a : T.nsip_b;
+                                if (m >= nX) continue;
+                                const int si = (D.sip + D.sip_off[type ? T.a : T.b])[m];
+                                const int* col = D.colof + D.seq_off[si];
+                                const int len = D.node_len[si];
+                                const int k = (int)(x / alnlen), j = (int)(x - (long long)k * alnlen);
+                                int lo = 0, hi = len - 1, p = -1;
+                                while (lo <= hi) {
+                                        const int mid = (lo + hi) >> 1, c = col[mid];
+                                        if (c == j) { p = mid; break; }
+                                        if (c < j) lo = mid + 1; else hi = mid - 1;
+                                }
+                                if (p < 0) continue;
+                                const int a = D.cons_maps[D.cons_map_off[si] + (long long)k * len + p];
+                                if (a >= 0 && a == vt[(type ? 2 * pl : 0) + x]) atomicAdd((unsigned int*)&vt[(type ? 3 * pl : pl) + x], 1u);
+                        }
+                        return;
+                }
+        }
         // marked cells: b's members are counted at c's first position (plane 1 at plane 0), a's at c's last (plane 3 at plane 2).
         // Gathers: four residues per lane and five anchors' marks in flight.  (Eight residues -- forty loads -- tipped the register allocation
         // of the whole task kernel, everything is inlined into it: 1514 spilled VGPRs against 568, the strips of every default-mode job 14 %

@@ -70,8 +70,8 @@ struct KaCtl {
         long long scratch_off;          // cluster: scratch block allocated by member 0
         long long newp_off;             // merged profile offset in the arena (-1: root / none)
         long long path_off;             // coded path offset in the path arena
-        int vote_conf;                  // carried votes: some column of the merged node needs the second operand's members counted (ka_votes_merge)
-        int pad2;
+        int vote_conf;                  // carried votes (ka_votes_merge): cells of the merged node that need an operand's members counted ...
+        int vote_types;                 // ... bit 0: some of them b's members, bit 1: a's
 };
 
 // Everything the waves of a workgroup share about the task being aligned.

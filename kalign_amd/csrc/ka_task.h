@@ -329,7 +329,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                 S.Gw = g_eff; S.member_w = member; S.split = 0;
                 S.ctl = (g_eff == 1) ? &S.ctl_lds : (D.ctl + task);
                 S.lctl = S.ctl;
-                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.nrec = 0; S.ctl_lds.vote_conf = 0; }
+                if (g_eff == 1) { S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.nrec = 0; S.ctl_lds.vote_conf = 0; S.ctl_lds.vote_types = 0; }
                 s_dbg = nullptr;
                 if (member == 0) {
                         const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, g_eff, false, (D.flags & KA_FLAG_EXACT_CONFIDENCE) != 0, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
@@ -534,7 +534,7 @@ __device__ __forceinline__ void ka_task_body_refine(const KaTreeDev& D, const in
                 S.reuse_ok = 0;
                 S.sub_ok = 0; S.rec_on = 0; S.nres_t = 23; S.sub_stride = 0; S.sub_base = nullptr; S.sub_tm = 0; S.mw_ok = 0;   // (flip trials decide in recursion order: no wave-local subtrees)
                 S.ctl = &S.ctl_lds; S.lctl = S.ctl;
-                S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.vote_conf = 0;
+                S.ctl_lds.fail = 0; S.ctl_lds.bar = 0; S.ctl_lds.vote_conf = 0; S.ctl_lds.vote_types = 0;
                 S.carried = (NB && D.cons_K > 0 && ka_votes_carried(D, T)) ? 1 : 0;
                 const long long need = ka_scratch_bytes(len_a, len_b, NB ? D.cons_maxlen : 0, 1, true, false, NB ? NB : KA_NB, NB > KA_NB ? D.cons_K : -1);
                 const unsigned long long so = atomicAdd(&D.counters[1], (unsigned long long)need);

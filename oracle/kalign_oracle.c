@@ -852,7 +852,8 @@ static ko_cons* ko_cons_build(int N, const uint8_t* codes, const int* off, const
 typedef struct { int f, fc, l, lc, n; } ko_vote;
 static int ko_carried_on = 0;
 static long long ko_carried_cells = 0, ko_carried_counted = 0;
-void ko_set_carried_votes(int on) { ko_carried_on = on; ko_carried_cells = 0; ko_carried_counted = 0; }
+static long long ko_carried_distinct[8];
+void ko_set_carried_votes(int on) { ko_carried_on = on; ko_carried_cells = 0; ko_carried_counted = 0; for(int i = 0; i < 8; i++) ko_carried_distinct[i] = 0; }
 void ko_carried_votes_cells(long long* cells, long long* counted) { *cells = ko_carried_cells; *counted = ko_carried_counted; }
 
 static ko_vote ko_vote_cell(const ko_cons* ct, int node, int nmem, const ko_vote* tab, int plen, int k, int i)
@@ -883,6 +884,31 @@ static int ko_vote_count(const ko_cons* ct, const int* xm, int xn, const int* le
                 }
         }
         return cnt;
+}
+
+/* statistics for DESIGN section 7 (ko_carried_votes_distinct): how many DIFFERENT positions the voters of a merged cell hold -- what a
+   carried cell would have to remember to never need a count */
+void ko_carried_votes_distinct(long long* out8) { for(int i = 0; i < 8; i++) out8[i] = ko_carried_distinct[i]; }
+static void ko_vote_distinct(const ko_cons* ct, const int* xm, int xn, const int* lens, int** gaps, int k, int col, int* seen, int* nseen)
+{
+        for(int mi = 0; mi < xn; mi++){
+                const int si = xm[mi];
+                const int* g = gaps[si];
+                int c = 0;
+                if(si >= ct->N) continue;
+                for(int q = 0; q < lens[si]; q++){
+                        c += g[q];
+                        if(c == col){
+                                const int p = ct->maps[si * ct->K + k][q];
+                                int known = p < 0;
+                                for(int s = 0; s < *nseen && !known; s++) known = seen[s] == p;
+                                if(!known && *nseen < 64) seen[(*nseen)++] = p;
+                                break;
+                        }
+                        if(c > col) break;
+                        c++;
+                }
+        }
 }
 
 static int ko_vote_known(const ko_vote* x, int p, int* cnt)
@@ -919,6 +945,12 @@ static ko_vote* ko_votes_merge(const ko_cons* ct, const int* coded, int a, int n
                         }
                         vt[(size_t)k * (size_t)alnlen + (size_t)j] = v;
                         ko_carried_cells++;
+                        if(ko_carried_on > 1 && A.n > 0 && B.n > 0){           /* (ko_set_carried_votes(2): with the statistics) */
+                                int seen[64], nseen = 0;
+                                ko_vote_distinct(ct, ma, na, lens, gaps, k, ca, seen, &nseen);
+                                ko_vote_distinct(ct, mb, nb, lens, gaps, k, cb, seen, &nseen);
+                                ko_carried_distinct[nseen < 7 ? nseen : 7]++;
+                        }
                 }
                 if(ca >= 0) ia++;
                 if(cb >= 0) ib++;

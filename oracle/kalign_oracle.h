@@ -101,6 +101,9 @@ void ko_set_prefix_reuse(int on);
    cells merged since the switch, and how many of them needed a count over an operand's members (what the device marks) */
 void ko_set_carried_votes(int on);
 void ko_carried_votes_cells(long long* cells, long long* counted);
+/* ko_set_carried_votes(2): also tallies, per merged cell in which both operands vote, how many different positions its voters hold
+   (out8[d], d = 1 .. 6, [7] = 7 and more) */
+void ko_carried_votes_distinct(long long* out8);
 void ko_prefix_reuse_cells(long long* run, long long* reused);
 
 /* distance estimation: bpm_block (lib/src/bpm.c:356-582) and calc_distance's pair rule

@@ -21,7 +21,7 @@ SWITCHES = {"KA_MAX_CLUSTER": ["1", "2", "4", "8", "16", "24", "32", None], "KA_
             # round 5: launch shapes of the 4-wave kernels, the chained launch beside the queued one, the queue's order
             "KA_QW": ["2", "1", None, None], "KA_LW": ["2", "1", None, None], "KA_OVERLAP": ["0", "1", None], "KA_QORDER": ["0", None, None],
             # anchor votes carried up the tree instead of counted at every task (off by default)
-            "KA_CARRY": ["1", None]}
+            "KA_CARRY": ["1", "3", None]}           # (3: marked cells always settled by the sweep, never one by one)
 
 
 @pytest.mark.parametrize("name", tree_cases() + cons_cases())
