@@ -220,6 +220,7 @@ KaTreeDev tree_dev(ka_ctx* c)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
         D.q_order = nullptr; D.q_n = 0; D.q_slots = 0; D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse; D.carry = c->env.carry;
+        D.tp = c->env.tp;
         D.overlap = c->overlap_plan ? 1 : 0;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
@@ -268,9 +269,14 @@ static int launch_chain(ka_ctx* c, const KaTreeDev& D, bool ov, bool join_now = 
         hipStream_t cs = ov ? c->s_chain : c->stream;
         KaTreeDev Dc = D;
         if (ov && c->env.overlap_help) {
-                // (its workgroups help the queue when they arrive before it is down to its last round: ka_task_entry)
-                const int per_cu = c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8);
-                Dc.q_order = c->d_blocks.p + c->queue_off; Dc.q_n = c->queue_n; Dc.q_slots = (c->env.overlap_help >= 2) ? (c->env.overlap_help - 2) : per_cu * c->n_cus;   // (KA_OVERLAP_HELP=2+n: help down to the last n tasks -- experiments)
+                // Its workgroups help the queue when they arrive first (ka_task_entry) -- down to an EMPTY list (round 6).  Round 5 stopped
+                // helping at the queue's last round (workgroup slots of the queued launch: "its own workgroups run that"), which assumes
+                // those workgroups are resident.  They need not be: the chain may hold every CU (spare workgroups fill it up to n_cus; one
+                // of its workgroups takes a CU's LDS), and the queued launch can start late -- seen deterministically when its kernel's code
+                // object is loaded at its first launch: the chain took all CUs, did all but the last round, and everybody waited for 768
+                // tasks nobody could run until the watchdog fired (2.4 s, then the shared plan).  Measured in round 5: where the helping
+                // stops makes no difference in the normal order (KA_OVERLAP_HELP=2+n: stop at the last n tasks -- experiments).
+                Dc.q_order = c->d_blocks.p + c->queue_off; Dc.q_n = c->queue_n; Dc.q_slots = (c->env.overlap_help >= 2) ? (c->env.overlap_help - 2) : 0;
         }
         ka_launch_task_level(&Dc, c->d_blocks.p + c->chain_blocks_off, (int)c->chain_blocks.size(), 0, 1, cs);
         c->n_launches++; if (mark_launch(c, cs)) return KA_FAIL;
@@ -322,7 +328,7 @@ int tree_launch(ka_ctx* c, bool reset)
                         // levels queue_first .. chain_level-1: one launch, two workgroups per CU pulling from the ordered list
                         // (workgroups per CU: two of four waves; of narrower ones as many as the registers (eight waves) and the LDS (160 KB) hold)
                         // (more than fit is harmless: a workgroup that starts late finds the rest of the list, or nothing)
-                        const int per_cu = c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8);
+                        const int per_cu = ka_tp_ok(&D) ? 3 : (c->env.qw == 4 ? 2 : (c->env.qw == 2 ? 4 : 8));
                         const int nwg = std::min(c->queue_n, per_cu * c->n_cus);
                         if (ov) {
                                 // (the chain's stream forks here: behind the leaf levels and the counter resets, beside the queue)
@@ -337,6 +343,7 @@ int tree_launch(ka_ctx* c, bool reset)
                                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
                         }
                         if (ka_cons_big(&D)) ka_unit7_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
+                        else if (ka_tp_ok(&D)) ka_unit10_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
                         else ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         L = (size_t)c->chain_level - 1;
@@ -487,6 +494,11 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         // workgroups that wait for each other were not all resident: somebody else is using the GPU.
                         // Fall back to the plan that needs no co-residency (ka_ctx_set_shared) and run again.
                         if (c->shared_gpu || c->partial) return fail("device watchdog: a wait between workgroups never completed");
+                        if (getenv("KA_VERBOSE")) {
+                                unsigned long long hc[6] = {0, 0, 0, 0, 0, 0};
+                                (void)hipMemcpy(hc, c->d_counters.p, sizeof(hc), hipMemcpyDeviceToHost);
+                                fprintf(stderr, "[kalign_amd] watchdog 6: queue head %llu of %d, helped %llu, launches %d -> shared plan\n", hc[4], c->queue_n, hc[5], c->n_launches);
+                        }
                         c->shared_gpu = true; c->shared_by_fallback = true; c->fallback_runs++;
                         if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
                         if (c->refine_mode && refine_blocks(c, c->refine_mode)) return KA_FAIL;       // one workgroup per edge from here on

@@ -32,6 +32,9 @@ extern "C" void ka_unit7_launch(const KaTreeDev* D, const int2* blocks_dev, int 
 extern "C" void ka_unit8_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
 extern "C" void ka_unit9_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, hipStream_t stream);
 static inline bool ka_cons_big(const KaTreeDev* D) { return D->cons_K > KA_NB - 1; }
+// round 6: the throughput kernel (unit 10; three four-wave workgroups per CU) in place of the half kernel: fast mode, no B / Z / X
+extern "C" void ka_unit10_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int nqueue, hipStream_t stream);
+static inline bool ka_tp_ok(const KaTreeDev* D) { return D->tp != 0 && D->cons_K == 0 && D->nres <= 20; }
 // kind: 0 = 8-wave kernel, 1 = lean (seq-seq only), 2 = half (4 waves, two workgroups per CU)
 static inline void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int kind, int chain, hipStream_t stream)
 {
@@ -43,6 +46,7 @@ static inline void ka_launch_task_level(const KaTreeDev* D, const int2* blocks_d
                 return;
         }
         if (kind == 1) ka_unit3_launch(D, blocks_dev, nblocks, cons, stream);
+        else if (kind == 2 && ka_tp_ok(D)) ka_unit10_launch(D, blocks_dev, nblocks, 0, stream);
         else if (kind == 2) ka_unit2_launch(D, blocks_dev, nblocks, cons, 0, stream);
         else if (cons) ka_unit1_launch(D, blocks_dev, nblocks, chain, stream);
         else ka_unit0_launch(D, blocks_dev, nblocks, chain, stream);
@@ -110,6 +114,7 @@ struct KaEnv {
         int overlap_help = 1;          // KA_OVERLAP_HELP: workgroups of the chained launch that arrive before the queue's last round take queue tasks
         int carry = 0;                 // KA_CARRY=1: carried vote tables (ka_votes_merge; measured, off: DESIGN 4i; 3: marks settled by the sweep only) -- 0: every task counts its members' votes
         int reuse = 1;                 // KA_REUSE: Hirschberg prefix reuse in the 4-wave kernels (queued levels, seq-seq leaves, pair batch)
+        int tp = 0;                    // KA_TP=1: the queued launch and the levels with more tasks than CUs on the throughput kernel (unit 10) where it applies (ka_tp_ok); measured slower than the 4-wave kernel: off
         int qw = 4, lw = 4, pw = 2;    // KA_QW / KA_LW / KA_PW: waves per workgroup of the queued launch, the seq-seq leaf levels, the pair batch (4, 2, 1)
         bool launch_ev = false;        // KA_LAUNCH_EV: an event behind every launch of a run (ka_tree_launch_ms)
         bool upgma_launches = false;   // KA_UPGMA_LAUNCHES: ka_aln_guide_tree's UPGMA as one launch per merge (the path for > 6144 sequences) at any size
@@ -130,6 +135,7 @@ static inline void read_env(KaEnv& v)
         v.carry = env_int("KA_CARRY", 0);
         v.overlap_help = env_int("KA_OVERLAP_HELP", 1);
         v.overlap = env_int("KA_OVERLAP", 1);
+        v.tp = env_int("KA_TP", 0);
         v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 2);
         for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;
         v.mw = env_int("KA_MW", 1);

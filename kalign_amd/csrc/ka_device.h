@@ -114,6 +114,7 @@ struct KaTreeDev {
                                        // node that currently contains the sequence (the device's form of gaps[])
         const int* sip;                // member lists of every node in the reference's order (aln_run.c:428-436)
         const long long* sip_off;      // [2N-1]
+        int tp;                        // round 6: launches of the 4-wave kind go to the throughput kernel (unit 10) when the job allows it (host: ka_tp_ok)
 };
 
 #define KA_NB 6                        // bonus entries a DP row carries: <= 5 anchors + the wrap-around entry

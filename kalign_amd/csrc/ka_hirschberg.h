@@ -31,6 +31,46 @@ __device__ void ka_cluster_sync(TaskShared& S)
 // debug breadcrumbs into a host-pinned buffer (KA_TRACE=1): survives a hung kernel
 #define KA_CRUMB(D_trace, slot, val) do { if (D_trace) { ((volatile int*)(D_trace))[slot] = (val); __threadfence_system(); } } while (0)
 
+#if KA_TP
+// THE THROUGHPUT KERNEL keeps its passes and meetups out of the task body (round 6): real functions with register allocations of
+// their own.  Inlined, everything shared the kernel's budget of 168 VGPRs (three workgroups per CU) and the kernel spilled 1099 of
+// them, in the strips' loops too.  What is wave-uniform arrives in vector registers and goes back to scalars first; the workgroup's
+// TaskShared is where it always is (the head of the dynamic LDS).
+#define KA_TPF __device__ __attribute__((noinline))
+__device__ __forceinline__ TaskShared& ka_tp_shared()
+{
+        extern __shared__ __attribute__((aligned(16))) char ka_smem[];
+        return *(TaskShared*)ka_smem;
+}
+template <int KIND, int NRES, int SLOT, int NB>
+KA_TPF void ka_packed_tp(const KaSub* qc, const int2* pack, int nslots, int job, const float* tss, char* wlds, int nreg, int reg_stride)
+{
+        ka_packed<KIND, NRES, SLOT, NB>(ka_tp_shared(), ka_uniform_ptr(qc), ka_uniform_ptr(pack), ka_u(nslots), ka_u(job), (int)(threadIdx.x & 63),
+                                        ka_uniform_ptr(tss), ka_uniform_ptr(wlds), ka_u(nreg), ka_u(reg_stride));
+}
+template <int KIND, int NRES, int NB>
+KA_TPF void ka_subtree_tp(const KaSub* sp, char* area, const float* tss)
+{
+        const KaSub* spu = ka_uniform_ptr(sp);
+        ka_subtree<KIND, NRES, NB>(ka_tp_shared(), *spu, (int)(threadIdx.x & 63), ka_uniform_ptr(area), ka_uniform_ptr(tss));
+}
+template <int KIND, int GL, bool MW>
+KA_TPF void ka_meetup_tp(const KaSub* qc, int k0, int ncur, KaSub* qn, const KaLevelOut lout, bool top_level, int kdig, int lvl)
+{
+        ka_meetup<KIND, GL, false, false, MW, false>(ka_tp_shared(), ka_uniform_ptr(qc), ka_u(k0), ka_u(ncur), ka_uniform_ptr(qn), lout, (int)(threadIdx.x & 63),
+                                                     ka_u((int)top_level) != 0, ka_u(kdig), ka_u(lvl));
+}
+struct KaStripArgsTP { int starta, enda, startb, endb, dir, k; float ja, jga, jgb; KaState* rows; int* prog; char* wlds; const float* tss; };
+template <int KIND, int NRES, int NB>
+KA_TPF void ka_strip_tp(const KaStripArgsTP a)
+{
+        ka_strip<KIND, NRES, NB, 2, false, false>(ka_tp_shared(), ka_u(a.starta), ka_u(a.enda), ka_u(a.startb), ka_u(a.endb),
+                                                  ka_uniform_f(a.ja), ka_uniform_f(a.jga), ka_uniform_f(a.jgb), ka_u(a.dir), ka_u(a.k),
+                                                  ka_uniform_ptr(a.rows), ka_uniform_ptr(a.prog), (int)(threadIdx.x & 63), ka_uniform_ptr(a.wlds), ka_uniform_ptr(a.tss),
+                                                  false, false);
+}
+#endif
+
 // The passes of one recursion level: its work items (strips, packed jobs) dealt to / pulled by the waves of the team.
 // Q1: the kernel also carries the one-row-per-lane strip (TaskShared::srows == 64 selects it per task)
 // HO: strips dealt to neighbouring waves of a workgroup hand over through LDS rings (ka_strip<.., HO>; TaskShared::ho_ok)
@@ -174,11 +214,19 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 if (pslot && lane == 0) { if (pslot[1] == 0) pslot[1] = __builtin_amdgcn_s_memtime(); pslot[5] += 1; }
         #endif
                                 if (it >= nitems + njobs16) {
+#if KA_TP
+                                        ka_packed_tp<KIND, NRES, 4, NB>(qc, pack4, n4, it - nitems - njobs16, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
+#else
                                         ka_packed<KIND, NRES, 4, NB>(S, qc, pack4, n4, it - nitems - njobs16, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
+#endif
                                         continue;
                                 }
                                 if (it >= nitems) {
+#if KA_TP
+                                        ka_packed_tp<KIND, NRES, 16, NB>(qc, pack16, n16, it - nitems, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
+#else
                                         ka_packed<KIND, NRES, 16, NB>(S, qc, pack16, n16, it - nitems, lane, tss, KIND != KA_SS ? lds_waves + wave * KA_WAVE_LDS : nullptr, nreg, reg_stride);
+#endif
                                         continue;
                                 }
                                 item = items[it];
@@ -190,7 +238,11 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                 const int dir = dk >> 16, k = dk & 0xffff;
                                 if (dir == KA_ITEM_SUBTREE) {
                                         // (a wide-subtree level: the wave's region and its idle neighbour's are one area)
+#if KA_TP
+                                        ka_subtree_tp<KIND, NRES, NB>(sp, S.sub_base + wave * S.sub_stride, tss);
+#else
                                         ka_subtree<KIND, NRES, NB>(S, *sp, lane, S.sub_base + wave * S.sub_stride, tss);
+#endif
                                         if (wide_n && lane == 0) ((KaSub*)sp)->pad = KA_SUB_MARK;
                                         continue;
                                 }
@@ -239,6 +291,31 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                                 continue;
                                         }
                                 }
+#if KA_TP
+                                // the throughput kernel: profile-profile strips in their lean form (ka_lstrip.h) -- ka_strip's column ring
+                                // does not fit this kernel's wave regions and is never instantiated for them
+                                if constexpr (KIND == KA_PP) {
+                                        KaLStripArgs la;
+                                        la.p1 = S.p1; la.p2 = S.p2; la.ent = S.ent; la.watchdog = S.watchdog;
+                                        la.rows = (dir == KA_FWD ? S.fbuf : S.bbuf) + roff; la.prog = prog + (it - k);
+                                        la.wlds = lds_waves + wave * KA_WAVE_LDS;
+                                        la.m1 = S.p1_mult; la.m2 = S.p2_mult; la.inj_a = ja; la.inj_ga = jga; la.inj_gb = jgb; la.Lb = S.Lb;
+                                        la.starta = sa; la.enda = ea; la.startb = sbb; la.endb = eb; la.dir = dir; la.k = k;
+#ifdef KA_L_PROF
+                                        la.prof = S.sub_tm ? S.sub_t : nullptr;
+#else
+                                        la.prof = nullptr;
+#endif
+                                        ka_lstrip<NRES, NB>(la);
+                                        continue;
+                                } else {
+                                        KaStripArgsTP ta;
+                                        ta.starta = sa; ta.enda = ea; ta.startb = sbb; ta.endb = eb; ta.dir = dir; ta.k = k; ta.ja = ja; ta.jga = jga; ta.jgb = jgb;
+                                        ta.rows = (dir == KA_FWD ? S.fbuf : S.bbuf) + roff; ta.prog = prog + (it - k); ta.wlds = lds_waves + wave * KA_WAVE_LDS; ta.tss = tss;
+                                        ka_strip_tp<KIND, NRES, NB>(ta);
+                                        continue;
+                                }
+#else
                                 if (Q1 && srows == KA_STRIP1_ROWS)
                                         ka_strip<KIND, NRES, NB, 1, HO, RU>(S, sa, ea, sbb, eb, ja, jga, jgb, dir, k,
                                                              ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
@@ -249,6 +326,7 @@ __device__ __forceinline__ void ka_run_items(TaskShared& S, KaCtl::Lvl* const cu
                                                              ka_uniform_ptr((dir == KA_FWD ? S.fbuf : S.bbuf) + roff), ka_uniform_ptr(prog + (it - k)), lane,
                                                              lds_waves + wave * KA_WAVE_LDS, tss, Gw > 1 && !prod_local, Gw > 1 && !(cons_local || k + 1 == ns), pslot,
                                                              in_lds, out_lds, ho_ctl_w, sv, sv_rows);
+#endif
                         }
         }
 }
@@ -257,6 +335,11 @@ __device__ const int ka_pow3[20] = { 1, 3, 9, 27, 81, 243, 729, 2187, 6561, 1968
                                      43046721, 129140163, 387420489, 1162261467 };
 #define KA_REC_DEPTH 19                                              // recursion levels the keys of ka_meetup<.., REC> can tell apart
 
+#if KA_TP
+#define KA_MEETUP_CALL(GL_, MW_) ka_meetup_tp<KIND, GL_, MW_>(qc, k, ncur, qn, lout, level == 0, kdig, level)
+#else
+#define KA_MEETUP_CALL(GL_, MW_) ka_meetup<KIND, GL_, false, REC, MW_, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level)
+#endif
 template <int KIND, int NRES, int NB, bool REC = false, bool Q1 = false, bool HO = false, bool HW = false, bool RU = false>
 __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, char* lds_waves, const float* tss, int* trace)
 {
@@ -385,17 +468,17 @@ __device__ __forceinline__ void ka_hirschberg(TaskShared& S, float* dbg_rows, ch
                                 if (S.member_w == 0)
                                         for (int k = 0; k < ncur; ++k) {
                                                 __syncthreads();
-                                                ka_meetup<KIND, 64, false, REC, true, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
+                                                KA_MEETUP_CALL(64, true);
                                         }
                         } else if (est_cols > 48) {
                                 for (int k = S.member_w * KA_NW + wave; k < ncur; k += KA_NW * S.Gw)
-                                        ka_meetup<KIND, 64, false, REC, false, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
+                                        KA_MEETUP_CALL(64, false);
                         } else if (est_cols > 6) {
                                 for (int k = (S.member_w * KA_NW + wave) * 4; k < ncur; k += KA_NW * S.Gw * 4)
-                                        ka_meetup<KIND, 16, false, REC, false, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
+                                        KA_MEETUP_CALL(16, false);
                         } else {
                                 for (int k = (S.member_w * KA_NW + wave) * 16; k < ncur; k += KA_NW * S.Gw * 16)
-                                        ka_meetup<KIND, 4, false, REC, false, RU && !REC>(S, qc, k, ncur, qn, lout, lane, level == 0, kdig, level);
+                                        KA_MEETUP_CALL(4, false);
                         }
                 }
                 ka_cluster_sync(S);

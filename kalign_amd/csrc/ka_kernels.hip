@@ -27,6 +27,7 @@
 #include "ka_best.h"
 #include "ka_subtree.h"       // wave-local subtrees
 #include "ka_wstrip.h"        // strips with helper waves
+#include "ka_lstrip.h"        // the lean strip of the throughput kernel (unit 10)
 #include "ka_meetup.h"
 #include "ka_hirschberg.h"
 #include "ka_path.h"
@@ -142,6 +143,24 @@ extern "C" void ka_unit2_launch(const KaTreeDev* D, const int2* blocks_dev, int 
                 if (ka_optin(ka_task_kernel_half, KA_LDS_HALF, &done0) != hipSuccess) return;
                 hipLaunchKernelGGL(ka_task_kernel_half, dim3(nblocks), dim3(64 * qw), qlds, stream, *D, blocks_dev, nqueue);
         }
+}
+#endif
+
+#if KA_UNIT == 10
+// THE THROUGHPUT KERNEL (round 6; compiled with -DKA_TP=1): the queued launch, the levels of forests and of shared contexts -- wherever
+// there are more tasks than workgroup slots and the rate is slots / latency.  The task body of the 4-wave kernel with
+// 11 KB of LDS per wave instead of 18 (ka_lstrip.h: an 80-column record-major ring; ka_pass.h KA_TP) and a register budget of 168:
+// THREE workgroups per CU where unit 2 has two.  Fast mode, alphabets without B / Z / X (the host picks the unit: ka_tp_ok).
+__global__ __launch_bounds__(KA_HALF_BLOCK, 3) void ka_task_kernel_tp(const KaTreeDev D, const int2* __restrict__ blocks, const int nqueue)
+{
+        ka_task_queue_entry<false, 0>(D, blocks, nqueue);
+}
+// nqueue > 0: `nblocks` workgroups share the `nqueue` tasks listed in blocks_dev; 0: one workgroup per entry
+extern "C" void ka_unit10_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int nqueue, hipStream_t stream)
+{
+        static bool done = false;
+        if (ka_optin(ka_task_kernel_tp, KA_LDS_HALF, &done) != hipSuccess) return;
+        hipLaunchKernelGGL(ka_task_kernel_tp, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
 }
 #endif
 

@@ -20,7 +20,11 @@ __device__ __forceinline__ bool ka_child_is_subtree(const KaLevelOut& o, int row
 // A thin but long pass (few rows, many columns -- gap-rich regions of deep profiles produce them) also runs
 // as a strip: its ncols + nrows/2 dependent steps are the level's critical path, a strip step costs about
 // 60 % of a packed step, and the other waves of the cluster are idle at that depth anyway.
+#if KA_TP
+#define KA_LONG_COLS 40                                        // (the throughput kernel stages 96 column records per wave region: a packed step that streams them from L2 costs eight strip steps)
+#else
 #define KA_LONG_COLS 96
+#endif
 __device__ __forceinline__ bool ka_pass_is_strip(int nrows, int ncols) { return nrows > 32 || (nrows > 2 && ncols >= KA_LONG_COLS); }
 
 __device__ __forceinline__ void ka_emit_pass(const KaLevelOut& o, int slot, int dir, int nrows, int ncols)

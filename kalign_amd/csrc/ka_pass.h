@@ -35,9 +35,23 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 #define KA_REC_CHUNKS 7                                         // 7 x 16 B = profile fields [32..59]
 #define KA_SLOT_BYTES (KA_REC_CHUNKS * KA_RING_BATCH * 16)      // 3584
 #define KA_RING_BYTES (KA_RING_SLOTS * KA_SLOT_BYTES)           // 14336 B: the column ring of a strip wave
+// KA_TP (round 6, unit 10: the THROUGHPUT kernel -- three four-wave workgroups per CU): profile-profile strips run as ka_lstrip
+// (ka_lstrip.h: an 80-column record-major ring + a 2 KB out ring), so a wave's region shrinks to 11 KB; the seq-profile score table
+// takes 21 floats per row (the kernel only runs jobs without B / Z / X: residues < 20), packed passes stage 64 records per region.
+#ifndef KA_TP
+#define KA_TP 0
+#endif
+#if KA_TP
+#define KA_WAVE_LDS 12288
+#define KA_SP_STRIDE 21
+#define KA_PK_RECS 96
+#else
 #define KA_WAVE_LDS 18432                                       // per-wave LDS region: the ring, or the staging area of a wave-local subtree (ka_subtree.h)
-#define KA_WAVE_LDS_LEAN 6144                                   // the same in the seq-seq kernels (no ring; residues instead of records)
 #define KA_SP_STRIDE 25                                         // floats per row in the seq-profile score table
+#define KA_PK_RECS 128                                          // packed passes: staged column records per region
+#endif
+#define KA_SP_FILL (KA_SP_STRIDE < 23 ? KA_SP_STRIDE : 23)      // scores copied into a row of the seq-profile table
+#define KA_WAVE_LDS_LEAN 6144                                   // the same in the seq-seq kernels (no ring; residues instead of records)
 #define KA_T_STRIDE 24                                          // floats per row in the seq-seq score table
 
 // Column-record reads of the DP steps (ka_strip, ka_sub_pass; ka_wstrip outside its steady octets): plain loads the compiler
@@ -227,7 +241,8 @@ struct KaBonus {
 #define KA_HO_RING KA_RING_BYTES                                // 256 slots x 16 B behind the column ring: [14336, 18432) of the wave's region
 #define KA_HO_SLOTS 256
 #define KA_LDS_HO_BACK 64                                       // control words, this many bytes below the wave regions: [wave] columns written, [8 + wave] columns read
-static_assert(KA_HO_RING + KA_HO_SLOTS * 16 <= KA_WAVE_LDS, "hand-over ring outgrew the wave's LDS region");
+static_assert(KA_TP || KA_HO_RING + KA_HO_SLOTS * 16 <= KA_WAVE_LDS, "hand-over ring outgrew the wave's LDS region");
+static_assert(128 * KA_SP_STRIDE * 4 <= KA_WAVE_LDS && KA_REC_CHUNKS * KA_PK_RECS * 16 <= KA_WAVE_LDS, "seq-profile table / packed staging outgrew the wave's LDS region");
 
 // SAVE (round 5, Hirschberg prefix reuse, ka_meetup.h): svrows != nullptr -- the pass leaves the row after `sv_rows` of its rows in
 // svrows[0 .. ncols] (indexed like `rows`): the strip that holds that row has its owner lane store the fresh state every step
@@ -387,14 +402,14 @@ __device__ __forceinline__ void ka_strip(const TaskShared& S, const int starta, 
 #pragma unroll
                         for (int i = 0; i < 6; ++i) sa[i] = ((const float4v*)(pA + 32))[i];
 #pragma unroll
-                        for (int c = 0; c < 23; ++c) tA_[c] = sa[c >> 2][c & 3];
+                        for (int c = 0; c < KA_SP_FILL; ++c) tA_[c] = sa[c >> 2][c & 3];
                         if constexpr (Q == 2) {
                                 float* tB_ = tA_ + KA_SP_STRIDE;
                                 float4v sb[6];
 #pragma unroll
                                 for (int i = 0; i < 6; ++i) sb[i] = ((const float4v*)(pB + 32))[i];
 #pragma unroll
-                                for (int c = 0; c < 23; ++c) tB_[c] = sb[c >> 2][c & 3];
+                                for (int c = 0; c < KA_SP_FILL; ++c) tB_[c] = sb[c >> 2][c & 3];
                         }
                 }
         }
@@ -1046,7 +1061,7 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                         float* tA_ = (float*)wlds + (2 * lane) * KA_SP_STRIDE;
                         float* tB_ = tA_ + KA_SP_STRIDE;
 #pragma unroll
-                        for (int c = 0; c < 23; ++c) { tA_[c] = pA[32 + c]; tB_[c] = pB[32 + c]; }
+                        for (int c = 0; c < KA_SP_FILL; ++c) { tA_[c] = pA[32 + c]; tB_[c] = pB[32 + c]; }
                 }
         }
 
@@ -1083,14 +1098,14 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                         if (sidx < lane / SLOT) lds_base += c;
                         total += c;
                 }
-                staged = total <= nreg * KA_RING_SLOTS * KA_RING_BATCH;   // 128 records per region (wave-uniform)
+                staged = total <= nreg * KA_PK_RECS;                      // 128 records per region, 64 in the throughput kernel (wave-uniform)
                 if (staged) {
                         for (int vv = ls; vv < cnt; vv += SLOT) {
                                 ka_gfloat4c* g = (ka_gfloat4c*)(S.p2 + ((long long)REC(vv) << 6) + 32);
                                 const int idx = lds_base + vv;
-                                char* dst = wlds + (idx >> 7) * reg_stride + (idx & 127) * 16;
+                                char* dst = wlds + (idx / KA_PK_RECS) * reg_stride + (idx % KA_PK_RECS) * 16;
 #pragma unroll
-                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) *(float4v*)(dst + ch * 2048) = g[ch];
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) *(float4v*)(dst + ch * (KA_PK_RECS * 16)) = g[ch];
                         }
                         // written and read by different lanes of this wave only
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1106,9 +1121,9 @@ __device__ __forceinline__ void ka_packed(const TaskShared& S, const KaSub* qc, 
                 if (KIND == KA_PP) {
                         if (STG) {
                                 const int idx = lds_base + vv;
-                                const char* src = wlds + (idx >> 7) * reg_stride + (idx & 127) * 16;
+                                const char* src = wlds + (idx / KA_PK_RECS) * reg_stride + (idx % KA_PK_RECS) * 16;
 #pragma unroll
-                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) dstq[ch] = *(const float4v*)(src + ch * 2048);
+                                for (int ch = 0; ch < KA_REC_CHUNKS; ++ch) if (ka_chunk_used<NRES>(ch)) dstq[ch] = *(const float4v*)(src + ch * (KA_PK_RECS * 16));
                         } else {
                                 ka_gfloat4c* g = (ka_gfloat4c*)(S.p2 + ((long long)REC(vv) << 6) + 32);
 #pragma unroll

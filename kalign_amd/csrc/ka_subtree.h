@@ -17,7 +17,11 @@
 
 #define KA_SUB_MAXROWS 64                                       // a subtree in ONE wave region: decided when the sub-problem is emitted (ka_child_is_subtree)
 #define KA_SUB_WIDEROWS 128                                     // ... in TWO regions (round 5): decided per recursion level at run time (ka_run_items)
+#if KA_TP
+#define KA_SUB_NQ 40                                            // (the throughput kernel's 12 KB regions: the floor only matters for windows of at most 32 rows)
+#else
 #define KA_SUB_NQ 72                                            // queue entries per level: a level has at most one sub-problem per row
+#endif
 #ifndef KA_WIDE_SUB
 #define KA_WIDE_SUB 0                                           // measured: slower everywhere (profiles/r05_wide_subtree_levels.log) -- the engine below pays ~1300 cycles per step
 #endif
@@ -598,10 +602,12 @@ __device__ __forceinline__ void ka_subtree(TaskShared& S, const KaSub root, cons
         }
         if (tmg && lane == 0) {
                 const long long tot = __builtin_amdgcn_s_memtime() - tq0;
+#ifndef KA_L_PROF
                 atomicAdd(&S.sub_t[0], 1ull); atomicAdd(&S.sub_t[1], (unsigned long long)(tq1 - tq0));
                 atomicAdd(&S.sub_t[2], (unsigned long long)tpass); atomicAdd(&S.sub_t[3], (unsigned long long)tmeet);
                 atomicAdd(&S.sub_t[4], (unsigned long long)tot); atomicMax(&S.sub_t[5], (unsigned long long)tot);
                 atomicAdd(&S.sub_t[6], (unsigned long long)(level * 1000000 + X.R * 1000 + min(X.C, 999)));
+#endif
         }
         if (lane == 0 && mcount) { atomicAdd(&S.lctl->msum, msum); atomicAdd(&S.lctl->mcount, mcount); }
 }
