@@ -172,6 +172,27 @@ def roofline_of(res, key, workload=None):
 # residues, helper-wave strips; 100 in ka_strip), seq-profile 36, seq-seq 31.5 -- and Hirschberg executes ~2.06 x the useful cells
 # of a task in the tree kernels (1.6 x in the pair batch, which takes rows over from the parent's pass).
 VALU_PER_STEP = {0: 31.5, 1: 36.0, 2: 78.0}
+VALU_PER_STEP_SOURCE = "constants typed into bench.py (ISA listings of round 4)"
+
+
+def _valu_from_build():
+    """The profile-profile figure from the BUILD (the constant drifts silently when the kernels change): __graft_entry__.build()
+    runs tools/check_hot_loops.py on unit 0 and leaves its octet table in kalign_amd/hot_loops.json -- the steady-state octet (no scratch
+    access) of the two-row strip at the job's alphabet is the one with 20 (23 with B / Z / X) v_pk_mul_f32 per step."""
+    global VALU_PER_STEP_SOURCE
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kalign_amd", "hot_loops.json")
+    try:
+        with open(path) as f:
+            octets = json.load(f)["octets"]
+        steady = [o["instructions_per_step"] for o in octets if o["v_pk_mul_per_step"] == 20 and o["scratch_per_step"] == 0]
+        if steady:
+            VALU_PER_STEP[2] = float(min(steady))
+            VALU_PER_STEP_SOURCE = "kalign_amd/hot_loops.json (tools/check_hot_loops.py on the built unit 0: steady two-row octet, 20 residues); seq-seq / seq-profile: ISA listings of round 4"
+    except (OSError, ValueError, KeyError):
+        pass
+
+
+_valu_from_build()
 EXECUTED_PER_USEFUL = 2.06
 ISSUE_PER_S = 256 * 4 * 2.4e9 / 4.0                                   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles
 
@@ -191,6 +212,7 @@ def roofline_valu(recs, gcups, copies=1):
     return {"bound": "valu_issue", "achieved": gcups, "peak": peak, "unit": "GCUPS", "frac": gcups / peak,
             "executed_cells_per_useful_cell": EXECUTED_PER_USEFUL,
             "valu_instructions_per_128_cell_step": {"seq_seq": VALU_PER_STEP[0], "seq_profile": VALU_PER_STEP[1], "profile_profile": VALU_PER_STEP[2]},
+            "valu_instructions_source": VALU_PER_STEP_SOURCE,
             "useful_cells_by_kind": {"seq_seq": cells[0] * copies, "seq_profile": cells[1] * copies, "profile_profile": cells[2] * copies}}
 
 
@@ -572,11 +594,45 @@ def saturation_leg(job, subm, scal, local_rank, cells_one, counts=(1, 2, 4, 8, 1
             cells = cells_one * n                              # (every copy is the same tree: same useful cells)
             kern_ms, n_launch = ctx.tree_kernel_ms()
             pts.append({"trees_in_flight": n, "ms_per_round": dt * 1e3, "gcups": cells / dt / 1e9, "launches": n_launch})
+        # north_star quotes its 200 GCUPS on PROFILE-PROFILE DP: the saturated point once more with the per-task phase timers
+        # (KA_FLAG_TIMING; outside the timed rounds) -- the round's wall time is shared out over the three kinds of task by the time
+        # their tasks held a workgroup (the slots are what the round is made of), and the profile-profile cells are divided by the
+        # profile-profile share.  Its own roofline object: SURVEY 8(d)'s bytes of those tasks over that time.
+        pp = None
+        try:
+            from kalign_amd import api
+            nb = pts[-1]["trees_in_flight"]
+            fc, ft, fd, _ = guide.forest([(job["codes"], job["tasks"], job["seq_distances"])] * nb)
+            ctx.tree_upload(fc, ft, subm, scal, fd, flags=api.FLAG_TIMING)
+            for _ in range(2):
+                ctx.tree_run()
+                ctx.tree_sync()
+            t0 = time.perf_counter()
+            ctx.tree_run(); ctx.tree_sync()
+            dt_t = time.perf_counter() - t0
+            recs, _, _ = ctx.tree_download(want_gaps=False)
+            tm = ctx.tree_timing()[:, :4].sum(1).astype(np.float64)
+            kind = np.array([r.kind for r in recs])
+            cells_k = np.array([float(r.len_a) * r.len_b for r in recs])
+            share = float(tm[kind == 2].sum() / max(tm.sum(), 1.0))
+            pp_cells = float(cells_k[kind == 2].sum())
+            pp_s = dt_t * share
+            pp_bytes = algorithmic_bytes([r for r in recs if r.kind == 2])
+            pp = {"trees_in_flight": nb, "gcups": pp_cells / pp_s / 1e9, "profile_profile_cells_per_round": pp_cells,
+                  "share_of_task_time": share, "ms_per_round_with_timers": dt_t * 1e3,
+                  "time_by_kind_share": {"seq_seq": float(tm[kind == 0].sum() / tm.sum()), "seq_profile": float(tm[kind == 1].sum() / tm.sum()), "profile_profile": share},
+                  "roofline": {"bound": "hbm", "achieved": pp_bytes / pp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pp_bytes / pp_s / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_round": pp_bytes, "traffic": None},
+                  "roofline_valu": roofline_valu([r for r in recs if r.kind == 2], pp_cells / pp_s / 1e9),
+                  "note": "profile-profile tasks only: the round's wall time x the share of task time (KA_FLAG_TIMING) the profile-profile tasks held workgroups for; useful cells"}
+        except Exception as e:                                     # pragma: no cover
+            pp = {"error": repr(e)}
     finally:
         ctx.close()
     best = max(pts, key=lambda p: p["gcups"])
     return {"workload": "independent copies of the headline job (4096 x ~400 protein, --fast) as one forest", "points": pts,
             "gcups_saturated": best["gcups"], "at_trees_in_flight": best["trees_in_flight"],
+            "profile_profile_only": pp,
             "valu_issue_bound_gcups": 256 * 4 * 2.4e9 / 4 / 100 * 128 / 1e9,
             "note": "valu_issue_bound: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction / ~100 instructions per "
                     "128-cell step (DESIGN.md section 4); the HBM roofline fraction of the same point is gcups x ~7.9 B per cell / 8 TB/s"}
@@ -1029,6 +1085,31 @@ def multi_gpu_main(args, rank, world, local_rank):
             run_rank, top = kd.plan_subtrees(job["tasks"], lens, world)
             sys.stderr.write("sharded run differs from the single-GPU run at tasks %s (of %d); ranks %s; above the cut: %s\n" % (
                 diff[:12], len(recs), [int(run_rank[t]) for t in diff[:12]], [t in set(top) for t in diff[:12]]))
+    # WEAK scaling beside it: the regime in which north_star's ">= 6x at 8 GPUs" can be answered whatever the
+    # guide tree's serial top costs -- one independent alignment per GPU (the headline tree, --fast: what a caller with many
+    # alignments, or the members of an ensemble, see), no data-path collective, the same barrier and max-over-ranks timing.
+    weak = None
+    try:
+        wjob = make_job(ctx, 4096, 400, False, seed=1)
+        ctx.tree_upload(wjob["codes"], wjob["tasks"], subm, scal, wjob["seq_distances"])
+        for _ in range(2):
+            ctx.tree_run()
+        ctx.tree_sync()
+        barrier()
+        tw = time.perf_counter()
+        wsteps = max(args.steps, 3)
+        for _ in range(wsteps):
+            ctx.tree_run()
+        ctx.tree_sync()
+        barrier()
+        w_elapsed = kd.reduce_scalar(time.perf_counter() - tw, "max", device=coll_dev)
+        wrecs, _, _ = ctx.tree_download(want_gaps=False)
+        wcells = float(sum(r.len_a * r.len_b for r in wrecs))
+        weak = {"workload": "one 4096 x ~400 protein tree (--fast) per GPU, independent replicas, no collective in the timed steps",
+                "scaling": "weak", "gcups": wcells * world * wsteps / w_elapsed / 1e9, "ms_per_step": w_elapsed / wsteps * 1e3,
+                "gcups_per_gpu": wcells * wsteps / w_elapsed / 1e9, "steps": wsteps}
+    except Exception as e:                                         # pragma: no cover
+        sys.stderr.write("rank %d: weak-scaling leg failed (%s)\n" % (rank, e))
     if rank == 0:
         kinds = np.bincount([r.kind for r in recs], minlength=3)
         real_stdout.write(json.dumps({
@@ -1051,6 +1132,7 @@ def multi_gpu_main(args, rank, world, local_rank):
             # N = 1 (KA_BENCH_FORCE_MULTI=1) the difference is what the sharding layer itself costs
             "single_gpu_step_ms": single_ms,
             "sharding_overhead_ms": (elapsed / args.steps * 1e3 - single_ms) if world == 1 else None,
+            "weak_scaling_replicas": weak,
         }) + "\n")
         real_stdout.flush()
     if cd is not None:

@@ -224,6 +224,9 @@ int ka_debug_reload_env(ka_ctx* ctx);
 /* Debug: 64 breadcrumb words written by workgroup 0 (context created with KA_TRACE=1 in the
    environment); readable while a kernel is still running. */
 int ka_debug_trace(ka_ctx* ctx, int* out64);
+/* Launches of the throughput kernel (round 6: unit 10, ka_task_kernel_tp; opt-in, KA_TP=1 in the environment) since the library was
+ * loaded -- tests assert that the path they mean to test is the one that ran. */
+long long ka_debug_tp_launches(void);
 /* Work done by the last run: sum over tasks of len_a*len_b ("useful cells") */
 double ka_tree_cells(ka_ctx* ctx);
 /* Milliseconds spent in the DP kernels of the last ka_tree_run, measured with HIP events

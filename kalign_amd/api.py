@@ -40,7 +40,7 @@ class TaskRec(C.Structure):
 DIST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
 EXPORTS = ["ka_tree_profile_dev", "ka_tree_reserve_profile_dev", "ka_tree_build_consistency_part",
-           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_debug_reload_env", "ka_ctx_fallback_runs", "ka_ctx_helped_tasks", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
+           "ka_tree_consistency_part_range", "ka_tree_consistency_maps_dev", "ka_debug_set_hooks", "ka_debug_reload_env", "ka_debug_tp_launches", "ka_ctx_fallback_runs", "ka_ctx_helped_tasks", "ka_ctx_create", "ka_ctx_destroy", "ka_ctx_set_stream", "ka_ctx_set_shared", "ka_last_error", "ka_abi_version",
            "ka_msa_tree", "ka_tree_upload", "ka_tree_run", "ka_tree_refine", "ka_tree_sync", "ka_tree_paths_size",
            "ka_tree_download", "ka_tree_get_profile", "ka_tree_get_timing", "ka_debug_trace", "ka_tree_cells", "ka_tree_kernel_ms", "ka_tree_launch_ms",
            "ka_pairwise_batch", "ka_pairwise_kernel_ms", "ka_tree_build_consistency", "ka_tree_get_consistency",
@@ -89,6 +89,8 @@ def load_library():
     L.ka_ctx_fallback_runs.argtypes = [vp]
     L.ka_ctx_helped_tasks.argtypes = [vp]
     L.ka_ctx_helped_tasks.restype = C.c_longlong
+    L.ka_debug_tp_launches.argtypes = []
+    L.ka_debug_tp_launches.restype = C.c_longlong
     L.ka_abi_version.restype = C.c_int
     L.ka_msa_tree.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                               C.POINTER(TaskRec), vp, C.c_longlong, vp]
@@ -240,6 +242,10 @@ class Context:
     def reload_env(self):
         """tools / tests: the KA_* environment switches are read once at context creation; read them again"""
         self._chk(self.L.ka_debug_reload_env(self.h))
+
+    def tp_launches(self):
+        """launches of the throughput kernel (KA_TP=1) since the library was loaded (ka_debug_tp_launches)"""
+        return int(self.L.ka_debug_tp_launches())
 
     def fallback_runs(self):
         return int(self.L.ka_ctx_fallback_runs(self.h))

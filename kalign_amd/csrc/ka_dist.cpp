@@ -64,9 +64,19 @@ Rccl g_rccl;
 int rccl_load()
 {
         if (g_rccl.lib) return KA_OK;
+        // One process must never hold two RCCLs: a caller that already carries one (PyTorch maps its own librccl.so; torch.distributed's
+        // "nccl" backend IS that library) gets exactly that one.  First the symbols already in the process (the global scope: whatever
+        // was linked or loaded RTLD_GLOBAL), then the library under each of its names if it is mapped already (RTLD_NOLOAD finds a copy that
+        // was loaded RTLD_LOCAL), and only then a fresh load.
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         void* h = nullptr;
-        for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        {
+                void* self = dlopen(nullptr, RTLD_NOW);
+                if (self && dlsym(self, "ncclCommInitRank") && dlsym(self, "ncclSend")) h = self;
+                else if (self) dlclose(self);
+        }
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (!h) return fail(std::string("ka_dist: cannot load RCCL (librccl.so.1): ") + dlerror());
 #define KA_SYM(field_, name_) *(void**)(&g_rccl.field_) = dlsym(h, name_); if (!g_rccl.field_) return fail(std::string("ka_dist: RCCL lacks ") + name_)
         KA_SYM(GetUniqueId, "ncclGetUniqueId"); KA_SYM(CommInitRank, "ncclCommInitRank"); KA_SYM(CommDestroy, "ncclCommDestroy");

@@ -156,10 +156,13 @@ __global__ __launch_bounds__(KA_HALF_BLOCK, 3) void ka_task_kernel_tp(const KaTr
         ka_task_queue_entry<false, 0>(D, blocks, nqueue);
 }
 // nqueue > 0: `nblocks` workgroups share the `nqueue` tasks listed in blocks_dev; 0: one workgroup per entry
+static long long ka_tp_launches = 0;
+extern "C" long long ka_debug_tp_launches(void) { return ka_tp_launches; }
 extern "C" void ka_unit10_launch(const KaTreeDev* D, const int2* blocks_dev, int nblocks, int nqueue, hipStream_t stream)
 {
         static bool done = false;
         if (ka_optin(ka_task_kernel_tp, KA_LDS_HALF, &done) != hipSuccess) return;
+        ka_tp_launches += 1;
         hipLaunchKernelGGL(ka_task_kernel_tp, dim3(nblocks), dim3(KA_HALF_BLOCK), KA_LDS_HALF, stream, *D, blocks_dev, nqueue);
 }
 #endif

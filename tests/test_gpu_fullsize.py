@@ -65,6 +65,19 @@ def test_config1_protein_1024x400_matches_reference():
     run_case(1024, 400, False)
 
 
+def test_headline_shape_protein_4096x400_matches_reference():
+    """The shape `value` is quoted on (north_star: 4096 x 400 aa; bench.py's default workload, where the same comparison runs
+    inside the CPU leg): every gap array of the whole tree against the real reference's create_msa_tree on the host cores."""
+    run_case(4096, 400, False)
+
+
+def test_headline_shape_through_the_throughput_kernel(monkeypatch):
+    """The same tree with the levels of the queued launch on the opt-in throughput kernel (KA_TP=1, unit 10: ka_lstrip's lean
+    profile-profile strips, three workgroups per CU): the reference's gap arrays bit for bit."""
+    monkeypatch.setenv("KA_TP", "1")
+    run_case(4096, 400, False)
+
+
 def test_config2_shape_dna_256x2000_matches_reference():
     """configs[2] shape (--type dna, ~2000 nt, profile-profile dominated), scaled to 256 sequences
     so the CPU reference finishes in seconds: long anti-diagonals, multi-strip passes, clusters."""

@@ -4,7 +4,8 @@ The STEADY-state octets must have NO scratch access: exit 1 when fewer than --st
 later strips, 20 / 23 / 5 residues as the unit has them) octets are scratch-free, or when any octet carries more than --max-scratch
 (default 20) scratch accesses per step.  The head / tail / edge forms of the step do spill (8-19 accesses per step in unit 0, DESIGN.md
 section 4f / 6d): reported, and bounded by --max-scratch so that they cannot grow unnoticed.  Run by __graft_entry__.build().
-usage: check_hot_loops.py [kalign_amd/csrc/build/ka_kernels_u0.o] [--steady N] [--max-scratch M]"""
+usage: check_hot_loops.py [kalign_amd/csrc/build/ka_kernels_u0.o] [--steady N] [--max-scratch M] [--json OUT: the octets as data -- bench.py reads
+the instructions per step of its VALU roofline from it (kalign_amd/hot_loops.json, written by __graft_entry__.build())]"""
 import os, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin/"
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -32,18 +33,26 @@ def count(a, b, pat=None):
     return n
 runs, cur = [], []
 for a, b in zip(idx, idx[1:]):
-    if b - a < 260: cur.append((count(a, b), count(a, b, "scratch_")))
+    if b - a < 260: cur.append((count(a, b), count(a, b, "scratch_"), count(a, b, "v_pk_mul_f32"), count(a, b, "v_")))
     else:
         if len(cur) >= 6: runs.append(cur)
         cur = []
 if len(cur) >= 6: runs.append(cur)
 bad, worst = 0, 0
+octets = []
 for r in runs:
     n = sorted(x[0] for x in r)[len(r) // 2]
     sc = max(x[1] for x in r[1:-1]) if len(r) > 2 else max(x[1] for x in r)
-    print("octet: %d steps, median %d instructions per step, scratch accesses per step (inner steps) <= %d" % (len(r) + 1, n, sc))
+    pk = sorted(x[2] for x in r)[len(r) // 2]
+    valu = sorted(x[3] for x in r)[len(r) // 2]
+    print("octet: %d steps, median %d instructions per step (%d vector, %d v_pk_mul_f32), scratch accesses per step (inner steps) <= %d" % (len(r) + 1, n, valu, pk, sc))
+    octets.append({"steps": len(r) + 1, "instructions_per_step": n, "vector_instructions_per_step": valu, "v_pk_mul_per_step": pk, "scratch_per_step": sc})
     bad += sc > 0
     worst = max(worst, sc)
+if "--json" in sys.argv:
+    import json
+    with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+        json.dump({"object": os.path.basename(obj), "octets": octets}, f)
 clean = len(runs) - bad
 print("octets with scratch traffic: %d of %d (the edge forms); scratch-free: %d (needed: %d); worst %d accesses per step (allowed: %d)" % (bad, len(runs), clean, STEADY, worst, MAXS))
 sys.exit(0 if (clean >= STEADY and worst <= MAXS) else 1)
