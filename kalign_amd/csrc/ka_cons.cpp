@@ -202,6 +202,18 @@ extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float we
         if (!c->have_colof && setup_colof(c)) return KA_FAIL;
         c->cons_K = K; c->cons_weight = weight;
         c->ran = false; c->synced = false; c->state_valid = false;
+        if (K > KA_NB - 1) {
+                // More than five anchors: the streamed kernels carve KA_NB_BIG bonus entries per DP row and K-sized position / confidence /
+                // vote tables -- ~3.6 x the bytes per row at K = 32 -- while the plan sized the scratch arena for the K <= 5 kernels
+                // (shared contexts overflowed, doubled twice and ran their first tree three times).  Grow it here, once K is known.
+                const double ratio = (double)ka_scratch_bytes_host_big(c->sum_len, c->sum_len, c->max_len, K) / (double)std::max<long long>(ka_scratch_bytes_host(c->sum_len, c->sum_len, c->max_len), 1);
+                const long long want = (long long)((double)c->scratch_cap * std::max(ratio, 1.0)) + 4096;
+                if (want > c->scratch_cap) {
+                        c->scratch_cap = want;
+                        c->d_scratch.release();
+                        if (c->d_scratch.alloc((size_t)c->scratch_cap)) return fail("hipMalloc failed while growing the scratch arena for the consistency table");
+                }
+        }
         // the launch plan knows about the table (cluster limit of big jobs, plan_launches): plan again if it would come out differently
         if (c->env.max_cluster <= 0 && !c->shared_gpu && N >= 2048 && c->max_cluster < 32) {
                 if (plan_launches(c) || upload_plan(c)) return KA_FAIL;

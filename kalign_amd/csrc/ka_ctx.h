@@ -65,6 +65,7 @@ extern "C" void ka_launch_bpm(const uint8_t* codes, const int* off, const int* l
 extern "C" long long ka_ctl_bytes_host(void);
 extern "C" void ka_launch_pairs(const KaPairDev* P, hipStream_t stream);
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen);
+extern "C" long long ka_scratch_bytes_host_big(long long la, long long lb, long long cons_maxlen, long long k_anchors);
 
 // the thread's error text (ka_last_error) and the one way to set it: defined in ka_api.cpp
 KA_INTERNAL int fail(const std::string& m);

@@ -486,10 +486,16 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         // the chained launch and the queued launch never reset the scratch counter: several levels' worth; grows on demand
         if (c->chain_level >= 0) scr = scr_level * (long long)std::min(max_level - c->chain_level, 8);
         if (c->max_cluster > 1 && !c->shared_gpu) scr *= 2;          // clusters: every member's private queues and row buffers
-        if (c->queue_first >= 0) scr = std::max(scr, scr_level * (long long)(c->chain_level - c->queue_first));
-        // (the chained launch that overlaps the queue shares its arena: where the two together outgrow the larger one's estimate the run
-        // reports an overflow, ka_tree_sync doubles the arena and repeats it -- once per job shape; adding the two estimates up asked
-        // for more than the GPU holds on a 16-tree forest)
+        if (c->queue_first >= 0) {
+                // The chained launch that overlaps the queue shares its arena (no reset between the two).  Where their sum is affordable --
+                // single trees: a few GB of 288 -- the arena holds both, so that a one-shot caller (the CLI, the drop-in: one alignment
+                // per process) does not pay an overflow, a doubled arena and a second run of the tree on its only job.  Big
+                // forests keep the larger of the two estimates (the sum asked for more than the GPU holds on a 16-tree forest) and grow on
+                // demand: ka_tree_sync doubles the arena and repeats the run, once per job shape.
+                const long long scr_queue = scr_level * (long long)(c->chain_level - c->queue_first);
+                const long long both = scr + scr_queue;
+                scr = (c->env.overlap && both <= (24LL << 30)) ? both : std::max(scr, scr_queue);
+        }
         c->scratch_cap = std::max(c->scratch_cap, scr);
         if (c->test_hooks & KA_DEBUG_SMALL_ARENAS) {
                 // tests: start with arenas that are certainly too small, so that the overflow -> grow -> re-run

@@ -201,8 +201,15 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
                         for (int k = 0; k < 2; ++k) {
                                 if (dep[k] < 0) continue;
                                 int spins = 0;
+                                unsigned long long head = 0;
                                 while (__hip_atomic_load(&D.join[dep[k]].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                                         __builtin_amdgcn_s_sleep(32);
+                                        // (only a STALLED queue may expire the wait: while the queued launch still hands tasks out -- its head
+                                        // moves -- the producer may simply not have been pulled yet, however long the launch is)
+                                        if ((spins & 1023) == 1023) {
+                                                const unsigned long long h = __hip_atomic_load(&D.counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                if (h != head) { head = h; spins = 0; }
+                                        }
                                         if (ka_spin_expired(D.error, ++spins, (1 << 21) * max(1, min(D.tasks[dep[k]].wait_mult, 64)), 6, true)) break;
                                 }
                         }

@@ -61,10 +61,10 @@ extern int kalign_ref_kalign_ensemble(struct msa* msa, int n_threads, int type, 
 /* how often each seam ran on the device / fell back to the reference (tests/test_gpu_dropin.py reads them) */
 enum { GLUE_TREE = 0, GLUE_INLINE, GLUE_REFINE, GLUE_REFINE_REF, GLUE_FINALISE, GLUE_FINALISE_REF,
        GLUE_CONS, GLUE_CONS_REF, GLUE_KMEANS, GLUE_KMEANS_NOISY, GLUE_ALNDIST, GLUE_ALNDIST_REF, GLUE_ALNTREE, GLUE_ALNTREE_REF, GLUE_INLINE_REF,
-       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_TREE_REF, GLUE_ENSEMBLE_MULTI, GLUE_MEMBER_AHEAD, GLUE_N };
+       GLUE_TREE_MULTI, GLUE_CONS_MULTI, GLUE_TREE_REF, GLUE_ENSEMBLE_MULTI, GLUE_MEMBER_AHEAD, GLUE_MEMBER_MISSED, GLUE_N };
 static const char* glue_names[GLUE_N] = { "tree", "inline", "refine", "refine_ref", "finalise", "finalise_ref",
                                           "cons", "cons_ref", "kmeans", "kmeans_noisy", "alndist", "alndist_ref", "alntree", "alntree_ref", "inline_ref",
-                                          "tree_multi", "cons_multi", "tree_ref", "ensemble_multi", "member_ahead" };
+                                          "tree_multi", "cons_multi", "tree_ref", "ensemble_multi", "member_ahead", "member_missed" };
 static int glue_counts[GLUE_N];
 #define GLUE_COUNT(which) __atomic_fetch_add(&glue_counts[which], 1, __ATOMIC_RELAXED)
 int kalign_amd_glue_count(int which)
@@ -929,7 +929,11 @@ ERROR:
 #define GLUE_SHARED_MEMBERS 8
 __attribute__((constructor)) static void glue_hw_queues(void)
 {
-        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        /* a process-wide side effect of linking this library, ensembles or not: KALIGN_AMD_KEEP_HW_QUEUES=1 leaves the runtime's default */
+        const char* keep = getenv("KALIGN_AMD_KEEP_HW_QUEUES");
+        if(!keep || atoi(keep) == 0){
+                setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        }
 }
 
 static const float glue_member_scale[12][4] = {
@@ -1130,6 +1134,22 @@ int kalign_ensemble(struct msa* msa, int n_threads, int type, int n_runs, float 
         }
         rc = kalign_ref_kalign_ensemble(msa, n_threads, type, n_runs, gpo, gpe, tgpe, seed, min_support, save_poar_path, refine, dist_scale, vsm_amax,
                                         realign, use_seq_weights, consistency_anchors, consistency_weight);
+        /* Members are handed over by EQUALITY of their parameters with the table restated above (glue_member_take): should the
+           reference's resolve_run_params ever drift from it, every take misses, every member is computed twice, and nothing fails.
+           Say so: a member that finished here and is still here was never asked for. */
+        if(rc == OK && glue_members){
+                int left = 0;
+                for(k = 0; k < glue_n_members; k++){
+                        if(glue_members[k].aln && glue_members[k].rc == OK){
+                                left++;
+                        }
+                }
+                if(left){
+                        fprintf(stderr, "kalign_amd glue: %d of %d ensemble members run ahead were not taken over by kalign_ensemble's loop "
+                                        "(member parameters differ from the glue's table: they were computed twice)\n", left, glue_n_members);
+                        GLUE_COUNT(GLUE_MEMBER_MISSED);
+                }
+        }
         glue_members_free();
         return rc;
 ERROR:

@@ -60,7 +60,7 @@ def _device_ran(c, flags):
     assert c["kmeans"] + c["kmeans_noisy"] >= members, c
     if members > 1:
         # the members ran ahead of the reference's loop, side by side on contexts sharing the GPU (kalign_ensemble in the glue)
-        assert c["ensemble_multi"] == 1 and c["member_ahead"] == members, c
+        assert c["ensemble_multi"] == 1 and c["member_ahead"] == members and c["member_missed"] == 0, c
     if members > 1 and not realign:
         assert c["kmeans_noisy"] >= 1, c                      # kalign_run_seeded: members after the first build their trees on noisy distances
     if realign:
@@ -236,7 +236,7 @@ def test_cli_with_several_ranks_under_the_dropin(tmp_path, name, flags, world):
     if members > 1:
         # round 5: the members of an ensemble run side by side, member k on device (here: context) k mod G, each through the
         # single-device seams on its own thread (kalign_ensemble in the glue); the reference's loop then takes them over
-        assert c["ensemble_multi"] == 1 and c["member_ahead"] == members, c
+        assert c["ensemble_multi"] == 1 and c["member_ahead"] == members and c["member_missed"] == 0, c
         assert c["tree"] >= members * (1 + realign), c
     else:
         assert c["tree_multi"] >= members * (1 + realign) and c["tree"] == 0, c

@@ -34,6 +34,19 @@ def test_steady_octets_of_the_helper_wave_strips_carry_no_scratch_access():
     assert "scratch-free:" in r.stdout
 
 
+def test_steady_octets_of_the_lean_strips_carry_no_scratch_access():
+    """the same on unit 10 (the throughput kernel, ka_lstrip.h): the strip is a real function per form with a register budget of 168
+    -- its steady-state octets (5 / 20 / 23 residues, first and later strips, last row A or B) are scratch-free, the head and tail
+    forms keep a handful of accesses per step"""
+    obj = os.path.join(ROOT, "kalign_amd", "csrc", "build", "ka_kernels_u10.o")
+    if not os.path.exists(obj) or not os.path.exists(LLVM + "llvm-objdump"):
+        pytest.skip("no built kernel object / no llvm-objdump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_hot_loops.py"), obj, "--steady", "6", "--max-scratch", "12"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:]
+    assert ".vgpr_count:     168" in r.stdout, r.stdout[:600]          # (three four-wave workgroups per CU)
+
+
 def test_the_checker_sees_a_use_before_the_wait(tmp_path):
     """The analysis itself, on a ten-line kernel with the hazard built in (and the same kernel with the wait in place)."""
     if not os.path.exists("/opt/rocm/bin/hipcc"):
