@@ -58,7 +58,7 @@ def pmc_traffic(key, workload=None, kernel_ms=None):
     profiler on itself, so it reports the committed measurement -- but only of THIS workload on THIS build: the
     committed record names its workload and the kernel time per step it was collected at; another workload string,
     or a live kernel time more than 5 % away, gives null (a stale profile is not this run's traffic)."""
-    for tag in ("r05", "r04", "r03", "r02"):                     # the newest collection that has this workload
+    for tag in ("r06", "r05", "r04", "r03", "r02"):              # the newest collection that has this workload
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")) as fh:
                 rec = json.load(fh)[key]

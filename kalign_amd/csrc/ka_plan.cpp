@@ -172,6 +172,17 @@ int plan_launches(ka_ctx* c)
                                 qup[t] = 2.0 * std::max(la, lb) + std::min(la, lb) + ((act(t) && c->descs[t].parent >= 0) ? qup[c->descs[t].parent] : 0.0);
                         }
                 }
+                if (env_int("KA_QORDER", 1) == 2) {
+                        // experiment (round 6; measured and not kept): ONE order over all the queue's levels, by the way to the root alone.  A
+                        // child's way is longer than its parent's, so the order is still topological (a producer is pulled before its consumer: no
+                        // deadlock) -- the subtrees under the spine go first whatever their level, at the price of consumers pulled right behind
+                        // their producers, whose workgroups then hold a slot and wait: the chain gains 0.3 ms, the queue loses 1.2 (headline
+                        // 14.70 -> 15.45 ms, C3 70.0 -> 77.6, 16384 x 500 41.4 -> 45.7, sixteen trees unchanged; profiles/r06_queue_order.log).
+                        std::vector<int> all;
+                        for (int L = c->queue_first; L < c->chain_level; L++) all.insert(all.end(), levels[L].begin(), levels[L].end());
+                        std::stable_sort(all.begin(), all.end(), [&](int x, int y) { return qup[x] > qup[y]; });
+                        for (int t : all) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
+                } else
                 for (int L = c->queue_first; L < c->chain_level; L++) {
                         std::vector<int> lv(levels[L].begin(), levels[L].end());
                         std::stable_sort(lv.begin(), lv.end(), [&](int x, int y) { return qup[x] > qup[y]; });
