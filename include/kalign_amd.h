@@ -248,9 +248,10 @@ int ka_tree_launch_ms(ka_ctx* ctx, float* ms, int cap);
  * In a forest job every alignment gets its own table (its own anchors among its own sequences).
  * ka_tree_upload drops the table again.
  */
-#define KA_CONS_MAX_ANCHORS 32  /* anchors ka_tree_build_consistency takes: up to 5 on the kernels every default-mode job uses (a DP row carries that many bonus
-                                   entries + the wrap-around one in registers), 6..32 on a second set that walks a row's entries, sorted by column, along
-                                   with the row's columns (`--consistency K`; round 4 stopped at 10) */
+#define KA_CONS_MAX_ANCHORS 128 /* anchors ka_tree_build_consistency takes: up to 5 on the kernels every default-mode job uses (a DP row carries that many bonus
+                                   entries + the wrap-around one in registers), 6..128 on a second set that walks a row's entries, sorted by column, along
+                                   with the row's columns (`--consistency K`; round 4 stopped at 10, round 5 at 32; the reference, anchor_consistency.c:200-275,
+                                   has no cap but the number of sequences) */
 int ka_tree_build_consistency(ka_ctx* ctx, int n_anchors, float weight);
 /* The N x K batch sharded over `nparts` GPUs: every rank uploads the same job and calls this with its
  * own `part`; it selects the same anchors, aligns only its contiguous share of the sequences (balanced by length) and

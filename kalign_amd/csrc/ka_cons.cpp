@@ -117,7 +117,7 @@ extern "C" int ka_tree_build_consistency_part(ka_ctx* c, int n_anchors, float we
         cons_part_seqs(c, part, nparts, &part_lo, &part_hi);
         // the reference silently declines in these cases (anchor_consistency.c:206-217)
         if (n_anchors <= 0 || N < 3 || c->seq_dist.empty()) return KA_OK;
-        if (n_anchors > KA_CONS_MAX_ANCHORS) return fail("this build takes at most 32 consistency anchors (KA_CONS_MAX_ANCHORS)");
+        if (n_anchors > KA_CONS_MAX_ANCHORS) return fail("this build takes at most 128 consistency anchors (KA_CONS_MAX_ANCHORS)");
         // One table per alignment.  A forest job holds several: every tree selects its own anchors among its own
         // sequences (in ascending index order = that alignment's own order); map k of a sequence is always against
         // anchor k of ITS tree, so the kernels need no notion of trees.

@@ -118,11 +118,11 @@ struct KaTreeDev {
 };
 
 #define KA_NB 6                        // bonus entries a DP row carries: <= 5 anchors + the wrap-around entry
-// ... of the second set of consistency kernels, `--consistency K` with 5 < K <= KA_CONS_MAX_ANCHORS (32).  Round 4 carried eleven entries in
+// ... of the second set of consistency kernels, `--consistency K` with 5 < K <= KA_CONS_MAX_ANCHORS (128; 32 until round 6).  Round 4 carried eleven entries in
 // registers (K <= 10: 1383 VGPR spills in the task kernel); round 5 STREAMS them: a row's entries lie sorted by column in the task's
 // scratch ([0] pad, [1] a lower sentinel that also holds the count, the entries, an upper sentinel, a pad) and every lane walks its row's
 // list along with its columns (KaBonus<NB>::STREAM, ka_pass.h) -- eight registers per DP row whatever K is.
-#define KA_NB_BIG 40
+#define KA_NB_BIG 136                   // (K + the wrap-around entry + two sentinels + two pads, K <= KA_CONS_MAX_ANCHORS = 128)
 
 struct KaPairDev {
         const uint8_t* codes;

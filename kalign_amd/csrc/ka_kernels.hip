@@ -64,7 +64,7 @@ extern "C" void ka_unit0_launch(const KaTreeDev* D, const int2* blocks_dev, int 
         hipLaunchKernelGGL(ka_task_kernel, dim3(nblocks), dim3(KA_BLOCK), KA_LDS_TOTAL, stream, *D, blocks_dev, chain);
 }
 extern "C" long long ka_scratch_bytes_host(long long la, long long lb, long long cons_maxlen) { return ka_scratch_bytes(la, lb, cons_maxlen); }
-// ... of the kernels that walk a DP row's bonus entries (KA_NB_BIG entries per row, K-sized anchor tables: `--consistency K`, 5 < K <= 32)
+// ... of the kernels that walk a DP row's bonus entries (KA_NB_BIG entries per row, K-sized anchor tables: `--consistency K`, 5 < K <= 128)
 extern "C" long long ka_scratch_bytes_host_big(long long la, long long lb, long long cons_maxlen, long long k_anchors) { return ka_scratch_bytes(la, lb, cons_maxlen, 1, false, false, KA_NB_BIG, k_anchors); }
 extern "C" long long ka_ctl_bytes_host(void) { return (long long)sizeof(KaCtl); }
 extern "C" int ka_max_g_host(void) { return KA_MAX_G; }

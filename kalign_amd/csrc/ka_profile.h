@@ -760,6 +760,27 @@ __device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
                 if (a >= 0) atomicMax(&S.invj[k * ml + a], j);
         }
         __syncthreads();
+        if constexpr (KaBonus<NBK>::STREAM) {
+                // the streamed set (any K up to KA_CONS_MAX_ANCHORS): a row's entries are collected in the row's own slice of the task's
+                // scratch -- [1] = (INT_MIN, count), the entries from [2] on -- not in per-thread arrays of NBK entries (a kilobyte of
+                // private memory per lane at 128 anchors); sorted below, once the wrap-around entry has joined them
+                for (int i = tid; i < rows; i += KA_NT) {
+                        int2* e = S.ent + (long long)i * NBK;
+                        int cnt = 0;
+                        for (int k = 0; k < K; ++k) {
+                                const int a = S.apos_r[k * n + i];
+                                if (a < 0) continue;
+                                const int bj = __hip_atomic_load(&S.invj[k * ml + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (bj < 0) continue;
+                                const float val = paw * S.conf_r[k * n + i] * S.conf_c[k * n + bj];                // :534-535
+                                int hit = -1;
+                                for (int m = 0; m < cnt; ++m) if (e[2 + m].x == bj) hit = m;
+                                if (hit >= 0) e[2 + hit].y = __float_as_int(__int_as_float(e[2 + hit].y) + val);
+                                else { e[2 + cnt] = make_int2(bj, __float_as_int(0.0f + val)); ++cnt; }
+                        }
+                        e[1] = make_int2((int)0x80000000, cnt);
+                }
+        } else
         for (int i = tid; i < rows; i += KA_NT) {
                 int mc[NBK];
                 float mv[NBK];
@@ -776,14 +797,7 @@ __device__ void ka_cons_entries(TaskShared& S, const KaTreeDev& D)
                         else { mc[cnt] = bj; mv[cnt] = 0.0f + val; ++cnt; }
                 }
                 int2* e = S.ent + (long long)i * NBK;
-                if constexpr (KaBonus<NBK>::STREAM) {
-                        // the streamed layout (KaBonus::STREAM): [1] = (INT_MIN, count), the entries from [2] on -- sorted below, once
-                        // the wrap-around entry has joined them
-                        e[1] = make_int2((int)0x80000000, cnt);
-                        for (int m = 0; m < cnt; ++m) e[2 + m] = make_int2(mc[m], __float_as_int(mv[m]));
-                } else {
-                        for (int m = 0; m < NBK - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
-                }
+                for (int m = 0; m < NBK - 1; ++m) e[m] = (m < cnt) ? make_int2(mc[m], __float_as_int(mv[m])) : make_int2(-1, 0);
         }
         __syncthreads();
         if constexpr (KaBonus<NBK>::STREAM) {

@@ -138,7 +138,7 @@ def test_consistency_declines_like_the_reference(ctx):
     ctx.tree_build_consistency(0, 2.0)
     assert ctx.tree_consistency() is None
     with pytest.raises(RuntimeError):
-        ctx.tree_build_consistency(33, 2.0)                      # (KA_CONS_MAX_ANCHORS = 32 is what the second kernel set walks per DP row)
+        ctx.tree_build_consistency(129, 2.0)                     # (KA_CONS_MAX_ANCHORS = 128 is what the second kernel set walks per DP row)
 
 
 def test_forest_in_default_mode_has_one_table_per_alignment(ctx):

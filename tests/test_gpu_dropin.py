@@ -106,16 +106,29 @@ def test_cli_output_is_byte_identical(tmp_path, name, flags):
 
 
 def test_cli_with_more_anchors_than_the_kernels_carry_takes_the_reference_seams(tmp_path):
-    """`--consistency 40` (the device kernels walk up to KA_CONS_MAX_ANCHORS = 32 entries per DP row): the library declines the table
+    """`--consistency 160` (the device kernels walk up to KA_CONS_MAX_ANCHORS = 128 entries per DP row): the library declines the table
     (cons_ref), the dispatcher hands the trees to the reference's own create_msa_tree (tree_ref) -- same bytes, no error."""
     from kalign_amd import synth
     inp = str(tmp_path / "in.fa")
-    _write_fasta(inp, synth.dssim(48, 150, dna=False, seed=3))   # (the reference caps the anchors at the number of sequences)
+    _write_fasta(inp, synth.dssim(176, 90, dna=False, seed=3))   # (the reference caps the anchors at the number of sequences)
     c = {}
-    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), "--consistency", "40", counters=c)
-    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), "--consistency", "40")
+    got = _cli("dropin/kalign", inp, str(tmp_path / "dropin.fa"), "--consistency", "160", counters=c)
+    want = _cli("kalign_ref", inp, str(tmp_path / "ref.fa"), "--consistency", "160")
     assert got == want
     assert c["cons_ref"] >= 1 and c["tree_ref"] >= 1 and c["cons"] == 0, c
+
+
+def test_cli_with_forty_and_a_hundred_anchors_stays_on_the_device(tmp_path):
+    """round 6: `--consistency K` up to 128 on the device (a row's entries are collected and walked in the task's scratch, whatever K)"""
+    from kalign_amd import synth
+    inp = str(tmp_path / "in.fa")
+    _write_fasta(inp, synth.dssim(120, 120, dna=False, seed=4))
+    for k in ("40", "100"):
+        c = {}
+        got = _cli("dropin/kalign", inp, str(tmp_path / ("dropin%s.fa" % k)), "--consistency", k, counters=c)
+        want = _cli("kalign_ref", inp, str(tmp_path / ("ref%s.fa" % k)), "--consistency", k)
+        assert got == want
+        assert c["cons"] >= 1 and c["cons_ref"] == 0 and c["tree_ref"] == 0, c
 
 
 @pytest.mark.parametrize("dna,n,length,flags", [(False, 32, 200, []), (False, 32, 200, ["--fast"]),

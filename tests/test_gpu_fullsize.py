@@ -121,9 +121,10 @@ def test_default_mode_2304_sequences_votes_shared_by_member_ranges_match_referen
 
 
 @pytest.mark.parametrize("nseq,length,dna,k", [(384, 200, False, 8), (96, 900, True, 10), (160, 300, False, 6),
-                                               (256, 250, False, 12), (128, 500, True, 16), (200, 180, False, 32), (700, 300, False, 24)])
+                                               (256, 250, False, 12), (128, 500, True, 16), (200, 180, False, 32), (700, 300, False, 24),
+                                               (160, 150, False, 48), (192, 120, False, 100), (140, 200, True, 128)])
 def test_more_than_five_anchors_match_reference(nseq, length, dna, k):
-    """`--consistency K` with 5 < K <= 32: the second set of consistency kernels -- round 5: a DP row's bonus entries are no longer held
+    """`--consistency K` with 5 < K <= 128 (32 until round 6): the second set of consistency kernels -- round 5: a DP row's bonus entries are no longer held
     in registers but walked, sorted by column, along with the row's columns (KaBonus::STREAM) -- anchor selection, position maps,
     votes (ten anchors per sweep), bonus entries and the whole tree against the reference."""
     run_case(nseq, length, dna, n_anchors=k)
