@@ -220,7 +220,7 @@ KaTreeDev tree_dev(ka_ctx* c)
         D.ho_mode = c->env.ho >= 0 ? c->env.ho : 1;
         D.per_target = c->env.per;
         D.q_order = nullptr; D.q_n = 0; D.q_slots = 0; D.qw = c->env.qw; D.lw = c->env.lw; D.reuse = c->env.reuse; D.carry = c->env.carry;
-        D.tp = c->env.tp;
+        D.tp = c->env.tp; D.reserve = 0;
         D.overlap = c->overlap_plan ? 1 : 0;
         D.hw_mode = c->env.hw ? (1 | (c->env.hw_prio << 4)) : 0;
         D.lean4 = c->env.lean4;
@@ -342,9 +342,11 @@ int tree_launch(ka_ctx* c, bool reset)
                                 // queue would still be dispatched first.  Hold it back until the chain's workgroups have the CUs.
                                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
                         }
-                        if (ka_cons_big(&D)) ka_unit7_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
-                        else if (ka_tp_ok(&D)) ka_unit10_launch(&D, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
-                        else ka_unit2_launch(&D, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
+                        KaTreeDev Dq = D;
+                        Dq.reserve = ov ? c->reserve_cus : 0;          // (CUs left to the head of the chain: only when the chain really goes out beside the queue)
+                        if (ka_cons_big(&D)) ka_unit7_launch(&Dq, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
+                        else if (ka_tp_ok(&D)) ka_unit10_launch(&Dq, c->d_blocks.p + c->queue_off, nwg, c->queue_n, c->stream);
+                        else ka_unit2_launch(&Dq, c->d_blocks.p + c->queue_off, nwg, D.cons_K > 0, c->queue_n, c->stream);
                         c->n_launches++; if (mark_launch(c)) return KA_FAIL;
                         L = (size_t)c->chain_level - 1;
                         if (chain_first) { HIPCHK(hipStreamWaitEvent(c->stream, c->e_chain, 0)); break; }

@@ -192,6 +192,8 @@ struct ka_ctx {
         int chain_level = -1;          // first level of the chained launch (-1: every level is its own launch)
         int queue_first = -1;          // queued launch: levels queue_first .. chain_level-1 run as ONE launch of the half kernel (-1: none)
         int queue_off = 0, queue_n = 0; // its task list in blocks_flat
+        std::vector<char> spine;       // round 6: tasks below the chain's first level that run in the chained launch all the same (plan_launches)
+        int reserve_cus = 0;           // round 6: CUs of XCC 0 the queued launch leaves to the head of the chained launch (plan_launches; 0: none)
         std::vector<int2> chain_blocks;
         int chain_blocks_off = 0;
         DevBuf<int2> d_blocks;

@@ -114,9 +114,12 @@ struct KaTreeDev {
                                        // node that currently contains the sequence (the device's form of gaps[])
         const int* sip;                // member lists of every node in the reference's order (aln_run.c:428-436)
         const long long* sip_off;      // [2N-1]
+        int reserve;                   // round 6, the queued launch of an overlapping run: its workgroups leave the first `reserve` CUs of XCC 0 (shader
+                                       // engines 0 .. reserve / 8 - 1) to the head of the chained launch (plan_launches; 0: none)
         int tp;                        // round 6: launches of the 4-wave kind go to the throughput kernel (unit 10) when the job allows it (host: ka_tp_ok)
 };
 
+#define KA_BLK_NOHELP (1 << 30)        // a block of the chained launch (blocks[b].y): this workgroup does not help the queued launch -- it sits on a CU kept for it
 #define KA_NB 6                        // bonus entries a DP row carries: <= 5 anchors + the wrap-around entry
 // ... of the second set of consistency kernels, `--consistency K` with 5 < K <= KA_CONS_MAX_ANCHORS (128; 32 until round 6).  Round 4 carried eleven entries in
 // registers (K <= 10: 1383 VGPR spills in the task kernel); round 5 STREAMS them: a row's entries lie sorted by column in the task's

@@ -72,13 +72,67 @@ int plan_launches(ka_ctx* c)
                                 if (!all_ss && (int)levels[L].size() <= chain_tasks) { c->chain_level = L; break; }   // one workgroup per CU, all resident
                         }
                 }
+                // SPINES IN THE CHAIN (round 6; KA_SPINE = how many; built, bit-identical, measured, OFF: DESIGN 4j).  What the single tree waits for is not
+                // a CU or an operand but the LATENCY of the tasks on its longest dependency chains (13.3 of 14.7 ms are the run times of 17
+                // tasks, tools/levels_real.py) -- and the first four or five of those run in the queued launch: one four-wave workgroup,
+                // ka_strip with its event steps, 0.54-0.72 ms for a 430 x 420 task that takes 0.33-0.45 ms in the chained launch (helper
+                // strips, two workgroups).  So the chain reaches DOWN along the most critical entries: from each of the KA_SPINE entries of
+                // the chain's first level with the longest estimated path through them (leaves .. entry .. root), the child with the later
+                // estimated finish, and its child, ... down to the queue's first level are tasks of the chained launch too (c->spine):
+                // the lowest one is an entry of its own (both children come from the leaf levels / the queue: done flags), the others
+                // have ONE child inside the launch (chain_need 1) and one from the queue (qa / qb).  Nothing in the queue consumes a spine
+                // task (its parent is the spine task above it), so the queue's order stays topological.
+                c->spine.assign(n_tasks, 0);
+                {
+                        int L0 = 0;
+                        while (c->chain_level >= 1 && L0 < c->chain_level) {
+                                bool all_ss = true;
+                                for (int t : levels[L0]) if (c->descs[t].nsip_a != 1 || c->descs[t].nsip_b != 1) all_ss = false;
+                                if (!all_ss) break;
+                                L0++;
+                        }
+                        const bool queue_ok = c->chain_level >= 1 && !c->env.no_queue && !c->env.no_half && c->chain_level - L0 >= 2 && (int)levels[L0].size() > c->n_cus;
+                        const bool overlap_ok = c->env.overlap > 0 && !subset && !c->env.no_lean && !c->shared_gpu;
+                        const int K = env_int("KA_SPINE", 0);             // (measured: 1 % at best with KA_RESERVE -- DESIGN 4j; off)
+                        if (K > 0 && queue_ok && overlap_ok && !c->env.no_crit) {
+                                std::vector<double> lmax(2 * numseq - 1, 0.0), nmem(2 * numseq - 1, 1.0), qlen(2 * numseq - 1, 0.0), fin(2 * numseq - 1, 0.0), dur(n_tasks, 0.0), upw(n_tasks, 0.0);
+                                for (int i = 0; i < numseq; i++) { lmax[i] = c->lens[i]; qlen[i] = c->lens[i]; }
+                                for (int t = 0; t < n_tasks; t++) {
+                                        const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                                        lmax[cc] = std::max(lmax[a], lmax[b]); nmem[cc] = nmem[a] + nmem[b];
+                                        qlen[cc] = lmax[cc] * (1.0 + 0.1 * std::sqrt(nmem[cc]));
+                                        dur[t] = 2.0 * std::max(qlen[a], qlen[b]) + std::min(qlen[a], qlen[b]);
+                                        fin[cc] = std::max(fin[a], fin[b]) + dur[t];
+                                }
+                                for (int t = n_tasks - 1; t >= 0; t--) upw[t] = dur[t] + ((act(t) && c->descs[t].parent >= 0) ? upw[c->descs[t].parent] : 0.0);
+                                std::vector<int> ent(levels[c->chain_level].begin(), levels[c->chain_level].end());
+                                std::stable_sort(ent.begin(), ent.end(), [&](int x, int y) { return fin[abc[3 * x + 2]] + upw[x] > fin[abc[3 * y + 2]] + upw[y]; });
+                                for (int e = 0; e < (int)ent.size() && e < K; e++) {
+                                        int cur = ent[e];
+                                        while (true) {
+                                                int best = -1;
+                                                for (int k = 0; k < 2; k++) {
+                                                        const int ch = abc[3 * cur + k];
+                                                        if (ch < numseq) continue;
+                                                        const int tc = task_of[ch];
+                                                        if (!act(tc) || c->task_level[tc] < L0 || c->task_level[tc] >= c->chain_level) continue;
+                                                        if (best < 0 || fin[ch] > fin[abc[3 * best + 2]]) best = tc;
+                                                }
+                                                if (best < 0) break;
+                                                c->spine[best] = 1;
+                                                cur = best;
+                                        }
+                                }
+                        }
+                }
+                auto inchain = [&](int t) { return t >= 0 && act(t) && (c->task_level[t] >= c->chain_level || c->spine[t]); };
                 if (c->chain_level >= 0) {
                         for (int t = 0; t < n_tasks; t++) {
-                                if (c->task_level[t] <= c->chain_level || !act(t)) continue;
+                                if (!inchain(t)) continue;
                                 int need = 0;
                                 for (int k = 0; k < 2; k++) {
                                         const int ch = abc[3 * t + k];
-                                        if (ch >= numseq && act(task_of[ch]) && c->task_level[task_of[ch]] >= c->chain_level) need++;
+                                        if (ch >= numseq && inchain(task_of[ch])) need++;
                                 }
                                 c->descs[t].chain_need = need;
                         }
@@ -112,13 +166,13 @@ int plan_launches(ka_ctx* c)
                                 for (int t = 0; t < n_tasks; t++) {
                                         if (c->task_level[t] < L0 || !act(t)) continue;
                                         // (a task of the chained launch: only what OTHER launches make -- inside the chain the join points order things)
-                                        const bool in_chain = c->task_level[t] >= c->chain_level;
+                                        const bool in_chain = inchain(t);
                                         if (in_chain && !c->overlap_plan) continue;
                                         const int a = abc[3 * t], b = abc[3 * t + 1];
                                         auto dep = [&](int node) -> int {
                                                 if (node < numseq || !act(task_of[node])) return -1;
                                                 const int lv = c->task_level[task_of[node]];
-                                                if (lv < lo || (in_chain && lv >= c->chain_level)) return -1;
+                                                if (lv < lo || (in_chain && inchain(task_of[node]))) return -1;
                                                 return task_of[node];
                                         };
                                         c->descs[t].qa = dep(a);
@@ -128,6 +182,12 @@ int plan_launches(ka_ctx* c)
                 }
         }
 
+        // (the spines only exist beside an overlapping queued launch: the conditions above are the queue block's own)
+        {
+                bool any = false;
+                for (int t = 0; t < n_tasks; t++) any = any || c->spine[t];
+                if (any && !(c->queue_first >= 0 && c->overlap_plan)) return fail("plan_launches: spine tasks without an overlapping queued launch");
+        }
         // ---- workgroup tables, one per dependency level (build_blocks) ----
         // Workgroups one task may use: 16, or 32 for jobs whose top tasks are big enough to be work-bound at 16 (round 4: a
         // 9000 x 9700 task of C3 takes 5.8 ms on 16 workgroups, of which ~1.6 ms are the wavefront's dependent steps) -- by the
@@ -179,12 +239,13 @@ int plan_launches(ka_ctx* c)
                         // their producers, whose workgroups then hold a slot and wait: the chain gains 0.3 ms, the queue loses 1.2 (headline
                         // 14.70 -> 15.45 ms, C3 70.0 -> 77.6, 16384 x 500 41.4 -> 45.7, sixteen trees unchanged; profiles/r06_queue_order.log).
                         std::vector<int> all;
-                        for (int L = c->queue_first; L < c->chain_level; L++) all.insert(all.end(), levels[L].begin(), levels[L].end());
+                        for (int L = c->queue_first; L < c->chain_level; L++) for (int t : levels[L]) if (!c->spine[t]) all.push_back(t);
                         std::stable_sort(all.begin(), all.end(), [&](int x, int y) { return qup[x] > qup[y]; });
                         for (int t : all) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
                 } else
                 for (int L = c->queue_first; L < c->chain_level; L++) {
-                        std::vector<int> lv(levels[L].begin(), levels[L].end());
+                        std::vector<int> lv;
+                        for (int t : levels[L]) if (!c->spine[t]) lv.push_back(t);       // (the spines' tasks run in the chained launch)
                         std::stable_sort(lv.begin(), lv.end(), [&](int x, int y) { return qup[x] > qup[y]; });
                         for (int t : lv) { c->blocks_flat.push_back(make_int2(t, 1 << 8)); c->queue_n++; }
                 }
@@ -197,15 +258,16 @@ int plan_launches(ka_ctx* c)
                 std::vector<int> task_of((2 * numseq - 1), -1), order;
                 for (int t = 0; t < n_tasks; t++) task_of[abc[3 * t + 2]] = t;
                 std::vector<int> stack;
+                auto inchain2 = [&](int t) { return t >= 0 && act(t) && (c->task_level[t] >= c->chain_level || c->spine[t]); };
                 for (int t = n_tasks - 1; t >= 0; t--) if (act(t) && c->descs[t].parent < 0 && c->task_level[t] >= c->chain_level) stack.push_back(t);   // every root above the cut
                 while (!stack.empty()) {
                         const int t = stack.back(); stack.pop_back();
-                        // an entry of the chain: no child of it runs inside the launch (the chain's first level; in a plan over a
-                        // subset also a task whose children were all run before)
-                        if (c->task_level[t] == c->chain_level || c->descs[t].chain_need == 0) { order.push_back(t); continue; }
+                        // an entry of the chain: no child of it runs inside the launch (the chain's first level -- unless a spine hangs below
+                        // it --, the lowest task of a spine; in a plan over a subset also a task whose children were all run before)
+                        if (c->descs[t].chain_need == 0) { order.push_back(t); continue; }
                         for (int k = 1; k >= 0; k--) {
                                 const int ch = abc[3 * t + k];
-                                if (ch >= numseq && act(task_of[ch]) && c->task_level[task_of[ch]] >= c->chain_level) stack.push_back(task_of[ch]);
+                                if (ch >= numseq && inchain2(task_of[ch])) stack.push_back(task_of[ch]);
                         }
                 }
                 const int m = ((int)order.size() + 7) / 8;
@@ -258,7 +320,7 @@ int plan_launches(ka_ctx* c)
                         if (c->env.crit_greedy) {
                                 std::vector<int> entry_of(n_tasks, -1);
                                 for (size_t r = 0; r < order.size(); r++) entry_of[order[r]] = (int)r;
-                                auto in_chain = [&](int t) { return t >= 0 && act(t) && c->task_level[t] >= c->chain_level; };
+                                auto in_chain = [&](int t) { return inchain2(t); };
                                 std::vector<double> fin(n_tasks, 0.0);
                                 std::vector<int> Gt(n_tasks, 0), crit_child(n_tasks, -1);
                                 const double ba = 1e-3 * (double)env_int("KA_CRIT_BA", 10);   // (b / a of the model, per mille; 10 from a sweep over five job shapes, profiles/r04_crit_ba.log)
@@ -332,6 +394,55 @@ int plan_launches(ka_ctx* c)
                                 }
                         }
                 }
+                // CUs KEPT FOR THE HEAD OF THE CHAIN (round 6; KA_RESERVE = 8 / 16 / 24; built, measured, OFF: the spine then starts 1 ms earlier and the run is as long -- other chains of the same length take over).  The chained launch goes out beside the
+                // queued one, but a workgroup of it wants a CU's whole LDS and the queue's 512 persistent workgroups hold two to a CU until
+                // their list is empty: the chain only ever started when the queue was over (the spine's first chained task of the headline
+                // tree waited 1.0 ms for a CU for its cluster's second workgroup; tools/levels_real.py, `prep`).  Now the queue's workgroups
+                // that find themselves on the first R CUs of XCC 0 (shader engines 0 .. R/8 - 1; ka_task_queue_entry reads HW_ID / XCC_ID)
+                // leave at once, and the chain's most critical entries -- by their estimated way to the root, all their workgroups, as
+                // many as fit R -- sit at the head of column 0 of the block table: block b goes to XCC b % 8 (tools/microbench/cu_map.hip:
+                // 0 exceptions in 512), XCC 0 dispatches its share of the chain in order onto the CUs the queue left, and those
+                // workgroups wait for their operands' done flags instead of for a CU (they do not help the queue: KA_BLK_NOHELP).
+                c->reserve_cus = 0;
+                int front_n = 0;
+                {
+                        int R = env_int("KA_RESERVE", 0);              // (measured: no gain -- DESIGN 4j; off)
+                        R = std::max(0, std::min(24, R / 8 * 8));
+                        if (R > 0 && c->overlap_plan && c->queue_first >= 0 && c->n_trees <= 1 && !subset && (int)order.size() > 8 && !c->env.no_crit) {
+                                std::vector<double> lmax(2 * numseq - 1, 0.0), nmem(2 * numseq - 1, 1.0), qlen(2 * numseq - 1, 0.0), crit(n_tasks, 0.0);
+                                for (int i = 0; i < numseq; i++) { lmax[i] = c->lens[i]; qlen[i] = c->lens[i]; }
+                                for (int t = 0; t < n_tasks; t++) {
+                                        const int a = abc[3 * t], b = abc[3 * t + 1], cc = abc[3 * t + 2];
+                                        lmax[cc] = std::max(lmax[a], lmax[b]); nmem[cc] = nmem[a] + nmem[b];
+                                        qlen[cc] = lmax[cc] * (1.0 + 0.1 * std::sqrt(nmem[cc]));
+                                }
+                                for (int t = n_tasks - 1; t >= 0; t--) {
+                                        const double la = qlen[abc[3 * t]], lb = qlen[abc[3 * t + 1]];
+                                        crit[t] = 2.0 * std::max(la, lb) + std::min(la, lb) + ((act(t) && c->descs[t].parent >= 0) ? crit[c->descs[t].parent] : 0.0);
+                                }
+                                std::vector<int> idx(order.size());
+                                for (size_t r = 0; r < order.size(); r++) idx[r] = (int)r;
+                                // (the lowest tasks of the spines first: they are what the kept CUs are for; a 430-row task uses two workgroups)
+                                for (size_t r = 0; r < order.size(); r++) if (c->task_level[order[r]] < c->chain_level) { crit[order[r]] += 1e12; extra[r] = std::min(extra[r], 1); }
+                                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return crit[order[x]] > crit[order[y]]; });
+                                std::vector<char> is_front(order.size(), 0);
+                                std::vector<int> front;
+                                int used = 0;
+                                for (int r : idx) {
+                                        const int Gr = G0 + extra[r];
+                                        if (used + Gr > R || (int)front.size() + 1 > m) break;
+                                        front.push_back(r); is_front[r] = 1; used += Gr;
+                                }
+                                if (!front.empty()) {
+                                        std::vector<int> o2, e2;
+                                        for (int r : front) { o2.push_back(order[r]); e2.push_back(extra[r]); }
+                                        for (size_t r = 0; r < order.size(); r++) if (!is_front[r]) { o2.push_back(order[r]); e2.push_back(extra[r]); }
+                                        order.swap(o2); extra.swap(e2);
+                                        front_n = (int)front.size();
+                                        c->reserve_cus = R;
+                                }
+                        }
+                }
                 int n_extra = 0;
                 std::vector<int> col_need(8, 0);
                 for (size_t r = 0; r < order.size(); r++) { n_extra += extra[r]; col_need[r / m] += extra[r]; }
@@ -350,6 +461,27 @@ int plan_launches(ka_ctx* c)
                                 c->chain_blocks[pos] = make_int2(order[r], g | (Gr << 8));
                         }
                 }
+                if (front_n > 0) {
+                        // The front entries' workgroups -- ALL of them: their extra members sit behind the regular table, in whatever column --
+                        // trade places with what the head of column 0 holds (a swap: every column keeps its number of workgroups, and with it
+                        // the guarantee that the whole launch is resident at once).
+                        std::vector<size_t> col0;
+                        for (size_t p = 0; p < c->chain_blocks.size(); p += 8) if (c->chain_blocks[p].x >= 0) col0.push_back(p);
+                        size_t i = 0;
+                        bool ok = true;
+                        for (int r = 0; r < front_n && ok; r++)
+                                for (int g = 0; g < G0 + extra[r] && ok; g++, i++) {
+                                        size_t src = c->chain_blocks.size();
+                                        for (size_t p = 0; p < c->chain_blocks.size(); p++)
+                                                if (c->chain_blocks[p].x == order[r] && (c->chain_blocks[p].y & 0xff) == g) { src = p; break; }
+                                        if (src == c->chain_blocks.size() || i >= col0.size()) { ok = false; break; }
+                                        std::swap(c->chain_blocks[col0[i]], c->chain_blocks[src]);
+                                        c->chain_blocks[col0[i]].y |= KA_BLK_NOHELP;
+                                }
+                        if (!ok) { c->reserve_cus = 0; for (auto& bb : c->chain_blocks) if (bb.x >= 0) bb.y &= ~KA_BLK_NOHELP; }
+                } else c->reserve_cus = 0;
+                if (getenv("KA_PLAN_VERBOSE")) fprintf(stderr, "chain plan: %d CUs kept for the head of the chain, %d front entries, m %d, G0 %d, by_column %d, overlap %d, queue_first %d\n",
+                                                       c->reserve_cus, front_n, m, G0, (int)by_column, c->overlap_plan, c->queue_first);
                 c->chain_blocks_off = (int)c->blocks_flat.size();
                 c->blocks_flat.insert(c->blocks_flat.end(), c->chain_blocks.begin(), c->chain_blocks.end());
         }

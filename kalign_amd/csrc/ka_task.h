@@ -773,14 +773,14 @@ __device__ __forceinline__ void ka_task_entry(const KaTreeDev& D, const int2* __
         const int2 blk = blocks[blockIdx.x];
         int task = blk.x;
         if (task < 0) return;
-        int member = blk.y & 0xff, g = blk.y >> 8;
+        int member = blk.y & 0xff, g = (blk.y >> 8) & 0xffff;
         const int tid = threadIdx.x;
         // Round 5, overlapping launches: this launch went out BESIDE the queued one.  Normally its workgroups become resident as the
         // queue's leave; when the dispatcher brings them in first (stream priorities are a hint) they would sit on the CUs the queue needs
         // and wait for it -- a slow round for one tree, seconds for a forest.  So a workgroup that arrives while more than a round of the
         // queue is still to be handed out takes tasks from the queue's list like one of the queue's own workgroups (same counter, same
         // done flags, this kernel's task body), and turns to its place in the chain when the list is down to its last round.
-        bool helping = chain && D.q_n > 0;
+        bool helping = chain && D.q_n > 0 && !(blk.y & KA_BLK_NOHELP);      // (the head of the chain sits on CUs kept for it: it waits for its operands, plan_launches)
         const int own_task = task, own_member = member, own_g = g;
         while (true) {
                 if (helping) {
@@ -881,6 +881,16 @@ __device__ __forceinline__ void ka_task_queue_entry(const KaTreeDev& D, const in
         extern __shared__ __attribute__((aligned(16))) char ka_smem[];
         TaskShared& S = *(TaskShared*)ka_smem;
         const int tid = threadIdx.x;
+        // round 6: CUs kept for the head of the chained launch (plan_launches) -- the queue's workgroups that landed there leave at once
+        if (n > 0 && D.reserve > 0) {
+                unsigned id, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                // (XCC 0 hands its share of a launch to its four shader engines in turn -- tools/microbench/cu_map.hip: blocks 0, 8, 16 on SE
+                // 0, 1, 3 --, so the kept CUs are the first reserve / 4 of EVERY engine: CU ids up to reserve / 4, one id being fused off in
+                // some engines)
+                if ((xcc & 15u) == 0u && (int)((id >> 8) & 15u) <= (D.reserve >> 2)) return;
+        }
         // n == 0: not a queue -- one workgroup per entry of `order` (a per-level launch); one body, one call site
         while (true) {
                 int task, member = 0, g = 1;

@@ -83,3 +83,30 @@ def test_throughput_kernel_against_the_default_kernels(shape, monkeypatch):
             assert np.array_equal(a, b)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("switches", [{"KA_SPINE": "8", "KA_RESERVE": "16"}, {"KA_SPINE": "3"}, {"KA_RESERVE": "24"}, {"KA_QORDER": "2"},
+                                      {"KA_SPINE": "6", "KA_RESERVE": "8", "KA_TP": "1"}])
+def test_round6_schedule_experiments_give_the_same_alignment(switches, monkeypatch):
+    """the planner experiments of round 6 (all off by default): the most critical entries' spines as tasks of the chained
+    launch (chain_need 1 + a done flag from the queue), CUs of XCC 0 that the queued launch leaves to the head of the chain, one
+    order over all the queue's levels -- WHO runs WHEN changes, the alignment must not, and no run may fall back"""
+    import bench
+    import kalign_amd
+    codes, tasks, dist = bench.make_workload(2560, 300, False, 5)
+    subm, scal = bench.scoring(False)
+    ctx = kalign_amd.Context(0)
+    try:
+        want = ctx.msa_tree(codes, tasks, subm, scal, dist)
+        for k, v in switches.items():
+            monkeypatch.setenv(k, v)
+        ctx.reload_env()
+        for _ in range(2):
+            got = ctx.msa_tree(codes, tasks, subm, scal, dist)
+            assert ctx.fallback_runs() == 0
+            assert [(r.plen, r.meet, r.transition, r.score) for r in got[0]] == [(r.plen, r.meet, r.transition, r.score) for r in want[0]]
+            assert np.array_equal(got[1], want[1])
+            for a, b in zip(got[2], want[2]):
+                assert np.array_equal(a, b)
+    finally:
+        ctx.close()
