@@ -58,6 +58,10 @@ extern "C" {
                                    its place in the recursion order; sorted and added in fp32 after the recursion.  Costs a sort per
                                    task and the wave-local subtrees (the records are not kept there); tasks with more than 8192
                                    recorded meetups keep the level-order sum. */
+#define KA_FLAG_LEAF_PROFILES 32 /* also write the profile records of the SEQUENCES (make_profile_n, aln_setup.c:40-99) that tasks consume.  Since
+                                   round 6 the first pass does not (without sequence weights): a sequence's record is a function of its
+                                   residue, and the merge makes what it needs of it on the fly -- ka_tree_get_profile of a node < numseq then
+                                   returns unwritten memory.  Set this to read leaf profiles back. */
 
 typedef struct ka_ctx ka_ctx;
 

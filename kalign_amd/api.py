@@ -16,6 +16,7 @@ FLAG_TIMING = 2
 FLAG_DEVICE_GAPS = 4
 FLAG_KEEP_CONSISTENCY = 8
 FLAG_EXACT_CONFIDENCE = 16
+FLAG_LEAF_PROFILES = 32
 
 
 class KalignAmdError(RuntimeError):

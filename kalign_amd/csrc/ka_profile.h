@@ -131,7 +131,31 @@ __device__ void ka_sp_score(TaskShared& S, const KaTreeDev& D, const KaTaskDesc&
 // ------------------------------------------------------------------------------------------
 // P4: update_n (aln_setup.c:230-436), one thread per (output column, field).
 // ------------------------------------------------------------------------------------------
-__device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen)
+// tss_syn (round 6; first pass without sequence weights): the leaf operands' records are NOT in HBM -- a sequence's record is a
+// function of its residue (make_profile_n, aln_setup.c:40-99: a count of one, the residue's row of pre-summed scores, the three gap
+// fields), so the merge makes the four floats it wants of it from the residue and the seq-seq score table in LDS, and the tasks that
+// consume a sequence neither write nor read 256 bytes per position for it (ka_make_leaf_profile: 60 of a leaf task's 475 us).
+__device__ __forceinline__ float4v ka_leaf_rec4(const uint8_t* __restrict__ seq, const int len, const int rec, const int k4,
+                                                const float gpo, const float gpe, const float tgpe, const float* tss)
+{
+        // k4 = first of four consecutive fields.  Fields: [c] = 1 (the residue's count), [32 .. 54] = tss[c][0 .. 22] (its row of scores
+        // -- 16-byte aligned in the table: one read for four of them), [55 .. 57] = -gpo, -gpe, -tgpe, the rest 0; the two boundary
+        // records (rec 0, len + 1) carry the gap fields only.
+        const bool inner = (rec >= 1 && rec <= len);
+        const int c = inner ? seq[rec - 1] : 0;
+        float4v out = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (k4 >= 32 && k4 < 56) {
+                if (inner) out = *(const float4v*)(tss + c * KA_T_STRIDE + (k4 - 32));       // (k4 == 52: [55] is overwritten below; the table's 24th float is 0)
+                if (k4 == 52) out.w = -gpo;
+        } else if (k4 == 56) {
+                out.x = -gpe; out.y = -tgpe;
+        } else if (inner && (c >> 2) == (k4 >> 2)) {
+                out.x = (c & 3) == 0 ? 1.0f : 0.0f; out.y = (c & 3) == 1 ? 1.0f : 0.0f; out.z = (c & 3) == 2 ? 1.0f : 0.0f; out.w = (c & 3) == 3 ? 1.0f : 0.0f;
+        }
+        return out;
+}
+
+__device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen, const float* tss_syn = nullptr)
 {
         const float* pa = S.profa;
         const float* pb = S.profb;
@@ -227,23 +251,26 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 const int c = (int)(x4 >> 4);
                 const int k4 = (int)(x4 & 15) << 2;
                 int code = 0;
-                const float* ra;
-                const float* rb;
-                if (c == 0) { ra = pa_r; rb = pb_r; }
-                else if (c == alnlen + 1) { ra = pa_r + ((long long)(S.len_a + 1) << 6); rb = pb_r + ((long long)(S.len_b + 1) << 6); }
-                else {
+                int reca = 0, recb = 0;
+                if (c == alnlen + 1) { reca = S.len_a + 1; recb = S.len_b + 1; }
+                else if (c != 0) {
                         code = coded[c];
                         const int ia = srcA[c], ib = srcB[c];
-                        ra = pa_r + ((long long)(ia < 0 ? 0 : ia) << 6);
-                        rb = pb_r + ((long long)(ib < 0 ? 0 : ib) << 6);
+                        reca = ia < 0 ? 0 : ia; recb = ib < 0 ? 0 : ib;
                 }
+                const float* ra = pa_r + ((long long)reca << 6);
+                const float* rb = pb_r + ((long long)recb << 6);
                 float4v out;
                 if (!rebalance && !(code & 20)) {
                         // The common case (no sequence weights; the coded path carries only the flags the reference
                         // really sets), four fields at a time -- same operations as elem() below, without the per-field
                         // branching: a match / boundary column is the sum of the two records, a gap column the present
                         // side with its gap counter bumped and the scores lowered by (t)gpe * members of the absent side.
-                        float4v A = *(const float4v*)(ra + k4), B = *(const float4v*)(rb + k4);
+                        float4v A, B;
+                        if (tss_syn && leaf_a) A = ka_leaf_rec4(D.codes + D.seq_off[T.a], S.len_a, reca, k4, T.gpo, T.gpe, T.tgpe, tss_syn);
+                        else A = *(const float4v*)(ra + k4);
+                        if (tss_syn && leaf_b) B = ka_leaf_rec4(D.codes + D.seq_off[T.b], S.len_b, recb, k4, T.gpo, T.gpe, T.tgpe, tss_syn);
+                        else B = *(const float4v*)(rb + k4);
                         if (k4 == 24) {                                  // field 27 (see fa / fb)
                                 A.w = leaf_a ? 0.0f : ra[55] * sipb; B.w = leaf_b ? 0.0f : rb[55] * sipa;
                         } else if (k4 == 28) {                           // fields 28, 29

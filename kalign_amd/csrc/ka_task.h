@@ -363,7 +363,10 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         // P1
         ka_build_tss(tss, D.subm, T.soff);
         __syncthreads();
-        if (S.member == 0) {
+        // (round 6: without sequence weights a sequence's record is never written -- the merge makes what it needs of it from the residue,
+        // ka_update_profile / ka_leaf_rec4; KA_FLAG_LEAF_PROFILES keeps them for callers that read a leaf's profile back)
+        const bool leaf_syn = !(D.usw > 0.0f) && !(D.flags & KA_FLAG_LEAF_PROFILES);
+        if (S.member == 0 && !leaf_syn) {
                 if (T.nsip_a == 1) ka_make_leaf_profile(S.profa, S.len_a, D.codes + D.seq_off[T.a], T.gpo, T.gpe, T.tgpe, tss);
                 if (T.nsip_b == 1) ka_make_leaf_profile(S.profb, S.len_b, D.codes + D.seq_off[T.b], T.gpo, T.gpe, T.tgpe, tss);
         }
@@ -452,7 +455,7 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         __syncthreads();
         const int alnlen = S.ctl->alnlen;
         if (S.member == 0) for (int i = tid; i < alnlen + 2; i += KA_NT) S.path_dst[i] = S.coded[i];
-        if (S.newp) ka_update_profile(S, D, T, alnlen);
+        if (S.newp) ka_update_profile(S, D, T, alnlen, leaf_syn ? tss : nullptr);
         if ((NB && !T.is_root) || (D.flags & KA_FLAG_DEVICE_GAPS)) ka_update_colof(S, D, T, alnlen);
         if (NB && D.cons_K > 0 && S.carried && S.newp) ka_votes_merge(S, D, T, alnlen, (int*)(S.newp + ((long long)alnlen + 2) * 64));
         if (D.timing && S.member == 0) {
