@@ -776,6 +776,7 @@ def c5_ensemble_leg(local_rank, n_members=8, nseq=2048, length=300):
         for t in th:
             t.join()
         side = time.perf_counter() - t0
+        fallbacks = alone.fallback_runs() + sum(c.fallback_runs() for c in ctxs)
     finally:
         for c in ctxs + [alone]:
             c.close()
@@ -785,6 +786,7 @@ def c5_ensemble_leg(local_rank, n_members=8, nseq=2048, length=300):
             "ms_one_after_the_other": serial * 1e3, "gcups_one_after_the_other": total / serial / 1e9,
             "ms_side_by_side": side * 1e3, "gcups_side_by_side": total / side / 1e9,
             "ms_per_member_alone": serial * 1e3 / n_members, "ms_per_member_side_by_side": side * 1e3 / n_members,
+            "fallback_runs": fallbacks,
             "note": "guide trees (distances on the device, bisection / UPGMA on the host) are inside these times; the consensus stage (POAR, host) is not; "
                     "useful cells = 2 x the first tree's (the realignment pass aligns the same sequences again) + the N x 5 seq-seq batch"}
 
@@ -950,6 +952,8 @@ def main():
         if not args.no_c4:
             out["c4_single_gpu"] = c4_single_gpu_leg(ctx)
             out["c5_ensemble8_2048x300"] = c5_ensemble_leg(local_rank)
+    # (runs that stalled on a wait between workgroups and were repeated on the plan without them: 0 unless the GPU is shared)
+    out["fallback_runs"] = ctx.fallback_runs()
     print(json.dumps(out))
     ctx.close()
 

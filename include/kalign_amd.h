@@ -221,6 +221,8 @@ int ka_tree_get_timing(ka_ctx* ctx, long long* out);
 #define KA_DEBUG_STARVE_REFINE_MEMBER 4   /* ka_tree_refine: a member of the first multi-workgroup edge never starts (watchdog -> re-plan) */
 #define KA_DEBUG_CHAIN_FIRST 8            /* overlapping launches: the chained launch is enqueued BEFORE the queued one -- its workgroups take the CUs
                                              first, as a dispatcher that ignores the streams' priorities would have it (they help the queue) */
+#define KA_DEBUG_POISON_ARENAS 16         /* every run starts with the profile, scratch and path arenas filled with 0xff bytes (NaN / -1): nothing may
+                                             depend on what an arena held before (round 6: sequences' profile records are no longer written) */
 int ka_debug_set_hooks(ka_ctx* ctx, int hooks);
 /* Tools and tests: the KA_* environment switches (experiments and measurements; none is needed in production) are read
    once, at ka_ctx_create.  This reads them again and rebuilds the launch plan of the uploaded job. */

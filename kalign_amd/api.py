@@ -237,7 +237,7 @@ class Context:
             pass
 
     def debug_set_hooks(self, hooks):
-        """tests only: ka_debug_set_hooks (KA_DEBUG_SMALL_ARENAS = 1, KA_DEBUG_STARVE_ROOT_JOIN = 2, KA_DEBUG_STARVE_REFINE_MEMBER = 4, KA_DEBUG_CHAIN_FIRST = 8)"""
+        """tests only: ka_debug_set_hooks (KA_DEBUG_SMALL_ARENAS = 1, KA_DEBUG_STARVE_ROOT_JOIN = 2, KA_DEBUG_STARVE_REFINE_MEMBER = 4, KA_DEBUG_CHAIN_FIRST = 8, KA_DEBUG_POISON_ARENAS = 16)"""
         self._chk(self.L.ka_debug_set_hooks(self.h, int(hooks)))
 
     def reload_env(self):

@@ -183,6 +183,11 @@ int tree_reset(ka_ctx* c)
         HIPCHK(hipMemsetAsync(c->d_ctl.p, 0, (size_t)ka_ctl_bytes_host() * c->n_tasks, c->stream));
         HIPCHK(hipMemsetAsync(c->d_recs.p, 0, sizeof(ka_task_rec) * c->n_tasks, c->stream));
         HIPCHK(hipMemsetAsync(c->d_join.p, 0, sizeof(KaJoin) * c->n_tasks, c->stream));
+        if (c->test_hooks & KA_DEBUG_POISON_ARENAS) {   // (tests: a run must not read what it has not written)
+                HIPCHK(hipMemsetAsync(c->d_prof_arena.p, 0xff, c->d_prof_arena.n * sizeof(*c->d_prof_arena.p), c->stream));
+                HIPCHK(hipMemsetAsync(c->d_scratch.p, 0xff, c->d_scratch.n * sizeof(*c->d_scratch.p), c->stream));
+                HIPCHK(hipMemsetAsync(c->d_path_arena.p, 0xff, c->d_path_arena.n * sizeof(*c->d_path_arena.p), c->stream));
+        }
         if (c->have_colof)                           // every leaf starts with residue p in column p
                 HIPCHK(hipMemcpyAsync(c->d_colof.p, c->d_colof_init.p, sizeof(int) * c->colof_n, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));          // the staging vectors above are stack/heap temporaries
@@ -226,6 +231,7 @@ KaTreeDev tree_dev(ka_ctx* c)
         D.lean4 = c->env.lean4;
         D.sub_mode = c->env.subtree;
         D.mw_mode = c->env.mw;
+        D.merge_batch = c->env.merge;
         D.cons_K = c->cons_K; D.cons_maxlen = c->max_len;
         D.cons_paw = c->cons_K > 0 ? c->cons_weight / (float)c->cons_K : 0.0f;
         D.cons_maps = c->d_cons_maps.p; D.cons_map_off = c->d_cons_map_off.p;
@@ -489,6 +495,7 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                 if (!err) {
                         HIPCHK(hipMemcpy(c->h_counters, c->d_counters.p, sizeof(c->h_counters), hipMemcpyDeviceToHost));
                         c->synced = true;
+                        if (!c->shared_gpu) c->fallback_streak = 0;        // (a clean run of the fast plan)
                         return KA_OK;
                 }
                 if (err == 5) return fail("device watchdog: a strip pipeline stopped making progress");
@@ -496,12 +503,19 @@ extern "C" int ka_tree_sync(ka_ctx* c)
                         // workgroups that wait for each other were not all resident: somebody else is using the GPU.
                         // Fall back to the plan that needs no co-residency (ka_ctx_set_shared) and run again.
                         if (c->shared_gpu || c->partial) return fail("device watchdog: a wait between workgroups never completed");
-                        if (getenv("KA_VERBOSE")) {
+                        // (a 2 s stall is never silent: one line per fallback; the queue's head and the helped count say which wait it was)
+                        c->shared_gpu = true; c->shared_by_fallback = true; c->fallback_runs++;
+                        // the next job tries the fast plan again -- unless that one stalled too: a GPU that stays shared (or a runtime
+                        // that keeps the launches apart) would otherwise cost every job its 2 s; then 4, 16, 64 jobs stay on the shared plan
+                        c->fallback_streak++;
+                        c->fallback_hold = c->fallback_streak >= 2 ? std::min(64, 1 << (2 * (c->fallback_streak - 1))) : 0;
+                        {
                                 unsigned long long hc[6] = {0, 0, 0, 0, 0, 0};
                                 (void)hipMemcpy(hc, c->d_counters.p, sizeof(hc), hipMemcpyDeviceToHost);
-                                fprintf(stderr, "[kalign_amd] watchdog 6: queue head %llu of %d, helped %llu, launches %d -> shared plan\n", hc[4], c->queue_n, hc[5], c->n_launches);
+                                fprintf(stderr, "[kalign_amd] a wait between workgroups expired (somebody else on the GPU?): queue head %llu of %d, helped %llu, launches %d; "
+                                        "the run is repeated on the plan without such waits (fallback %d of this context, the next %d jobs stay on it)\n",
+                                        hc[4], c->queue_n, hc[5], c->n_launches, c->fallback_runs, c->fallback_hold);
                         }
-                        c->shared_gpu = true; c->shared_by_fallback = true; c->fallback_runs++;
                         if (plan_launches(c) || upload_plan(c)) return KA_FAIL;
                         if (c->refine_mode && refine_blocks(c, c->refine_mode)) return KA_FAIL;       // one workgroup per edge from here on
                         if (tree_launch(c)) return KA_FAIL;

@@ -512,7 +512,11 @@ extern "C" int ka_tree_upload(ka_ctx* c, int numseq, const uint8_t* codes, const
         c->have_job = false; c->ran = false; c->synced = false; c->state_valid = false;
         // a join watchdog of an earlier job forced the no-cluster plan: a new job gets the fast plan again (the
         // fallback is counted, ka_ctx_fallback_runs); a caller's own ka_ctx_set_shared stays
-        if (c->shared_by_fallback) { c->shared_gpu = false; c->shared_by_fallback = false; }
+        // -- unless the fallback before it was a fast-plan job's too: then fallback_hold jobs stay on the shared plan first (ka_tree_sync)
+        if (c->shared_by_fallback) {
+                if (c->fallback_hold > 0) c->fallback_hold--;
+                else { c->shared_gpu = false; c->shared_by_fallback = false; }
+        }
         if (!keep_cons) c->cons_K = 0;           // a new job starts without a consistency table
         c->have_colof = false;
         c->rows_n = 0;

@@ -155,6 +155,9 @@ __device__ __forceinline__ float4v ka_leaf_rec4(const uint8_t* __restrict__ seq,
         return out;
 }
 
+#ifndef KA_MERGE_BATCH
+#define KA_MERGE_BATCH 4                                       // output items a thread of the merge has in flight (0: one)
+#endif
 __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const KaTaskDesc& T, const int alnlen, const float* tss_syn = nullptr)
 {
         const float* pa = S.profa;
@@ -245,8 +248,157 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 }
                 return val;
         };
+        // the two successive adjustments of a gap column at the end / start of its run (code & 16, code & 4): elem()'s statements on a
+        // value that is already here -- a synthesized record (tss_syn) is in no memory elem() could read it from
+        auto adj2 = [&](float val, const int k, const int code) -> float {
+                const float sip = (code & 1) ? sipa : sipb;
+                for (int pass = 0; pass < 2; ++pass) {
+                        const int bit = pass == 0 ? 16 : 4;
+                        if (!(code & bit)) continue;
+                        float gp;
+                        if (code & 32) {
+                                if (k == 25) val += sip;
+                                gp = D.tgpe0 * sip;
+                                if (k == 23) val += sip;
+                                gp += D.gpo0 * sip;
+                        } else {
+                                if (k == 23) val += sip;
+                                gp = D.gpo0 * sip;
+                        }
+                        if (k >= 32 && k < 55) val -= gp;
+                }
+                return val;
+        };
         const long long total4 = (long long)(alnlen + 2) * 16;
         const float gpe_a = D.gpe0 * sipa, gpe_b = D.gpe0 * sipb, tgpe_a = D.tgpe0 * sipa, tgpe_b = D.tgpe0 * sipb;
+#if KA_MERGE_BATCH
+        if (!rebalance && S.G == 1 && (D.merge_batch & (tss_syn && (leaf_a || leaf_b) ? 2 : 1))) {
+                // (Measured, tools/phase_means.py with KA_MERGE=0 / 1 / 3 on one context: profile-profile tasks of the queued launch 53 -> 38 us;
+                // a cluster's workgroups have too few items per thread to fill a batch, 21 -> 25 us: they keep the plain loop; tasks that consume
+                // a sequence all reach their merge together -- the leaf launch writes 170 MB in one burst -- and are not latency-bound: seq-seq
+                // 57 -> 61 us, seq-profile 75 -> 66 us with bit 1, which therefore stays off.  The single tree's time does not move, section 4j.)
+                // Round 6: the same statements, KA_MERGE_BATCH output items per thread at a time.  The walk is a chain of dependent trips
+                // to memory per item (op code and source records -> the two records, written by other XCDs: they come from HBM -> the
+                // store) and a task's 4 or 8 waves have ~27 items per thread: one after the other that is 45-70 us of every task, on
+                // every dependency chain of the tree, with the memory pipe all but idle.  Here the codes of a batch are fetched
+                // together, then its records, then it is stored: loads without branches around them (clamped indices, selects
+                // behind) and through global pointers -- a flat load counts on vmcnt AND lgkmcnt and the compiler then waits
+                // for everything at every use.  (The stride is a multiple of 16: a thread's four fields are the same in every item.)
+                typedef const __attribute__((address_space(1))) int* ka_gint;
+                typedef const __attribute__((address_space(1))) float* ka_gf;
+                typedef const __attribute__((address_space(1))) float4v* ka_gf4;
+                typedef const __attribute__((address_space(1))) uint8_t* ka_gu8;
+                constexpr int U = KA_MERGE_BATCH;
+                const long long stride = (long long)S.G * KA_NT;
+                const long long first = (long long)S.member * KA_NT + threadIdx.x;
+                const int k4 = (int)(first & 15) << 2;
+                const bool syn_a = tss_syn && leaf_a, syn_b = tss_syn && leaf_b;
+                const ka_gint g_coded = (ka_gint)coded, g_srcA = (ka_gint)srcA, g_srcB = (ka_gint)srcB;
+                const ka_gf g_pa = (ka_gf)pa_r, g_pb = (ka_gf)pb_r;
+                const ka_gu8 g_seqa = (ka_gu8)(D.codes + (syn_a ? D.seq_off[T.a] : 0)), g_seqb = (ka_gu8)(D.codes + (syn_b ? D.seq_off[T.b] : 0));
+                const int la = S.len_a, lb = S.len_b;
+                // a sequence's record from its residue (ka_leaf_rec4, the residue already here)
+                auto leaf4 = [&](const int cres, const bool inner) -> float4v {
+                        float4v out = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (k4 >= 32 && k4 < 56) {
+                                if (inner) out = *(const ka_lf4*)((const ka_lf*)tss_syn + cres * KA_T_STRIDE + (k4 - 32));   // (the table is in LDS: ds_read, not a flat load)
+                                if (k4 == 52) out.w = -T.gpo;
+                        } else if (k4 == 56) {
+                                out.x = -T.gpe; out.y = -T.tgpe;
+                        } else if (inner && (cres >> 2) == (k4 >> 2)) {
+                                out.x = (cres & 3) == 0 ? 1.0f : 0.0f; out.y = (cres & 3) == 1 ? 1.0f : 0.0f; out.z = (cres & 3) == 2 ? 1.0f : 0.0f; out.w = (cres & 3) == 3 ? 1.0f : 0.0f;
+                        }
+                        return out;
+                };
+                auto run = [&](auto sa_tag, auto sb_tag) {
+                constexpr bool SA = decltype(sa_tag)::value, SB = decltype(sb_tag)::value;   // (the operand is a sequence whose records are made here)
+                for (long long x0 = first; x0 < total4; x0 += U * stride) {
+                        int code[U], reca[U], recb[U], col[U];
+                        int lc[U], lia[U], lib[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                                const long long x4 = x0 + u * stride;
+                                col[u] = x4 < total4 ? (int)(x4 >> 4) : -1;
+                                const int cc = min(max(col[u], 0), alnlen + 1);
+                                lc[u] = g_coded[cc]; lia[u] = g_srcA[cc]; lib[u] = g_srcB[cc];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                                const int c = col[u];
+                                const bool inner = c > 0 && c <= alnlen;
+                                code[u] = inner ? lc[u] : 0;
+                                reca[u] = c == alnlen + 1 ? la + 1 : (inner ? max(lia[u], 0) : 0);
+                                recb[u] = c == alnlen + 1 ? lb + 1 : (inner ? max(lib[u], 0) : 0);
+                        }
+                        float4v A[U], B[U];
+                        int resa[U], resb[U];
+                        // (one block of loads, no branch inside: a branch between two loads costs a wait for everything in flight --
+                        // which operand is a sequence is a template argument of this loop)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                                if constexpr (SA) resa[u] = g_seqa[min(max(reca[u] - 1, 0), la - 1)];
+                                else A[u] = *(ka_gf4)(g_pa + ((long long)reca[u] << 6) + k4);
+                                if constexpr (SB) resb[u] = g_seqb[min(max(recb[u] - 1, 0), lb - 1)];
+                                else B[u] = *(ka_gf4)(g_pb + ((long long)recb[u] << 6) + k4);
+                        }
+                        float xa[U][2], xb[U][2];
+                        if (k4 == 24 || k4 == 28) {                     // fields 27 / 28, 29 (see fa / fb)
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                        const int f = k4 == 24 ? 55 : 56;
+                                        // (a sequence's fields 27 .. 29 are zero whatever its record holds: read anyway where the record exists, selected below)
+                                        if constexpr (SA) { xa[u][0] = 0.0f; xa[u][1] = 0.0f; }
+                                        else { xa[u][0] = g_pa[((long long)reca[u] << 6) + f]; xa[u][1] = g_pa[((long long)reca[u] << 6) + f + 1]; }
+                                        if constexpr (SB) { xb[u][0] = 0.0f; xb[u][1] = 0.0f; }
+                                        else { xb[u][0] = g_pb[((long long)recb[u] << 6) + f]; xb[u][1] = g_pb[((long long)recb[u] << 6) + f + 1]; }
+                                }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                                if constexpr (SA) A[u] = leaf4(resa[u], reca[u] >= 1 && reca[u] <= la);
+                                if constexpr (SB) B[u] = leaf4(resb[u], recb[u] >= 1 && recb[u] <= lb);
+                        }
+                        if (k4 == 24) {
+#pragma unroll
+                                for (int u = 0; u < U; ++u) { A[u].w = leaf_a ? 0.0f : xa[u][0] * sipb; B[u].w = leaf_b ? 0.0f : xb[u][0] * sipa; }
+                        } else if (k4 == 28) {
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                        A[u].x = leaf_a ? 0.0f : xa[u][0] * sipb; A[u].y = leaf_a ? 0.0f : xa[u][1] * sipb;
+                                        B[u].x = leaf_b ? 0.0f : xb[u][0] * sipa; B[u].y = leaf_b ? 0.0f : xb[u][1] * sipa;
+                                }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                                const int c = col[u];
+                                if (c < 0) continue;
+                                float4v out;
+                                if (code[u] & 20) {                      // (a gap column at the end / start of its run)
+                                        out = (code[u] & 1) ? B[u] : A[u];
+                                        out.x = adj2(out.x, k4 + 0, code[u]); out.y = adj2(out.y, k4 + 1, code[u]);
+                                        out.z = adj2(out.z, k4 + 2, code[u]); out.w = adj2(out.w, k4 + 3, code[u]);
+                                } else if (c == 0 || c == alnlen + 1 || !code[u]) {
+                                        out = A[u] + B[u];
+                                } else {
+                                        const bool gap_in_a = (code[u] & 1) != 0, term = (code[u] & 32) != 0;
+                                        const float sip = gap_in_a ? sipa : sipb;
+                                        const float g = term ? (gap_in_a ? tgpe_a : tgpe_b) : (gap_in_a ? gpe_a : gpe_b);
+                                        out = gap_in_a ? B[u] : A[u];
+                                        if (k4 == 24) { if (term) out.y += sip; else out.x += sip; }        // [25] / [24]
+                                        else if (k4 >= 32 && k4 < 52) { out.x -= g; out.y -= g; out.z -= g; out.w -= g; }
+                                        else if (k4 == 52) { out.x -= g; out.y -= g; out.z -= g; }           // [55] is not a score
+                                }
+                                *(float4v*)(np_r + ((x0 + u * stride) << 2)) = out;
+                        }
+                }
+                };
+                if (syn_a && syn_b) run(std::true_type(), std::true_type());
+                else if (syn_a) run(std::true_type(), std::false_type());
+                else if (syn_b) run(std::false_type(), std::true_type());
+                else run(std::false_type(), std::false_type());
+                return;
+        }
+#endif
         for (long long x4 = (long long)S.member * KA_NT + threadIdx.x; x4 < total4; x4 += (long long)S.G * KA_NT) {
                 const int c = (int)(x4 >> 4);
                 const int k4 = (int)(x4 & 15) << 2;
@@ -261,7 +413,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 const float* ra = pa_r + ((long long)reca << 6);
                 const float* rb = pb_r + ((long long)recb << 6);
                 float4v out;
-                if (!rebalance && !(code & 20)) {
+                if (!rebalance) {
                         // The common case (no sequence weights; the coded path carries only the flags the reference
                         // really sets), four fields at a time -- same operations as elem() below, without the per-field
                         // branching: a match / boundary column is the sum of the two records, a gap column the present
@@ -277,7 +429,11 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                                 A.x = leaf_a ? 0.0f : ra[56] * sipb; A.y = leaf_a ? 0.0f : ra[57] * sipb;
                                 B.x = leaf_b ? 0.0f : rb[56] * sipa; B.y = leaf_b ? 0.0f : rb[57] * sipa;
                         }
-                        if (c == 0 || c == alnlen + 1 || !code) {
+                        if (code & 20) {                                 // (a gap column at the end / start of its run)
+                                out = (code & 1) ? B : A;
+                                out.x = adj2(out.x, k4 + 0, code); out.y = adj2(out.y, k4 + 1, code);
+                                out.z = adj2(out.z, k4 + 2, code); out.w = adj2(out.w, k4 + 3, code);
+                        } else if (c == 0 || c == alnlen + 1 || !code) {
                                 out = A + B;
                         } else {
                                 const bool gap_in_a = (code & 1) != 0, term = (code & 32) != 0;

@@ -219,3 +219,21 @@ def test_starved_join_is_reported_and_the_run_replanned():
         assert np.array_equal(paths[r.path_off:r.path_off + r.plen + 2], g.path(t)), t
     for got, want in zip(gaps, g.gaps_list()):
         assert np.array_equal(got, want)
+
+
+def test_a_gpu_that_stays_shared_costs_two_stalls_not_one_per_job():
+    """The job after a fallback tries the fast plan again (above).  When that one stalls too the context stays on the plan
+    without waits for 4 jobs (then 16, 64) before the next try -- a GPU somebody else keeps using, or a runtime that keeps
+    the two launches apart, must not cost every job its two seconds (ka_tree_sync, ka_tree_upload)."""
+    import kalign_amd
+    from util import Golden
+    g = Golden("tree_prot64_gon")
+    ctx = kalign_amd.Context(0)
+    ctx.debug_set_hooks(2)                                   # KA_DEBUG_STARVE_ROOT_JOIN, for every job from here
+    for want in (1, 2, 2, 2, 2, 2, 3):                       # stall, stall, four jobs held on the shared plan, the next try stalls again
+        recs, paths, gaps = ctx.msa_tree(g.codes, g.tasks, g.subm, g.scal, g.seq_distances)
+        assert ctx.fallback_runs() == want
+        for got, ref in zip(gaps, g.gaps_list()):
+            assert np.array_equal(got, ref)
+    ctx.debug_set_hooks(0)
+    ctx.close()
