@@ -394,7 +394,13 @@ __device__ __forceinline__ int ka_task_body(const KaTreeDev& D, const int task, 
         else if (D.nres <= 5) ka_hirschberg<KA_PP, 5, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
         // no B / Z / X in the job (the usual case): every profile's counts [20..22] are zero and the reference skips
         // zero counts (aln_profileprofile.c:70-77) -- 20 terms per cell instead of 23
+#ifdef KA_FAKE_NRES
+        // (measurement only, WRONG results: the profile-profile DP with KA_FAKE_NRES terms per cell -- an upper bound of what a sparse dot
+        // product for shallow profiles could gain; tools/build_alt.sh)
+        else if (D.nres <= 20) ka_hirschberg<KA_PP, KA_FAKE_NRES, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
+#else
         else if (D.nres <= 20) ka_hirschberg<KA_PP, 20, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
+#endif
         else ka_hirschberg<KA_PP, 23, NB, false, Q1, Q1 && NB == 0, Q1, KA_RU_TREE && !Q1>(S, s_dbg, lds_waves, tss, D.trace);
         __syncthreads();
         // exact confidence: the cluster's last barrier (inside ka_hirschberg) has published every member's records
