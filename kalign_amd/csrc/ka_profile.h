@@ -155,6 +155,32 @@ __device__ __forceinline__ float4v ka_leaf_rec4(const uint8_t* __restrict__ seq,
         return out;
 }
 
+// update_n's two successive adjustments of a gap column at the end / start of its run (code & 16, then code & 4; aln_setup.c:230-436): elem()'s
+// statements on a value that is already in a register -- a synthesized record (tss_syn) is in no memory elem() could read it from.
+// (A function with scalar arguments, not a lambda: captured, `(code & 1) ? sipa : sipb` became an indexed load from a closure in scratch.)
+__device__ __forceinline__ float ka_adj2(float val, const int k, const int code, const float sip, const float gpo0, const float tgpe0)
+{
+        for (int pass = 0; pass < 2; ++pass) {
+                const int bit = pass == 0 ? 16 : 4;
+                if (!(code & bit)) continue;
+                float gp;
+                if (code & 32) {
+                        if (k == 25) val += sip;
+                        gp = tgpe0 * sip;
+                        if (k == 23) val += sip;
+                        gp += gpo0 * sip;
+                } else {
+                        if (k == 23) val += sip;
+                        gp = gpo0 * sip;
+                }
+                if (k >= 32 && k < 55) val -= gp;
+        }
+        return val;
+}
+
+#if !defined(KA_MERGE_BATCH) && defined(KA_UNIT) && (KA_UNIT == 3 || KA_UNIT == 8)
+#define KA_MERGE_BATCH 0                                       // (the 128-register units run seq-seq tasks only, which keep the plain loop: built in, the batches' code spilled at every call)
+#endif
 #ifndef KA_MERGE_BATCH
 #define KA_MERGE_BATCH 4                                       // output items a thread of the merge has in flight (0: one)
 #endif
@@ -179,11 +205,11 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
         // for this merge, aln_run.c:239-253).  They are dead values (always rewritten before
         // use) but part of the merged record, so they are reproduced for bit-identical profiles.
         const bool leaf_a = (T.nsip_a == 1), leaf_b = (T.nsip_b == 1);
-        auto fa = [&](const float* rec, int k) -> float {
+        auto fa = [&](const float* rec, int k) __attribute__((always_inline)) -> float {
                 if (k >= 27 && k <= 29) return leaf_a ? 0.0f : rec[k + 28] * sipb;
                 return rec[k];
         };
-        auto fb = [&](const float* rec, int k) -> float {
+        auto fb = [&](const float* rec, int k) __attribute__((always_inline)) -> float {
                 if (k >= 27 && k <= 29) return leaf_b ? 0.0f : rec[k + 28] * sipa;
                 return rec[k];
         };
@@ -195,7 +221,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
         const int* __restrict__ coded = S.coded;
         const int* __restrict__ srcA = S.srcA;
         const int* __restrict__ srcB = S.srcB;
-        auto elem = [&](const int c, const int k, const int code, const float* __restrict__ ra, const float* __restrict__ rb) -> float {
+        auto elem = [&](const int c, const int k, const int code, const float* __restrict__ ra, const float* __restrict__ rb) __attribute__((always_inline)) -> float {
                 float val;
                 if (c == 0 || c == alnlen + 1) {
                         const float va = fa(ra, k), vb = fb(rb, k);
@@ -248,35 +274,18 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 }
                 return val;
         };
-        // the two successive adjustments of a gap column at the end / start of its run (code & 16, code & 4): elem()'s statements on a
-        // value that is already here -- a synthesized record (tss_syn) is in no memory elem() could read it from
-        auto adj2 = [&](float val, const int k, const int code) -> float {
-                const float sip = (code & 1) ? sipa : sipb;
-                for (int pass = 0; pass < 2; ++pass) {
-                        const int bit = pass == 0 ? 16 : 4;
-                        if (!(code & bit)) continue;
-                        float gp;
-                        if (code & 32) {
-                                if (k == 25) val += sip;
-                                gp = D.tgpe0 * sip;
-                                if (k == 23) val += sip;
-                                gp += D.gpo0 * sip;
-                        } else {
-                                if (k == 23) val += sip;
-                                gp = D.gpo0 * sip;
-                        }
-                        if (k >= 32 && k < 55) val -= gp;
-                }
-                return val;
-        };
+        const float adj_gpo = D.gpo0, adj_tgpe = D.tgpe0;
         const long long total4 = (long long)(alnlen + 2) * 16;
         const float gpe_a = D.gpe0 * sipa, gpe_b = D.gpe0 * sipb, tgpe_a = D.tgpe0 * sipa, tgpe_b = D.tgpe0 * sipb;
 #if KA_MERGE_BATCH
         if (!rebalance && S.G == 1 && (D.merge_batch & (tss_syn && (leaf_a || leaf_b) ? 2 : 1))) {
-                // (Measured, tools/phase_means.py with KA_MERGE=0 / 1 / 3 on one context: profile-profile tasks of the queued launch 53 -> 38 us;
-                // a cluster's workgroups have too few items per thread to fill a batch, 21 -> 25 us: they keep the plain loop; tasks that consume
-                // a sequence all reach their merge together -- the leaf launch writes 170 MB in one burst -- and are not latency-bound: seq-seq
-                // 57 -> 61 us, seq-profile 75 -> 66 us with bit 1, which therefore stays off.  The single tree's time does not move, section 4j.)
+                // (Measured, tools/phase_means.py with KA_MERGE=0 / 1 / 3 on one context: profile-profile tasks of the queued launch 52 -> 29 us,
+                // seq-profile tasks 72 -> 41 us (bit 1); a cluster's workgroups have too few items per thread to fill a batch, 21 -> 25 us:
+                // they keep the plain loop; the seq-seq tasks of the leaf launch reach their merge together -- 170 MB written in one burst -- and
+                // are bandwidth-, not latency-bound (57 -> 61 us): the 128-register units are built without the batches.  A first version spent
+                // the gain again on scratch: lambdas that capture by reference keep their closure in memory as soon as two captured scalars
+                // are SELECTED between (`gap_in_a ? sipa : sipb` became an indexed load of an address) -- 424 B per lane and call, 0.4 GB of
+                // HBM writes per headline tree; hence ka_adj2 as a function and the c_ copies below.)
                 // Round 6: the same statements, KA_MERGE_BATCH output items per thread at a time.  The walk is a chain of dependent trips
                 // to memory per item (op code and source records -> the two records, written by other XCDs: they come from HBM -> the
                 // store) and a task's 4 or 8 waves have ~27 items per thread: one after the other that is 45-70 us of every task, on
@@ -298,7 +307,7 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 const ka_gu8 g_seqa = (ka_gu8)(D.codes + (syn_a ? D.seq_off[T.a] : 0)), g_seqb = (ka_gu8)(D.codes + (syn_b ? D.seq_off[T.b] : 0));
                 const int la = S.len_a, lb = S.len_b;
                 // a sequence's record from its residue (ka_leaf_rec4, the residue already here)
-                auto leaf4 = [&](const int cres, const bool inner) -> float4v {
+                auto leaf4 = [&](const int cres, const bool inner) __attribute__((always_inline)) -> float4v {
                         float4v out = {0.0f, 0.0f, 0.0f, 0.0f};
                         if (k4 >= 32 && k4 < 56) {
                                 if (inner) out = *(const ka_lf4*)((const ka_lf*)tss_syn + cres * KA_T_STRIDE + (k4 - 32));   // (the table is in LDS: ds_read, not a flat load)
@@ -310,25 +319,43 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                         }
                         return out;
                 };
-                auto run = [&](auto sa_tag, auto sb_tag) {
+                auto run = [&](auto sa_tag, auto sb_tag) __attribute__((always_inline)) {   // (inlined: as a call its captures went through 424 B of scratch per lane -- 0.4 GB of HBM writes per headline tree)
+                // (scalars by value first: selected between through the closure's references they became indexed loads of addresses kept in scratch)
+                const float c_sipa = sipa;
+                const float c_sipb = sipb;
+                const float c_gpe_a = gpe_a;
+                const float c_gpe_b = gpe_b;
+                const float c_tgpe_a = tgpe_a;
+                const float c_tgpe_b = tgpe_b;
+                const float c_adj_gpo = adj_gpo;
+                const float c_adj_tgpe = adj_tgpe;
+                const int c_la = la;
+                const int c_lb = lb;
+                const int c_k4 = k4;
+                const int c_alnlen = alnlen;
+                const bool c_leaf_a = leaf_a;
+                const bool c_leaf_b = leaf_b;
+                const long long c_stride = stride;
+                const long long c_first = first;
+                const long long c_total4 = total4;
                 constexpr bool SA = decltype(sa_tag)::value, SB = decltype(sb_tag)::value;   // (the operand is a sequence whose records are made here)
-                for (long long x0 = first; x0 < total4; x0 += U * stride) {
+                for (long long x0 = c_first; x0 < c_total4; x0 += U * c_stride) {
                         int code[U], reca[U], recb[U], col[U];
                         int lc[U], lia[U], lib[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                                const long long x4 = x0 + u * stride;
-                                col[u] = x4 < total4 ? (int)(x4 >> 4) : -1;
-                                const int cc = min(max(col[u], 0), alnlen + 1);
+                                const long long x4 = x0 + u * c_stride;
+                                col[u] = x4 < c_total4 ? (int)(x4 >> 4) : -1;
+                                const int cc = min(max(col[u], 0), c_alnlen + 1);
                                 lc[u] = g_coded[cc]; lia[u] = g_srcA[cc]; lib[u] = g_srcB[cc];
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                                 const int c = col[u];
-                                const bool inner = c > 0 && c <= alnlen;
+                                const bool inner = c > 0 && c <= c_alnlen;
                                 code[u] = inner ? lc[u] : 0;
-                                reca[u] = c == alnlen + 1 ? la + 1 : (inner ? max(lia[u], 0) : 0);
-                                recb[u] = c == alnlen + 1 ? lb + 1 : (inner ? max(lib[u], 0) : 0);
+                                reca[u] = c == c_alnlen + 1 ? c_la + 1 : (inner ? max(lia[u], 0) : 0);
+                                recb[u] = c == c_alnlen + 1 ? c_lb + 1 : (inner ? max(lib[u], 0) : 0);
                         }
                         float4v A[U], B[U];
                         int resa[U], resb[U];
@@ -336,16 +363,16 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                         // which operand is a sequence is a template argument of this loop)
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                                if constexpr (SA) resa[u] = g_seqa[min(max(reca[u] - 1, 0), la - 1)];
-                                else A[u] = *(ka_gf4)(g_pa + ((long long)reca[u] << 6) + k4);
-                                if constexpr (SB) resb[u] = g_seqb[min(max(recb[u] - 1, 0), lb - 1)];
-                                else B[u] = *(ka_gf4)(g_pb + ((long long)recb[u] << 6) + k4);
+                                if constexpr (SA) resa[u] = g_seqa[min(max(reca[u] - 1, 0), c_la - 1)];
+                                else A[u] = *(ka_gf4)(g_pa + ((long long)reca[u] << 6) + c_k4);
+                                if constexpr (SB) resb[u] = g_seqb[min(max(recb[u] - 1, 0), c_lb - 1)];
+                                else B[u] = *(ka_gf4)(g_pb + ((long long)recb[u] << 6) + c_k4);
                         }
                         float xa[U][2], xb[U][2];
-                        if (k4 == 24 || k4 == 28) {                     // fields 27 / 28, 29 (see fa / fb)
+                        if (c_k4 == 24 || c_k4 == 28) {                     // fields 27 / 28, 29 (see fa / fb)
 #pragma unroll
                                 for (int u = 0; u < U; ++u) {
-                                        const int f = k4 == 24 ? 55 : 56;
+                                        const int f = c_k4 == 24 ? 55 : 56;
                                         // (a sequence's fields 27 .. 29 are zero whatever its record holds: read anyway where the record exists, selected below)
                                         if constexpr (SA) { xa[u][0] = 0.0f; xa[u][1] = 0.0f; }
                                         else { xa[u][0] = g_pa[((long long)reca[u] << 6) + f]; xa[u][1] = g_pa[((long long)reca[u] << 6) + f + 1]; }
@@ -355,17 +382,17 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                         }
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                                if constexpr (SA) A[u] = leaf4(resa[u], reca[u] >= 1 && reca[u] <= la);
-                                if constexpr (SB) B[u] = leaf4(resb[u], recb[u] >= 1 && recb[u] <= lb);
+                                if constexpr (SA) A[u] = leaf4(resa[u], reca[u] >= 1 && reca[u] <= c_la);
+                                if constexpr (SB) B[u] = leaf4(resb[u], recb[u] >= 1 && recb[u] <= c_lb);
                         }
-                        if (k4 == 24) {
+                        if (c_k4 == 24) {
 #pragma unroll
-                                for (int u = 0; u < U; ++u) { A[u].w = leaf_a ? 0.0f : xa[u][0] * sipb; B[u].w = leaf_b ? 0.0f : xb[u][0] * sipa; }
-                        } else if (k4 == 28) {
+                                for (int u = 0; u < U; ++u) { A[u].w = c_leaf_a ? 0.0f : xa[u][0] * c_sipb; B[u].w = c_leaf_b ? 0.0f : xb[u][0] * c_sipa; }
+                        } else if (c_k4 == 28) {
 #pragma unroll
                                 for (int u = 0; u < U; ++u) {
-                                        A[u].x = leaf_a ? 0.0f : xa[u][0] * sipb; A[u].y = leaf_a ? 0.0f : xa[u][1] * sipb;
-                                        B[u].x = leaf_b ? 0.0f : xb[u][0] * sipa; B[u].y = leaf_b ? 0.0f : xb[u][1] * sipa;
+                                        A[u].x = c_leaf_a ? 0.0f : xa[u][0] * c_sipb; A[u].y = c_leaf_a ? 0.0f : xa[u][1] * c_sipb;
+                                        B[u].x = c_leaf_b ? 0.0f : xb[u][0] * c_sipa; B[u].y = c_leaf_b ? 0.0f : xb[u][1] * c_sipa;
                                 }
                         }
 #pragma unroll
@@ -374,21 +401,23 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                                 if (c < 0) continue;
                                 float4v out;
                                 if (code[u] & 20) {                      // (a gap column at the end / start of its run)
-                                        out = (code[u] & 1) ? B[u] : A[u];
-                                        out.x = adj2(out.x, k4 + 0, code[u]); out.y = adj2(out.y, k4 + 1, code[u]);
-                                        out.z = adj2(out.z, k4 + 2, code[u]); out.w = adj2(out.w, k4 + 3, code[u]);
-                                } else if (c == 0 || c == alnlen + 1 || !code[u]) {
+                                        const bool gap_in_a = (code[u] & 1) != 0;
+                                        const float sip = gap_in_a ? c_sipa : c_sipb;
+                                        out = gap_in_a ? B[u] : A[u];
+                                        out.x = ka_adj2(out.x, c_k4 + 0, code[u], sip, c_adj_gpo, c_adj_tgpe); out.y = ka_adj2(out.y, c_k4 + 1, code[u], sip, c_adj_gpo, c_adj_tgpe);
+                                        out.z = ka_adj2(out.z, c_k4 + 2, code[u], sip, c_adj_gpo, c_adj_tgpe); out.w = ka_adj2(out.w, c_k4 + 3, code[u], sip, c_adj_gpo, c_adj_tgpe);
+                                } else if (c == 0 || c == c_alnlen + 1 || !code[u]) {
                                         out = A[u] + B[u];
                                 } else {
                                         const bool gap_in_a = (code[u] & 1) != 0, term = (code[u] & 32) != 0;
-                                        const float sip = gap_in_a ? sipa : sipb;
-                                        const float g = term ? (gap_in_a ? tgpe_a : tgpe_b) : (gap_in_a ? gpe_a : gpe_b);
+                                        const float sip = gap_in_a ? c_sipa : c_sipb;
+                                        const float g = term ? (gap_in_a ? c_tgpe_a : c_tgpe_b) : (gap_in_a ? c_gpe_a : c_gpe_b);
                                         out = gap_in_a ? B[u] : A[u];
-                                        if (k4 == 24) { if (term) out.y += sip; else out.x += sip; }        // [25] / [24]
-                                        else if (k4 >= 32 && k4 < 52) { out.x -= g; out.y -= g; out.z -= g; out.w -= g; }
-                                        else if (k4 == 52) { out.x -= g; out.y -= g; out.z -= g; }           // [55] is not a score
+                                        if (c_k4 == 24) { if (term) out.y += sip; else out.x += sip; }        // [25] / [24]
+                                        else if (c_k4 >= 32 && c_k4 < 52) { out.x -= g; out.y -= g; out.z -= g; out.w -= g; }
+                                        else if (c_k4 == 52) { out.x -= g; out.y -= g; out.z -= g; }           // [55] is not a score
                                 }
-                                *(float4v*)(np_r + ((x0 + u * stride) << 2)) = out;
+                                *(float4v*)(np_r + ((x0 + u * c_stride) << 2)) = out;
                         }
                 }
                 };
@@ -430,9 +459,11 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                                 B.x = leaf_b ? 0.0f : rb[56] * sipa; B.y = leaf_b ? 0.0f : rb[57] * sipa;
                         }
                         if (code & 20) {                                 // (a gap column at the end / start of its run)
-                                out = (code & 1) ? B : A;
-                                out.x = adj2(out.x, k4 + 0, code); out.y = adj2(out.y, k4 + 1, code);
-                                out.z = adj2(out.z, k4 + 2, code); out.w = adj2(out.w, k4 + 3, code);
+                                const bool gap_in_a = (code & 1) != 0;
+                                const float sip = gap_in_a ? sipa : sipb;
+                                out = gap_in_a ? B : A;
+                                out.x = ka_adj2(out.x, k4 + 0, code, sip, adj_gpo, adj_tgpe); out.y = ka_adj2(out.y, k4 + 1, code, sip, adj_gpo, adj_tgpe);
+                                out.z = ka_adj2(out.z, k4 + 2, code, sip, adj_gpo, adj_tgpe); out.w = ka_adj2(out.w, k4 + 3, code, sip, adj_gpo, adj_tgpe);
                         } else if (c == 0 || c == alnlen + 1 || !code) {
                                 out = A + B;
                         } else {
