@@ -117,7 +117,7 @@ struct KaTreeDev {
         int reserve;                   // round 6, the queued launch of an overlapping run: its workgroups leave the first `reserve` CUs of XCC 0 (shader
                                        // engines 0 .. reserve / 8 - 1) to the head of the chained launch (plan_launches; 0: none)
         int tp;                        // round 6: launches of the 4-wave kind go to the throughput kernel (unit 10) when the job allows it (host: ka_tp_ok)
-        int merge_batch;               // round 6, ka_update_profile: bit 0 = items in batches when both operands' records are in HBM, bit 1 = also when one is a sequence (KA_MERGE)
+        int merge_batch;               // round 6, ka_update_profile: bit 0 = items in batches when both operands' records are in HBM, bit 1 = also when one is a sequence, bit 2 = also in a cluster of workgroups (KA_MERGE)
 };
 
 #define KA_BLK_NOHELP (1 << 30)        // a block of the chained launch (blocks[b].y): this workgroup does not help the queued launch -- it sits on a CU kept for it

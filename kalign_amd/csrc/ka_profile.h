@@ -278,10 +278,9 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
         const long long total4 = (long long)(alnlen + 2) * 16;
         const float gpe_a = D.gpe0 * sipa, gpe_b = D.gpe0 * sipb, tgpe_a = D.tgpe0 * sipa, tgpe_b = D.tgpe0 * sipb;
 #if KA_MERGE_BATCH
-        if (!rebalance && S.G == 1 && (D.merge_batch & (tss_syn && (leaf_a || leaf_b) ? 2 : 1))) {
+        if (!rebalance && (S.G == 1 || (D.merge_batch & 4)) && (D.merge_batch & (tss_syn && (leaf_a || leaf_b) ? 2 : 1))) {
                 // (Measured, tools/phase_means.py with KA_MERGE=0 / 1 / 3 on one context: profile-profile tasks of the queued launch 52 -> 29 us,
-                // seq-profile tasks 72 -> 41 us (bit 1); a cluster's workgroups have too few items per thread to fill a batch, 21 -> 25 us:
-                // they keep the plain loop; the seq-seq tasks of the leaf launch reach their merge together -- 170 MB written in one burst -- and
+                // seq-profile tasks 72 -> 41 us (bit 1), the workgroups of a cluster 20 -> 16 us (bit 2); the seq-seq tasks of the leaf launch reach their merge together -- 170 MB written in one burst -- and
                 // are bandwidth-, not latency-bound (57 -> 61 us): the 128-register units are built without the batches.  A first version spent
                 // the gain again on scratch: lambdas that capture by reference keep their closure in memory as soon as two captured scalars
                 // are SELECTED between (`gap_in_a ? sipa : sipb` became an indexed load of an address) -- 424 B per lane and call, 0.4 GB of
