@@ -106,7 +106,7 @@ struct KaEnv {
         int q1 = -1;                   // KA_Q1 (-1: the default -- 4 for protein jobs: 64-row strips per recursion level where every strip still gets a helper wave, 0 for nucleotides): 64-row strips (KaTreeDev::q1_mode); measured no faster with 64-column hand-over batches (round 3)
         int lean4 = 1;                 // KA_LEAN4: leaf levels on 4-wave workgroups, four per CU (1.60 -> 1.28 ms on the 4096 x 400 leaf level)
         int mw = 1;                    // KA_MW: multi-wave scan of the top-level meetups
-        int merge = 7;                 // KA_MERGE: ka_update_profile in batches (bit 0: operands with records in HBM, bit 1: sequences too, bit 2: clusters too)
+        int merge = 15;                // KA_MERGE: ka_update_profile in batches (bit 0: operands with records in HBM, bit 1: sequences too, bit 2: clusters too, bit 3: the seq-seq tasks of the 128-register units)
         int per = 0;                   // KA_PER: strips per workgroup (KaTreeDev::per_target; experiments)
         int ho = -1;                   // KA_HO: hand-over between neighbouring strips through LDS (KaTreeDev::ho_mode); -1: on (1)
         int hw = 1;                    // KA_HW: profile-profile strips with helper waves (ka_wstrip.h; KaTreeDev::hw_mode)
@@ -141,7 +141,7 @@ static inline void read_env(KaEnv& v)
         v.qw = env_int("KA_QW", 4); v.lw = env_int("KA_LW", 4); v.pw = env_int("KA_PW", 2);
         for (int* w : { &v.qw, &v.lw, &v.pw }) if (*w != 1 && *w != 2) *w = 4;
         v.mw = env_int("KA_MW", 1);
-        v.merge = env_int("KA_MERGE", 7);
+        v.merge = env_int("KA_MERGE", 15);
         v.ho = env_int("KA_HO", -1);
         v.per = env_int("KA_PER", 0);
         v.hw = env_int("KA_HW", 1);

@@ -178,8 +178,10 @@ __device__ __forceinline__ float ka_adj2(float val, const int k, const int code,
         return val;
 }
 
-#if !defined(KA_MERGE_BATCH) && defined(KA_UNIT) && (KA_UNIT == 3 || KA_UNIT == 8)
-#define KA_MERGE_BATCH 0                                       // (the 128-register units run seq-seq tasks only, which keep the plain loop: built in, the batches' code spilled at every call)
+#if defined(KA_UNIT) && (KA_UNIT == 3 || KA_UNIT == 8)
+#define KA_MERGE_LEAN 1                                        // the 128-register units run seq-seq tasks only: the batches' loop for two sequences alone (all four variants spilled there)
+#else
+#define KA_MERGE_LEAN 0
 #endif
 #ifndef KA_MERGE_BATCH
 #define KA_MERGE_BATCH 4                                       // output items a thread of the merge has in flight (0: one)
@@ -278,10 +280,15 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
         const long long total4 = (long long)(alnlen + 2) * 16;
         const float gpe_a = D.gpe0 * sipa, gpe_b = D.gpe0 * sipb, tgpe_a = D.tgpe0 * sipa, tgpe_b = D.tgpe0 * sipb;
 #if KA_MERGE_BATCH
+#if KA_MERGE_LEAN
+        if (!rebalance && tss_syn && leaf_a && leaf_b && (D.merge_batch & 8)) {
+#else
         if (!rebalance && (S.G == 1 || (D.merge_batch & 4)) && (D.merge_batch & (tss_syn && (leaf_a || leaf_b) ? 2 : 1))) {
+#endif
                 // (Measured, tools/phase_means.py with KA_MERGE=0 / 1 / 3 on one context: profile-profile tasks of the queued launch 52 -> 29 us,
-                // seq-profile tasks 72 -> 41 us (bit 1), the workgroups of a cluster 20 -> 16 us (bit 2); the seq-seq tasks of the leaf launch reach their merge together -- 170 MB written in one burst -- and
-                // are bandwidth-, not latency-bound (57 -> 61 us): the 128-register units are built without the batches.  A first version spent
+                // seq-profile tasks 72 -> 41 us (bit 1), the workgroups of a cluster 20 -> 16 us (bit 2), the seq-seq tasks of the leaf launch
+                // 51 -> 32 us (bit 3: the 128-register units build the loop for two sequences only -- with all four variants it spilled, 61 us).
+                // A first version spent
                 // the gain again on scratch: lambdas that capture by reference keep their closure in memory as soon as two captured scalars
                 // are SELECTED between (`gap_in_a ? sipa : sipb` became an indexed load of an address) -- 424 B per lane and call, 0.4 GB of
                 // HBM writes per headline tree; hence ka_adj2 as a function and the c_ copies below.)
@@ -420,10 +427,14 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                         }
                 }
                 };
+#if KA_MERGE_LEAN
+                run(std::true_type(), std::true_type());
+#else
                 if (syn_a && syn_b) run(std::true_type(), std::true_type());
                 else if (syn_a) run(std::true_type(), std::false_type());
                 else if (syn_b) run(std::false_type(), std::true_type());
                 else run(std::false_type(), std::false_type());
+#endif
                 return;
         }
 #endif
