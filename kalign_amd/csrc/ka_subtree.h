@@ -15,6 +15,9 @@
 // aln_seqseq.c:241-420, aln_controller.c:194-436): the sub-problems of a level are independent given their windows.
 #pragma once
 
+#ifndef KA_SUB_EARLY
+#define KA_SUB_EARLY 0                                           // ka_sub_pass: the next step's column record is read right behind this step's wait (1) or behind the dot products (0); round 6, measured: no difference (passes of a 430 x 420 task 464 / 466 us) -- the reads are covered either way
+#endif
 #define KA_SUB_MAXROWS 64                                       // a subtree in ONE wave region: decided when the sub-problem is emitted (ka_child_is_subtree)
 #define KA_SUB_WIDEROWS 128                                     // ... in TWO regions (round 5): decided per recursion level at run time (ka_run_items)
 #if KA_TP
@@ -272,7 +275,15 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                 if (KIND != KA_PP) resq[1 - P] = res_fetch(v + 1);
 
                 float copen, cext, ctext;
-                if (KIND == KA_PP) { pp_wait(q[P]); copen = q[P][NV].x; cext = q[P][NV].y; ctext = q[P][NV].z; }
+                if (KIND == KA_PP) {
+                        pp_wait(q[P]); copen = q[P][NV].x; cext = q[P][NV].y; ctext = q[P][NV].z;
+#if KA_SUB_EARLY
+                        // (the next step's record right behind this step's wait, as ka_wstrip's KA_W_EARLY: a whole step covers the reads)
+                        __builtin_amdgcn_sched_barrier(0);
+                        pp_read(q[1 - P], rec_addr(v + 1), copen);
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
                 else { copen = X.kc_open; cext = X.kc_ext; ctext = X.kc_text; }
                 {
                         const float gx = near_t ? ctext : cext, gy = near_t ? ctext : copen;
@@ -308,9 +319,11 @@ __device__ __forceinline__ void ka_sub_pass(const KaSubCtx& X, const ka_li* qc, 
                                 a1 += prod.y;
                                 a1 += prod.x;
                         }
+#if !KA_SUB_EARLY
                         __builtin_amdgcn_sched_barrier(0);
                         pp_read(q[1 - P], rec_addr(v + 1), a1);
                         __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 if (NB) { const int jb = (dir == KA_FWD) ? (X.b0 + sb + v) : (X.b0 + eb - v); a1 += bon.template at<true>(jb); }
                 const bool at0 = (v == 0), atN = (v == ncols);
