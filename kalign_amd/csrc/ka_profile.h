@@ -285,13 +285,6 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
 #else
         if (!rebalance && (S.G == 1 || (D.merge_batch & 4)) && (D.merge_batch & (tss_syn && (leaf_a || leaf_b) ? 2 : 1))) {
 #endif
-                // (Measured, tools/phase_means.py with KA_MERGE=0 / 1 / 3 on one context: profile-profile tasks of the queued launch 52 -> 29 us,
-                // seq-profile tasks 72 -> 41 us (bit 1), the workgroups of a cluster 20 -> 16 us (bit 2), the seq-seq tasks of the leaf launch
-                // 51 -> 32 us (bit 3: the 128-register units build the loop for two sequences only -- with all four variants it spilled, 61 us).
-                // A first version spent
-                // the gain again on scratch: lambdas that capture by reference keep their closure in memory as soon as two captured scalars
-                // are SELECTED between (`gap_in_a ? sipa : sipb` became an indexed load of an address) -- 424 B per lane and call, 0.4 GB of
-                // HBM writes per headline tree; hence ka_adj2 as a function and the c_ copies below.)
                 // Round 6: the same statements, KA_MERGE_BATCH output items per thread at a time.  The walk is a chain of dependent trips
                 // to memory per item (op code and source records -> the two records, written by other XCDs: they come from HBM -> the
                 // store) and a task's 4 or 8 waves have ~27 items per thread: one after the other that is 45-70 us of every task, on
@@ -299,6 +292,13 @@ __device__ void ka_update_profile(const TaskShared& S, const KaTreeDev& D, const
                 // together, then its records, then it is stored: loads without branches around them (clamped indices, selects
                 // behind) and through global pointers -- a flat load counts on vmcnt AND lgkmcnt and the compiler then waits
                 // for everything at every use.  (The stride is a multiple of 16: a thread's four fields are the same in every item.)
+                // Measured (tools/phase_means.py with KA_MERGE=0 / 1 / 3 / 7 / 15 on one context): profile-profile tasks of the queued launch
+                // 52 -> 29 us (bit 0), seq-profile tasks 72 -> 41 us (bit 1), the workgroups of a cluster 20 -> 16 us (bit 2), the seq-seq tasks
+                // of the leaf launch 51 -> 32 us (bit 3: the 128-register units build the loop for two sequences only -- with all four
+                // variants it spilled, 61 us).  A first version gave the gain back to scratch: a lambda that captures by reference keeps its
+                // closure in memory as soon as two captured scalars are SELECTED between (`gap_in_a ? sipa : sipb` became an indexed load
+                // of an address, then a flat load through it) -- 424 B per lane and call, 0.4 GB of HBM writes per headline tree; hence
+                // ka_adj2 as a function with scalar arguments and the c_ copies at the top of the loop's lambda.
                 typedef const __attribute__((address_space(1))) int* ka_gint;
                 typedef const __attribute__((address_space(1))) float* ka_gf;
                 typedef const __attribute__((address_space(1))) float4v* ka_gf4;
