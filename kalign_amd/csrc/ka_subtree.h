@@ -528,28 +528,44 @@ __device__ __forceinline__ void ka_sub_setup(TaskShared& S, const KaSub& root, c
         // ---- stage the operand windows: 16-byte chunks, four loads in flight per lane before their LDS writes ----
         const float m1 = ka_uniform_f(S.p1_mult), m2 = ka_uniform_f(S.p2_mult);
         // one record = `per` chunks: nsc chunks of 4 floats from field `src0` on, then (open, ext, text) * mult
+        // (round 6: two loops without a branch between their loads -- the score chunks, then the gap fields -- through global pointers: a
+        // flat load counts on vmcnt AND lgkmcnt, and a branch between two loads costs a wait for everything in flight; ka_update_profile
+        // has the measurement of the same change)
         auto stage = [&](const float* prof, const int rec0, const int nrec, const int src0, const int nsc, const float mult, ka_lf* dst) {
-                const int per = nsc + 1;
-                const int nit = nrec * per;
+                typedef const __attribute__((address_space(1))) float* ka_gfp;
+                typedef const __attribute__((address_space(1))) float4v* ka_gf4p;
+                const ka_gfp gp = (ka_gfp)prof + ((long long)rec0 << 6);
+                const int nit = nrec * nsc;
                 for (int base = 0; base < nit; base += 256) {
                         float4v val[4];
                         int off[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                                 const int it = min(base + 64 * u + lane, nit - 1);
-                                const int k = it / per, ch = it - k * per;
-                                const float* rec = prof + ((long long)(rec0 + k) << 6);
-                                if (ch < nsc) val[u] = *(const float4v*)(rec + src0 + 4 * ch);
-                                else { val[u].x = rec[55]; val[u].y = rec[56]; val[u].z = rec[57]; val[u].w = 0.0f; }
-                                off[u] = (ch < nsc) ? (k * RW + 4 * ch) : -(k * RW + G0) - 1;
+                                const int k = it / nsc, ch = it - k * nsc;
+                                val[u] = *(ka_gf4p)(gp + ((long long)k << 6) + src0 + 4 * ch);
+                                off[u] = k * RW + 4 * ch;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                                if (base + 64 * u + lane >= nit) continue;
-                                float4v w = val[u];
-                                int o2 = off[u];
-                                if (o2 < 0) { o2 = -o2 - 1; w.x = w.x * mult; w.y = w.y * mult; w.z = w.z * mult; }
-                                *(ka_lf4*)(dst + o2) = w;
+                        for (int u = 0; u < 4; ++u)
+                                if (base + 64 * u + lane < nit) *(ka_lf4*)(dst + off[u]) = val[u];
+                }
+                // (open, ext, text) * mult: fields 55 .. 57 of every record
+                for (int base = 0; base < nrec; base += 128) {
+                        float g[2][3];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                                const int k = min(base + 64 * u + lane, nrec - 1);
+                                const ka_gfp r = gp + ((long long)k << 6);
+                                g[u][0] = r[55]; g[u][1] = r[56]; g[u][2] = r[57];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                                const int k = base + 64 * u + lane;
+                                if (k >= nrec) continue;
+                                float4v w;
+                                w.x = g[u][0] * mult; w.y = g[u][1] * mult; w.z = g[u][2] * mult; w.w = 0.0f;
+                                *(ka_lf4*)(dst + k * RW + G0) = w;
                         }
                 }
         };
